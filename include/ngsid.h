@@ -1,0 +1,169 @@
+/* ngsid.h - C-ABI of libngsid_hip.so: the MI355X (gfx950) hot path of NGSpeciesID.
+ *
+ * This library replaces, for the read-clustering + consensus + polishing path only, what the
+ * reference reaches through its four native third-party tools (parasail, spoa, minimap2, racon)
+ * and the pure-Python loops around them.  Citations are file:line into ksahlin/NGSpeciesID v0.3.1.
+ *
+ * Conventions
+ *   - plain C, POD only; every function returns int32 (0 = NGSID_OK, <0 = error code);
+ *     ngsid_last_error(ctx) returns the text of the last failure on that ctx.
+ *   - read sets are CSR: concatenated bytes + uint64 offsets[n+1]; `mem` says where the three
+ *     pointers live (NGSID_MEM_HOST: the library copies them to HBM; NGSID_MEM_DEVICE: they already
+ *     are HBM pointers on the ctx's device and are used in place).  Outputs are host pointers
+ *     unless stated.  The library never frees caller memory and never keeps a caller pointer after
+ *     the call returns.
+ *   - one ctx = one HIP device + one HIP stream.  Not thread-safe across threads sharing a ctx.
+ *   - there is NO CPU implementation behind these symbols: without a usable HIP device
+ *     ngsid_create fails with NGSID_ERR_NO_DEVICE.  (The CPU restatement used for testing lives
+ *     in oracle/ under the ongsid_* names and is never linked here.)
+ */
+#ifndef NGSID_H
+#define NGSID_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGSID_OK                 0
+#define NGSID_ERR_NO_DEVICE     -1   /* no HIP device / kernel image not loadable */
+#define NGSID_ERR_ARG           -2   /* bad argument (NULL, k>21, w<k, ...) */
+#define NGSID_ERR_ALPHABET      -3   /* base outside {A,C,G,T,N} met by the minimizer encoder */
+#define NGSID_ERR_CAPACITY      -4   /* caller buffer too small; required size reported in *needed */
+#define NGSID_ERR_HIP           -5   /* HIP runtime error (text in ngsid_last_error) */
+#define NGSID_ERR_TOO_LONG      -6   /* a read exceeds NGSID_MAX_READ_LEN */
+#define NGSID_ERR_NO_PTABLE     -7   /* (e1,e2) looked up in a p_shared table with a NaN hole (KeyError in cluster.py:367) */
+
+#define NGSID_MEM_HOST   0u
+#define NGSID_MEM_DEVICE 1u
+
+#define NGSID_MAX_K          21      /* 3-bit order-preserving codes (0=end,A,C,G,N,T) in a uint64 */
+#define NGSID_MAX_READ_LEN   16384   /* bases per read handled by the LDS-staged kernels */
+
+typedef struct ngsid_ctx ngsid_ctx;
+
+typedef struct {
+    const uint8_t*  seq;    /* concatenated bases (ASCII) */
+    const uint8_t*  qual;   /* concatenated phred+33 characters; may be NULL where a function says so */
+    const uint64_t* off;    /* n+1 offsets into seq/qual */
+    uint64_t        n;      /* number of reads */
+    uint32_t        mem;    /* NGSID_MEM_HOST or NGSID_MEM_DEVICE */
+    uint32_t        _pad;
+} ngsid_reads_t;
+
+/* Clustering parameters = the argparse flags the path reads (NGSpeciesID:225-233) + the selected
+ * 15x15 slice of the empirical table (NGSpeciesID:72-77), p_shared[(i*15)+j] for e1=(i+1)/100,
+ * e2=(j+1)/100, NaN where the reference dict would have no key. */
+typedef struct {
+    int32_t k, w, min_shared, symmetric;
+    double  min_fraction, mapped_threshold, aligned_threshold, min_prob_no_hits;
+    double  p_shared[225];
+} ngsid_cluster_params_t;
+
+/* status_out codes of ngsid_cluster_greedy */
+#define NGSID_ST_NEWREP   0   /* read founded a cluster (cluster.py:328-334) */
+#define NGSID_ST_MAPPED   1   /* joined by the mapping criterion (cluster.py:307-308) */
+#define NGSID_ST_ALIGNED  2   /* joined by the block-alignment criterion (cluster.py:313-314) */
+#define NGSID_ST_SHORT    3   /* HPC length < k: skipped, stays a singleton (cluster.py:266-268) */
+#define NGSID_ST_SEEDED   4   /* prev_batch_index == lowest: pre-existing representative (cluster.py:243-248) */
+
+int32_t     ngsid_create(int32_t device_ordinal, uint32_t flags, ngsid_ctx** out);
+void        ngsid_destroy(ngsid_ctx* ctx);
+const char* ngsid_last_error(ngsid_ctx* ctx);
+/* ABI/version probe usable without a device (tests check the library loads and exports all symbols). */
+uint32_t    ngsid_abi_version(void);
+
+/* (f1) replaces get_sorted_fastq_for_cluster.calc_score_new / fastq_single_core :23-33,124-155.
+ * score[i] = expected number of error-free k-mers, err_rate[i] = mean 10^-(q/10) (no clamp),
+ * keep[i] = 0 when len<2k, HPC len<k or 10*-log10(err)<=q_threshold. */
+int32_t ngsid_score_reads(ngsid_ctx* ctx, const ngsid_reads_t* reads, int32_t k, double q_threshold,
+                          double* score, double* err_rate, uint8_t* keep);
+
+/* (a1-a3) replaces the inline HPC (cluster.py:265), get_kmer_minimizers (cluster.py:16-39) and the
+ * HPC quality / error-rate block (cluster.py:279-291).  Output is CSR over reads in read order:
+ * mz_off[n+1], codes/pos with capacity `cap` entries (NGSID_ERR_CAPACITY + *needed otherwise).
+ * codes are 3-bit-per-base order-preserving k-mer codes; pos are positions in the HPC string.
+ * hpc_len[i] = HPC length, hpc_err[i] = error rate (sum over quality characters in ascending
+ * character code), reads with hpc_len<k get 0 minimizers.
+ * codes/pos/mz_off follow reads->mem (device outputs for device inputs); hpc_len/hpc_err are host. */
+int32_t ngsid_hpc_minimizers(ngsid_ctx* ctx, const ngsid_reads_t* reads, int32_t k, int32_t w,
+                             uint64_t* mz_off, uint64_t* codes, uint32_t* pos, uint64_t cap, uint64_t* needed,
+                             uint32_t* hpc_len, double* hpc_err);
+
+/* (a4-a11) replaces cluster.reads_to_clusters (cluster.py:207-353) incl. get_all_hits :43-62,
+ * get_best_cluster :67-127, get_best_cluster_block_align :172-205, parasail_block_alignment :130-169.
+ * reads           score-ordered read set (the order IS the greedy order)
+ * acc_rank[n]     rank of the accession string (incl. "_score" suffix) under byte-wise comparison,
+ *                 equal strings equal rank: the third sort key of cluster.py:79,174
+ * prev_batch[n]   previous batch index per read or NULL (= all 0, single_clustering NGSpeciesID:20-33);
+ *                 reads whose index equals max(1,min(prev_batch)) seed the database and are not
+ *                 re-clustered (cluster.py:221-223,243-248)
+ * known_err[n]    HPC error rates carried over from an earlier round (8-tuples, cluster.py:273-277),
+ *                 NaN / NULL = compute
+ * rep_of_read[n]  out: index of the representative read each read ends up with (itself for
+ *                 representatives, seeded and skipped reads) = cluster_to_new_cluster_id (:324)
+ * hpc_err_out[n]  out: the error rate in the representative 8-tuple (NaN for NGSID_ST_SHORT)
+ * status_out[n]   out: NGSID_ST_*
+ * counters[4]     out: mapped_passed, aln_passed, aln_called (cluster.py:349-351), number of new representatives */
+int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* reads, const ngsid_cluster_params_t* prm,
+                             const uint32_t* acc_rank, const int32_t* prev_batch, const double* known_err,
+                             int32_t* rep_of_read, double* hpc_err_out, uint8_t* status_out, uint64_t counters[4]);
+
+/* (a10,a15) replaces parasail.sg_trace_scan_16/32 + cigar_to_seq + the k-window identity filter
+ * (cluster.py:130-169) and the identity count of consensus.highest_aln_identity (consensus.py:129-145).
+ * Pair p aligns query read q_idx[p] of `queries` (rows) against target t_idx[p] of `targets` (columns),
+ * semi-global (all four end gaps free), substitution match/mismatch over ACGT (case-insensitive, any other
+ * character scores 0), first gap base costs open[p], each further one ext.
+ * Outputs per pair: score; n_cols = length of the two gapped strings (both sequences covered);
+ * n_match = columns whose two characters are equal; region = number of k-column windows holding
+ * >= match_id[p] equal columns (sum(aligned_region), cluster.py:147-167).  Any output may be NULL. */
+int32_t ngsid_sg_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const ngsid_reads_t* targets,
+                             const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                             int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,
+                             int32_t k, const int32_t* match_id,
+                             int32_t* score, int32_t* n_cols, int32_t* n_match, int32_t* region);
+
+/* POA modes */
+#define NGSID_POA_LOCAL   0   /* spoa -l 0 */
+#define NGSID_POA_GLOBAL  1   /* spoa -l 1 (racon windows) */
+#define NGSID_POA_SEMI    2   /* sequence end-to-end, graph ends free (racon sub-graph layers) */
+
+typedef struct {
+    int32_t mode;          /* NGSID_POA_* */
+    int32_t match, mismatch, gap;   /* spoa -m/-n/-g ; linear gaps (g >= e in consensus.py:87) */
+    int32_t tile_depth;    /* reads per exact-order POA tile; <=0 = one tile per group (exact spoa order) */
+    int32_t band;          /* DP band width in columns (64/128/256); <=0 = library default */
+    int32_t node_cap;      /* graph node capacity per tile as a multiple of 1/16 of the first read length (<=0 default) */
+    int32_t _pad;
+} ngsid_poa_params_t;
+
+/* (a13,a14) replaces form_draft_consensus' per-cluster `spoa reads.fq -l 0 -r 0 -g -2` (consensus.py:83-92,249-278).
+ * reads are grouped: group g = reads [grp_off[g], grp_off[g+1]) in spoa file order (representative
+ * first).  qual==NULL means unit weights (FASTA input).  Consensus strings come back CSR:
+ * cons_off[n_groups+1] + cons bytes (capacity cons_cap). */
+int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint64_t* grp_off, uint64_t n_groups,
+                            const ngsid_poa_params_t* prm,
+                            uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed);
+
+typedef struct {
+    int32_t iters;            /* --racon_iter (NGSpeciesID:212) */
+    int32_t window;           /* racon -w 500 */
+    double  quality_threshold;/* racon -q 10 */
+    double  error_threshold;  /* racon -e 0.3 */
+    int32_t match, mismatch, gap;   /* racon -m 3 -x -5 -g -4 */
+    int32_t k, w;             /* minimizer parameters used for strand detection (replaces minimap2 -x map-ont) */
+    int32_t tile_depth, band, node_cap;
+    int32_t aln_match, aln_mismatch, aln_open, aln_ext;  /* read->backbone aligner (replaces the edlib NW path of racon) */
+    int32_t trim;             /* racon window trimming for TGS windows (mean read length > 1000) */
+} ngsid_polish_params_t;
+
+/* (a16,a17) replaces run_racon's (minimap2 -> racon) x racon_iter chain (consensus.py:107-126).
+ * backbones: one sequence per group (qual ignored); reads grouped like ngsid_poa_consensus.
+ * n_used[g] (may be NULL) = reads that contributed at least one window layer in the last iteration. */
+int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads,
+                     const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                     uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,200 @@
+"""ctypes view of the C-ABI declared in include/ngsid.h (structs + call wrappers).
+
+`Api` binds one shared library.  The product binds libngsid_hip.so (prefix ``ngsid_``, ctx first);
+the tests bind the CPU oracle with the same wrapper (prefix ``ongsid_``, no ctx) - the oracle is
+never bound from inside this package.
+"""
+from __future__ import annotations
+import ctypes as C
+import numpy as np
+
+MEM_HOST, MEM_DEVICE = 0, 1
+ERRORS = {-1: "NGSID_ERR_NO_DEVICE", -2: "NGSID_ERR_ARG", -3: "NGSID_ERR_ALPHABET", -4: "NGSID_ERR_CAPACITY",
+          -5: "NGSID_ERR_HIP", -6: "NGSID_ERR_TOO_LONG", -7: "NGSID_ERR_NO_PTABLE"}
+ST_NEWREP, ST_MAPPED, ST_ALIGNED, ST_SHORT, ST_SEEDED = 0, 1, 2, 3, 4
+POA_LOCAL, POA_GLOBAL, POA_SEMI = 0, 1, 2
+
+
+class NgsidError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "NGSID_ERR"), code, text))
+        self.code = code
+
+
+class Reads(C.Structure):
+    _fields_ = [("seq", C.c_void_p), ("qual", C.c_void_p), ("off", C.c_void_p), ("n", C.c_uint64), ("mem", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class ClusterParams(C.Structure):
+    _fields_ = [("k", C.c_int32), ("w", C.c_int32), ("min_shared", C.c_int32), ("symmetric", C.c_int32),
+                ("min_fraction", C.c_double), ("mapped_threshold", C.c_double), ("aligned_threshold", C.c_double),
+                ("min_prob_no_hits", C.c_double), ("p_shared", C.c_double * 225)]
+
+
+class PoaParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32), ("gap", C.c_int32),
+                ("tile_depth", C.c_int32), ("band", C.c_int32), ("node_cap", C.c_int32), ("_pad", C.c_int32)]
+
+
+class PolishParams(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("window", C.c_int32), ("quality_threshold", C.c_double), ("error_threshold", C.c_double),
+                ("match", C.c_int32), ("mismatch", C.c_int32), ("gap", C.c_int32), ("k", C.c_int32), ("w", C.c_int32),
+                ("tile_depth", C.c_int32), ("band", C.c_int32), ("node_cap", C.c_int32),
+                ("aln_match", C.c_int32), ("aln_mismatch", C.c_int32), ("aln_open", C.c_int32), ("aln_ext", C.c_int32), ("trim", C.c_int32)]
+
+
+def cluster_params(k=13, w=20, min_shared=5, min_fraction=0.8, mapped_threshold=0.7, aligned_threshold=0.4,
+                   min_prob_no_hits=0.1, symmetric=False, p_shared=None):
+    p = ClusterParams()
+    p.k, p.w, p.min_shared, p.symmetric = int(k), int(w), int(min_shared), int(bool(symmetric))
+    p.min_fraction, p.mapped_threshold, p.aligned_threshold, p.min_prob_no_hits = min_fraction, mapped_threshold, aligned_threshold, min_prob_no_hits
+    t = np.full(225, np.nan) if p_shared is None else np.asarray(p_shared, dtype=np.float64)
+    for i in range(225):
+        p.p_shared[i] = t[i]
+    return p
+
+
+def poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=0, node_cap=0):
+    """Defaults = `spoa -l 0 -r 0 -g -2` (consensus.py:87; spoa 4.0.x m=5 n=-4, linear because g>=e)."""
+    return PoaParams(int(mode), int(match), int(mismatch), int(gap), int(tile_depth), int(band), int(node_cap), 0)
+
+
+def polish_params(iters=2, window=500, quality_threshold=10.0, error_threshold=0.3, match=3, mismatch=-5, gap=-4,
+                  k=13, w=20, tile_depth=0, band=0, node_cap=0, aln_match=2, aln_mismatch=-2, aln_open=3, aln_ext=1, trim=1):
+    """Defaults = racon 1.4.x (-w 500 -q 10 -e 0.3 -m 3 -x -5 -g -4), iters = --racon_iter (NGSpeciesID:212)."""
+    return PolishParams(int(iters), int(window), float(quality_threshold), float(error_threshold), int(match), int(mismatch), int(gap),
+                        int(k), int(w), int(tile_depth), int(band), int(node_cap), int(aln_match), int(aln_mismatch), int(aln_open), int(aln_ext), int(trim))
+
+
+class ReadSet:
+    """CSR read set backed by numpy arrays (host) or by raw device pointers (torch tensors kept alive by the caller)."""
+
+    def __init__(self, seq, qual, off, mem=MEM_HOST, keep=None):
+        self.mem = mem
+        self.keep = keep
+        if mem == MEM_HOST:
+            self.seq = np.ascontiguousarray(seq, dtype=np.uint8)
+            self.qual = None if qual is None else np.ascontiguousarray(qual, dtype=np.uint8)
+            self.off = np.ascontiguousarray(off, dtype=np.uint64)
+            self.n = len(self.off) - 1
+            self.c = Reads(self.seq.ctypes.data, None if self.qual is None else self.qual.ctypes.data, self.off.ctypes.data, self.n, MEM_HOST, 0)
+        else:
+            self.seq, self.qual, self.off = seq, qual, off            # integers (device addresses)
+            self.n = int(keep["n"])
+            self.c = Reads(int(seq), None if qual is None else int(qual), int(off), self.n, MEM_DEVICE, 0)
+
+    @staticmethod
+    def from_strings(seqs, quals=None):
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        seq = np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy() if len(seqs) else np.zeros(0, np.uint8)
+        qual = None
+        if quals is not None:
+            qual = np.frombuffer("".join(quals).encode(), dtype=np.uint8).copy() if len(quals) else np.zeros(0, np.uint8)
+        return ReadSet(seq, qual, off)
+
+    @staticmethod
+    def from_torch(seq_t, qual_t, off_t):
+        """torch tensors on a cuda/hip device: uint8, uint8, int64 (n+1)."""
+        keep = dict(seq=seq_t, qual=qual_t, off=off_t, n=off_t.numel() - 1)
+        return ReadSet(seq_t.data_ptr(), None if qual_t is None else qual_t.data_ptr(), off_t.data_ptr(), MEM_DEVICE, keep)
+
+    def get(self, i):
+        a, b = int(self.off[i]), int(self.off[i + 1])
+        return self.seq[a:b].tobytes().decode(), (None if self.qual is None else self.qual[a:b].tobytes().decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Api:
+    def __init__(self, lib: C.CDLL, prefix: str, ctx=None):
+        self.lib, self.prefix, self.ctx = lib, prefix, ctx
+        self.has_ctx = ctx is not None
+
+    def _fn(self, name):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = C.c_int32
+        return f
+
+    def _call(self, name, *args):
+        f = self._fn(name)
+        rc = f(self.ctx, *args) if self.has_ctx else f(*args)
+        return rc
+
+    def _err(self, rc):
+        if self.has_ctx:
+            g = getattr(self.lib, self.prefix + "last_error"); g.restype = C.c_char_p
+            txt = g(self.ctx)
+        else:
+            g = getattr(self.lib, self.prefix + "last_error"); g.restype = C.c_char_p
+            txt = g()
+        raise NgsidError(rc, (txt or b"").decode(errors="replace"))
+
+    # ---- (f1)
+    def score_reads(self, rs: ReadSet, k, q_threshold=7.0):
+        n = rs.n
+        score = np.zeros(n); err = np.zeros(n); keep = np.zeros(n, dtype=np.uint8)
+        rc = self._call("score_reads", C.byref(rs.c), C.c_int32(k), C.c_double(q_threshold), _p(score), _p(err), _p(keep))
+        if rc: self._err(rc)
+        return score, err, keep
+
+    # ---- (a1-a3)
+    def hpc_minimizers(self, rs: ReadSet, k, w, cap=None):
+        assert rs.mem == MEM_HOST, "host wrapper; device callers use the raw C-ABI"
+        n = rs.n
+        if cap is None:
+            cap = max(16, int(len(rs.seq)))
+        moff = np.zeros(n + 1, dtype=np.uint64); codes = np.zeros(cap, dtype=np.uint64); pos = np.zeros(cap, dtype=np.uint32)
+        hl = np.zeros(n, dtype=np.uint32); he = np.zeros(n); needed = C.c_uint64(0)
+        rc = self._call("hpc_minimizers", C.byref(rs.c), C.c_int32(k), C.c_int32(w), _p(moff), _p(codes), _p(pos), C.c_uint64(cap), C.byref(needed), _p(hl), _p(he))
+        if rc: self._err(rc)
+        t = int(moff[-1])
+        return moff, codes[:t], pos[:t], hl, he
+
+    # ---- (a4-a11)
+    def cluster_greedy(self, rs: ReadSet, prm: ClusterParams, acc_rank=None, prev_batch=None, known_err=None):
+        n = rs.n
+        rep = np.zeros(n, dtype=np.int32); herr = np.zeros(n); st = np.zeros(n, dtype=np.uint8); cnt = np.zeros(4, dtype=np.uint64)
+        ar = None if acc_rank is None else np.ascontiguousarray(acc_rank, dtype=np.uint32)
+        pb = None if prev_batch is None else np.ascontiguousarray(prev_batch, dtype=np.int32)
+        ke = None if known_err is None else np.ascontiguousarray(known_err, dtype=np.float64)
+        rc = self._call("cluster_greedy", C.byref(rs.c), C.byref(prm), _p(ar), _p(pb), _p(ke), _p(rep), _p(herr), _p(st), _p(cnt))
+        if rc: self._err(rc)
+        return rep, herr, st, cnt
+
+    # ---- (a10,a15)
+    def sg_align_batch(self, q: ReadSet, t: ReadSet, q_idx, t_idx, open_, ext=1, match=2, mismatch=-2, k=13, match_id=None):
+        q_idx = np.ascontiguousarray(q_idx, dtype=np.uint32); t_idx = np.ascontiguousarray(t_idx, dtype=np.uint32)
+        n = len(q_idx)
+        open_ = np.ascontiguousarray(np.broadcast_to(np.asarray(open_, dtype=np.int32), (n,)))
+        mid = np.ascontiguousarray(np.broadcast_to(np.asarray(k if match_id is None else match_id, dtype=np.int32), (n,)))
+        score = np.zeros(n, dtype=np.int32); ncols = np.zeros(n, dtype=np.int32); nmatch = np.zeros(n, dtype=np.int32); region = np.zeros(n, dtype=np.int32)
+        rc = self._call("sg_align_batch", C.byref(q.c), C.byref(t.c), _p(q_idx), _p(t_idx), C.c_uint64(n), C.c_int32(match), C.c_int32(mismatch),
+                        _p(open_), C.c_int32(ext), C.c_int32(k), _p(mid), _p(score), _p(ncols), _p(nmatch), _p(region))
+        if rc: self._err(rc)
+        return score, ncols, nmatch, region
+
+    # ---- (a13,a14)
+    def poa_consensus(self, rs: ReadSet, grp_off, prm: PoaParams, cap=None):
+        grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
+        ng = len(grp_off) - 1
+        if cap is None:
+            lens = np.diff(rs.off.astype(np.int64)) if rs.mem == MEM_HOST else None
+            cap = int(4 * (lens.max() if lens is not None and len(lens) else 4096) * max(ng, 1) + 1024)
+        coff = np.zeros(ng + 1, dtype=np.uint64); cons = np.zeros(cap, dtype=np.uint8); needed = C.c_uint64(0)
+        rc = self._call("poa_consensus", C.byref(rs.c), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(coff), _p(cons), C.c_uint64(cap), C.byref(needed))
+        if rc: self._err(rc)
+        return [cons[int(coff[g]):int(coff[g + 1])].tobytes().decode() for g in range(ng)]
+
+    # ---- (a16,a17)
+    def polish(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None):
+        grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
+        ng = len(grp_off) - 1
+        if cap is None:
+            cap = int(4 * len(backbones.seq) + 4096) if backbones.mem == MEM_HOST else 1 << 24
+        ooff = np.zeros(ng + 1, dtype=np.uint64); out = np.zeros(cap, dtype=np.uint8); needed = C.c_uint64(0); used = np.zeros(max(ng, 1), dtype=np.uint64)
+        rc = self._call("polish", C.byref(backbones.c), C.byref(rs.c), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(ooff), _p(out), C.c_uint64(cap), C.byref(needed), _p(used))
+        if rc: self._err(rc)
+        return [out[int(ooff[g]):int(ooff[g + 1])].tobytes().decode() for g in range(ng)], used[:ng]

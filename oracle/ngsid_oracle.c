@@ -1,0 +1,480 @@
+/* ngsid_oracle.c - sequential CPU restatement of the NGSpeciesID clustering path.
+ * TEST INFRASTRUCTURE ONLY (see ngsid_oracle.h).  Build: oracle/Makefile (gcc -O2 -ffp-contract=off).
+ * Citations are file:line into /root/reference (ksahlin/NGSpeciesID v0.3.1).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include "ngsid_oracle.h"
+#include "../include/ngsid_tables.h"
+
+static char g_err[512] = "";
+#define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
+
+uint32_t ongsid_abi_version(void) { return 1u; }
+const char* ongsid_last_error(void) { return g_err; }
+
+/* ------------------------------------------------------------------------------------------------
+ * (a1) homopolymer compression: ''.join(ch for ch,_ in itertools.groupby(seq))        cluster.py:265
+ * (a3) per run the phred char with the LOWEST error probability, first on ties         cluster.py:279-286
+ * returns hpc length; hs/hq need capacity n
+ * ---------------------------------------------------------------------------------------------- */
+static int hpc_compress(const uint8_t* s, const uint8_t* q, int n, uint8_t* hs, uint8_t* hq) {
+    int m = 0, i = 0;
+    while (i < n) {
+        int j = i; uint8_t best = q ? q[i] : 0;
+        while (j + 1 < n && s[j + 1] == s[i]) {
+            ++j;
+            if (q && NGSID_PHRED_P[q[j] & 127] < NGSID_PHRED_P[best & 127]) best = q[j];
+        }
+        hs[m] = s[i]; if (hq) hq[m] = best; ++m; i = j + 1;
+    }
+    return m;
+}
+
+/* sum([ s.count(c) * p[c] for c in set(s) ]) / float(len(s))                 cluster.py:290-291,185-188
+ * The reference iterates a set (hash order, PYTHONHASHSEED dependent); this build fixes ascending
+ * character code (SURVEY 8a dagger). */
+static double mean_err(const uint8_t* q, int n, const double* table) {
+    int hist[128]; memset(hist, 0, sizeof hist);
+    for (int i = 0; i < n; ++i) hist[q[i] & 127]++;
+    double sum = 0.0; int first = 1;
+    for (int c = 0; c < 128; ++c) if (hist[c]) {
+        double term = (double)hist[c] * table[c];
+        if (first) { sum = term; first = 0; } else sum = sum + term;   /* python sum() starts at int 0: 0+term == term */
+    }
+    return sum / (double)n;
+}
+
+/* 3-bit order-preserving base code: raw-byte lexicographic order A<C<G<N<T */
+static inline int enc3(uint8_t c) {
+    switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'N': return 4; case 'T': return 5; default: return -1; }
+}
+
+/* (a2) get_kmer_minimizers(seq,k,w)                                                    cluster.py:16-39
+ * = leftmost minimum of every window of w-k+1 consecutive k-mers, emitted when its position changes.
+ * For len < w the first (only) window holds end-truncated / empty slices (cluster.py:19): codes are
+ * left-aligned and zero padded so that a proper prefix sorts before its extensions.
+ * Returns count or -1 on alphabet error. codes/pos need capacity max(1, n-k+1). */
+static int minimizers(const uint8_t* hs, int n, int k, int w, uint64_t* codes, uint32_t* pos) {
+    int W = w - k + 1, nk = n - k + 1;
+    int nc = nk > W ? nk : W;
+    uint64_t* kc = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)nc);
+    for (int i = 0; i < nc; ++i) {
+        uint64_t c = 0;
+        for (int t = 0; t < k; ++t) {
+            int e = 0;
+            if (i + t < n) { e = enc3(hs[i + t]); if (e < 0) { free(kc); return -1; } }
+            c = (c << 3) | (uint64_t)e;
+        }
+        kc[i] = c;
+    }
+    int nwin = nk >= W ? nk - W + 1 : 1, cnt = 0, prev = -1;
+    for (int s = 0; s < nwin; ++s) {
+        int best = s;
+        for (int j = s + 1; j < s + W; ++j) if (kc[j] < kc[best]) best = j;
+        if (best != prev) { codes[cnt] = kc[best]; pos[cnt] = (uint32_t)best; ++cnt; prev = best; }
+    }
+    free(kc);
+    return cnt;
+}
+
+/* p_shared_minimizer_empirical: round(e,2) clamped to [0.01,0.15]                      cluster.py:356-368 */
+static inline int eidx(double e) {
+    int j = 0;
+    while (j < 15 && e >= NGSID_ROUND2_T[j]) ++j;
+    if (j < 1) j = 1;
+    return j;   /* 1..15 */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * (a10) semi-global affine alignment with traceback.  Restates parasail.sg_trace_scan_16/32 as the
+ * reference calls it (cluster.py:131-135, consensus.py:59-63): all end gaps free, gap of length l
+ * costs open+(l-1)*ext, matrix_create("ACGT",match,mismatch) (case-insensitive, other characters 0).
+ * Tie-breaks are THIS BUILD'S (parity unpinned): H prefers diag, then E (gap in query, consumes
+ * target, CIGAR 'D'), then F ('I'); E/F prefer extension over opening; end cell = first maximum over
+ * the last row (ascending column) then strictly larger over the last column (ascending row).
+ * ---------------------------------------------------------------------------------------------- */
+#define NEGINF (-(1 << 29))
+static inline int bcode(uint8_t c) {
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+typedef struct { int score, i_end, j_end; uint8_t* tb; int n, m; } sg_result;
+
+static int sg_align(const uint8_t* q, int n, const uint8_t* t, int m, int match, int mismatch, int open, int ext, sg_result* R) {
+    R->n = n; R->m = m; R->tb = NULL; R->score = 0; R->i_end = 0; R->j_end = 0;
+    if (n <= 0 || m <= 0) return 0;
+    uint8_t* tb = (uint8_t*)malloc((size_t)n * (size_t)m);
+    int* H = (int*)malloc(sizeof(int) * (size_t)(m + 1));
+    int* F = (int*)malloc(sizeof(int) * (size_t)(m + 1));
+    int* lastcol = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int j = 0; j <= m; ++j) { H[j] = 0; F[j] = NEGINF; }
+    for (int i = 1; i <= n; ++i) {
+        int hdiag = H[0], hleft = 0, e = NEGINF; H[0] = 0;
+        int qa = bcode(q[i - 1]);
+        for (int j = 1; j <= m; ++j) {
+            int tbv;
+            int e_ext = e - ext, e_opn = hleft - open; int ebit = e_ext >= e_opn; e = ebit ? e_ext : e_opn;
+            int f_ext = F[j] - ext, f_opn = H[j] - open; int fbit = f_ext >= f_opn; int f = fbit ? f_ext : f_opn;
+            int ta = bcode(t[j - 1]);
+            int s = (qa > 3 || ta > 3) ? 0 : (qa == ta ? match : mismatch);
+            int d = hdiag + s, h, src;
+            if (d >= e && d >= f) { h = d; src = 0; } else if (e >= f) { h = e; src = 1; } else { h = f; src = 2; }
+            tbv = src | (ebit << 2) | (fbit << 3);
+            tb[(size_t)(i - 1) * m + (j - 1)] = (uint8_t)tbv;
+            hdiag = H[j]; H[j] = h; F[j] = f; hleft = h;
+        }
+        lastcol[i] = H[m];
+    }
+    int best = NEGINF, bi = n, bj = 1;
+    for (int j = 1; j <= m; ++j) if (H[j] > best) { best = H[j]; bi = n; bj = j; }
+    for (int i = 1; i <= n; ++i) if (lastcol[i] > best) { best = lastcol[i]; bi = i; bj = m; }
+    R->score = best; R->i_end = bi; R->j_end = bj; R->tb = tb;
+    free(H); free(F); free(lastcol);
+    return 0;
+}
+
+/* walk the path backwards; ops[] receives op codes in REVERSE order: 0 '=', 1 'X', 2 'I' (query only), 3 'D' (target only).
+ * returns number of ops (= alignment columns incl. end gaps). ops needs capacity n+m. */
+static int sg_traceback(const uint8_t* q, const uint8_t* t, const sg_result* R, uint8_t* ops) {
+    int n = R->n, m = R->m, c = 0;
+    if (n <= 0 || m <= 0) { for (int i = 0; i < n; ++i) ops[c++] = 2; for (int j = 0; j < m; ++j) ops[c++] = 3; return c; }
+    int i = R->i_end, j = R->j_end;
+    for (int x = n; x > i; --x) ops[c++] = 2;      /* query suffix  */
+    for (int x = m; x > j; --x) ops[c++] = 3;      /* target suffix */
+    int state = 0;
+    while (i > 0 && j > 0) {
+        int v = R->tb[(size_t)(i - 1) * m + (j - 1)];
+        if (state == 0) {
+            int src = v & 3;
+            if (src == 0) { ops[c++] = (q[i - 1] == t[j - 1]) ? 0 : 1; --i; --j; }
+            else state = src;
+        } else if (state == 1) { ops[c++] = 3; if (!((v >> 2) & 1)) state = 0; --j; }
+        else { ops[c++] = 2; if (!((v >> 3) & 1)) state = 0; --i; }
+    }
+    for (; i > 0; --i) ops[c++] = 2;
+    for (; j > 0; --j) ops[c++] = 3;
+    return c;
+}
+
+/* rolling k-column window of matches                                                   cluster.py:146-167 */
+static int window_regions(const uint8_t* ops, int ncols, int k, int match_id) {
+    /* ops in any order (the count is symmetric under reversal); a column matches iff op==0 */
+    if (ncols <= 0) return (0 >= match_id) ? 1 : 0;
+    int first = ncols < k ? ncols : k, cur = 0, regions = 0;
+    for (int i = 0; i < first; ++i) cur += (ops[i] == 0);
+    regions += (cur >= match_id);
+    for (int i = k; i < ncols; ++i) { cur += (ops[i] == 0) - (ops[i - k] == 0); regions += (cur >= match_id); }
+    return regions;
+}
+
+int32_t ongsid_sg_align_cigar(const uint8_t* q, int32_t n, const uint8_t* t, int32_t m,
+                              int32_t match, int32_t mismatch, int32_t open, int32_t ext,
+                              char* cigar, int32_t cap, int32_t* score) {
+    sg_result R; sg_align(q, n, t, m, match, mismatch, open, ext, &R);
+    uint8_t* ops = (uint8_t*)malloc((size_t)(n + m + 1));
+    int c = sg_traceback(q, t, &R, ops);
+    static const char sym[4] = { '=', 'X', 'I', 'D' };
+    int o = 0, i = c - 1;
+    while (i >= 0) {
+        int j = i; while (j - 1 >= 0 && ops[j - 1] == ops[i]) --j;
+        int len = i - j + 1;
+        int w = snprintf(cigar + o, (size_t)(cap - o), "%d%c", len, sym[ops[i]]);
+        if (w < 0 || o + w >= cap) { free(ops); free(R.tb); FAIL(NGSID_ERR_CAPACITY, "cigar buffer too small"); }
+        o += w; i = j - 1;
+    }
+    cigar[o] = 0;
+    if (score) *score = R.score;
+    free(ops); free(R.tb);
+    return NGSID_OK;
+}
+
+int32_t ongsid_sg_align_batch(const ngsid_reads_t* Q, const ngsid_reads_t* T,
+                              const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                              int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,
+                              int32_t k, const int32_t* match_id,
+                              int32_t* score, int32_t* n_cols, int32_t* n_match, int32_t* region) {
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        uint32_t qi = q_idx[p], ti = t_idx[p];
+        const uint8_t* q = Q->seq + Q->off[qi]; int n = (int)(Q->off[qi + 1] - Q->off[qi]);
+        const uint8_t* t = T->seq + T->off[ti]; int m = (int)(T->off[ti + 1] - T->off[ti]);
+        sg_result R; sg_align(q, n, t, m, match, mismatch, open[p], ext, &R);
+        uint8_t* ops = (uint8_t*)malloc((size_t)(n + m + 1));
+        int c = sg_traceback(q, t, &R, ops);
+        if (score) score[p] = R.score;
+        if (n_cols) n_cols[p] = c;
+        if (n_match) { int nm = 0; for (int i = 0; i < c; ++i) nm += (ops[i] == 0); n_match[p] = nm; }
+        if (region) region[p] = window_regions(ops, c, k, match_id ? match_id[p] : k);
+        free(ops); free(R.tb);
+    }
+    return NGSID_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * (f1) read scoring                                              get_sorted_fastq_for_cluster.py:23-33,124-155
+ * ---------------------------------------------------------------------------------------------- */
+int32_t ongsid_score_reads(const ngsid_reads_t* reads, int32_t k, double q_threshold,
+                           double* score, double* err_rate, uint8_t* keep) {
+    for (uint64_t r = 0; r < reads->n; ++r) {
+        const uint8_t* s = reads->seq + reads->off[r]; const uint8_t* q = reads->qual + reads->off[r];
+        int n = (int)(reads->off[r + 1] - reads->off[r]);
+        score[r] = 0.0; err_rate[r] = 0.0; keep[r] = 0;
+        if (n < 2 * k) continue;
+        int hl = 0; for (int i = 0; i < n; ++i) if (i == 0 || s[i] != s[i - 1]) ++hl;
+        if (hl < k) continue;
+        /* expected_number_of_erroneous_kmers :23-33 */
+        double cur = 1.0;
+        for (int i = 0; i < k; ++i) cur = cur * (1.0 - NGSID_PHRED_P[q[i] & 127]);
+        double sum = cur;
+        for (int i = k; i < n; ++i) {
+            double p_to_leave = 1.0 - NGSID_PHRED_P[q[i - k] & 127];
+            cur *= ((1.0 - NGSID_PHRED_P[q[i] & 127]) / p_to_leave);
+            sum += cur;
+        }
+        double exp_err = (double)(n - k + 1) - sum;
+        double p_no = 1.0 - exp_err / (double)(n - k + 1);
+        score[r] = p_no * (double)(n - k + 1);
+        double er = mean_err(q, n, NGSID_PHRED_P_NOMIN);
+        err_rate[r] = er;
+        /* 10*-math.log(error_rate, 10) <= q_threshold  (math.log(x,b) = log(x)/log(b)) :147 */
+        if (10.0 * -(log(er) / log(10.0)) <= q_threshold) continue;
+        keep[r] = 1;
+    }
+    return NGSID_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * (a1-a3) batch HPC + minimizers
+ * ---------------------------------------------------------------------------------------------- */
+int32_t ongsid_hpc_minimizers(const ngsid_reads_t* reads, int32_t k, int32_t w,
+                              uint64_t* mz_off, uint64_t* codes, uint32_t* pos, uint64_t cap, uint64_t* needed,
+                              uint32_t* hpc_len, double* hpc_err) {
+    if (k < 1 || k > NGSID_MAX_K || w < k) FAIL(NGSID_ERR_ARG, "bad k/w");
+    uint64_t total = 0; int overflow = 0;
+    mz_off[0] = 0;
+    for (uint64_t r = 0; r < reads->n; ++r) {
+        const uint8_t* s = reads->seq + reads->off[r]; const uint8_t* q = reads->qual ? reads->qual + reads->off[r] : NULL;
+        int n = (int)(reads->off[r + 1] - reads->off[r]);
+        uint8_t* hs = (uint8_t*)malloc((size_t)n + 1), *hq = (uint8_t*)malloc((size_t)n + 1);
+        int hl = hpc_compress(s, q, n, hs, hq);
+        if (hpc_len) hpc_len[r] = (uint32_t)hl;
+        if (hpc_err) hpc_err[r] = (q && hl > 0) ? mean_err(hq, hl, NGSID_PHRED_P) : NAN;
+        int cnt = 0;
+        if (hl >= k) {
+            int capn = hl - k + 1; if (capn < 1) capn = 1;
+            uint64_t* c = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)capn); uint32_t* p = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)capn);
+            cnt = minimizers(hs, hl, k, w, c, p);
+            if (cnt < 0) { free(c); free(p); free(hs); free(hq); FAIL(NGSID_ERR_ALPHABET, "read %llu: base outside ACGTN", (unsigned long long)r); }
+            if (total + (uint64_t)cnt <= cap) { memcpy(codes + total, c, sizeof(uint64_t) * (size_t)cnt); memcpy(pos + total, p, sizeof(uint32_t) * (size_t)cnt); }
+            else overflow = 1;
+            free(c); free(p);
+        }
+        total += (uint64_t)cnt; mz_off[r + 1] = total;
+        free(hs); free(hq);
+    }
+    if (needed) *needed = total;
+    if (overflow) FAIL(NGSID_ERR_CAPACITY, "minimizer buffer too small: need %llu", (unsigned long long)total);
+    return NGSID_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * (a4-a11) greedy clustering                                                         cluster.py:207-353
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint64_t key; int head; } dbslot;            /* open-addressing hash: code -> posting list */
+typedef struct { int rep; int next; } posting;
+typedef struct {
+    dbslot* tab; uint64_t cap, used;
+    posting* post; int npost, cappost;
+} mdb;
+static uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+static void mdb_init(mdb* d) { d->cap = 1 << 12; d->used = 0; d->tab = (dbslot*)malloc(sizeof(dbslot) * d->cap); for (uint64_t i = 0; i < d->cap; ++i) d->tab[i].head = -2; d->npost = 0; d->cappost = 1 << 12; d->post = (posting*)malloc(sizeof(posting) * (size_t)d->cappost); }
+static void mdb_free(mdb* d) { free(d->tab); free(d->post); }
+static dbslot* mdb_find(mdb* d, uint64_t key, int create) {
+    uint64_t i = mix64(key) & (d->cap - 1);
+    while (d->tab[i].head != -2) { if (d->tab[i].key == key) return &d->tab[i]; i = (i + 1) & (d->cap - 1); }
+    if (!create) return NULL;
+    if ((d->used + 1) * 2 > d->cap) {
+        uint64_t oc = d->cap; dbslot* ot = d->tab; d->cap *= 2; d->tab = (dbslot*)malloc(sizeof(dbslot) * d->cap);
+        for (uint64_t j = 0; j < d->cap; ++j) d->tab[j].head = -2;
+        for (uint64_t j = 0; j < oc; ++j) if (ot[j].head != -2) { uint64_t x = mix64(ot[j].key) & (d->cap - 1); while (d->tab[x].head != -2) x = (x + 1) & (d->cap - 1); d->tab[x] = ot[j]; }
+        free(ot);
+        return mdb_find(d, key, 1);
+    }
+    d->tab[i].key = key; d->tab[i].head = -1; d->used++;
+    return &d->tab[i];
+}
+/* minimizer_database[m].add(read_cl_id)   cluster.py:329-334 (a set: one entry per (m,rep)) */
+static void mdb_add(mdb* d, uint64_t key, int rep) {
+    dbslot* s = mdb_find(d, key, 1);
+    for (int p = s->head; p >= 0; p = d->post[p].next) if (d->post[p].rep == rep) return;
+    if (d->npost == d->cappost) { d->cappost *= 2; d->post = (posting*)realloc(d->post, sizeof(posting) * (size_t)d->cappost); }
+    d->post[d->npost].rep = rep; d->post[d->npost].next = s->head; s->head = d->npost++;
+}
+
+typedef struct { int n; int64_t sum; int* idx; int* pos; int cap; int stamp; } hitlist;
+typedef struct { int slot; int n; int64_t sum; uint32_t rank; } cand;
+static int cand_cmp(const void* a, const void* b) {           /* sorted(..., key=(len, sum, acc), reverse=True)  cluster.py:79 */
+    const cand* x = (const cand*)a; const cand* y = (const cand*)b;
+    if (x->n != y->n) return x->n > y->n ? -1 : 1;
+    if (x->sum != y->sum) return x->sum > y->sum ? -1 : 1;
+    if (x->rank != y->rank) return x->rank > y->rank ? -1 : 1;
+    return x->slot < y->slot ? -1 : (x->slot > y->slot);       /* full ties: lower slot first (build-defined) */
+}
+
+static int32_t* g_tr_best = NULL; static int32_t* g_tr_ns = NULL; static double* g_tr_ratio = NULL; static uint64_t g_tr_n = 0;
+int32_t ongsid_debug_enable_trace(int32_t* best_m, int32_t* nshared, double* ratio, uint64_t n) { g_tr_best = best_m; g_tr_ns = nshared; g_tr_ratio = ratio; g_tr_n = n; return 0; }
+
+int32_t ongsid_cluster_greedy(const ngsid_reads_t* reads, const ngsid_cluster_params_t* prm,
+                              const uint32_t* acc_rank, const int32_t* prev_batch, const double* known_err,
+                              int32_t* rep_of_read, double* hpc_err_out, uint8_t* status_out, uint64_t counters[4]) {
+    const int k = prm->k, w = prm->w;
+    if (k < 1 || k > NGSID_MAX_K || w < k) FAIL(NGSID_ERR_ARG, "bad k/w");
+    const uint64_t N = reads->n;
+    int rc = NGSID_OK;
+    /* per representative slot data */
+    int nrep = 0, caprep = 64;
+    int* rep_read = (int*)malloc(sizeof(int) * (size_t)caprep);
+    int* rep_hlen = (int*)malloc(sizeof(int) * (size_t)caprep);
+    hitlist* hits = (hitlist*)calloc((size_t)caprep, sizeof(hitlist));
+    double* herr = (double*)malloc(sizeof(double) * (size_t)(N ? N : 1));
+    double* rawerr = (double*)malloc(sizeof(double) * (size_t)(N ? N : 1));
+    for (uint64_t i = 0; i < N; ++i) { herr[i] = NAN; rawerr[i] = NAN; }
+    mdb db; mdb_init(&db);
+    uint64_t mapped_passed = 0, aln_passed = 0, aln_called = 0, newreps = 0;
+    int maxlen = 1; for (uint64_t i = 0; i < N; ++i) { int n = (int)(reads->off[i + 1] - reads->off[i]); if (n > maxlen) maxlen = n; }
+    uint8_t* hs = (uint8_t*)malloc((size_t)maxlen + 1); uint8_t* hq = (uint8_t*)malloc((size_t)maxlen + 1);
+    uint64_t* mc = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)maxlen); uint32_t* mp = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)maxlen);
+    int* touched = (int*)malloc(sizeof(int) * 16); int captouched = 16;
+    cand* cands = (cand*)malloc(sizeof(cand) * 16); int capcand = 16;
+    uint8_t* ops = (uint8_t*)malloc((size_t)maxlen * 2 + 2);
+
+    /* lowest_batch_index = max(1, min(prev_b_indices or [1]))   cluster.py:221-222 */
+    int lowest = 1;
+    if (prev_batch && N) { int mn = prev_batch[0]; for (uint64_t i = 1; i < N; ++i) if (prev_batch[i] < mn) mn = prev_batch[i]; lowest = mn > 1 ? mn : 1; }
+
+#define ADD_REP(readidx, hlen, cnt_) do { \
+        if (nrep == caprep) { int oc = caprep; caprep *= 2; rep_read = (int*)realloc(rep_read, sizeof(int) * (size_t)caprep); rep_hlen = (int*)realloc(rep_hlen, sizeof(int) * (size_t)caprep); \
+            hits = (hitlist*)realloc(hits, sizeof(hitlist) * (size_t)caprep); memset(hits + oc, 0, sizeof(hitlist) * (size_t)(caprep - oc)); } \
+        rep_read[nrep] = (int)(readidx); rep_hlen[nrep] = (hlen); \
+        for (int z_ = 0; z_ < (cnt_); ++z_) mdb_add(&db, mc[z_], nrep); \
+        ++nrep; } while (0)
+
+    /* the database handed over from the lower batch = minimizers of its surviving representatives
+     * (parallelize.py:209-215); rebuilt here from the seeded reads */
+    for (uint64_t i = 0; i < N; ++i) {
+        rep_of_read[i] = (int32_t)i; if (status_out) status_out[i] = NGSID_ST_NEWREP; if (hpc_err_out) hpc_err_out[i] = NAN;
+        if (!(prev_batch && prev_batch[i] == lowest)) continue;
+        if (status_out) status_out[i] = NGSID_ST_SEEDED;
+        const uint8_t* s = reads->seq + reads->off[i]; const uint8_t* q = reads->qual + reads->off[i]; int n = (int)(reads->off[i + 1] - reads->off[i]);
+        int hl = hpc_compress(s, q, n, hs, hq);
+        double e = (known_err && !isnan(known_err[i])) ? known_err[i] : (hl > 0 ? mean_err(hq, hl, NGSID_PHRED_P) : NAN);
+        herr[i] = e; if (hpc_err_out) hpc_err_out[i] = e;
+        if (hl < k) continue;
+        int cnt = minimizers(hs, hl, k, w, mc, mp);
+        if (cnt < 0) { rc = NGSID_ERR_ALPHABET; snprintf(g_err, sizeof g_err, "read %llu: base outside ACGTN", (unsigned long long)i); goto done; }
+        ADD_REP(i, hl, cnt);
+    }
+
+    int stamp = 0;
+    for (uint64_t i = 0; i < N; ++i) {
+        if (prev_batch && prev_batch[i] == lowest) continue;                         /* cluster.py:243-248 */
+        const uint8_t* s = reads->seq + reads->off[i]; const uint8_t* q = reads->qual + reads->off[i]; int n = (int)(reads->off[i + 1] - reads->off[i]);
+        int hl = hpc_compress(s, q, n, hs, hq);
+        if (g_tr_best && i < g_tr_n) { g_tr_best[i] = -2; g_tr_ns[i] = 0; g_tr_ratio[i] = 0.0; }
+        if (hl < k) { if (status_out) status_out[i] = NGSID_ST_SHORT; continue; }    /* cluster.py:266-268 */
+        int M = minimizers(hs, hl, k, w, mc, mp);                                     /* cluster.py:269 */
+        if (M < 0) { rc = NGSID_ERR_ALPHABET; snprintf(g_err, sizeof g_err, "read %llu: base outside ACGTN", (unsigned long long)i); goto done; }
+        double e_read = (known_err && !isnan(known_err[i])) ? known_err[i] : mean_err(hq, hl, NGSID_PHRED_P);   /* :273-292 */
+        herr[i] = e_read; if (hpc_err_out) hpc_err_out[i] = e_read;
+
+        /* get_all_hits  cluster.py:43-62 */
+        ++stamp; int ntouched = 0;
+        for (int a = 0; a < M; ++a) {
+            dbslot* sl = mdb_find(&db, mc[a], 0);
+            if (!sl) continue;
+            for (int p = sl->head; p >= 0; p = db.post[p].next) {
+                hitlist* h = &hits[db.post[p].rep];
+                if (h->stamp != stamp) { h->stamp = stamp; h->n = 0; h->sum = 0;
+                    if (ntouched == captouched) { captouched *= 2; touched = (int*)realloc(touched, sizeof(int) * (size_t)captouched); }
+                    touched[ntouched++] = db.post[p].rep; }
+                if (h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 32; h->idx = (int*)realloc(h->idx, sizeof(int) * (size_t)h->cap); h->pos = (int*)realloc(h->pos, sizeof(int) * (size_t)h->cap); }
+                h->idx[h->n] = a; h->pos[h->n] = (int)mp[a]; h->n++; h->sum += mp[a];
+            }
+        }
+        /* get_best_cluster  cluster.py:67-127 */
+        int best_m = -1, nshared = 0; double mapped_ratio = 0.0; int ncand = 0;
+        if (ntouched) {
+            if (ntouched > capcand) { capcand = ntouched * 2; cands = (cand*)realloc(cands, sizeof(cand) * (size_t)capcand); }
+            for (int c = 0; c < ntouched; ++c) { int sl = touched[c]; cands[c].slot = sl; cands[c].n = hits[sl].n; cands[c].sum = hits[sl].sum; cands[c].rank = acc_rank ? acc_rank[rep_read[sl]] : (uint32_t)rep_read[sl]; }
+            ncand = ntouched; qsort(cands, (size_t)ncand, sizeof(cand), cand_cmp);
+            int top_hits = cands[0].n; nshared = top_hits;
+            if (top_hits >= prm->min_shared) {
+                for (int c = 0; c < ncand; ++c) {
+                    int nm = cands[c].n;
+                    if ((double)nm < prm->min_fraction * (double)top_hits || nm < prm->min_shared) break;     /* :88 */
+                    hitlist* h = &hits[cands[c].slot];
+                    int i1 = eidx(e_read), i2 = eidx(herr[rep_read[cands[c].slot]]);
+                    double pshared = prm->p_shared[(i1 - 1) * 15 + (i2 - 1)];
+                    if (isnan(pshared)) { rc = NGSID_ERR_NO_PTABLE; snprintf(g_err, sizeof g_err, "no p_shared entry for (%d,%d)", i1, i2); goto done; }
+                    double perr = 1.0 - pshared;                                                             /* :97 */
+                    long total_mapped = 0;
+                    for (int t = 0; t <= h->n; ++t) {                                                        /* :101-115 */
+                        int gap = (t == 0) ? h->idx[0] : (t == h->n ? M - 1 - h->idx[h->n - 1] : h->idx[t] - h->idx[t - 1] - 1);
+                        double pr = 1.0; for (int g = 0; g < gap; ++g) pr = pr * perr;                       /* reduce(mul,[p]*gap,1) */
+                        if (pr < prm->min_prob_no_hits) continue;
+                        if (t == 0) total_mapped += h->pos[0];
+                        else if (t == h->n) total_mapped += hl - h->pos[h->n - 1];
+                        else total_mapped += h->pos[t] - h->pos[t - 1];
+                    }
+                    mapped_ratio = (double)total_mapped / (double)hl;                                        /* :117 */
+                    double rep_ratio = (double)total_mapped / (double)rep_hlen[cands[c].slot];               /* :120 */
+                    if (prm->symmetric) { double mn = mapped_ratio < rep_ratio ? mapped_ratio : rep_ratio; if (mn > prm->mapped_threshold) { best_m = cands[c].slot; nshared = nm; mapped_ratio = mn; break; } }
+                    else if (mapped_ratio > prm->mapped_threshold) { best_m = cands[c].slot; nshared = nm; break; }
+                }
+            }
+        }
+        if (g_tr_best && i < g_tr_n) { g_tr_best[i] = best_m >= 0 ? rep_read[best_m] : -1; g_tr_ns[i] = nshared; g_tr_ratio[i] = mapped_ratio; }
+        int best_a = -1;
+        if (best_m >= 0) mapped_passed++;                                                                    /* :307-308 */
+        if (best_m < 0 && nshared >= prm->min_shared) {                                                      /* :310 */
+            aln_called++;
+            /* get_best_cluster_block_align  cluster.py:172-205 */
+            int top_hits = cands[0].n;
+            if (isnan(rawerr[i])) rawerr[i] = mean_err(q, n, NGSID_PHRED_P);
+            for (int c = 0; c < ncand; ++c) {
+                if (cands[c].n < top_hits) break;                                                            /* :181 */
+                int rr = rep_read[cands[c].slot];
+                const uint8_t* cs = reads->seq + reads->off[rr]; const uint8_t* cq = reads->qual + reads->off[rr]; int cn = (int)(reads->off[rr + 1] - reads->off[rr]);
+                if (isnan(rawerr[rr])) rawerr[rr] = mean_err(cq, cn, NGSID_PHRED_P);
+                double ers = rawerr[i] + rawerr[rr];                                                         /* :188 */
+                int gopen = ers <= 0.01 ? 5 : (ers <= 0.04 ? 4 : (ers <= 0.1 ? 3 : 2));                      /* :189-196 */
+                int match_id = (int)floor((1.0 - ers) * (double)k);                                          /* :198 */
+                sg_result R; sg_align(s, n, cs, cn, 2, -2, gopen, 1, &R);
+                if (n + cn + 2 > maxlen * 2 + 2) { /* cannot happen: both <= maxlen */ }
+                int ncols = sg_traceback(s, cs, &R, ops);
+                int regions = window_regions(ops, ncols, k, match_id);
+                free(R.tb);
+                double ar = (double)regions / (double)n, tr = (double)regions / (double)cn;                 /* :167-168 */
+                if (prm->symmetric) { double mn = ar < tr ? ar : tr; if (mn >= prm->aligned_threshold) { best_a = cands[c].slot; break; } }
+                else if (ar >= prm->aligned_threshold) { best_a = cands[c].slot; break; }
+            }
+            if (best_a >= 0) aln_passed++;
+        }
+        int best = best_m > best_a ? best_m : best_a;            /* max(best_cluster_id_m,best_cluster_id_a)  :322 */
+        /* NOTE the reference takes max() over read ids; with one of them always -1 this is the single hit. */
+        if (best >= 0) {
+            rep_of_read[i] = rep_read[best];
+            if (status_out) status_out[i] = best_m >= 0 ? NGSID_ST_MAPPED : NGSID_ST_ALIGNED;
+        } else {
+            ADD_REP(i, hl, M); newreps++;                                                                    /* :328-334 */
+        }
+    }
+done:
+    if (counters) { counters[0] = mapped_passed; counters[1] = aln_passed; counters[2] = aln_called; counters[3] = newreps; }
+    for (int r = 0; r < caprep; ++r) { free(hits[r].idx); free(hits[r].pos); }
+    free(hits); free(rep_read); free(rep_hlen); free(herr); free(rawerr); mdb_free(&db);
+    free(hs); free(hq); free(mc); free(mp); free(touched); free(cands); free(ops);
+    return rc;
+}
