@@ -1,0 +1,514 @@
+// k_cluster.hip - (a4-a11) greedy clustering: representative index, hit counting, mapping criterion,
+// alignment criterion, and the speculative-block driver that reproduces the sequential semantics of
+// cluster.reads_to_clusters (cluster.py:207-353) exactly.
+//
+// Data in HBM
+//   reads            CSR (bases, qualities, uint64 offsets), score order = greedy order
+//   minimizers       (code u64, pos u32) written sparsely at the read's base offset by k_hpc_minimizers
+//   representatives  slot -> read id; per slot the SORTED UNIQUE codes of its minimizers (pool + offsets)
+//   index "DB"       all (code, slot) pairs sorted by code = minimizer_database (cluster.py:329-334)
+//   hit matrix       block_items x stride uint64, each cell = n_hits<<48 | sum(pos)  (get_all_hits :43-62)
+// Exactness of the parallel form: a block of reads is evaluated against a database snapshot; the first
+// read (in greedy order) that founds a new cluster is committed together with everything before it, its
+// minimizers are merged into the index, only the DELTA (hits against that one representative) is added to
+// the hit matrix of the later reads, and those are re-decided.  Aligner results are cached per
+// (read, representative) since they do not depend on the database.
+#include "ngsid_internal.h"
+#include "../../include/ngsid_tables.h"
+#include <math.h>
+#include <algorithm>
+
+#define DEC_NEWREP   (-1)
+#define DEC_SHORT    (-2)
+#define DEC_PENDING  (-3)
+#define DEC_UNDEC    (-4)
+#define NCACHE 4
+
+__constant__ double c_round2_t[15];
+static bool g_cl_tables[16] = {false};
+
+struct ClDev {
+    const uint8_t* seq; const uint8_t* qual; const uint64_t* off; uint64_t n;
+    const uint32_t* hlen; const uint32_t* mzcnt; const double* herr; const double* rawerr; const uint8_t* eidx; const uint32_t* accrank;
+    const uint64_t* mzcode; const uint32_t* mzpos;
+    const uint32_t* rep_read; const uint64_t* pool; const uint64_t* pool_off;
+    const int32_t* maxgap;      // 225 ints, -2 = missing table entry
+    int k, min_shared, symmetric; double min_fraction, mapped_threshold, aligned_threshold;
+    // per read state
+    int32_t* dec; uint8_t* kind; uint8_t* alnflag; int32_t* top;
+    uint64_t* cur_hi; uint64_t* cur_lo;
+    int32_t* cache_slot; int32_t* cache_region; uint8_t* cache_ptr;
+    int* errflag;
+};
+
+__global__ void k_eidx(const double* __restrict__ herr, const double* __restrict__ known, uint64_t n, double* __restrict__ herr_out, uint8_t* __restrict__ eidx)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double e = herr[i];
+    if (known) { const double kv = known[i]; if (kv == kv) e = kv; }
+    herr_out[i] = e;
+    int j = 0;
+    while (j < 15 && e >= c_round2_t[j]) ++j;       // round(e,2) clamped to [0.01,0.15]  cluster.py:356-366
+    if (j < 1) j = 1;
+    eidx[i] = (uint8_t)j;
+}
+
+// ---- hit counting: one wave per item, lanes over the read's minimizers, binary search in the sorted index
+__global__ __launch_bounds__(256)
+void k_count_hits(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t row0,
+                  const uint64_t* __restrict__ db_code, const uint32_t* __restrict__ db_slot, uint32_t const_slot, uint64_t n_db,
+                  uint64_t* __restrict__ cnt, uint32_t stride)
+{
+    // db_slot == nullptr: the index is one representative's own sorted unique codes (delta pass), slot = const_slot
+    const int lane = threadIdx.x & 63;
+    const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (it >= it_hi || n_db == 0) return;
+    const uint32_t read = items[it];
+    if (D.hlen[read] < (uint32_t)D.k) return;
+    const uint32_t M = D.mzcnt[read];
+    const uint64_t base = D.off[read];
+    unsigned long long* row = (unsigned long long*)(cnt + (uint64_t)(it - row0) * stride);
+    for (uint32_t a = lane; a < M; a += 64) {
+        const uint64_t code = D.mzcode[base + a]; const uint32_t pos = D.mzpos[base + a];
+        uint64_t lo = 0, hi = n_db;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (db_code[mid] < code) lo = mid + 1; else hi = mid; }
+        for (uint64_t p = lo; p < n_db && db_code[p] == code; ++p)
+            atomicAdd(&row[db_slot ? db_slot[p] : const_slot], (1ull << 48) + (unsigned long long)pos);
+    }
+}
+
+// wave-wide maximum of a 128-bit key (hi,lo); every lane returns the winner
+__device__ __forceinline__ void wave_max128(uint64_t& hi, uint64_t& lo)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t oh = __shfl_xor((unsigned long long)hi, d), ol = __shfl_xor((unsigned long long)lo, d);
+        if (oh > hi || (oh == hi && ol > lo)) { hi = oh; lo = ol; }
+    }
+}
+
+// candidate order = sorted(key=(len(hits), sum(pos), accession), reverse=True)  cluster.py:79,174 ; full ties: lower slot first
+__device__ __forceinline__ bool next_candidate(const ClDev& D, const uint64_t* row, uint32_t R, int lane, uint64_t bound_hi, uint64_t bound_lo,
+                                               int need_n /* -1 = any */, uint64_t& out_hi, uint64_t& out_lo)
+{
+    uint64_t bh = 0, bl = 0;
+    for (uint32_t s = lane; s < R; s += 64) {
+        const uint64_t v = row[s];
+        if ((v >> 48) == 0) continue;
+        if (need_n >= 0 && (int)(v >> 48) != need_n) continue;
+        const uint64_t lo = ((uint64_t)D.accrank[D.rep_read[s]] << 32) | (uint64_t)(0xffffffffu - s);
+        if (v > bound_hi || (v == bound_hi && lo >= bound_lo)) continue;        // strictly below the bound
+        if (v > bh || (v == bh && lo > bl)) { bh = v; bl = lo; }
+    }
+    wave_max128(bh, bl);
+    out_hi = bh; out_lo = bl;
+    return bh != 0;
+}
+
+// mapped span of a read against one representative (the body of get_best_cluster, cluster.py:92-117):
+// hit = read minimizer present in the representative's code set; a gap of g non-hit minimizers between two hits counts as
+// mapped iff p_err^g >= min_prob_no_hits <=> g <= maxgap.
+__device__ __forceinline__ long long mapped_span(const ClDev& D, uint32_t read, uint32_t slot, int maxgap, int lane)
+{
+    const uint32_t M = D.mzcnt[read]; const uint64_t base = D.off[read];
+    const uint64_t* rc = D.pool + D.pool_off[slot]; const uint32_t rn = (uint32_t)(D.pool_off[slot + 1] - D.pool_off[slot]);
+    long long total = 0;
+    int last_idx = -1, last_pos = 0;
+    for (uint32_t c0 = 0; c0 < M; c0 += 64) {
+        const uint32_t a = c0 + lane;
+        bool hit = false; int pos = 0;
+        if (a < M) {
+            const uint64_t code = D.mzcode[base + a]; pos = (int)D.mzpos[base + a];
+            uint32_t lo = 0, hi = rn;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rc[mid] < code) lo = mid + 1; else hi = mid; }
+            hit = lo < rn && rc[lo] == code;
+        }
+        const unsigned long long mask = __ballot(hit);
+        const unsigned long long below = mask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+        const int pl = below ? 63 - __clzll(below) : 0;
+        const int ppos = __shfl(pos, pl);                       // unconditional: no cross-lane op under divergence
+        const int prev_idx = below ? (int)c0 + pl : last_idx;
+        const int prev_pos = below ? ppos : last_pos;
+        long long contrib = 0;
+        if (hit) { const int gap = (int)a - prev_idx - 1; if (gap <= maxgap) contrib = pos - prev_pos; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) contrib += __shfl_xor(contrib, d);
+        total += contrib;
+        if (mask) { const int hl = 63 - __clzll(mask); last_idx = (int)c0 + hl; last_pos = __shfl(pos, hl); }
+    }
+    if (last_idx >= 0) { const int gap = (int)M - 1 - last_idx; if (gap <= maxgap) total += (long long)D.hlen[read] - last_pos; }
+    return total;
+}
+
+// ---- mapping criterion for every undecided item of the block (get_best_cluster, cluster.py:67-127)
+__global__ __launch_bounds__(256)
+void k_decide_map(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t row0,
+                  const uint64_t* __restrict__ cnt, uint32_t stride, uint32_t R)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (it >= it_hi) return;
+    const uint32_t read = items[it];
+    if (D.hlen[read] < (uint32_t)D.k) { if (lane == 0) { D.dec[read] = DEC_SHORT; D.alnflag[read] = 0; } return; }
+    const uint64_t* row = cnt + (uint64_t)(it - row0) * stride;
+    int top = 0;
+    for (uint32_t s = lane; s < R; s += 64) top = max(top, (int)(row[s] >> 48));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) top = max(top, __shfl_xor(top, d));
+    if (lane == 0) { D.top[read] = top; D.alnflag[read] = 0; D.cur_hi[read] = ~0ull; D.cur_lo[read] = ~0ull; }
+    if (top < D.min_shared) { if (lane == 0) D.dec[read] = DEC_NEWREP; return; }         // :82-83, and :310 fails
+    uint64_t bh = ~0ull, bl = ~0ull;
+    const int i1 = D.eidx[read];
+    const double hl = (double)D.hlen[read];
+    for (;;) {
+        uint64_t kh, kl;
+        if (!next_candidate(D, row, R, lane, bh, bl, -1, kh, kl)) break;
+        const int nm = (int)(kh >> 48);
+        if ((double)nm < D.min_fraction * (double)top || nm < D.min_shared) break;          // :88
+        const uint32_t slot = 0xffffffffu - (uint32_t)(kl & 0xffffffffu);
+        const uint32_t rr = D.rep_read[slot];
+        const int mg = D.maxgap[(i1 - 1) * 15 + (D.eidx[rr] - 1)];
+        if (mg == -2) { if (lane == 0) atomicExch(D.errflag, 1); break; }
+        const long long tm = mapped_span(D, read, slot, mg, lane);
+        const double ratio = (double)tm / hl;                                               // :117
+        bool pass;
+        if (D.symmetric) { const double rratio = (double)tm / (double)D.hlen[rr]; pass = fmin(ratio, rratio) > D.mapped_threshold; }
+        else pass = ratio > D.mapped_threshold;
+        if (pass) { if (lane == 0) { D.dec[read] = (int32_t)slot; D.kind[read] = NGSID_ST_MAPPED; } return; }
+        bh = kh; bl = kl;
+    }
+    if (lane == 0) { D.dec[read] = DEC_PENDING; D.alnflag[read] = 1; }                      // :310-311
+}
+
+// ---- alignment criterion cursor (get_best_cluster_block_align, cluster.py:172-205): resolve from cache or request a pair
+__global__ __launch_bounds__(256)
+void k_aln_next(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t row0,
+                const uint64_t* __restrict__ cnt, uint32_t stride, uint32_t R,
+                uint32_t* __restrict__ req_q, uint32_t* __restrict__ req_t, uint32_t* __restrict__ req_slot, int32_t* __restrict__ req_open, int32_t* __restrict__ req_mid,
+                uint32_t* __restrict__ req_count)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (it >= it_hi) return;
+    const uint32_t read = items[it];
+    if (D.dec[read] != DEC_PENDING) return;
+    const uint64_t* row = cnt + (uint64_t)(it - row0) * stride;
+    const int top = D.top[read];
+    uint64_t bh = D.cur_hi[read], bl = D.cur_lo[read];
+    const double qlen = (double)(D.off[read + 1] - D.off[read]);
+    for (;;) {
+        uint64_t kh, kl;
+        if (!next_candidate(D, row, R, lane, bh, bl, top, kh, kl)) { if (lane == 0) D.dec[read] = DEC_NEWREP; return; }   // :181 / :205
+        const uint32_t slot = 0xffffffffu - (uint32_t)(kl & 0xffffffffu);
+        const uint32_t rr = D.rep_read[slot];
+        int region = -1;
+        for (int c = 0; c < NCACHE; ++c) if (D.cache_slot[(uint64_t)read * NCACHE + c] == (int32_t)slot) region = D.cache_region[(uint64_t)read * NCACHE + c];
+        if (region < 0) {
+            if (lane == 0) {
+                const double ers = D.rawerr[read] + D.rawerr[rr];                                         // :188
+                const int gopen = ers <= 0.01 ? 5 : (ers <= 0.04 ? 4 : (ers <= 0.1 ? 3 : 2));             // :189-196
+                const int mid = (int)floor((1.0 - ers) * (double)D.k);                                    // :198
+                const uint32_t idx = atomicAdd(req_count, 1u);
+                req_q[idx] = read; req_t[idx] = rr; req_slot[idx] = slot; req_open[idx] = gopen; req_mid[idx] = mid;
+                D.cur_hi[read] = bh; D.cur_lo[read] = bl;
+            }
+            return;
+        }
+        const double ar = (double)region / qlen;                                                          // :167
+        bool pass;
+        if (D.symmetric) { const double tr = (double)region / (double)(D.off[rr + 1] - D.off[rr]); pass = fmin(ar, tr) >= D.aligned_threshold; }
+        else pass = ar >= D.aligned_threshold;
+        if (pass) { if (lane == 0) { D.dec[read] = (int32_t)slot; D.kind[read] = NGSID_ST_ALIGNED; } return; }
+        bh = kh; bl = kl;
+    }
+}
+
+__global__ void k_cache_insert(ClDev D, const uint32_t* __restrict__ req_q, const uint32_t* __restrict__ req_slot, const int32_t* __restrict__ region, uint32_t nreq)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nreq) return;
+    const uint32_t read = req_q[i];                 // one outstanding request per read -> no race on its cache line
+    const uint8_t ptr = D.cache_ptr[read];
+    D.cache_slot[(uint64_t)read * NCACHE + (ptr % NCACHE)] = (int32_t)req_slot[i];
+    D.cache_region[(uint64_t)read * NCACHE + (ptr % NCACHE)] = region[i];
+    D.cache_ptr[read] = (uint8_t)((ptr + 1) % NCACHE);
+}
+
+__global__ void k_first_newrep(const int32_t* __restrict__ dec, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t* __restrict__ first)
+{
+    const uint32_t it = it_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= it_hi) return;
+    if (dec[items[it]] == DEC_NEWREP) atomicMin(first, it);
+}
+
+// sort + unique the minimizer codes of one read into the representative pool (single workgroup, bitonic in LDS);
+// also registers the slot: rep_read[slot] = read, pool_off[slot+1] = pool_off[slot] + #unique
+__global__ __launch_bounds__(256)
+void k_rep_build(const uint64_t* __restrict__ mzcode, uint64_t base, uint32_t M, uint32_t P2, uint64_t* __restrict__ pool, uint64_t* __restrict__ pool_off,
+                 uint32_t* __restrict__ rep_read, uint32_t slot, uint32_t read, uint32_t* __restrict__ out_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* a = (uint64_t*)smem;
+    for (uint32_t i = threadIdx.x; i < P2; i += 256) a[i] = i < M ? mzcode[base + i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1)
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P2; i += 256) {
+                const uint32_t l = i ^ j;
+                if (l > i) { const uint64_t x = a[i], y = a[l]; const bool up = (i & k2) == 0; if ((x > y) == up) { a[i] = y; a[l] = x; } }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0) {
+        uint64_t* dst = pool + pool_off[slot];
+        uint32_t c = 0; for (uint32_t i = 0; i < M; ++i) if (i == 0 || a[i] != a[i - 1]) dst[c++] = a[i];
+        pool_off[slot + 1] = pool_off[slot] + c; rep_read[slot] = read; *out_count = c;
+    }
+}
+
+__global__ void k_db_merge(const uint64_t* __restrict__ oc, const uint32_t* __restrict__ os, uint64_t n_old,
+                           const uint64_t* __restrict__ rc, uint32_t n_new, uint32_t slot, uint64_t* __restrict__ nc, uint32_t* __restrict__ ns)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_old) {
+        const uint64_t code = oc[i]; uint32_t lo = 0, hi = n_new;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rc[mid] < code) lo = mid + 1; else hi = mid; }   // rep codes < old code
+        nc[i + lo] = code; ns[i + lo] = os[i];
+    } else if (i < n_old + n_new) {
+        const uint32_t j = (uint32_t)(i - n_old); const uint64_t code = rc[j]; uint64_t lo = 0, hi = n_old;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (oc[mid] <= code) lo = mid + 1; else hi = mid; }  // old codes <= rep code
+        nc[j + lo] = code; ns[j + lo] = slot;
+    }
+}
+
+__global__ void k_reset_items(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi)
+{
+    const uint32_t it = it_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= it_hi) return;
+    D.dec[items[it]] = DEC_UNDEC;
+}
+
+__global__ void k_finalize(ClDev D, uint64_t n, const uint8_t* __restrict__ seeded, int32_t* __restrict__ rep_of, uint8_t* __restrict__ status,
+                           double* __restrict__ herr_out, unsigned long long* __restrict__ counters)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double nan = __longlong_as_double(0x7ff8000000000000ULL);
+    if (seeded && seeded[i]) { rep_of[i] = (int32_t)i; status[i] = NGSID_ST_SEEDED; herr_out[i] = D.herr[i]; return; }
+    const int32_t d = D.dec[i];
+    if (d == DEC_SHORT) { rep_of[i] = (int32_t)i; status[i] = NGSID_ST_SHORT; herr_out[i] = nan; return; }
+    herr_out[i] = D.herr[i];
+    if (D.alnflag[i]) atomicAdd(&counters[2], 1ull);
+    if (d >= 0) {
+        rep_of[i] = (int32_t)D.rep_read[d]; status[i] = D.kind[i];
+        atomicAdd(&counters[D.kind[i] == NGSID_ST_MAPPED ? 0 : 1], 1ull);
+    } else { rep_of[i] = (int32_t)i; status[i] = NGSID_ST_NEWREP; atomicAdd(&counters[3], 1ull); }
+}
+
+// ------------------------------------------------------------------------------------------------ host driver
+namespace {
+struct RepStore {
+    ngsid_ctx* ctx; uint32_t R = 0, Rcap = 0;
+    DevBuf<uint32_t> rep_read; DevBuf<uint64_t> pool, pool_off; std::vector<uint64_t> h_pool_off;
+    DevBuf<uint64_t> dbc[2]; DevBuf<uint32_t> dbs[2]; int cur = 0; uint64_t n_db = 0;
+    DevBuf<uint32_t> d_count;
+};
+}
+
+static int32_t add_rep(ngsid_ctx* ctx, RepStore& S, uint32_t read, const uint64_t* d_mzcode, uint64_t base, uint32_t M)
+{
+    if (S.R + 1 > S.Rcap) {
+        const uint32_t nc = S.Rcap ? S.Rcap * 2 : 1024;
+        HIPCHK(ctx, S.rep_read.grow(nc, ctx->stream)); HIPCHK(ctx, S.pool_off.grow((size_t)nc + 1, ctx->stream));
+        S.Rcap = nc;
+    }
+    const uint64_t po = S.h_pool_off[S.R];
+    if (po + M + 1 > S.pool.n) HIPCHK(ctx, S.pool.grow(std::max<size_t>((po + M + 1) * 2, 1 << 16), ctx->stream));
+    uint32_t P2 = 1; while (P2 < M) P2 <<= 1; if (P2 < 2) P2 = 2;
+    const size_t lds = (size_t)P2 * 8;
+    if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_rep_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_rep_build, dim3(1), dim3(256), lds, ctx->stream, d_mzcode, base, M, P2, S.pool.p, S.pool_off.p, S.rep_read.p, S.R, read, S.d_count.p);
+    HIPCHK(ctx, hipGetLastError());
+    uint32_t u = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&u, S.d_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    S.h_pool_off.push_back(po + u);
+    const int nx = S.cur ^ 1;
+    if (S.n_db + u + 1 > S.dbc[nx].n) { const size_t cap = std::max<size_t>((S.n_db + u + 1) * 2, 1 << 16); HIPCHK(ctx, S.dbc[nx].alloc(cap)); HIPCHK(ctx, S.dbs[nx].alloc(cap)); }
+    const uint64_t tot = S.n_db + u;
+    if (tot) hipLaunchKernelGGL(k_db_merge, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                                S.dbc[S.cur].p, S.dbs[S.cur].p, S.n_db, S.pool.p + po, u, S.R, S.dbc[nx].p, S.dbs[nx].p);
+    HIPCHK(ctx, hipGetLastError());
+    S.cur = nx; S.n_db = tot; S.R += 1;
+    return NGSID_OK;
+}
+
+extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* reads, const ngsid_cluster_params_t* prm,
+                                        const uint32_t* acc_rank, const int32_t* prev_batch, const double* known_err,
+                                        int32_t* rep_of_read, double* hpc_err_out, uint8_t* status_out, uint64_t counters[4])
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!reads || !prm || !rep_of_read) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    const int k = prm->k, w = prm->w;
+    if (k < 1 || k > NGSID_MAX_K || w < k) NGSID_FAIL(ctx, NGSID_ERR_ARG, "bad k/w (k=%d, w=%d; k <= %d)", k, w, NGSID_MAX_K);
+    DevReads RD; int32_t rc = ngsid_upload_reads(ctx, reads, &RD, true); if (rc) return rc;
+    const uint64_t N = RD.n;
+    if (counters) counters[0] = counters[1] = counters[2] = counters[3] = 0;
+    if (N == 0) return NGSID_OK;
+    if (N > 0x7fffffffull) NGSID_FAIL(ctx, NGSID_ERR_ARG, "too many reads");
+    if (!g_cl_tables[ctx->device & 15]) { HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_round2_t), NGSID_ROUND2_T, sizeof(double) * 15)); g_cl_tables[ctx->device & 15] = true; }
+
+    // ---- per-read preprocessing (a1-a3)
+    DevBuf<uint64_t> mzcode; DevBuf<uint32_t> mzpos, mzcnt, hlen, d_acc; DevBuf<double> herr0, herr, rawerr, d_known; DevBuf<uint8_t> eidx; DevBuf<int> flag;
+    HIPCHK(ctx, mzcode.alloc(RD.total + 1)); HIPCHK(ctx, mzpos.alloc(RD.total + 1)); HIPCHK(ctx, mzcnt.alloc(N)); HIPCHK(ctx, hlen.alloc(N));
+    HIPCHK(ctx, herr0.alloc(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N)); HIPCHK(ctx, eidx.alloc(N)); HIPCHK(ctx, flag.alloc(2)); HIPCHK(ctx, d_acc.alloc(N));
+    HIPCHK(ctx, hipMemsetAsync(flag.p, 0, 2 * sizeof(int), ctx->stream));
+    rc = ngsid_launch_minimizers(ctx, RD, k, w, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr0.p, rawerr.p, flag.p); if (rc) return rc;
+    if (known_err) { HIPCHK(ctx, d_known.alloc(N)); HIPCHK(ctx, hipMemcpyAsync(d_known.p, known_err, 8 * N, hipMemcpyHostToDevice, ctx->stream)); }
+    hipLaunchKernelGGL(k_eidx, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, herr0.p, known_err ? d_known.p : nullptr, N, herr.p, eidx.p);
+    HIPCHK(ctx, hipGetLastError());
+    if (acc_rank) HIPCHK(ctx, hipMemcpyAsync(d_acc.p, acc_rank, 4 * N, hipMemcpyHostToDevice, ctx->stream));
+    else { std::vector<uint32_t> id(N); for (uint64_t i = 0; i < N; ++i) id[i] = (uint32_t)i; HIPCHK(ctx, hipMemcpyAsync(d_acc.p, id.data(), 4 * N, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
+    std::vector<uint32_t> h_hlen(N), h_mzcnt(N); int h_flag[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h_hlen.data(), hlen.p, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_mzcnt.data(), mzcnt.p, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_flag, flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_flag[0]) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "read %d: base outside ACGTN", h_flag[0] - 1);
+
+    // ---- max tolerated run of non-shared minimizers per (e1,e2): largest g with p_err^g >= min_prob_no_hits,
+    //      p_err^g by left-to-right repeated multiplication exactly like reduce(mul,[p]*g,1)  (cluster.py:97-105)
+    std::vector<int32_t> h_maxgap(225);
+    for (int i = 0; i < 225; ++i) {
+        const double ps = prm->p_shared[i];
+        if (ps != ps) { h_maxgap[i] = -2; continue; }
+        const double perr = 1.0 - ps; double pr = 1.0; int g = -1;
+        for (int t = 0; t < (1 << 20); ++t) { if (pr < prm->min_prob_no_hits) break; g = t; pr = pr * perr; }
+        h_maxgap[i] = g;
+    }
+    DevBuf<int32_t> d_maxgap; HIPCHK(ctx, d_maxgap.alloc(225));
+    HIPCHK(ctx, hipMemcpyAsync(d_maxgap.p, h_maxgap.data(), 225 * 4, hipMemcpyHostToDevice, ctx->stream));
+
+    // ---- items (reads to process) and seeded representatives
+    int lowest = 1;
+    if (prev_batch) { int mn = prev_batch[0]; for (uint64_t i = 1; i < N; ++i) mn = std::min(mn, prev_batch[i]); lowest = std::max(1, mn); }
+    std::vector<uint32_t> h_items; h_items.reserve(N);
+    std::vector<uint8_t> h_seeded;
+    if (prev_batch) { h_seeded.assign(N, 0); for (uint64_t i = 0; i < N; ++i) { if (prev_batch[i] == lowest) h_seeded[i] = 1; else h_items.push_back((uint32_t)i); } }
+    else for (uint64_t i = 0; i < N; ++i) h_items.push_back((uint32_t)i);
+    const uint32_t NI = (uint32_t)h_items.size();
+    DevBuf<uint32_t> d_items; DevBuf<uint8_t> d_seeded;
+    HIPCHK(ctx, d_items.alloc(NI)); if (NI) HIPCHK(ctx, hipMemcpyAsync(d_items.p, h_items.data(), 4ull * NI, hipMemcpyHostToDevice, ctx->stream));
+    if (prev_batch) { HIPCHK(ctx, d_seeded.alloc(N)); HIPCHK(ctx, hipMemcpyAsync(d_seeded.p, h_seeded.data(), N, hipMemcpyHostToDevice, ctx->stream)); }
+
+    // ---- state
+    DevBuf<int32_t> dec, top, cache_slot, cache_region; DevBuf<uint8_t> kind, alnflag, cache_ptr; DevBuf<uint64_t> cur_hi, cur_lo;
+    HIPCHK(ctx, dec.alloc(N)); HIPCHK(ctx, top.alloc(N)); HIPCHK(ctx, cache_slot.alloc(N * NCACHE)); HIPCHK(ctx, cache_region.alloc(N * NCACHE));
+    HIPCHK(ctx, kind.alloc(N)); HIPCHK(ctx, alnflag.alloc(N)); HIPCHK(ctx, cache_ptr.alloc(N)); HIPCHK(ctx, cur_hi.alloc(N)); HIPCHK(ctx, cur_lo.alloc(N));
+    HIPCHK(ctx, hipMemsetAsync(dec.p, 0xfc, 4 * N, ctx->stream));          // 0xfcfcfcfc is not a valid decision; every processed item is written
+    HIPCHK(ctx, hipMemsetAsync(cache_slot.p, 0xff, 4 * N * NCACHE, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(cache_ptr.p, 0, N, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(alnflag.p, 0, N, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(kind.p, 0, N, ctx->stream));
+
+    RepStore S; S.ctx = ctx; S.h_pool_off.push_back(0);
+    HIPCHK(ctx, S.d_count.alloc(4)); HIPCHK(ctx, S.rep_read.alloc(1024)); HIPCHK(ctx, S.pool_off.alloc(1025)); S.Rcap = 1024;
+    HIPCHK(ctx, hipMemsetAsync(S.pool_off.p, 0, 8, ctx->stream));
+    HIPCHK(ctx, S.pool.alloc(1 << 16)); HIPCHK(ctx, S.dbc[0].alloc(1 << 16)); HIPCHK(ctx, S.dbs[0].alloc(1 << 16)); HIPCHK(ctx, S.dbc[1].alloc(1 << 16)); HIPCHK(ctx, S.dbs[1].alloc(1 << 16));
+    if (prev_batch) for (uint64_t i = 0; i < N; ++i) if (h_seeded[i] && h_hlen[i] >= (uint32_t)k) { rc = add_rep(ctx, S, (uint32_t)i, mzcode.p, RD.h_off[i], h_mzcnt[i]); if (rc) return rc; }
+
+    ClDev D{};
+    D.seq = RD.seq; D.qual = RD.qual; D.off = RD.off; D.n = N; D.hlen = hlen.p; D.mzcnt = mzcnt.p; D.herr = herr.p; D.rawerr = rawerr.p; D.eidx = eidx.p; D.accrank = d_acc.p;
+    D.mzcode = mzcode.p; D.mzpos = mzpos.p; D.maxgap = d_maxgap.p; D.k = k; D.min_shared = prm->min_shared; D.symmetric = prm->symmetric;
+    D.min_fraction = prm->min_fraction; D.mapped_threshold = prm->mapped_threshold; D.aligned_threshold = prm->aligned_threshold;
+    D.dec = dec.p; D.kind = kind.p; D.alnflag = alnflag.p; D.top = top.p; D.cur_hi = cur_hi.p; D.cur_lo = cur_lo.p;
+    D.cache_slot = cache_slot.p; D.cache_region = cache_region.p; D.cache_ptr = cache_ptr.p; D.errflag = flag.p + 1;
+
+    const uint32_t BLK = 32768;
+    DevBuf<uint64_t> cnt; uint32_t stride = 0;
+    DevBuf<uint32_t> req_q, req_t, req_slot, d_scal; DevBuf<int32_t> req_open, req_mid, req_region;
+    HIPCHK(ctx, req_q.alloc(BLK)); HIPCHK(ctx, req_t.alloc(BLK)); HIPCHK(ctx, req_slot.alloc(BLK)); HIPCHK(ctx, req_open.alloc(BLK)); HIPCHK(ctx, req_mid.alloc(BLK)); HIPCHK(ctx, req_region.alloc(BLK));
+    HIPCHK(ctx, d_scal.alloc(4));
+    auto refresh = [&]() { D.rep_read = S.rep_read.p; D.pool = S.pool.p; D.pool_off = S.pool_off.p; };
+
+    for (uint32_t b0 = 0; b0 < NI; b0 += BLK) {
+        const uint32_t b1 = std::min<uint32_t>(NI, b0 + BLK);
+        uint32_t lo = b0;                         // first uncommitted item
+        bool need_full = true;
+        while (lo < b1) {
+            refresh();
+            if (need_full) {
+                // hit matrix for items [lo,b1) against the whole index; stride leaves room for new representatives
+                const uint32_t want = ((S.R + 256 + 63) / 64) * 64;
+                if (want > stride || cnt.n < (uint64_t)BLK * stride) { stride = std::max(stride, want); HIPCHK(ctx, cnt.alloc((uint64_t)BLK * stride)); }
+                HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, 8ull * (uint64_t)(b1 - b0) * stride, ctx->stream));
+                hipLaunchKernelGGL(k_count_hits, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0,
+                                   S.dbc[S.cur].p, S.dbs[S.cur].p, 0u, S.n_db, cnt.p, stride);
+                HIPCHK(ctx, hipGetLastError());
+                need_full = false;
+            }
+            hipLaunchKernelGGL(k_decide_map, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R);
+            HIPCHK(ctx, hipGetLastError());
+            for (;;) {      // alignment rounds: resolve from cache or request pairs, align, cache, repeat
+                HIPCHK(ctx, hipMemsetAsync(d_scal.p, 0, 4, ctx->stream));
+                hipLaunchKernelGGL(k_aln_next, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R,
+                                   req_q.p, req_t.p, req_slot.p, req_open.p, req_mid.p, d_scal.p);
+                HIPCHK(ctx, hipGetLastError());
+                uint32_t nreq = 0;
+                HIPCHK(ctx, hipMemcpyAsync(&nreq, d_scal.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                if (!nreq) break;
+                AlignJob J{};
+                J.qseq = RD.seq; J.qoff = RD.off; J.tseq = RD.seq; J.toff = RD.off; J.qidx = req_q.p; J.tidx = req_t.p; J.npairs = nreq;
+                J.match = 2; J.mismatch = -2; J.ext = 1; J.k = k; J.open = req_open.p; J.match_id = req_mid.p;     // cluster.py:130
+                J.score = nullptr; J.ncols = nullptr; J.nmatch = nullptr; J.region = req_region.p; J.bp = nullptr; J.bp_windows = 0; J.window = 1; J.span = nullptr;
+                rc = ngsid_launch_align(ctx, J, RD.maxlen, RD.maxlen); if (rc) return rc;
+                hipLaunchKernelGGL(k_cache_insert, dim3((nreq + 255) / 256), dim3(256), 0, ctx->stream, D, req_q.p, req_slot.p, req_region.p, nreq);
+                HIPCHK(ctx, hipGetLastError());
+            }
+            uint32_t first = 0xffffffffu;
+            HIPCHK(ctx, hipMemsetAsync(d_scal.p + 1, 0xff, 4, ctx->stream));
+            hipLaunchKernelGGL(k_first_newrep, dim3((b1 - lo + 255) / 256), dim3(256), 0, ctx->stream, dec.p, d_items.p, lo, b1, d_scal.p + 1);
+            HIPCHK(ctx, hipGetLastError());
+            int eflag = 0;
+            HIPCHK(ctx, hipMemcpyAsync(&first, d_scal.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(&eflag, flag.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (eflag) NGSID_FAIL(ctx, NGSID_ERR_NO_PTABLE, "no p_shared entry for an (e1,e2) pair met during mapping (KeyError in cluster.py:367)");
+            if (first == 0xffffffffu) { lo = b1; break; }
+            // commit [lo, first]; `first` founds a cluster: merge it into the index
+            const uint32_t fread = h_items[first];
+            rc = add_rep(ctx, S, fread, mzcode.p, RD.h_off[fread], h_mzcnt[fread]); if (rc) return rc;
+            lo = first + 1;
+            if (lo >= b1) break;
+            refresh();
+            if (S.R > stride) { need_full = true; }
+            else {
+                // delta: hits of the later items against the new representative only
+                hipLaunchKernelGGL(k_count_hits, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0,
+                                   S.pool.p + S.h_pool_off[S.R - 1], (const uint32_t*)nullptr, S.R - 1, S.h_pool_off[S.R] - S.h_pool_off[S.R - 1], cnt.p, stride);
+                HIPCHK(ctx, hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_reset_items, dim3((b1 - lo + 255) / 256), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1);
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
+    // ---- results
+    DevBuf<int32_t> d_rep; DevBuf<uint8_t> d_status; DevBuf<double> d_herr_out; DevBuf<unsigned long long> d_counters;
+    HIPCHK(ctx, d_rep.alloc(N)); HIPCHK(ctx, d_status.alloc(N)); HIPCHK(ctx, d_herr_out.alloc(N)); HIPCHK(ctx, d_counters.alloc(4));
+    HIPCHK(ctx, hipMemsetAsync(d_counters.p, 0, 32, ctx->stream));
+    refresh();
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, D, N, prev_batch ? d_seeded.p : nullptr, d_rep.p, d_status.p, d_herr_out.p, d_counters.p);
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<uint8_t> h_status(N); std::vector<double> h_herr(N); unsigned long long h_cnt[4];
+    HIPCHK(ctx, hipMemcpyAsync(rep_of_read, d_rep.p, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_status.data(), d_status.p, N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_herr.data(), d_herr_out.p, 8 * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_cnt, d_counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (status_out) memcpy(status_out, h_status.data(), N);
+    if (hpc_err_out) memcpy(hpc_err_out, h_herr.data(), 8 * N);
+    if (counters) for (int i = 0; i < 4; ++i) counters[i] = h_cnt[i];
+    return NGSID_OK;
+}

@@ -1,0 +1,237 @@
+// ngsid_api.hip - C-ABI entry points that are thin (context, uploads, aligner batch, minimizer CSR, scoring)
+#include "ngsid_internal.h"
+#include "../../include/ngsid_tables.h"
+#include <math.h>
+#include <algorithm>
+
+extern "C" uint32_t ngsid_abi_version(void) { return 1u; }
+
+static char g_static_err[256] = "";
+extern "C" const char* ngsid_last_error(ngsid_ctx* ctx) { return ctx ? ctx->err : g_static_err; }
+
+extern "C" int32_t ngsid_create(int32_t device_ordinal, uint32_t flags, ngsid_ctx** out)
+{
+    (void)flags;
+    if (!out) return NGSID_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { snprintf(g_static_err, sizeof g_static_err, "no HIP device (%s); this library has no CPU path", hipGetErrorString(e)); return NGSID_ERR_NO_DEVICE; }
+    if (device_ordinal < 0 || device_ordinal >= ndev) { snprintf(g_static_err, sizeof g_static_err, "device ordinal %d out of range (0..%d)", device_ordinal, ndev - 1); return NGSID_ERR_ARG; }
+    e = hipSetDevice(device_ordinal);
+    if (e != hipSuccess) { snprintf(g_static_err, sizeof g_static_err, "hipSetDevice: %s", hipGetErrorString(e)); return NGSID_ERR_HIP; }
+    ngsid_ctx* c = new ngsid_ctx();
+    c->device = device_ordinal;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) {
+        c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        size_t freeb = 0, totalb = 0;
+        if (hipMemGetInfo(&freeb, &totalb) == hipSuccess && freeb > ((size_t)8 << 30)) c->scratch_budget = std::min<size_t>(freeb / 4, (size_t)32 << 30);
+    }
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { snprintf(g_static_err, sizeof g_static_err, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return NGSID_ERR_HIP; }
+    *out = c;
+    return NGSID_OK;
+}
+
+extern "C" void ngsid_destroy(ngsid_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+}
+
+int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* out, bool need_qual)
+{
+    if (!in || (!in->off) || (in->n && !in->seq)) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null read set");
+    if (need_qual && in->n && !in->qual) NGSID_FAIL(ctx, NGSID_ERR_ARG, "this entry point needs qualities");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    out->n = in->n;
+    out->h_off.resize(in->n + 1);
+    if (in->mem == NGSID_MEM_DEVICE) {
+        HIPCHK(ctx, hipMemcpy(out->h_off.data(), in->off, sizeof(uint64_t) * (in->n + 1), hipMemcpyDeviceToHost));
+        out->seq = in->seq; out->qual = in->qual; out->off = in->off;
+    } else {
+        memcpy(out->h_off.data(), in->off, sizeof(uint64_t) * (in->n + 1));
+        const uint64_t total = out->h_off[in->n];
+        HIPCHK(ctx, out->own_seq.alloc(total + 16)); HIPCHK(ctx, out->own_off.alloc(in->n + 1));
+        if (total) HIPCHK(ctx, hipMemcpyAsync(out->own_seq.p, in->seq, total, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(out->own_off.p, in->off, sizeof(uint64_t) * (in->n + 1), hipMemcpyHostToDevice, ctx->stream));
+        out->seq = out->own_seq.p; out->off = out->own_off.p; out->qual = nullptr;
+        if (in->qual) { HIPCHK(ctx, out->own_qual.alloc(total + 16)); if (total) HIPCHK(ctx, hipMemcpyAsync(out->own_qual.p, in->qual, total, hipMemcpyHostToDevice, ctx->stream)); out->qual = out->own_qual.p; }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    out->total = out->h_off[in->n];
+    uint32_t mx = 0;
+    for (uint64_t i = 0; i < in->n; ++i) {
+        if (out->h_off[i + 1] < out->h_off[i]) NGSID_FAIL(ctx, NGSID_ERR_ARG, "offsets not monotone at read %llu", (unsigned long long)i);
+        const uint64_t l = out->h_off[i + 1] - out->h_off[i];
+        if (l > 0xffffffffull) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "read %llu too long", (unsigned long long)i);
+        mx = std::max<uint32_t>(mx, (uint32_t)l);
+    }
+    out->maxlen = mx;
+    return NGSID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- (a10,a15)
+extern "C" int32_t ngsid_sg_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const ngsid_reads_t* targets,
+                                        const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                                        int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,
+                                        int32_t k, const int32_t* match_id,
+                                        int32_t* score, int32_t* n_cols, int32_t* n_match, int32_t* region)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!queries || !targets || (n_pairs && (!q_idx || !t_idx || !open))) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    DevReads Q, T;
+    int32_t rc = ngsid_upload_reads(ctx, queries, &Q, false); if (rc) return rc;
+    rc = ngsid_upload_reads(ctx, targets, &T, false); if (rc) return rc;
+    if (n_pairs == 0) return NGSID_OK;
+    uint32_t mq = 0, mt = 0;
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        if (q_idx[p] >= Q.n || t_idx[p] >= T.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "pair %llu out of range", (unsigned long long)p);
+        mq = std::max<uint32_t>(mq, (uint32_t)(Q.h_off[q_idx[p] + 1] - Q.h_off[q_idx[p]]));
+        mt = std::max<uint32_t>(mt, (uint32_t)(T.h_off[t_idx[p] + 1] - T.h_off[t_idx[p]]));
+    }
+    DevBuf<uint32_t> dq, dt; DevBuf<int32_t> dopen, dmid, dout;
+    HIPCHK(ctx, dq.alloc(n_pairs)); HIPCHK(ctx, dt.alloc(n_pairs)); HIPCHK(ctx, dopen.alloc(n_pairs)); HIPCHK(ctx, dmid.alloc(n_pairs)); HIPCHK(ctx, dout.alloc(n_pairs * 4));
+    HIPCHK(ctx, hipMemcpyAsync(dq.p, q_idx, 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dt.p, t_idx, 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dopen.p, open, 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    if (match_id) HIPCHK(ctx, hipMemcpyAsync(dmid.p, match_id, 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    AlignJob J{};
+    J.qseq = Q.seq; J.qoff = Q.off; J.tseq = T.seq; J.toff = T.off; J.qidx = dq.p; J.tidx = dt.p; J.npairs = n_pairs;
+    J.match = match; J.mismatch = mismatch; J.ext = ext; J.k = k; J.open = dopen.p; J.match_id = match_id ? dmid.p : nullptr;
+    J.score = dout.p; J.ncols = dout.p + n_pairs; J.nmatch = dout.p + 2 * n_pairs; J.region = dout.p + 3 * n_pairs;
+    J.bp = nullptr; J.bp_windows = 0; J.window = 1; J.span = nullptr;
+    rc = ngsid_launch_align(ctx, J, mq, mt); if (rc) return rc;
+    std::vector<int32_t> h(n_pairs * 4);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), dout.p, 16 * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (score) memcpy(score, h.data(), 4 * n_pairs);
+    if (n_cols) memcpy(n_cols, h.data() + n_pairs, 4 * n_pairs);
+    if (n_match) memcpy(n_match, h.data() + 2 * n_pairs, 4 * n_pairs);
+    if (region) memcpy(region, h.data() + 3 * n_pairs, 4 * n_pairs);
+    return NGSID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- (a1-a3)
+__global__ void k_csr_gather(const uint64_t* __restrict__ roff, const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ moff,
+                             const uint64_t* __restrict__ scodes, const uint32_t* __restrict__ spos, uint64_t n,
+                             uint64_t* __restrict__ codes, uint32_t* __restrict__ pos)
+{
+    const uint64_t r = blockIdx.x;
+    if (r >= n) return;
+    const uint64_t src = roff[r], dst = moff[r]; const uint32_t c = cnt[r];
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) { codes[dst + i] = scodes[src + i]; pos[dst + i] = spos[src + i]; }
+}
+
+extern "C" int32_t ngsid_hpc_minimizers(ngsid_ctx* ctx, const ngsid_reads_t* reads, int32_t k, int32_t w,
+                                        uint64_t* mz_off, uint64_t* codes, uint32_t* pos, uint64_t cap, uint64_t* needed,
+                                        uint32_t* hpc_len, double* hpc_err)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!reads || !mz_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    DevReads R; int32_t rc = ngsid_upload_reads(ctx, reads, &R, false); if (rc) return rc;
+    const uint64_t n = R.n;
+    DevBuf<uint64_t> scodes; DevBuf<uint32_t> spos, dcnt, dhl; DevBuf<double> dherr, draw; DevBuf<int> dflag;
+    HIPCHK(ctx, scodes.alloc(R.total + 1)); HIPCHK(ctx, spos.alloc(R.total + 1)); HIPCHK(ctx, dcnt.alloc(n)); HIPCHK(ctx, dhl.alloc(n));
+    HIPCHK(ctx, dherr.alloc(n)); HIPCHK(ctx, draw.alloc(n)); HIPCHK(ctx, dflag.alloc(1));
+    HIPCHK(ctx, hipMemsetAsync(dflag.p, 0, sizeof(int), ctx->stream));
+    rc = ngsid_launch_minimizers(ctx, R, k, w, scodes.p, spos.p, dcnt.p, dhl.p, dherr.p, draw.p, dflag.p); if (rc) return rc;
+    std::vector<uint32_t> hcnt(n), hhl(n); std::vector<double> hherr(n); int hflag = 0;
+    if (n) {
+        HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), dcnt.p, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hhl.data(), dhl.p, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hherr.data(), dherr.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(&hflag, dflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (hflag) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "read %d: base outside ACGTN", hflag - 1);
+    std::vector<uint64_t> hmoff(n + 1); hmoff[0] = 0;
+    for (uint64_t i = 0; i < n; ++i) hmoff[i + 1] = hmoff[i] + hcnt[i];
+    const uint64_t total = hmoff[n];
+    if (needed) *needed = total;
+    if (hpc_len) memcpy(hpc_len, hhl.data(), 4 * n);
+    if (hpc_err) memcpy(hpc_err, hherr.data(), 8 * n);
+    const bool dev_out = reads->mem == NGSID_MEM_DEVICE;
+    if (total > cap || (total && (!codes || !pos))) {
+        if (!dev_out) memcpy(mz_off, hmoff.data(), 8 * (n + 1));
+        NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "minimizer buffer too small: need %llu entries", (unsigned long long)total);
+    }
+    DevBuf<uint64_t> dmoff, ocodes; DevBuf<uint32_t> opos;
+    HIPCHK(ctx, dmoff.alloc(n + 1));
+    HIPCHK(ctx, hipMemcpyAsync(dmoff.p, hmoff.data(), 8 * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    uint64_t* tc = codes; uint32_t* tp = pos;
+    if (!dev_out) { HIPCHK(ctx, ocodes.alloc(total + 1)); HIPCHK(ctx, opos.alloc(total + 1)); tc = ocodes.p; tp = opos.p; }
+    if (n) hipLaunchKernelGGL(k_csr_gather, dim3((unsigned)n), dim3(64), 0, ctx->stream, R.off, dcnt.p, dmoff.p, scodes.p, spos.p, n, tc, tp);
+    HIPCHK(ctx, hipGetLastError());
+    if (dev_out) {
+        HIPCHK(ctx, hipMemcpyAsync(mz_off, dmoff.p, 8 * (n + 1), hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        memcpy(mz_off, hmoff.data(), 8 * (n + 1));
+        if (total) { HIPCHK(ctx, hipMemcpyAsync(codes, tc, 8 * total, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(pos, tp, 4 * total, hipMemcpyDeviceToHost, ctx->stream)); }
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NGSID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- (f1)
+// get_sorted_fastq_for_cluster.py:23-33,124-155.  One thread per read: the sliding product
+// cur *= (1-p_new)/(1-p_old) is a sequential recurrence that must be replayed op for op to give the
+// reference's exact double; reads are independent, so the batch is the parallel axis.
+__constant__ double c_p_clamped[128];
+__constant__ double c_p_nomin[128];
+static bool g_score_tables[16] = {false};
+
+__global__ void k_score_reads(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t n,
+                              int k, double qthr, double* __restrict__ score, double* __restrict__ err, uint8_t* __restrict__ keep)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t b = off[r]; const int len = (int)(off[r + 1] - b);
+    const uint8_t* s = seq + b; const uint8_t* q = qual + b;
+    score[r] = 0.0; err[r] = 0.0; keep[r] = 0;
+    if (len < 2 * k) return;
+    int hl = 0; for (int i = 0; i < len; ++i) hl += (i == 0 || s[i] != s[i - 1]);
+    if (hl < k) return;
+    double cur = 1.0;
+    for (int i = 0; i < k; ++i) cur = cur * (1.0 - c_p_clamped[q[i] & 127]);
+    double sum = cur;
+    for (int i = k; i < len; ++i) { const double leave = 1.0 - c_p_clamped[q[i - k] & 127]; cur *= ((1.0 - c_p_clamped[q[i] & 127]) / leave); sum += cur; }
+    const double ee = (double)(len - k + 1) - sum;
+    const double pno = 1.0 - ee / (double)(len - k + 1);
+    score[r] = pno * (double)(len - k + 1);
+    int hist[128];
+    for (int c = 0; c < 128; ++c) hist[c] = 0;
+    for (int i = 0; i < len; ++i) hist[q[i] & 127]++;
+    double se = 0.0;
+    for (int c = 0; c < 128; ++c) if (hist[c]) se = se + (double)hist[c] * c_p_nomin[c];
+    const double er = se / (double)len;
+    err[r] = er;
+    if (10.0 * -(log(er) / log(10.0)) <= qthr) return;      // device log(): last-ulp differences only matter exactly on the threshold
+    keep[r] = 1;
+}
+
+extern "C" int32_t ngsid_score_reads(ngsid_ctx* ctx, const ngsid_reads_t* reads, int32_t k, double q_threshold,
+                                     double* score, double* err_rate, uint8_t* keep)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!reads || !score || !err_rate || !keep || k < 1) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    DevReads R; int32_t rc = ngsid_upload_reads(ctx, reads, &R, true); if (rc) return rc;
+    if (!g_score_tables[ctx->device & 15]) {
+        HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_p_clamped), NGSID_PHRED_P, sizeof(double) * 128));
+        HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_p_nomin), NGSID_PHRED_P_NOMIN, sizeof(double) * 128));
+        g_score_tables[ctx->device & 15] = true;
+    }
+    const uint64_t n = R.n; if (!n) return NGSID_OK;
+    DevBuf<double> ds, de; DevBuf<uint8_t> dk;
+    HIPCHK(ctx, ds.alloc(n)); HIPCHK(ctx, de.alloc(n)); HIPCHK(ctx, dk.alloc(n));
+    hipLaunchKernelGGL(k_score_reads, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, R.seq, R.qual, R.off, n, k, q_threshold, ds.p, de.p, dk.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(score, ds.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(err_rate, de.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(keep, dk.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NGSID_OK;
+}

@@ -1,0 +1,68 @@
+// ngsid_internal.h - shared internals of libngsid_hip.so (gfx950 only; no CPU implementation exists)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+#include "../../include/ngsid.h"
+
+// RAII device buffer (freed at scope exit; all work is synchronised before return)
+template <typename T> struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; if (!count) count = 1; return hipMalloc((void**)&p, count * sizeof(T)); }
+    hipError_t grow(size_t count, hipStream_t s) {   // keeps contents
+        if (count <= n) return hipSuccess;
+        T* q = nullptr; hipError_t e = hipMalloc((void**)&q, count * sizeof(T)); if (e != hipSuccess) return e;
+        if (p && n) { e = hipMemcpyAsync(q, p, n * sizeof(T), hipMemcpyDeviceToDevice, s); if (e != hipSuccess) return e; e = hipStreamSynchronize(s); if (e != hipSuccess) return e; }
+        if (p) (void)hipFree(p); p = q; n = count; return hipSuccess;
+    }
+};
+
+struct ngsid_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[1024] = {0};
+    size_t scratch_budget = (size_t)24 << 30;   // upper bound for traceback scratch (bytes)
+    int n_cu = 256;
+    DevBuf<uint64_t> tb;      // aligner traceback scratch (grow-only)
+    DevBuf<int32_t> bnd;      // aligner strip boundary rows
+};
+
+#define NGSID_FAIL(ctx, code, ...) do { snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); return (code); } while (0)
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return NGSID_ERR_HIP; } } while (0)
+
+// A read set resident in HBM (+ host copy of the offsets, which every host-side planner needs)
+struct DevReads {
+    const uint8_t* seq = nullptr; const uint8_t* qual = nullptr; const uint64_t* off = nullptr;
+    uint64_t n = 0, total = 0; uint32_t maxlen = 0;
+    std::vector<uint64_t> h_off;
+    DevBuf<uint8_t> own_seq, own_qual; DevBuf<uint64_t> own_off;
+};
+int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* out, bool need_qual);
+
+// ---- kernels' host launchers (defined in the .hip files) ----
+// per read: HPC length, minimizer count, HPC error rate, raw mean error; minimizers written sparsely at [off[r], off[r]+cnt)
+int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
+                                uint64_t* d_codes, uint32_t* d_pos, uint32_t* d_cnt, uint32_t* d_hlen, double* d_herr, double* d_rawerr,
+                                int* d_flag);
+
+struct AlignJob {            // device pointers
+    const uint8_t* qseq; const uint64_t* qoff; const uint8_t* tseq; const uint64_t* toff;
+    const uint32_t* qidx; const uint32_t* tidx; uint64_t npairs;
+    int match, mismatch, ext, k; const int32_t* open; const int32_t* match_id;
+    int32_t* score; int32_t* ncols; int32_t* nmatch; int32_t* region;
+    // optional window break points (polish): per pair `bp_windows` records of 4 int32 {q_first,q_last,t_first,t_last}, -1 = none
+    int32_t* bp; int bp_windows; int window; int32_t* span;  // span: per pair {q_begin,q_end,t_begin,t_end} of the aligned part
+};
+int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen);
+
+__device__ __forceinline__ int ngsid_bcode(uint8_t c) {
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}

@@ -1,0 +1,124 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the golden fixtures.  Bit-exact integer results."""
+import os, json
+import numpy as np
+import pytest
+from oracle_lib import GOLD
+from ngspeciesid_amd._capi import ReadSet, cluster_params
+from test_oracle_golden import _acc_rank, _load
+
+pytestmark = pytest.mark.gpu
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _dump(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+
+
+@pytest.mark.parametrize("tag", ["sample_h1", "synth200"])
+@pytest.mark.parametrize("kw", [(13, 20), (15, 50), (10, 100), (21, 21)])
+def test_minimizers(gpu_api, oracle, tag, kw):
+    g = _load("minimizers_%s.npz" % tag)
+    k, w = kw
+    rs = ReadSet(g["seq"], g["qual"], g["off"])
+    got = gpu_api.hpc_minimizers(rs, k, w)
+    exp = oracle.hpc_minimizers(rs, k, w)
+    names = ["moff", "codes", "pos", "hpc_len"]
+    for nm, a, b in zip(names, got[:4], exp[:4]):
+        if not np.array_equal(a, b):
+            _dump("fail_minimizers_%s_%d_%d" % (tag, k, w), **{"got_" + n: x for n, x in zip(names, got[:4])}, **{"exp_" + n: x for n, x in zip(names, exp[:4])})
+        assert np.array_equal(a, b), nm
+    assert np.array_equal(got[4], exp[4], equal_nan=True)          # HPC error rate: same op order -> bit-exact doubles
+    assert np.array_equal(got[1], g["codes_%d_%d" % (k, w)])         # and against the reference's own output
+
+
+def _rand_pairs(rng, n, lmin, lmax, sim=True):
+    qs, ts = [], []
+    for _ in range(n):
+        L = int(rng.integers(lmin, lmax + 1))
+        a = rng.integers(0, 4, L)
+        if sim:
+            b = a.copy()
+            m = rng.random(L) < 0.08
+            b[m] = rng.integers(0, 4, int(m.sum()))
+            keep = rng.random(L) > 0.04
+            b = b[keep]
+            ins = rng.integers(0, 4, int(rng.integers(0, 6)))
+            cut = int(rng.integers(0, len(b) + 1))
+            b = np.concatenate([b[:cut], ins, b[cut:]])
+            if rng.random() < 0.3:
+                b = b[int(rng.integers(0, 20)):]
+            if rng.random() < 0.3:
+                a = a[:len(a) - int(rng.integers(0, 20))]
+        else:
+            b = rng.integers(0, 4, int(rng.integers(lmin, lmax + 1)))
+        qs.append("".join("ACGT"[x] for x in a)); ts.append("".join("ACGT"[x] for x in b))
+    return qs, ts
+
+
+@pytest.mark.parametrize("case", [("tiny", 40, 1, 40), ("rpl4", 60, 100, 256), ("rpl8", 40, 300, 512), ("rpl12", 60, 600, 768),
+                                  ("rpl16", 30, 800, 1024), ("strips", 12, 1100, 2600), ("random", 40, 50, 400)])
+def test_align_vs_oracle(gpu_api, oracle, case):
+    name, n, lmin, lmax = case
+    rng = np.random.default_rng(abs(hash(name)) % 1000)
+    qs, ts = _rand_pairs(rng, n, lmin, lmax, sim=(name != "random"))
+    if name == "tiny":
+        qs += ["A", "ACGT", "ACGTN", "acgtacgt", "GATTACA"]; ts += ["C", "ACGT", "NACGT", "ACGTACGT", "TTTTGATTACATTT"]
+    q = ReadSet.from_strings(qs); t = ReadSet.from_strings(ts)
+    idx = np.arange(len(qs), dtype=np.uint32)
+    opens = rng.integers(2, 6, len(qs)).astype(np.int32); mids = rng.integers(-1, 14, len(qs)).astype(np.int32)
+    got = gpu_api.sg_align_batch(q, t, idx, idx, opens, 1, 2, -2, 13, mids)
+    exp = oracle.sg_align_batch(q, t, idx, idx, opens, 1, 2, -2, 13, mids)
+    for nm, a, b in zip(["score", "ncols", "nmatch", "region"], got, exp):
+        if not np.array_equal(a, b):
+            _dump("fail_align_%s" % name, got=np.stack(got), exp=np.stack(exp))
+            bad = np.nonzero(a != b)[0]
+            raise AssertionError("%s differs at pairs %s: got %s exp %s (len q %s t %s)" % (nm, bad[:8], a[bad[:8]], b[bad[:8]], [len(qs[i]) for i in bad[:8]], [len(ts[i]) for i in bad[:8]]))
+
+
+def test_align_golden(gpu_api):
+    g = _load("align_sample_h1.npz")
+    q = ReadSet(g["q"], None, g["q_off"]); t = ReadSet(g["t"], None, g["t_off"])
+    idx = np.arange(q.n, dtype=np.uint32)
+    score, ncols, nmatch, region = gpu_api.sg_align_batch(q, t, idx, idx, g["open"], 1, 2, -2, 13, g["match_id"])
+    assert np.array_equal(score, g["score"]) and np.array_equal(ncols, g["n_cols"]) and np.array_equal(nmatch, g["n_match"])
+    qlen = np.diff(g["q_off"].astype(np.int64))
+    assert np.array_equal(region / qlen.astype(np.float64), g["ratio"])
+
+
+@pytest.mark.parametrize("tag", ["sample_h1", "synth2k_d15", "synth600_d10_q14", "synth300_ccs"])
+def test_cluster_t1(gpu_api, oracle, tag):
+    g = _load("cluster_%s.npz" % tag)
+    rs = ReadSet(g["seq"], g["qual"], g["off"])
+    prm = cluster_params(k=int(g["k"]), w=int(g["w"]), p_shared=g["p_table"])
+    ar = _acc_rank([str(a) for a in g["acc"]])
+    rep, herr, st, cnt = gpu_api.cluster_greedy(rs, prm, acc_rank=ar)
+    orep, oherr, ost, ocnt = oracle.cluster_greedy(rs, prm, acc_rank=ar)
+    if not (np.array_equal(rep, orep) and np.array_equal(st, ost)):
+        _dump("fail_cluster_%s" % tag, rep=rep, orep=orep, st=st, ost=ost, cnt=cnt, ocnt=ocnt)
+        bad = np.nonzero((rep != orep) | (st != ost))[0]
+        raise AssertionError("cluster %s: %d reads differ, first %s got rep %s st %s exp rep %s st %s; counters %s vs %s" %
+                             (tag, len(bad), bad[:10], rep[bad[:10]], st[bad[:10]], orep[bad[:10]], ost[bad[:10]], cnt, ocnt))
+    assert np.array_equal(cnt, ocnt)
+    assert np.array_equal(herr, oherr, equal_nan=True)
+    assert np.array_equal(rep, g["t1_rep_of"])                      # = the reference's own membership
+    assert [int(c) for c in cnt[:3]] == [int(c) for c in g["t1_counters"]]
+
+
+def test_cluster_seeded_merge_round(gpu_api, oracle):
+    """merge-round semantics (cluster.py:221-223,243-248): lower-batch representatives seed the index, higher-batch ones are re-clustered."""
+    g = _load("cluster_synth2k_d15.npz")
+    rs_all = ReadSet(g["seq"], g["qual"], g["off"])
+    n = rs_all.n
+    # take 400 reads, pretend the first half is batch 1 and the second batch 2, everything is a representative with a known error rate
+    sel = np.arange(0, 400)
+    seqs = [rs_all.get(i)[0] for i in sel]; quals = [rs_all.get(i)[1] for i in sel]
+    rs = ReadSet.from_strings(seqs, quals)
+    prm = cluster_params(k=13, w=20, p_shared=g["p_table"])
+    prev = np.where(sel < 200, 1, 2).astype(np.int32)
+    _, _, _, _, he = oracle.hpc_minimizers(rs, 13, 20)
+    ar = _acc_rank([str(a) for a in g["acc"][sel]])
+    got = gpu_api.cluster_greedy(rs, prm, acc_rank=ar, prev_batch=prev, known_err=he)
+    exp = oracle.cluster_greedy(rs, prm, acc_rank=ar, prev_batch=prev, known_err=he)
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b, equal_nan=True)
