@@ -32,6 +32,7 @@ struct ngsid_ctx {
     int n_cu = 256;
     DevBuf<uint64_t> tb;      // aligner traceback scratch (grow-only)
     DevBuf<int32_t> bnd;      // aligner strip boundary rows
+    DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
 };
 
 #define NGSID_FAIL(ctx, code, ...) do { snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); return (code); } while (0)

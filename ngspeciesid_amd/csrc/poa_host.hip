@@ -1,0 +1,395 @@
+// poa_host.hip - host drivers over the POA tile engine: the depth-tiled hierarchy, ngsid_poa_consensus (a13,a14)
+// and ngsid_polish (a16,a17).  Mirrors oracle/ngsid_oracle_poa.c: run_hierarchy / ongsid_poa_consensus / ongsid_polish.
+#include "ngsid_internal.h"
+#include "k_poa.h"
+#include <algorithm>
+#include <vector>
+#include <string>
+#include <memory>
+
+namespace {
+
+struct Unit {                       // one consensus problem: a cluster (spoa stage) or a backbone window (polish)
+    std::vector<uint32_t> seqs;     // indices into the CURRENT level's PSeq array, in order
+    int bb = -1;                    // backbone index (into the bbs array) or -1
+    bool done = false;
+    std::string result; std::vector<uint32_t> cov; bool has_result = false;
+};
+
+struct Level {                      // device buffers of one hierarchy level (kept alive while the next level reads them)
+    DevBuf<PSeq> seqs; DevBuf<uint8_t> out; DevBuf<int32_t> out_len; DevBuf<uint64_t> out_cw; DevBuf<uint32_t> out_n, out_cov;
+};
+
+__global__ void k_make_pseq_reads(const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint64_t n, int mode, PSeq* out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PSeq S; S.s = seq + off[i]; S.q = qual ? qual + off[i] : nullptr; S.len = (int32_t)(off[i + 1] - off[i]); S.uw = 1; S.cw = 1; S.mode = mode; S.a0 = 0; S.a1 = -1;
+    out[i] = S;
+}
+
+struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; };
+
+// Runs all units to completion.  level0: device PSeq array (nseq0 entries) whose max length is maxlen0;
+// bbs: device backbone PSeqs (may be null), maxbb = longest backbone.
+int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
+                      std::vector<Unit>& units, const HierParams& hp)
+{
+    std::vector<std::unique_ptr<Level>> keep;
+    const PSeq* cur = d_level0; uint32_t cur_maxlen = maxlen0;
+    int slots_cap = 0;
+    for (int level = 0;; ++level) {
+        // ---- jobs of this level
+        std::vector<uint32_t> job_off{0}, seq_idx, job_unit; std::vector<int32_t> job_bb; uint32_t maxD = 0; int maxL0 = 1; bool any_nobb = false;
+        for (size_t u = 0; u < units.size(); ++u) {
+            Unit& U = units[u]; if (U.done) continue;
+            const uint32_t ncur = (uint32_t)U.seqs.size();
+            if (ncur == 0) { U.done = true; continue; }
+            const uint32_t Dl = hp.D > 0 ? (uint32_t)hp.D : ncur;
+            for (uint32_t a = 0; a < ncur; a += Dl) {
+                const uint32_t b = std::min(ncur, a + Dl);
+                for (uint32_t x = a; x < b; ++x) seq_idx.push_back(U.seqs[x]);
+                job_off.push_back((uint32_t)seq_idx.size()); job_bb.push_back(U.bb); job_unit.push_back((uint32_t)u);
+                maxD = std::max(maxD, b - a);
+            }
+            if (U.bb >= 0) maxL0 = std::max(maxL0, bb_len[U.bb]); else any_nobb = true;
+        }
+        const uint32_t njobs = (uint32_t)job_unit.size();
+        if (njobs == 0) break;
+        if (any_nobb) maxL0 = std::max<int>(maxL0, (int)cur_maxlen);   // without a backbone the first member sets L0 (<= the longest member)
+        // capacity (LDS sizing): the largest per-job capacity the oracle rule can produce
+        long long capV = (long long)maxL0 * (hp.node_cap > 0 ? hp.node_cap : 32) / 16; capV = std::max<long long>(capV, maxL0 + 64); capV = std::max<long long>(capV, (long long)cur_maxlen + 1);
+        capV = (capV + 7) & ~7ll;
+        const int Lmax = (int)((std::max<uint32_t>(cur_maxlen, 1) + 15) & ~15u);
+        DevBuf<uint32_t> d_job_off, d_seq_idx, d_flags; DevBuf<int32_t> d_job_bb;
+        HIPCHK(ctx, d_job_off.alloc(job_off.size())); HIPCHK(ctx, d_seq_idx.alloc(seq_idx.size())); HIPCHK(ctx, d_job_bb.alloc(job_bb.size())); HIPCHK(ctx, d_flags.alloc(4));
+        HIPCHK(ctx, hipMemcpyAsync(d_job_off.p, job_off.data(), 4 * job_off.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_seq_idx.p, seq_idx.data(), 4 * seq_idx.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_job_bb.p, job_bb.data(), 4 * job_bb.size(), hipMemcpyHostToDevice, ctx->stream));
+        int slots = slots_cap ? slots_cap : (int)std::min<uint32_t>(maxD, 4);
+        std::unique_ptr<Level> Lv(new Level());
+        std::vector<uint32_t> h_out_n; std::vector<int32_t> h_out_len; std::vector<uint64_t> h_out_cw;
+        for (;;) {      // retry with more output slots if a tile had to split more often than `slots`
+            HIPCHK(ctx, Lv->out.alloc((size_t)njobs * slots * capV)); HIPCHK(ctx, Lv->out_len.alloc((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_cw.alloc((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_n.alloc(njobs));
+            if (hp.want_cov) HIPCHK(ctx, Lv->out_cov.alloc((size_t)njobs * slots * capV));
+            HIPCHK(ctx, hipMemsetAsync(d_flags.p, 0, 16, ctx->stream));
+            PoaJobSet J{};
+            J.seqs = cur; J.bbs = d_bbs; J.seq_idx = d_seq_idx.p; J.job_off = d_job_off.p; J.job_bb = d_job_bb.p; J.njobs = njobs;
+            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(2 * capV); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap;
+            J.out = Lv->out.p; J.out_len = Lv->out_len.p; J.out_cw = Lv->out_cw.p; J.out_n = Lv->out_n.p; J.out_cov = hp.want_cov ? Lv->out_cov.p : nullptr;
+            J.dropped = d_flags.p; J.slot_overflow = d_flags.p + 1;
+            int32_t rc = poa_run_jobs(ctx, J, hp.band); if (rc) return rc;
+            uint32_t h_flags[4];
+            h_out_n.resize(njobs); h_out_len.resize((size_t)njobs * slots); h_out_cw.resize((size_t)njobs * slots);
+            HIPCHK(ctx, hipMemcpyAsync(h_flags, d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_out_n.data(), Lv->out_n.p, 4ull * njobs, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_out_len.data(), Lv->out_len.p, 4ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_out_cw.data(), Lv->out_cw.p, 8ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (!h_flags[1]) break;
+            if (slots >= (int)maxD) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA output slot overflow at full depth");
+            slots = (int)std::min<uint32_t>(maxD, (uint32_t)slots * 4); slots_cap = slots;
+        }
+        // ---- distribute outputs to units
+        std::vector<std::vector<uint32_t>> outs(units.size());         // flat slot indices (job*slots + s) in job order
+        for (uint32_t j = 0; j < njobs; ++j) for (uint32_t s = 0; s < h_out_n[j]; ++s) outs[job_unit[j]].push_back(j * (uint32_t)slots + s);
+        std::vector<PSeq> next; uint32_t next_maxlen = 0;
+        for (size_t u = 0; u < units.size(); ++u) {
+            Unit& U = units[u]; if (U.done) continue;
+            const std::vector<uint32_t>& O = outs[u];
+            const size_t ncur = U.seqs.size();
+            int pick = -1;
+            if (O.empty()) { U.done = true; continue; }
+            if (O.size() == 1) pick = 0;
+            else if (O.size() >= ncur) { pick = 0; for (size_t i = 1; i < O.size(); ++i) if (h_out_cw[O[i]] > h_out_cw[O[pick]]) pick = (int)i; }
+            if (pick >= 0) {
+                const uint32_t sl = O[pick]; const int len = h_out_len[sl];
+                U.result.resize(len);
+                if (len) HIPCHK(ctx, hipMemcpy(&U.result[0], Lv->out.p + (size_t)sl * capV, len, hipMemcpyDeviceToHost));
+                if (hp.want_cov) { U.cov.resize(len); if (len) HIPCHK(ctx, hipMemcpy(U.cov.data(), Lv->out_cov.p + (size_t)sl * capV, 4ull * len, hipMemcpyDeviceToHost)); }
+                U.has_result = true; U.done = true; continue;
+            }
+            U.seqs.clear();
+            for (uint32_t sl : O) {
+                const uint64_t cw = h_out_cw[sl];
+                PSeq S; S.s = Lv->out.p + (size_t)sl * capV; S.q = nullptr; S.len = h_out_len[sl];
+                S.uw = cw > (1u << 20) ? (1 << 20) : (int)cw; if (S.uw < 1) S.uw = 1;
+                S.cw = (uint32_t)(cw > 0xffffffffull ? 0xffffffffull : cw); S.mode = hp.upper_mode; S.a0 = 0; S.a1 = -1;
+                U.seqs.push_back((uint32_t)next.size()); next.push_back(S); next_maxlen = std::max<uint32_t>(next_maxlen, (uint32_t)S.len);
+            }
+        }
+        if (next.empty()) { keep.push_back(std::move(Lv)); break; }
+        HIPCHK(ctx, Lv->seqs.alloc(next.size()));
+        HIPCHK(ctx, hipMemcpyAsync(Lv->seqs.p, next.data(), sizeof(PSeq) * next.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        cur = Lv->seqs.p; cur_maxlen = next_maxlen;
+        keep.push_back(std::move(Lv));
+    }
+    return NGSID_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- (a13,a14)
+extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint64_t* grp_off, uint64_t n_groups,
+                                       const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!reads || !grp_off || !prm || !cons_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    DevReads RD; int32_t rc = ngsid_upload_reads(ctx, reads, &RD, false); if (rc) return rc;
+    if (grp_off[n_groups] > RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "group offsets exceed the read set");
+    DevBuf<PSeq> d_seqs; HIPCHK(ctx, d_seqs.alloc(RD.n));
+    if (RD.n) hipLaunchKernelGGL(k_make_pseq_reads, dim3((unsigned)((RD.n + 255) / 256)), dim3(256), 0, ctx->stream, RD.seq, RD.qual, RD.off, RD.n, prm->mode, d_seqs.p);
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<Unit> units(n_groups);
+    for (uint64_t g = 0; g < n_groups; ++g) { units[g].seqs.reserve(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs.push_back((uint32_t)r); }
+    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, prm->mode, false};
+    std::vector<int> nobb;
+    rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;
+    uint64_t total = 0; bool overflow = false; cons_off[0] = 0;
+    for (uint64_t g = 0; g < n_groups; ++g) {
+        const std::string& s = units[g].result;
+        if (total + s.size() <= cons_cap && cons) memcpy(cons + total, s.data(), s.size()); else if (s.size()) overflow = true;
+        total += s.size(); cons_off[g + 1] = total;
+    }
+    if (needed) *needed = total;
+    if (overflow) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "consensus buffer too small: need %llu bytes", (unsigned long long)total);
+    return NGSID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- (a16,a17)
+namespace {
+
+__global__ __launch_bounds__(256)
+void k_strand(const uint64_t* __restrict__ off, const uint32_t* __restrict__ mzcnt, const uint32_t* __restrict__ hlen, const uint64_t* __restrict__ mzcode, int k,
+              const uint32_t* __restrict__ rgroup, const uint64_t* __restrict__ bcodes, const uint64_t* __restrict__ boff /* 2G+1: fw lists then rc lists */, uint32_t G,
+              uint64_t n, uint8_t* __restrict__ orient)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const uint32_t g = rgroup[r];
+    const uint32_t M = hlen[r] >= (uint32_t)k ? mzcnt[r] : 0;
+    const uint64_t* cf = bcodes + boff[g]; const uint32_t nf = (uint32_t)(boff[g + 1] - boff[g]);
+    const uint64_t* cr = bcodes + boff[G + g]; const uint32_t nr = (uint32_t)(boff[G + g + 1] - boff[G + g]);
+    int a = 0, b = 0;
+    for (uint32_t x = lane; x < M; x += 64) {
+        const uint64_t code = mzcode[off[r] + x];
+        uint32_t lo = 0, hi = nf; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cf[mid] < code) lo = mid + 1; else hi = mid; }
+        a += (lo < nf && cf[lo] == code);
+        lo = 0; hi = nr; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cr[mid] < code) lo = mid + 1; else hi = mid; }
+        b += (lo < nr && cr[lo] == code);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    if (lane == 0) orient[r] = (a == 0 && b == 0) ? 255 : (b > a ? 1 : 0);
+}
+
+__device__ __forceinline__ uint8_t comp_base(uint8_t c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
+
+__global__ void k_orient(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t n,
+                         const uint8_t* __restrict__ orient, uint8_t* __restrict__ oseq, uint8_t* __restrict__ oqual)
+{
+    const uint64_t r = blockIdx.x;
+    if (r >= n) return;
+    const uint64_t b = off[r]; const int len = (int)(off[r + 1] - b); const bool rc = orient[r] == 1;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        if (rc) { oseq[b + i] = comp_base(seq[b + len - 1 - i]); if (qual) oqual[b + i] = qual[b + len - 1 - i]; }
+        else { oseq[b + i] = seq[b + i]; if (qual) oqual[b + i] = qual[b + i]; }
+    }
+}
+
+// one thread per (pair, window): validity filters of racon's window assignment + the PSeq of the layer (oracle ongsid_polish)
+__global__ void k_layers(const uint8_t* __restrict__ oseq, const uint8_t* __restrict__ oqual, const uint64_t* __restrict__ off,
+                         const uint32_t* __restrict__ pair_read, const uint32_t* __restrict__ pair_group, uint64_t npairs, int nwinmax,
+                         const int32_t* __restrict__ bp, const int32_t* __restrict__ span, const int32_t* __restrict__ blen /* per group */,
+                         int W, double qthr, double ethr, PSeq* __restrict__ lay, uint8_t* __restrict__ valid, int* __restrict__ maxlen_out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npairs * (uint64_t)nwinmax) return;
+    const uint64_t p = t / nwinmax; const int wdx = (int)(t % nwinmax);
+    valid[t] = 0;
+    const int qb = span[p * 4 + 0], qe = span[p * 4 + 1], tb = span[p * 4 + 2], te = span[p * 4 + 3];
+    if (qb < 0) return;
+    const int qs = qe - qb + 1, ts = te - tb + 1; const int mn = qs < ts ? qs : ts, mx = qs < ts ? ts : qs;
+    if (1.0 - (double)mn / (double)mx > ethr) return;
+    const int32_t* b = bp + (p * (uint64_t)nwinmax + wdx) * 4;
+    const int qf = b[0], ql = b[1], tf = b[2], tl = b[3];
+    if (qf < 0) return;
+    const int len = ql - qf + 1; if ((double)len < 0.02 * (double)W) return;
+    const uint32_t read = pair_read[p]; const uint64_t rb = off[read];
+    if (oqual) { long long sq = 0; for (int x = qf; x <= ql; ++x) sq += (long long)oqual[rb + x] - 33; if ((double)sq / (double)len < qthr) return; }
+    const int Bl = blen[pair_group[p]]; const int ws = wdx * W; const int wlen = (Bl - ws) < W ? (Bl - ws) : W;
+    const int begin = tf - ws, end = tl - ws; const int offset = (int)(0.01 * (double)wlen);
+    PSeq S; S.s = oseq + rb + qf; S.q = oqual ? oqual + rb + qf : nullptr; S.len = len; S.uw = 1; S.cw = 1; S.a0 = begin; S.a1 = end;
+    S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI;
+    lay[t] = S; valid[t] = 1; atomicMax(maxlen_out, len);
+}
+
+std::string revcomp(const std::string& s) { std::string r(s.size(), 'N'); for (size_t i = 0; i < s.size(); ++i) { char c = s[s.size() - 1 - i]; r[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; } return r; }
+
+}  // namespace
+
+extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads,
+                                const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                                uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!backbones || !reads || !grp_off || !prm || !out_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    if (backbones->n != n_groups) NGSID_FAIL(ctx, NGSID_ERR_ARG, "one backbone per group expected");
+    DevReads RD; int32_t rc = ngsid_upload_reads(ctx, reads, &RD, false); if (rc) return rc;
+    if (grp_off[n_groups] > RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "group offsets exceed the read set");
+    const uint64_t N = RD.n; const uint32_t G = (uint32_t)n_groups;
+    const int W = prm->window > 0 ? prm->window : 500;
+    // backbones to host strings (they are tiny and are rebuilt on the host after every iteration)
+    std::vector<std::string> B(G);
+    {
+        std::vector<uint64_t> boff(G + 1); std::vector<uint8_t> bseq;
+        if (backbones->mem == NGSID_MEM_DEVICE) {
+            HIPCHK(ctx, hipMemcpy(boff.data(), backbones->off, 8 * (G + 1), hipMemcpyDeviceToHost)); bseq.resize(boff[G] + 1);
+            if (boff[G]) HIPCHK(ctx, hipMemcpy(bseq.data(), backbones->seq, boff[G], hipMemcpyDeviceToHost));
+        } else { memcpy(boff.data(), backbones->off, 8 * (G + 1)); bseq.assign(backbones->seq, backbones->seq + boff[G]); bseq.push_back(0); }
+        for (uint32_t g = 0; g < G; ++g) B[g].assign((const char*)bseq.data() + boff[g], (size_t)(boff[g + 1] - boff[g]));
+    }
+    if (N == 0 || G == 0) {
+        uint64_t total = 0; out_off[0] = 0; bool ovf = false;
+        for (uint32_t g = 0; g < G; ++g) { if (total + B[g].size() <= out_cap && out) memcpy(out + total, B[g].data(), B[g].size()); else if (B[g].size()) ovf = true; total += B[g].size(); out_off[g + 1] = total; if (n_used) n_used[g] = 0; }
+        if (needed) *needed = total; if (ovf) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "output buffer too small"); return NGSID_OK;
+    }
+    // ---- read -> group map, mean read length per group (TGS/NGS window type)
+    std::vector<uint32_t> h_rgroup(N, 0xffffffffu); std::vector<uint8_t> tgs(G, 0);
+    for (uint32_t g = 0; g < G; ++g) {
+        double tot = 0; const uint64_t ns = grp_off[g + 1] - grp_off[g];
+        for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) { h_rgroup[r] = g; tot += (double)(RD.h_off[r + 1] - RD.h_off[r]); }
+        tgs[g] = ns > 0 && (tot / (double)ns) > 1000.0;
+    }
+    // ---- strand detection (replaces minimap2's strand call): shared HPC minimizers with the initial backbone, fw vs rc
+    DevBuf<uint64_t> mzcode; DevBuf<uint32_t> mzpos, mzcnt, hlen, d_rgroup; DevBuf<double> herr, rawerr; DevBuf<int> flag; DevBuf<uint8_t> d_orient;
+    HIPCHK(ctx, mzcode.alloc(RD.total + 1)); HIPCHK(ctx, mzpos.alloc(RD.total + 1)); HIPCHK(ctx, mzcnt.alloc(N)); HIPCHK(ctx, hlen.alloc(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N));
+    HIPCHK(ctx, flag.alloc(1)); HIPCHK(ctx, d_rgroup.alloc(N)); HIPCHK(ctx, d_orient.alloc(N));
+    HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_rgroup.p, h_rgroup.data(), 4 * N, hipMemcpyHostToDevice, ctx->stream));
+    rc = ngsid_launch_minimizers(ctx, RD, prm->k, prm->w, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr.p, rawerr.p, flag.p); if (rc) return rc;
+    {
+        // backbone fw + rc minimizers through the same kernel, then sorted on the host (a handful of short lists)
+        std::vector<std::string> two; for (uint32_t g = 0; g < G; ++g) two.push_back(B[g]); for (uint32_t g = 0; g < G; ++g) two.push_back(revcomp(B[g]));
+        std::vector<uint64_t> toff(2 * G + 1, 0); std::string cat; for (size_t i = 0; i < two.size(); ++i) { cat += two[i]; toff[i + 1] = cat.size(); }
+        ngsid_reads_t br{(const uint8_t*)cat.data(), nullptr, toff.data(), 2ull * G, NGSID_MEM_HOST, 0};
+        DevReads BR; rc = ngsid_upload_reads(ctx, &br, &BR, false); if (rc) return rc;
+        DevBuf<uint64_t> bc; DevBuf<uint32_t> bp_, bcnt, bhl; DevBuf<double> be, bw; DevBuf<int> bflag;
+        HIPCHK(ctx, bc.alloc(BR.total + 1)); HIPCHK(ctx, bp_.alloc(BR.total + 1)); HIPCHK(ctx, bcnt.alloc(2 * G)); HIPCHK(ctx, bhl.alloc(2 * G)); HIPCHK(ctx, be.alloc(2 * G)); HIPCHK(ctx, bw.alloc(2 * G)); HIPCHK(ctx, bflag.alloc(1));
+        HIPCHK(ctx, hipMemsetAsync(bflag.p, 0, sizeof(int), ctx->stream));
+        rc = ngsid_launch_minimizers(ctx, BR, prm->k, prm->w, bc.p, bp_.p, bcnt.p, bhl.p, be.p, bw.p, bflag.p); if (rc) return rc;
+        std::vector<uint64_t> hc(BR.total + 1); std::vector<uint32_t> hcnt(2 * G), hhl(2 * G); int hf = 0, rf = 0;
+        HIPCHK(ctx, hipMemcpyAsync(hc.data(), bc.p, 8 * (BR.total + 1), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), bcnt.p, 4 * 2 * G, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(hhl.data(), bhl.p, 4 * 2 * G, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(&hf, bflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(&rf, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (hf || rf) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "base outside ACGTN in %s", hf ? "a backbone" : "a read");
+        std::vector<uint64_t> lists, loff(2 * G + 1, 0);
+        for (uint32_t i = 0; i < 2 * G; ++i) {
+            const uint32_t c = hhl[i] >= (uint32_t)prm->k ? hcnt[i] : 0;
+            std::vector<uint64_t> v(hc.begin() + toff[i], hc.begin() + toff[i] + c); std::sort(v.begin(), v.end());
+            lists.insert(lists.end(), v.begin(), v.end()); loff[i + 1] = lists.size();
+        }
+        DevBuf<uint64_t> d_lists, d_loff; HIPCHK(ctx, d_lists.alloc(lists.size() + 1)); HIPCHK(ctx, d_loff.alloc(loff.size()));
+        if (!lists.empty()) HIPCHK(ctx, hipMemcpyAsync(d_lists.p, lists.data(), 8 * lists.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_loff.p, loff.data(), 8 * loff.size(), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_strand, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, RD.off, mzcnt.p, hlen.p, mzcode.p, prm->k, d_rgroup.p, d_lists.p, d_loff.p, G, N, d_orient.p);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<uint8_t> h_orient(N);
+    HIPCHK(ctx, hipMemcpy(h_orient.data(), d_orient.p, N, hipMemcpyDeviceToHost));
+    (void)mzcode.alloc(0); (void)mzpos.alloc(0);
+    // ---- oriented copies of the reads
+    DevBuf<uint8_t> oseq, oqual; HIPCHK(ctx, oseq.alloc(RD.total + 16)); if (RD.qual) HIPCHK(ctx, oqual.alloc(RD.total + 16));
+    hipLaunchKernelGGL(k_orient, dim3((unsigned)N), dim3(128), 0, ctx->stream, RD.seq, RD.qual, RD.off, N, d_orient.p, oseq.p, RD.qual ? oqual.p : nullptr);
+    HIPCHK(ctx, hipGetLastError());
+    // ---- pairs (usable reads of reads that belong to a group), fixed over the iterations
+    std::vector<uint32_t> pair_read, pair_group;
+    for (uint64_t r = 0; r < N; ++r) if (h_rgroup[r] != 0xffffffffu && h_orient[r] != 255) { pair_read.push_back((uint32_t)r); pair_group.push_back(h_rgroup[r]); }
+    const uint64_t NP = pair_read.size();
+    DevBuf<uint32_t> d_pair_read, d_pair_group; DevBuf<int32_t> d_open, d_span, d_bp, d_blen; DevBuf<PSeq> d_lay; DevBuf<uint8_t> d_valid;
+    HIPCHK(ctx, d_pair_read.alloc(NP)); HIPCHK(ctx, d_pair_group.alloc(NP)); HIPCHK(ctx, d_open.alloc(NP)); HIPCHK(ctx, d_span.alloc(NP * 4)); HIPCHK(ctx, d_blen.alloc(G));
+    if (NP) { HIPCHK(ctx, hipMemcpyAsync(d_pair_read.p, pair_read.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d_pair_group.p, pair_group.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream));
+              HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)d_open.p, prm->aln_open, NP, ctx->stream)); }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> used(G, 0);
+
+    for (int it = 0; it < prm->iters; ++it) {
+        // upload the current backbones
+        std::vector<uint64_t> boff(G + 1, 0); std::string cat; std::vector<int32_t> blen(G); int nwinmax = 1; uint32_t maxb = 0;
+        for (uint32_t g = 0; g < G; ++g) { cat += B[g]; boff[g + 1] = cat.size(); blen[g] = (int32_t)B[g].size(); nwinmax = std::max(nwinmax, (int)((B[g].size() + W - 1) / W)); maxb = std::max<uint32_t>(maxb, (uint32_t)B[g].size()); }
+        ngsid_reads_t br{(const uint8_t*)cat.data(), nullptr, boff.data(), G, NGSID_MEM_HOST, 0};
+        DevReads BB; rc = ngsid_upload_reads(ctx, &br, &BB, false); if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(d_blen.p, blen.data(), 4 * G, hipMemcpyHostToDevice, ctx->stream));
+        std::fill(used.begin(), used.end(), 0);
+        std::vector<Unit> units; std::vector<PSeq> bbs; std::vector<int> bb_len; std::vector<std::pair<uint32_t, int>> unit_gw;
+        std::vector<uint8_t> h_valid; int max_layer = 1;
+        HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+        if (NP) {
+            HIPCHK(ctx, d_bp.alloc(NP * (uint64_t)nwinmax * 4)); HIPCHK(ctx, d_lay.alloc(NP * (uint64_t)nwinmax)); HIPCHK(ctx, d_valid.alloc(NP * (uint64_t)nwinmax));
+            AlignJob J{};
+            J.qseq = oseq.p; J.qoff = RD.off; J.tseq = BB.seq; J.toff = BB.off; J.qidx = d_pair_read.p; J.tidx = d_pair_group.p; J.npairs = NP;
+            J.match = prm->aln_match; J.mismatch = prm->aln_mismatch; J.ext = prm->aln_ext; J.k = 1; J.open = d_open.p; J.match_id = nullptr;
+            J.score = nullptr; J.ncols = nullptr; J.nmatch = nullptr; J.region = nullptr; J.bp = d_bp.p; J.bp_windows = nwinmax; J.window = W; J.span = d_span.p;
+            rc = ngsid_launch_align(ctx, J, RD.maxlen, maxb); if (rc) return rc;
+            const uint64_t T = NP * (uint64_t)nwinmax;
+            hipLaunchKernelGGL(k_layers, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, oseq.p, RD.qual ? oqual.p : nullptr, RD.off, d_pair_read.p, d_pair_group.p, NP, nwinmax,
+                               d_bp.p, d_span.p, d_blen.p, W, prm->quality_threshold, prm->error_threshold, d_lay.p, d_valid.p, flag.p);
+            HIPCHK(ctx, hipGetLastError());
+            h_valid.resize(T);
+            HIPCHK(ctx, hipMemcpyAsync(&max_layer, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_valid.data(), d_valid.p, T, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        // ---- units = (group, window) with their layers in read order
+        std::vector<std::vector<int>> unit_of(G);
+        for (uint32_t g = 0; g < G; ++g) { const int nw = (int)((B[g].size() + W - 1) / W); unit_of[g].assign(nw, -1);
+            for (int wdx = 0; wdx < nw; ++wdx) { unit_of[g][wdx] = (int)units.size(); units.emplace_back(); unit_gw.push_back({g, wdx}); } }
+        for (uint64_t p = 0; p < NP; ++p) {
+            bool any = false; const uint32_t g = pair_group[p];
+            for (int wdx = 0; wdx < (int)unit_of[g].size(); ++wdx) if (h_valid[p * (uint64_t)nwinmax + wdx]) { units[unit_of[g][wdx]].seqs.push_back((uint32_t)(p * (uint64_t)nwinmax + wdx)); any = true; }
+            if (any) used[g]++;
+        }
+        std::vector<size_t> nlayers(units.size());
+        for (size_t u = 0; u < units.size(); ++u) {
+            nlayers[u] = units[u].seqs.size();
+            if (units[u].seqs.size() < 2) { units[u].seqs.clear(); units[u].done = true; continue; }          // racon: < 3 sequences incl. backbone -> keep backbone
+            const uint32_t g = unit_gw[u].first; const int ws = unit_gw[u].second * W; const int wlen = std::min<int>(W, (int)B[g].size() - ws);
+            PSeq S; S.s = BB.seq + boff[g] + ws; S.q = nullptr; S.len = wlen; S.uw = 0; S.cw = 0; S.mode = NGSID_POA_GLOBAL; S.a0 = 0; S.a1 = -1;
+            units[u].bb = (int)bbs.size(); bbs.push_back(S); bb_len.push_back(wlen);
+        }
+        DevBuf<PSeq> d_bbs; HIPCHK(ctx, d_bbs.alloc(bbs.size()));
+        if (!bbs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_bbs.p, bbs.data(), sizeof(PSeq) * bbs.size(), hipMemcpyHostToDevice, ctx->stream));
+        bool any_tgs = false; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
+        HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs};
+        rc = run_hierarchy(ctx, d_lay.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
+        // ---- new backbones
+        std::vector<std::string> NB(G);
+        for (size_t u = 0; u < units.size(); ++u) {
+            const uint32_t g = unit_gw[u].first; const int ws = unit_gw[u].second * W; const int wlen = std::min<int>(W, (int)B[g].size() - ws);
+            std::string c = units[u].has_result ? units[u].result : std::string();
+            if (!c.empty() && tgs[g] && prm->trim && units[u].cov.size() == c.size()) {
+                const uint32_t avg = (uint32_t)(nlayers[u] / 2); int b = 0, e = (int)c.size() - 1;
+                for (; b < (int)c.size(); ++b) if (units[u].cov[b] >= avg) break;
+                for (; e >= 0; --e) if (units[u].cov[e] >= avg) break;
+                if (b < e) c = c.substr(b, e - b + 1);
+            }
+            if (c.empty()) c = B[g].substr(ws, wlen);
+            NB[g] += c;
+        }
+        B.swap(NB);
+    }
+    uint64_t total = 0; bool ovf = false; out_off[0] = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        if (total + B[g].size() <= out_cap && out) memcpy(out + total, B[g].data(), B[g].size()); else if (B[g].size()) ovf = true;
+        total += B[g].size(); out_off[g + 1] = total; if (n_used) n_used[g] = used[g];
+    }
+    if (needed) *needed = total;
+    if (ovf) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "output buffer too small: need %llu bytes", (unsigned long long)total);
+    return NGSID_OK;
+}

@@ -478,3 +478,20 @@ done:
     free(hs); free(hq); free(mc); free(mp); free(touched); free(cands); free(ops);
     return rc;
 }
+
+/* ---- helpers shared with ngsid_oracle_poa.c ---- */
+int ongsid_i_hpc_minimizers(const uint8_t* s, int n, int k, int w, uint64_t* codes, uint32_t* pos) {
+    uint8_t* hs = (uint8_t*)malloc((size_t)n + 1);
+    int hl = hpc_compress(s, NULL, n, hs, NULL), cnt = 0;
+    if (hl >= k) cnt = minimizers(hs, hl, k, w, codes, pos);
+    free(hs);
+    return cnt;       /* -1 = alphabet error */
+}
+/* forward-order op list (0 '=',1 'X',2 'I' query only,3 'D' target only) of the semi-global alignment; returns #ops */
+int ongsid_i_sg_ops(const uint8_t* q, int n, const uint8_t* t, int m, int match, int mismatch, int open, int ext, uint8_t* ops) {
+    sg_result R; sg_align(q, n, t, m, match, mismatch, open, ext, &R);
+    int c = sg_traceback(q, t, &R, ops);
+    for (int i = 0, j = c - 1; i < j; ++i, --j) { uint8_t x = ops[i]; ops[i] = ops[j]; ops[j] = x; }
+    free(R.tb);
+    return c;
+}

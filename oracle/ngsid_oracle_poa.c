@@ -1,0 +1,459 @@
+/* ngsid_oracle_poa.c - CPU restatement of the consensus + polishing path (spoa-style POA, racon-style windows).
+ * TEST INFRASTRUCTURE ONLY (see ngsid_oracle.h).
+ *
+ * PARITY UNPINNED: spoa 4.0.7, racon 1.4.20 and minimap2 2.23 are external binaries that are not in
+ * /root/reference and not in this image (call sites consensus.py:87,121,122; the reference holds no test
+ * vectors for them).  What follows restates their published algorithms [from memory of the upstream
+ * sources] with this build's documented choices, and is pinned by synthetic ground truth
+ * (tests/test_consensus_*.py: consensus == generating amplicon).
+ *
+ *   spoa  `spoa reads.fq -l 0 -r 0 -g -2`: m=+5 n=-4 g=-2, e=-6 => g>=e selects LINEAR gaps; local (SW)
+ *         alignment of each read to the DAG in file order; FASTQ => edge weight += (q[i-1]-33)+(q[i]-33);
+ *         mismatching base -> aligned sibling node; unaligned head/tail -> new branch;
+ *         consensus = heaviest bundle with branch completion.
+ *   racon defaults -w 500 -q 10 -e 0.3 -m 3 -x -5 -g -4: windows of the backbone, backbone first with
+ *         zero weight, layers added by global alignment (full-span) or to the spanned sub-graph
+ *         (here: graph ends free), consensus = heaviest bundle; TGS windows are end-trimmed by coverage.
+ *
+ * BUILD CHOICES (shared, bit for bit, with the HIP kernels in ngspeciesid_amd/csrc/k_poa.hip):
+ *   - banded DP: row of node v covers `band` columns centred on the node's anchor (its coordinate in the
+ *     first sequence of the graph) scaled to the aligned sequence;
+ *   - topological order is maintained incrementally: a new node is inserted immediately before the next
+ *     already-existing node the alignment uses (or at the end);
+ *   - depth tiling: a group is consumed in tiles of `tile_depth` sequences in file order; every tile is an
+ *     exact-order POA; tile consensuses (weighted by the reads they stand for) are merged by the same
+ *     procedure, level by level.  tile_depth<=0 means one tile = plain spoa order for the whole group;
+ *   - a graph that would exceed its node capacity is closed (its consensus is emitted) and a new graph is
+ *     started with the sequence that did not fit.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include "ngsid_oracle.h"
+
+#define PNEG (-(1 << 28))
+#define SRC_SLOT 63
+
+/* ---------------------------------------------------------------- graph */
+typedef struct {
+    int V, E, capV, capE;
+    uint8_t* code; int* anchor; int* in_first; int* in_last; int* out_first; int* out_last; int* ring; uint32_t* cov;
+    int* e_tail; int* e_head; int64_t* e_w; int* e_next_in; int* e_next_out;
+    int* order; int* rank;
+    int L0;            /* length of the first sequence (anchor coordinate range) */
+    uint64_t cw_sum;   /* count weight of the sequences merged (backbone excluded) */
+} graph;
+
+static void g_init(graph* G, int capV) {
+    memset(G, 0, sizeof *G); G->capV = capV; G->capE = capV * 4 + 16;
+    G->code = malloc((size_t)capV); G->anchor = malloc(sizeof(int) * (size_t)capV); G->in_first = malloc(sizeof(int) * (size_t)capV); G->in_last = malloc(sizeof(int) * (size_t)capV);
+    G->out_first = malloc(sizeof(int) * (size_t)capV); G->out_last = malloc(sizeof(int) * (size_t)capV); G->ring = malloc(sizeof(int) * (size_t)capV); G->cov = malloc(sizeof(uint32_t) * (size_t)capV);
+    G->order = malloc(sizeof(int) * (size_t)capV); G->rank = malloc(sizeof(int) * (size_t)capV);
+    G->e_tail = malloc(sizeof(int) * (size_t)G->capE); G->e_head = malloc(sizeof(int) * (size_t)G->capE); G->e_w = malloc(sizeof(int64_t) * (size_t)G->capE);
+    G->e_next_in = malloc(sizeof(int) * (size_t)G->capE); G->e_next_out = malloc(sizeof(int) * (size_t)G->capE);
+}
+static void g_free(graph* G) {
+    free(G->code); free(G->anchor); free(G->in_first); free(G->in_last); free(G->out_first); free(G->out_last); free(G->ring); free(G->cov);
+    free(G->order); free(G->rank); free(G->e_tail); free(G->e_head); free(G->e_w); free(G->e_next_in); free(G->e_next_out);
+}
+static void g_reset(graph* G) { G->V = 0; G->E = 0; G->L0 = 0; G->cw_sum = 0; }
+static int g_new_node(graph* G, uint8_t c, int anchor) {
+    int v = G->V++; G->code[v] = c; G->anchor[v] = anchor; G->in_first[v] = G->in_last[v] = G->out_first[v] = G->out_last[v] = -1; G->ring[v] = v; G->cov[v] = 0; return v;
+}
+static void g_add_edge(graph* G, int a, int b, int64_t w) {
+    for (int e = G->out_first[a]; e >= 0; e = G->e_next_out[e]) if (G->e_head[e] == b) { G->e_w[e] += w; return; }
+    if (G->E == G->capE) { G->capE *= 2; G->e_tail = realloc(G->e_tail, sizeof(int) * (size_t)G->capE); G->e_head = realloc(G->e_head, sizeof(int) * (size_t)G->capE); G->e_w = realloc(G->e_w, sizeof(int64_t) * (size_t)G->capE);
+        G->e_next_in = realloc(G->e_next_in, sizeof(int) * (size_t)G->capE); G->e_next_out = realloc(G->e_next_out, sizeof(int) * (size_t)G->capE); }
+    int e = G->E++; G->e_tail[e] = a; G->e_head[e] = b; G->e_w[e] = w; G->e_next_in[e] = -1; G->e_next_out[e] = -1;
+    if (G->out_last[a] < 0) G->out_first[a] = e; else G->e_next_out[G->out_last[a]] = e; G->out_last[a] = e;
+    if (G->in_last[b] < 0) G->in_first[b] = e; else G->e_next_in[G->in_last[b]] = e; G->in_last[b] = e;
+}
+
+/* one sequence handed to the tile engine */
+typedef struct {
+    const uint8_t* s; const uint8_t* q; int len;   /* q == NULL: uniform weight uw */
+    int uw; uint32_t cw; int mode; int a0, a1;     /* a1 < a0: span = whole first sequence */
+} pseq;
+static inline int wt(const pseq* S, int i) { return S->q ? (int)S->q[i] - 33 : S->uw; }
+
+static void g_add_first(graph* G, const pseq* S) {
+    for (int i = 0; i < S->len; ++i) { int v = g_new_node(G, S->s[i], i); G->order[v] = v; G->rank[v] = v; G->cov[v] = S->cw; if (i) g_add_edge(G, v - 1, v, (int64_t)wt(S, i - 1) + wt(S, i)); }
+    G->L0 = S->len; G->cw_sum += S->cw;
+}
+
+/* ---------------------------------------------------------------- banded alignment of one sequence to the graph
+ * H[r][c]: r = rank, c = column - lo[r]; columns 0..L (column j = j bases consumed).  Returns path pairs in forward order. */
+typedef struct { int node, pos; } ppair;
+
+static inline int band_lo(const graph* G, const pseq* S, int v, int BW) {
+    int a0 = S->a0, a1 = S->a1; if (a1 < a0) { a0 = 0; a1 = G->L0 - 1; }
+    long span = (long)a1 - a0 + 1; if (span < 1) span = 1;
+    long c = ((long)(G->anchor[v] - a0) * (long)S->len) / span;
+    long lo = c - BW / 2; long mx = (long)S->len + 1 - BW; if (mx < 0) mx = 0;
+    if (lo < 0) lo = 0; if (lo > mx) lo = mx;
+    return (int)lo;
+}
+
+static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW, ppair* path /* cap len+V */, int* npath) {
+    const int V = G->V, L = S->len, mode = S->mode;
+    int* H = malloc(sizeof(int) * (size_t)V * (size_t)BW); uint8_t* dir = malloc((size_t)V * (size_t)BW); int* lo = malloc(sizeof(int) * (size_t)V);
+    for (int r = 0; r < V; ++r) lo[r] = band_lo(G, S, G->order[r], BW);
+    int best = PNEG, br = -1, bc = -1;
+    for (int r = 0; r < V; ++r) {
+        const int v = G->order[r]; const int l0 = lo[r]; int* Hr = H + (size_t)r * BW; uint8_t* Dr = dir + (size_t)r * BW;
+        const int nopred = G->in_first[v] < 0;
+        const int use_src = nopred || mode == NGSID_POA_SEMI;
+        for (int c = 0; c < BW; ++c) {
+            const int j = l0 + c;
+            if (j > L) { Hr[c] = PNEG; Dr[c] = 3; continue; }
+            int bestv = PNEG, bd = 3, slot = 0;
+            /* diag over predecessors in in-edge order, then the virtual source */
+            if (j >= 1) {
+                const int sc = (G->code[v] == S->s[j - 1]) ? m : n;
+                for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e], ++slot) {
+                    const int pr = G->rank[G->e_tail[e]]; const int pc = j - 1 - lo[pr];
+                    if (pc < 0 || pc >= BW) continue;
+                    const int hv = H[(size_t)pr * BW + pc]; if (hv <= PNEG) continue;
+                    if (hv + sc > bestv) { bestv = hv + sc; bd = 0 | (slot << 2); }
+                }
+                if (use_src) { const int sv = (mode == NGSID_POA_LOCAL) ? 0 : (j - 1) * g; if (sv + sc > bestv) { bestv = sv + sc; bd = 0 | (SRC_SLOT << 2); } }
+            }
+            /* up (node consumed, no base) */
+            slot = 0;
+            for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e], ++slot) {
+                const int pr = G->rank[G->e_tail[e]]; const int pc = j - lo[pr];
+                if (pc < 0 || pc >= BW) continue;
+                const int hv = H[(size_t)pr * BW + pc]; if (hv <= PNEG) continue;
+                if (hv + g > bestv) { bestv = hv + g; bd = 1 | (slot << 2); }
+            }
+            if (nopred && mode != NGSID_POA_SEMI) { const int sv = (mode == NGSID_POA_LOCAL) ? 0 : j * g; if (sv + g > bestv) { bestv = sv + g; bd = 1 | (SRC_SLOT << 2); } }
+            /* left (base consumed, no node) */
+            if (c >= 1 && Hr[c - 1] > PNEG && Hr[c - 1] + g > bestv) { bestv = Hr[c - 1] + g; bd = 2; }
+            if (mode == NGSID_POA_LOCAL && bestv <= 0) { bestv = 0; bd = 3; }
+            Hr[c] = bestv; Dr[c] = (uint8_t)bd;
+            if (bestv > PNEG) {
+                if (mode == NGSID_POA_LOCAL) { if (bestv > best) { best = bestv; br = r; bc = c; } }
+                else if (j == L && (mode == NGSID_POA_SEMI || G->out_first[v] < 0)) { if (bestv > best) { best = bestv; br = r; bc = c; } }
+            }
+        }
+    }
+    int np = 0, ok = 1;
+    if (br < 0 || (mode == NGSID_POA_LOCAL && best <= 0)) {
+        if (mode == NGSID_POA_LOCAL) { for (int i = 0; i < L; ++i) { path[np].node = -1; path[np].pos = i; ++np; } }   /* nothing aligned: whole read becomes a branch */
+        else ok = 0;
+    } else {
+        /* walk back; collect reversed */
+        int r = br, c = bc, jend = lo[br] + bc;
+        ppair* rev = malloc(sizeof(ppair) * (size_t)(L + V + 2)); int nr = 0;
+        for (int i = L - 1; i >= jend; --i) { rev[nr].node = -1; rev[nr].pos = i; ++nr; }        /* unaligned tail (local) */
+        int j = jend;
+        for (;;) {
+            const int v = G->order[r]; const int d = dir[(size_t)r * BW + c]; const int type = d & 3, slot = d >> 2;
+            if (type == 3) break;
+            if (type == 2) { rev[nr].node = -1; rev[nr].pos = j - 1; ++nr; --j; --c; continue; }
+            if (type == 0) { rev[nr].node = v; rev[nr].pos = j - 1; ++nr; --j; } else { rev[nr].node = v; rev[nr].pos = -1; ++nr; }
+            if (slot == SRC_SLOT) break;
+            int e = G->in_first[v]; for (int t = 0; t < slot; ++t) e = G->e_next_in[e];
+            r = G->rank[G->e_tail[e]]; c = j - lo[r];
+        }
+        for (int i = j - 1; i >= 0; --i) { rev[nr].node = -1; rev[nr].pos = i; ++nr; }           /* unaligned head / leading insertions */
+        for (int i = nr - 1; i >= 0; --i) path[np++] = rev[i];
+        free(rev);
+    }
+    *npath = np;
+    free(H); free(dir); free(lo);
+    return ok;
+}
+
+/* ---------------------------------------------------------------- add an aligned sequence (returns 0 if it does not fit) */
+static int g_add_alignment(graph* G, const pseq* S, const ppair* path, int np) {
+    const int L = S->len, V0 = G->V;
+    int* alnode = malloc(sizeof(int) * (size_t)(L + 1)); int* nodeof = malloc(sizeof(int) * (size_t)(L + 1)); int* ref = malloc(sizeof(int) * (size_t)(L + 1));
+    for (int i = 0; i < L; ++i) alnode[i] = -1;
+    for (int p = 0; p < np; ++p) if (path[p].pos >= 0 && path[p].node >= 0) alnode[path[p].pos] = path[p].node;
+    /* existing node per position, count new */
+    int nnew = 0;
+    for (int i = 0; i < L; ++i) {
+        int v = alnode[i], found = -1;
+        if (v >= 0) { if (G->code[v] == S->s[i]) found = v; else for (int u = G->ring[v]; u != v; u = G->ring[u]) if (G->code[u] == S->s[i]) { found = u; break; } }
+        nodeof[i] = found; if (found < 0) ++nnew;
+    }
+    if (V0 + nnew > G->capV || G->E + L > 2 * G->capV) { free(alnode); free(nodeof); free(ref); return 0; }   /* node / edge (2x) capacity */
+    /* ref(i) = aligned node of the first aligned position >= i (insertion point: immediately before it), -1 = end */
+    { int nx = -1; for (int i = L - 1; i >= 0; --i) { if (alnode[i] >= 0) nx = alnode[i]; ref[i] = nx; } }
+    /* create nodes in sequence order; anchor from the nearest aligned position at or before i, else after, else a0 */
+    int lastal = -1;
+    int* newlist = malloc(sizeof(int) * (size_t)(nnew + 1)); int* newref = malloc(sizeof(int) * (size_t)(nnew + 1)); int nn = 0;
+    for (int i = 0; i < L; ++i) {
+        if (alnode[i] >= 0) lastal = alnode[i];
+        if (nodeof[i] >= 0) continue;
+        int anc = lastal >= 0 ? G->anchor[lastal] : (ref[i] >= 0 ? G->anchor[ref[i]] : (S->a1 < S->a0 ? 0 : S->a0));
+        int y = g_new_node(G, S->s[i], anc);
+        if (alnode[i] >= 0) { int v = alnode[i]; G->ring[y] = G->ring[v]; G->ring[v] = y; }
+        nodeof[i] = y; newlist[nn] = y; newref[nn] = ref[i]; ++nn;
+    }
+    /* ranks: every new node goes immediately before its ref node (in sequence order), or to the end */
+    {
+        int* before = calloc((size_t)V0 + 1, sizeof(int));
+        for (int t = 0; t < nn; ++t) before[newref[t] >= 0 ? G->rank[newref[t]] : V0]++;
+        int* norder = malloc(sizeof(int) * (size_t)G->V); int* start = malloc(sizeof(int) * ((size_t)V0 + 1)); int acc = 0;
+        for (int r = 0; r <= V0; ++r) { start[r] = r + acc; acc += before[r]; if (r < V0) norder[r + acc] = G->order[r]; }
+        memset(before, 0, sizeof(int) * ((size_t)V0 + 1));
+        for (int t = 0; t < nn; ++t) { int r = newref[t] >= 0 ? G->rank[newref[t]] : V0; norder[start[r] + before[r]] = newlist[t]; before[r]++; }
+        for (int r = 0; r < G->V; ++r) { G->order[r] = norder[r]; G->rank[norder[r]] = r; }
+        free(before); free(norder); free(start);
+    }
+    for (int i = 0; i < L; ++i) { G->cov[nodeof[i]] += S->cw; if (i) g_add_edge(G, nodeof[i - 1], nodeof[i], (int64_t)wt(S, i - 1) + wt(S, i)); }
+    G->cw_sum += S->cw;
+    free(alnode); free(nodeof); free(ref); free(newlist); free(newref);
+    return 1;
+}
+
+/* ---------------------------------------------------------------- heaviest bundle (spoa Graph::TraverseHeaviestBundle + BranchCompletion) */
+static int g_consensus(const graph* G, uint8_t* out, uint32_t* cov_out) {
+    const int V = G->V; if (V == 0) return 0;
+    int* pred = malloc(sizeof(int) * (size_t)V); int64_t* sc = malloc(sizeof(int64_t) * (size_t)V);
+    for (int v = 0; v < V; ++v) { pred[v] = -1; sc[v] = -1; }
+    int mx = -1;
+    for (int r = 0; r < V; ++r) {
+        int v = G->order[r];
+        for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e]) {
+            int t = G->e_tail[e];
+            if (sc[v] < G->e_w[e] || (sc[v] == G->e_w[e] && sc[pred[v]] <= sc[t])) { sc[v] = G->e_w[e]; pred[v] = t; }
+        }
+        if (pred[v] != -1) sc[v] += sc[pred[v]];
+        if (mx < 0 || sc[mx] < sc[v]) mx = v;
+    }
+    while (G->out_first[mx] >= 0) {            /* branch completion */
+        int start = mx;
+        for (int e = G->out_first[start]; e >= 0; e = G->e_next_out[e])
+            for (int f = G->in_first[G->e_head[e]]; f >= 0; f = G->e_next_in[f]) if (G->e_tail[f] != start) sc[G->e_tail[f]] = -1;
+        int m2 = -1;
+        for (int r = G->rank[start] + 1; r < V; ++r) {
+            int v = G->order[r]; sc[v] = -1; pred[v] = -1;
+            for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e]) {
+                int t = G->e_tail[e]; if (sc[t] == -1) continue;
+                if (sc[v] < G->e_w[e] || (sc[v] == G->e_w[e] && sc[pred[v]] <= sc[t])) { sc[v] = G->e_w[e]; pred[v] = t; }
+            }
+            if (pred[v] != -1) sc[v] += sc[pred[v]];
+            if (m2 < 0 || sc[m2] < sc[v]) m2 = v;
+        }
+        if (m2 < 0) break;
+        mx = m2;
+    }
+    int n = 0; for (int v = mx; v != -1; v = pred[v]) ++n;
+    int i = n; for (int v = mx; v != -1; v = pred[v]) { --i; out[i] = G->code[v]; if (cov_out) { uint32_t c = G->cov[v]; for (int u = G->ring[v]; u != v; u = G->ring[u]) c += G->cov[u]; cov_out[i] = c; } }
+    free(pred); free(sc);
+    return n;
+}
+
+/* ---------------------------------------------------------------- tile engine: sequences in order -> one or more (consensus, cw) */
+typedef struct { uint8_t* s; uint32_t* cov; int len; uint64_t cw; } pout;
+typedef struct { int m, n, g, band, node_cap; } pprm;
+
+static int cap_for(int L0, int node_cap) { long c = (long)L0 * (node_cap > 0 ? node_cap : 32) / 16; if (c < L0 + 64) c = L0 + 64; return (int)c; }
+
+/* returns number of outputs appended to outs (caller frees .s/.cov) */
+static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* P, pout* outs, int want_cov) {
+    int nout = 0, maxlen = backbone ? backbone->len : 0;
+    for (int i = 0; i < ns; ++i) if (seqs[i].len > maxlen) maxlen = seqs[i].len;
+    int L0 = backbone ? backbone->len : (ns ? seqs[0].len : 0);
+    int capV = cap_for(L0 > 0 ? L0 : 1, P->node_cap); if (capV < 2 * maxlen + 64) { /* capacity follows the FIRST sequence; longer members may trigger a split */ }
+    graph G; g_init(&G, capV > maxlen + 1 ? capV : maxlen + 1);
+    ppair* path = malloc(sizeof(ppair) * (size_t)(maxlen + G.capV + 4));
+    int members = 0;
+#define EMIT() do { if (G.V > 0 && members > 0) { pout* o = &outs[nout++]; o->s = malloc((size_t)G.V + 1); o->cov = want_cov ? malloc(sizeof(uint32_t) * ((size_t)G.V + 1)) : NULL; o->len = g_consensus(&G, o->s, o->cov); o->cw = G.cw_sum; } } while (0)
+    for (int i = 0; i < ns; ++i) {
+        const pseq* S = &seqs[i];
+        if (S->len <= 0) continue;
+        if (G.V == 0) {
+            if (backbone) { g_add_first(&G, backbone); }
+            else { if (S->len > G.capV) continue; g_add_first(&G, S); members = 1; continue; }
+        }
+        int np = 0;
+        int ok = poa_align(&G, S, P->m, P->n, P->g, P->band, path, &np);
+        if (!ok) continue;                                   /* no valid end cell inside the band: sequence dropped */
+        if (!g_add_alignment(&G, S, path, np)) {
+            /* does not fit: close this graph, start a new one with this sequence */
+            EMIT(); g_reset(&G); members = 0;
+            if (backbone) { g_add_first(&G, backbone); ok = poa_align(&G, S, P->m, P->n, P->g, P->band, path, &np); if (ok && g_add_alignment(&G, S, path, np)) members = 1; }
+            else if (S->len <= G.capV) { g_add_first(&G, S); members = 1; }
+            continue;
+        }
+        members++;
+    }
+    EMIT();
+    free(path); g_free(&G);
+    return nout;
+}
+
+/* hierarchy: level 0 = the given sequences; tiles of D in order; repeat on the tile consensuses until one is left */
+static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P, int D, int upper_mode, uint8_t** cons, uint32_t** cov, int want_cov) {
+    pseq* cur = seqs; int ncur = ns; uint8_t** owned = NULL; int nowned = 0; int level = 0;
+    *cons = NULL; if (cov) *cov = NULL;
+    if (ns == 0) return 0;
+    for (;;) {
+        int Dl = D > 0 ? D : ncur;
+        int ntiles = (ncur + Dl - 1) / Dl;
+        pout* outs = malloc(sizeof(pout) * (size_t)(ncur + 1)); int nout = 0;
+        for (int t = 0; t < ntiles; ++t) { int a = t * Dl, b = a + Dl < ncur ? a + Dl : ncur; nout += run_tile(cur + a, b - a, backbone, P, outs + nout, want_cov && ntiles == 1); }
+        if (level > 0) { free(cur); for (int i = 0; i < nowned; ++i) free(owned[i]); free(owned); owned = NULL; nowned = 0; }
+        if (nout == 0) { free(outs); return 0; }
+        int pick = -1;
+        if (nout == 1) pick = 0;
+        else if (nout >= ncur) { pick = 0; for (int i = 1; i < nout; ++i) if (outs[i].cw > outs[pick].cw) pick = i; }   /* no progress: keep the best supported */
+        if (pick >= 0) {
+            *cons = outs[pick].s; int len = outs[pick].len; if (cov) *cov = outs[pick].cov; else free(outs[pick].cov);
+            for (int i = 0; i < nout; ++i) if (i != pick) { free(outs[i].s); free(outs[i].cov); }
+            free(outs); return len;
+        }
+        pseq* nx = malloc(sizeof(pseq) * (size_t)nout); owned = malloc(sizeof(uint8_t*) * (size_t)nout); nowned = nout;
+        for (int i = 0; i < nout; ++i) {
+            uint64_t cw = outs[i].cw; int uw = cw > (1u << 20) ? (1 << 20) : (int)cw; if (uw < 1) uw = 1;
+            nx[i].s = outs[i].s; nx[i].q = NULL; nx[i].len = outs[i].len; nx[i].uw = uw; nx[i].cw = (uint32_t)(cw > 0xffffffffull ? 0xffffffffull : cw); nx[i].mode = upper_mode; nx[i].a0 = 0; nx[i].a1 = -1;
+            owned[i] = outs[i].s; free(outs[i].cov);
+        }
+        free(outs); cur = nx; ncur = nout; ++level;
+    }
+}
+
+int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint64_t* grp_off, uint64_t n_groups,
+                             const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed) {
+    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap };
+    uint64_t total = 0; int overflow = 0; cons_off[0] = 0;
+    for (uint64_t g = 0; g < n_groups; ++g) {
+        int ns = (int)(grp_off[g + 1] - grp_off[g]);
+        pseq* seqs = malloc(sizeof(pseq) * (size_t)(ns + 1));
+        for (int i = 0; i < ns; ++i) {
+            uint64_t r = grp_off[g] + (uint64_t)i;
+            seqs[i].s = reads->seq + reads->off[r]; seqs[i].q = reads->qual ? reads->qual + reads->off[r] : NULL; seqs[i].len = (int)(reads->off[r + 1] - reads->off[r]);
+            seqs[i].uw = 1; seqs[i].cw = 1; seqs[i].mode = prm->mode; seqs[i].a0 = 0; seqs[i].a1 = -1;
+        }
+        uint8_t* c = NULL; int len = run_hierarchy(seqs, ns, NULL, &P, prm->tile_depth, prm->mode, &c, NULL, 0);
+        if (total + (uint64_t)len <= cons_cap) memcpy(cons + total, c, (size_t)len); else overflow = 1;
+        total += (uint64_t)len; cons_off[g + 1] = total;
+        free(c); free(seqs);
+    }
+    if (needed) *needed = total;
+    if (overflow) return NGSID_ERR_CAPACITY;
+    return NGSID_OK;
+}
+
+/* ---------------------------------------------------------------- racon-style polishing (consensus.py:107-126) */
+int ongsid_i_hpc_minimizers(const uint8_t* s, int n, int k, int w, uint64_t* codes, uint32_t* pos);
+int ongsid_i_sg_ops(const uint8_t* q, int n, const uint8_t* t, int m, int match, int mismatch, int open, int ext, uint8_t* ops);
+
+static int cmp_u64(const void* a, const void* b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : (x > y); }
+static int in_sorted(const uint64_t* a, int n, uint64_t key) { int lo = 0, hi = n; while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; } return lo < n && a[lo] == key; }
+static uint8_t comp_base(uint8_t c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
+
+typedef struct { pseq* v; int n, cap; } layervec;
+static void lv_push(layervec* L, pseq s) { if (L->n == L->cap) { L->cap = L->cap ? L->cap * 2 : 16; L->v = realloc(L->v, sizeof(pseq) * (size_t)L->cap); } L->v[L->n++] = s; }
+
+int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint64_t* grp_off, uint64_t n_groups,
+                      const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used) {
+    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap };
+    const int W = prm->window > 0 ? prm->window : 500;
+    uint64_t total = 0; int overflow = 0; out_off[0] = 0;
+    for (uint64_t g = 0; g < n_groups; ++g) {
+        int Blen = (int)(backbones->off[g + 1] - backbones->off[g]);
+        uint8_t* B = malloc((size_t)Blen + 1); memcpy(B, backbones->seq + backbones->off[g], (size_t)Blen);
+        const int ns = (int)(grp_off[g + 1] - grp_off[g]);
+        /* ---- strand detection by shared (HPC) minimizers with the initial backbone: replaces minimap2's strand call */
+        uint64_t* cf = malloc(sizeof(uint64_t) * (size_t)(Blen + 1)); uint64_t* cr = malloc(sizeof(uint64_t) * (size_t)(Blen + 1)); uint32_t* tp = malloc(sizeof(uint32_t) * (size_t)(Blen + 1));
+        uint8_t* Brc = malloc((size_t)Blen + 1); for (int i = 0; i < Blen; ++i) Brc[i] = comp_base(B[Blen - 1 - i]);
+        int nf = ongsid_i_hpc_minimizers(B, Blen, prm->k, prm->w, cf, tp); int nr = ongsid_i_hpc_minimizers(Brc, Blen, prm->k, prm->w, cr, tp);
+        if (nf < 0 || nr < 0) { free(B); free(cf); free(cr); free(tp); free(Brc); return NGSID_ERR_ALPHABET; }
+        qsort(cf, (size_t)nf, sizeof(uint64_t), cmp_u64); qsort(cr, (size_t)nr, sizeof(uint64_t), cmp_u64);
+        int8_t* orient = malloc((size_t)ns + 1); uint8_t** rs = calloc((size_t)ns + 1, sizeof(uint8_t*)); uint8_t** rq = calloc((size_t)ns + 1, sizeof(uint8_t*)); int* rl = malloc(sizeof(int) * ((size_t)ns + 1));
+        double totlen = 0.0; int rc_err = 0;
+        for (int i = 0; i < ns; ++i) {
+            uint64_t r = grp_off[g] + (uint64_t)i; const uint8_t* s = reads->seq + reads->off[r]; const uint8_t* q = reads->qual ? reads->qual + reads->off[r] : NULL; int n = (int)(reads->off[r + 1] - reads->off[r]);
+            rl[i] = n; totlen += n;
+            uint64_t* c = malloc(sizeof(uint64_t) * (size_t)(n + 1)); uint32_t* p = malloc(sizeof(uint32_t) * (size_t)(n + 1));
+            int cnt = ongsid_i_hpc_minimizers(s, n, prm->k, prm->w, c, p);
+            if (cnt < 0) { rc_err = 1; free(c); free(p); orient[i] = -1; continue; }
+            int a = 0, b = 0; for (int t = 0; t < cnt; ++t) { a += in_sorted(cf, nf, c[t]); b += in_sorted(cr, nr, c[t]); }
+            orient[i] = (a == 0 && b == 0) ? -1 : (b > a ? 1 : 0);
+            free(c); free(p);
+            if (orient[i] < 0) continue;
+            rs[i] = malloc((size_t)n + 1); rq[i] = q ? malloc((size_t)n + 1) : NULL;
+            if (orient[i] == 0) { memcpy(rs[i], s, (size_t)n); if (q) memcpy(rq[i], q, (size_t)n); }
+            else for (int x = 0; x < n; ++x) { rs[i][x] = comp_base(s[n - 1 - x]); if (q) rq[i][x] = q[n - 1 - x]; }
+        }
+        free(cf); free(cr); free(tp); free(Brc);
+        if (rc_err) { for (int i = 0; i < ns; ++i) { free(rs[i]); free(rq[i]); } free(rs); free(rq); free(rl); free(orient); free(B); return NGSID_ERR_ALPHABET; }
+        const int tgs = ns > 0 && (totlen / (double)ns) > 1000.0;
+        uint64_t used = 0;
+        for (int it = 0; it < prm->iters; ++it) {
+            const int nwin = (Blen + W - 1) / W;
+            layervec* LV = calloc((size_t)nwin + 1, sizeof(layervec));
+            used = 0;
+            for (int i = 0; i < ns; ++i) {
+                if (orient[i] < 0) continue;
+                const int n = rl[i];
+                uint8_t* ops = malloc((size_t)(n + Blen + 2));
+                int c = ongsid_i_sg_ops(rs[i], n, B, Blen, prm->aln_match, prm->aln_mismatch, prm->aln_open, prm->aln_ext, ops);
+                int qi = 0, ti = 0, qb = -1, tb = -1, qe = -1, te = -1;
+                int* wf = malloc(sizeof(int) * 4 * ((size_t)nwin + 1)); for (int x = 0; x < 4 * nwin; ++x) wf[x] = -1;
+                for (int x = 0; x < c; ++x) {
+                    if (ops[x] <= 1) {
+                        if (qb < 0) { qb = qi; tb = ti; } qe = qi; te = ti;
+                        int wdx = ti / W; if (wf[wdx * 4] < 0) { wf[wdx * 4] = qi; wf[wdx * 4 + 2] = ti; } wf[wdx * 4 + 1] = qi; wf[wdx * 4 + 3] = ti;
+                        ++qi; ++ti;
+                    } else if (ops[x] == 2) ++qi; else ++ti;
+                }
+                free(ops);
+                int contributed = 0;
+                if (qb >= 0) {
+                    int qs = qe - qb + 1, ts = te - tb + 1; int mn = qs < ts ? qs : ts, mx = qs < ts ? ts : qs;
+                    if (!(1.0 - (double)mn / (double)mx > prm->error_threshold)) {
+                        for (int wdx = 0; wdx < nwin; ++wdx) {
+                            if (wf[wdx * 4] < 0) continue;
+                            int qf = wf[wdx * 4], ql = wf[wdx * 4 + 1], tf = wf[wdx * 4 + 2], tl = wf[wdx * 4 + 3];
+                            int len = ql - qf + 1; if ((double)len < 0.02 * (double)W) continue;
+                            if (rq[i]) { long sq = 0; for (int x = qf; x <= ql; ++x) sq += (long)rq[i][x] - 33; if ((double)sq / (double)len < prm->quality_threshold) continue; }
+                            int ws = wdx * W, wlen = (Blen - ws) < W ? (Blen - ws) : W;
+                            int begin = tf - ws, end = tl - ws; int offset = (int)(0.01 * (double)wlen);
+                            pseq S; S.s = rs[i] + qf; S.q = rq[i] ? rq[i] + qf : NULL; S.len = len; S.uw = 1; S.cw = 1; S.a0 = begin; S.a1 = end;
+                            S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI;
+                            lv_push(&LV[wdx], S); contributed = 1;
+                        }
+                    }
+                }
+                free(wf);
+                used += (uint64_t)contributed;
+            }
+            /* ---- window consensuses */
+            uint8_t* NB = malloc((size_t)Blen * 3 + 1024); int nb = 0, nbcap = Blen * 3 + 1024;
+            for (int wdx = 0; wdx < nwin; ++wdx) {
+                int ws = wdx * W, wlen = (Blen - ws) < W ? (Blen - ws) : W;
+                uint8_t* c = NULL; uint32_t* cov = NULL; int len = 0;
+                if (LV[wdx].n >= 2) {
+                    pseq bb; bb.s = B + ws; bb.q = NULL; bb.len = wlen; bb.uw = 0; bb.cw = 0; bb.mode = NGSID_POA_GLOBAL; bb.a0 = 0; bb.a1 = -1;
+                    len = run_hierarchy(LV[wdx].v, LV[wdx].n, &bb, &P, prm->tile_depth, NGSID_POA_GLOBAL, &c, &cov, 1);
+                    if (len > 0 && tgs && prm->trim && cov) {
+                        uint32_t avg = (uint32_t)(LV[wdx].n / 2); int b = 0, e = len - 1;
+                        for (; b < len; ++b) if (cov[b] >= avg) break;
+                        for (; e >= 0; --e) if (cov[e] >= avg) break;
+                        if (b < e) { memmove(c, c + b, (size_t)(e - b + 1)); len = e - b + 1; }
+                    }
+                }
+                if (len <= 0) { free(c); c = malloc((size_t)wlen + 1); memcpy(c, B + ws, (size_t)wlen); len = wlen; }
+                if (nb + len > nbcap) { nbcap = (nb + len) * 2; NB = realloc(NB, (size_t)nbcap); }
+                memcpy(NB + nb, c, (size_t)len); nb += len;
+                free(c); free(cov); free(LV[wdx].v);
+            }
+            free(LV); free(B); B = NB; Blen = nb;
+        }
+        if (n_used) n_used[g] = used;
+        if (total + (uint64_t)Blen <= out_cap) memcpy(out + total, B, (size_t)Blen); else overflow = 1;
+        total += (uint64_t)Blen; out_off[g + 1] = total;
+        for (int i = 0; i < ns; ++i) { free(rs[i]); free(rq[i]); } free(rs); free(rq); free(rl); free(orient); free(B);
+    }
+    if (needed) *needed = total;
+    if (overflow) return NGSID_ERR_CAPACITY;
+    return NGSID_OK;
+}

@@ -1,0 +1,73 @@
+"""GPU parity for the POA tile engine and the polisher: HIP (through the C-ABI) == CPU oracle, byte for byte."""
+import numpy as np
+import pytest
+from ngspeciesid_amd import synth
+from ngspeciesid_amd._capi import ReadSet, poa_params, polish_params, POA_LOCAL, POA_GLOBAL
+from test_consensus_oracle import make_set, interior_ed
+
+pytestmark = pytest.mark.gpu
+
+
+def test_identical_reads(gpu_api):
+    s = "ACGTTGCATGCATGCCGATAGCTAGCTAGGATCGATCGATTTAGCGCGATATCGCGATCGATCGGGATATATCGCGC"
+    rs = ReadSet.from_strings([s] * 5, ["I" * len(s)] * 5)
+    for mode in (POA_LOCAL, POA_GLOBAL):
+        assert gpu_api.poa_consensus(rs, [0, 5], poa_params(mode=mode, band=64))[0] == s
+
+
+@pytest.mark.parametrize("cfg", [dict(n=12, L=200, D=0, band=64), dict(n=40, L=500, D=8, band=128), dict(n=40, L=500, D=0, band=128),
+                                 dict(n=100, L=750, D=8, band=128), dict(n=30, L=400, D=4, band=256), dict(n=64, L=1500, D=16, band=128, mu=25.0, node_cap=24)])
+@pytest.mark.parametrize("mode", [POA_LOCAL, POA_GLOBAL])
+def test_poa_vs_oracle(gpu_api, oracle, cfg, mode):
+    sp, rd, rs = make_set(cfg["n"], L=cfg["L"], mu=cfg.get("mu", 17.0), seed=5)
+    prm = poa_params(mode=mode, tile_depth=cfg["D"], band=cfg["band"], node_cap=cfg.get("node_cap", 0))
+    got = gpu_api.poa_consensus(rs, [0, rs.n], prm)[0]
+    exp = oracle.poa_consensus(rs, [0, rs.n], prm)[0]
+    assert got == exp, "len got %d exp %d" % (len(got), len(exp))
+    assert interior_ed(got, sp[0].tobytes().decode()) <= 2
+
+
+def test_poa_groups_vs_oracle(gpu_api, oracle):
+    sp, rd, rs = make_set(90, L=300, nsp=3, seed=9)
+    order = np.argsort(rd["species"].numpy(), kind="stable")
+    rs2 = ReadSet.from_strings([rs.get(i)[0] for i in order], [rs.get(i)[1] for i in order])
+    cnt = np.bincount(rd["species"].numpy(), minlength=3)
+    goff = np.concatenate(([0], np.cumsum(cnt)))
+    goff = np.insert(goff, 2, goff[1])                # add an empty group
+    prm = poa_params(tile_depth=8, band=128)
+    assert gpu_api.poa_consensus(rs2, goff, prm) == oracle.poa_consensus(rs2, goff, prm)
+    # FASTA input (no qualities): unit weights
+    rs3 = ReadSet(rs2.seq, None, rs2.off)
+    assert gpu_api.poa_consensus(rs3, goff, prm) == oracle.poa_consensus(rs3, goff, prm)
+
+
+def test_poa_small_capacity_splits(gpu_api, oracle):
+    """node_cap small enough that tiles overflow and are split: the capacity rule must match the oracle exactly."""
+    sp, rd, rs = make_set(48, L=400, mu=12.0, seed=7)
+    prm = poa_params(tile_depth=16, band=128, node_cap=18)
+    assert gpu_api.poa_consensus(rs, [0, rs.n], prm) == oracle.poa_consensus(rs, [0, rs.n], prm)
+
+
+@pytest.mark.parametrize("cfg", [dict(n=60, L=600, it=1, D=8, rc=0.5), dict(n=120, L=750, it=3, D=8, rc=0.0), dict(n=40, L=1300, it=2, D=8, rc=0.3, mu=25.0), dict(n=30, L=500, it=2, D=0, rc=0.5)])
+def test_polish_vs_oracle(gpu_api, oracle, cfg):
+    sp, rd, rs = make_set(cfg["n"], L=cfg["L"], mu=cfg.get("mu", 17.0), seed=11, rc_fraction=cfg["rc"])
+    fw = int(np.nonzero(rd["strand"].numpy() == 0)[0][0])
+    bb = ReadSet.from_strings([rs.get(fw)[0]])
+    prm = polish_params(iters=cfg["it"], tile_depth=cfg["D"], band=128)
+    got, gused = gpu_api.polish(bb, rs, [0, rs.n], prm)
+    exp, eused = oracle.polish(bb, rs, [0, rs.n], prm)
+    assert got == exp, "len got %d exp %d" % (len(got[0]), len(exp[0]))
+    assert np.array_equal(gused, eused)
+    assert interior_ed(got[0], sp[0].tobytes().decode()) <= 3
+
+
+def test_polish_two_groups(gpu_api, oracle):
+    sp, rd, rs = make_set(80, L=600, nsp=2, seed=13, rc_fraction=0.4)
+    order = np.argsort(rd["species"].numpy(), kind="stable")
+    rs2 = ReadSet.from_strings([rs.get(i)[0] for i in order], [rs.get(i)[1] for i in order])
+    cnt = np.bincount(rd["species"].numpy(), minlength=2); goff = [0, int(cnt[0]), int(cnt[0] + cnt[1])]
+    bb = ReadSet.from_strings([sp[0].tobytes().decode()[5:-7], sp[1].tobytes().decode()])
+    prm = polish_params(iters=2, tile_depth=8, band=128)
+    got, gused = gpu_api.polish(bb, rs2, goff, prm)
+    exp, eused = oracle.polish(bb, rs2, goff, prm)
+    assert got == exp and np.array_equal(gused, eused)
