@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py - reads/s end-to-end (cluster + spoa-style consensus + racon-style polish x3) on synthetic 750 bp ONT reads.
+
+    python bench.py --gpus 1 --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one pass of the hot path over the whole batch of synthetic reads, inputs resident in HBM.
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for how roofline / cpu_baseline are obtained.
+"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+
+def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device):
+    """synthetic reads, scored (f1) and physically ordered by score descending (stable) = the greedy order."""
+    from ngspeciesid_amd import synth
+    from ngspeciesid_amd._capi import ReadSet
+    sp = synth.make_species(n_species, L, 0.15, seed=1)
+    rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed, device=device)
+    rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
+    score, err, keep = api.score_reads(rs, 13, 7.0)
+    keep_idx = np.nonzero(keep)[0]
+    perm = keep_idx[np.argsort(-score[keep_idx], kind="stable")]
+    off = rd["off"]; lens = (off[1:] - off[:-1])
+    perm_t = torch.from_numpy(perm).to(device)
+    nlen = lens[perm_t]
+    noff = torch.zeros(len(perm) + 1, dtype=torch.int64, device=device); noff[1:] = torch.cumsum(nlen, 0)
+    total = int(noff[-1].item())
+    nseq = torch.empty(total, dtype=torch.uint8, device=device); nqual = torch.empty(total, dtype=torch.uint8, device=device)
+    CH = 1 << 17
+    for a in range(0, len(perm), CH):
+        b = min(len(perm), a + CH)
+        l = nlen[a:b]; src0 = off[perm_t[a:b]]; dst0 = noff[a:b]
+        idx = torch.arange(int(l.sum().item()), device=device) - torch.repeat_interleave(dst0 - dst0[0], l)
+        src = idx + torch.repeat_interleave(src0, l)
+        d0 = int(dst0[0].item())
+        nseq[d0:d0 + len(src)] = rd["seq"][src]; nqual[d0:d0 + len(src)] = rd["qual"][src]
+    out = dict(seq=nseq, qual=nqual, off=noff, species=rd["species"][perm_t], score=score[perm], orig=perm)
+    return sp, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("NGSID_BENCH_READS", 1000000)), help="reads per GPU")
+    ap.add_argument("--species", type=int, default=5)
+    ap.add_argument("--length", type=int, default=750)
+    ap.add_argument("--mu", type=float, default=17.0)
+    ap.add_argument("--tile-depth", type=int, default=8)
+    ap.add_argument("--cpu-sample", type=int, default=1500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from ngspeciesid_amd import runtime, pipeline
+    from ngspeciesid_amd._capi import ReadSet
+    from ngspeciesid_amd.ptable import select_p_table
+    api = runtime.get_api(local)
+    ptab = select_p_table(13, 20)
+    sp, rd = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7 + rank, device=dev)
+    torch.cuda.synchronize()
+    rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
+    n = rs.n
+    acc_rank = np.asarray(rd["orig"], dtype=np.uint32)            # stand-in for the accession order (unique, deterministic)
+    kw = dict(k=13, w=20, abundance_ratio=0.02, racon_iter=3, tile_depth=args.tile_depth, band=128, p_shared=ptab)
+
+    def step(T=None):
+        return pipeline.run_hot_path(api, rs, rd["score"], acc_rank=acc_rank, timings=T, **kw)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    import ctypes as C
+    api.lib.ngsid_profile_enable(api.ctx, C.c_int32(1))
+    T = {}
+    barrier(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(T)
+    barrier(); dt = time.perf_counter() - t0
+    buf = C.create_string_buffer(1 << 16)
+    api.lib.ngsid_profile_read(api.ctx, buf, C.c_uint64(len(buf)))
+    api.lib.ngsid_profile_enable(api.ctx, C.c_int32(0))
+    kern = {}
+    for line in buf.value.decode().splitlines():
+        nm, cnt, ms = line.split(); kern[nm] = (int(cnt), float(ms))
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        tn = torch.tensor([n], device=dev, dtype=torch.float64); dist.all_reduce(tn); n_total = int(tn.item())
+    else:
+        n_total = n
+    if rank != 0:
+        return
+    reads_per_s = n_total * args.steps / dt
+    # ---- quality / property checks at full size (size-independent): cluster purity, consensus vs generating amplicon
+    spc = rd["species"].cpu().numpy(); rep_of = res["rep_of"]
+    big = [c for c in res["centers"]]
+    purity = float(sum(np.bincount(spc[rep_of == r]).max() for r in np.unique(rep_of)) / n)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util_seq import edit_distance
+    truths = [s.tobytes().decode() for s in sp]
+    ed = []
+    for c in big:
+        ed.append(min(min(edit_distance(c[3][a:len(c[3]) - b if b else None], t) for a in range(4) for b in range(4)) for t in truths))
+    # ---- roofline of the dominant kernel (HIP-event times on the library's own stream)
+    dom = max(kern.items(), key=lambda kv: kv[1][1]) if kern else (None, (0, 0.0))
+    f_aln = float(res["counters"][2]) / n
+    L, M = args.length, 118
+    per_read_bytes = {"k_sg_align": 4 * L, "k_poa_tile": 2 * L, "k_hpc_minimizers": 2 * L + 12 * M, "k_count_hits": 12 * M + 8, "k_decide_map": 12 * M + 8, "k_aln_next": 8}
+    roof = None
+    if dom[0]:
+        cnt, ms = dom[1]
+        if dom[0] == "k_sg_align":      # cluster aligner (f_aln*N pairs) + 3 polish alignments per read
+            units = (f_aln + 3.0) * n * args.steps
+        elif dom[0] == "k_poa_tile":    # 1 spoa pass + 3 polish passes per read
+            units = 4.0 * n * args.steps
+        else:
+            units = 1.0 * n * args.steps
+        alg_bytes_per_launch = units * per_read_bytes.get(dom[0], 2 * L) / max(cnt, 1)
+        avg_s = ms / 1e3 / max(cnt, 1)
+        ach = alg_bytes_per_launch / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": None,
+                "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
+                "note": "integer DP kernel: VALU/LDS-latency bound by construction, HBM fraction is small (DESIGN.md)"}
+    # ---- CPU baseline: the oracle (port of the reference CPU path) on a bounded sample of the same workload, 1 core
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        from oracle_lib import load_oracle
+        orc = load_oracle()
+        ns = min(args.cpu_sample, n)
+        # sample = an evenly strided subset (keeps the score order and the species mix)
+        idx = np.linspace(0, n - 1, ns).astype(np.int64)
+        seq = rd["seq"].cpu().numpy(); qual = rd["qual"].cpu().numpy(); off = rd["off"].cpu().numpy()
+        ss = [seq[off[i]:off[i + 1]].tobytes().decode() for i in idx]; qq = [qual[off[i]:off[i + 1]].tobytes().decode() for i in idx]
+        srs = ReadSet.from_strings(ss, qq)
+        tc = time.perf_counter()
+        pipeline.run_hot_path(orc, srs, rd["score"][idx], acc_rank=acc_rank[idx], **kw)
+        dtc = time.perf_counter() - tc
+        cpu = {"value": round(ns / dtc, 2), "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "%d reads strided from the same batch (same params, tile_depth %d), oracle/libngsid_oracle.so, %.1f s" % (ns, args.tile_depth, dtc)}
+    out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), 750 bp ONT", "value": round(reads_per_s, 1), "unit": "reads/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "int32/u8 (f64 thresholds)", "data": "synthetic",
+           "config": {"workload": "%d synthetic %d bp ONT-profile reads per GPU (mu=%.0f), %d species @15%% divergence, k=13 w=20, cluster + spoa-style POA + racon-style polish x3, abundance_ratio 0.02, POA tile depth %d band 128"
+                      % (args.reads, args.length, args.mu, args.species, args.tile_depth),
+                      "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()},
+                      "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()},
+                      "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed}},
+           "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

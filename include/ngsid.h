@@ -137,10 +137,10 @@ typedef struct {
 } ngsid_poa_params_t;
 
 /* (a13,a14) replaces form_draft_consensus' per-cluster `spoa reads.fq -l 0 -r 0 -g -2` (consensus.py:83-92,249-278).
- * reads are grouped: group g = reads [grp_off[g], grp_off[g+1]) in spoa file order (representative
- * first).  qual==NULL means unit weights (FASTA input).  Consensus strings come back CSR:
- * cons_off[n_groups+1] + cons bytes (capacity cons_cap). */
-int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint64_t* grp_off, uint64_t n_groups,
+ * Group g = positions [grp_off[g], grp_off[g+1]) of `read_order` (host array of read indices; NULL = identity),
+ * in spoa file order (representative first), so clusters need no data movement.  qual==NULL means unit
+ * weights (FASTA input).  Consensus strings come back CSR: cons_off[n_groups+1] + cons bytes (capacity cons_cap). */
+int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                             const ngsid_poa_params_t* prm,
                             uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed);
 
@@ -153,15 +153,20 @@ typedef struct {
     int32_t k, w;             /* minimizer parameters used for strand detection (replaces minimap2 -x map-ont) */
     int32_t tile_depth, band, node_cap;
     int32_t aln_match, aln_mismatch, aln_open, aln_ext;  /* read->backbone aligner (replaces the edlib NW path of racon) */
-    int32_t trim;             /* racon window trimming for TGS windows (mean read length > 1000) */
+    int32_t trim;             /* 0 none; 1 = racon: coverage-trim the consensus of TGS windows (mean read length > 1000); 2 = trim every window */
 } ngsid_polish_params_t;
 
 /* (a16,a17) replaces run_racon's (minimap2 -> racon) x racon_iter chain (consensus.py:107-126).
  * backbones: one sequence per group (qual ignored); reads grouped like ngsid_poa_consensus.
  * n_used[g] (may be NULL) = reads that contributed at least one window layer in the last iteration. */
-int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads,
+int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                      const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                      uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used);
+
+/* Measurement hooks (bench.py): when enabled every kernel launch of this ctx is bracketed by HIP events on the
+ * ctx's own stream; ngsid_profile_read synchronises and writes "kernel_name launches total_ms\n" lines (and resets). */
+int32_t ngsid_profile_enable(ngsid_ctx* ctx, int32_t on);
+int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap);
 
 #ifdef __cplusplus
 }

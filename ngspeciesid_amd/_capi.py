@@ -177,24 +177,26 @@ class Api:
         return score, ncols, nmatch, region
 
     # ---- (a13,a14)
-    def poa_consensus(self, rs: ReadSet, grp_off, prm: PoaParams, cap=None):
+    def poa_consensus(self, rs: ReadSet, grp_off, prm: PoaParams, cap=None, read_order=None):
         grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
+        ro = None if read_order is None else np.ascontiguousarray(read_order, dtype=np.uint32)
         ng = len(grp_off) - 1
         if cap is None:
             lens = np.diff(rs.off.astype(np.int64)) if rs.mem == MEM_HOST else None
-            cap = int(4 * (lens.max() if lens is not None and len(lens) else 4096) * max(ng, 1) + 1024)
+            cap = int(4 * (lens.max() if lens is not None and len(lens) else 16384) * max(ng, 1) + 1024)
         coff = np.zeros(ng + 1, dtype=np.uint64); cons = np.zeros(cap, dtype=np.uint8); needed = C.c_uint64(0)
-        rc = self._call("poa_consensus", C.byref(rs.c), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(coff), _p(cons), C.c_uint64(cap), C.byref(needed))
+        rc = self._call("poa_consensus", C.byref(rs.c), _p(ro), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(coff), _p(cons), C.c_uint64(cap), C.byref(needed))
         if rc: self._err(rc)
         return [cons[int(coff[g]):int(coff[g + 1])].tobytes().decode() for g in range(ng)]
 
     # ---- (a16,a17)
-    def polish(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None):
+    def polish(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None, read_order=None):
         grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
+        ro = None if read_order is None else np.ascontiguousarray(read_order, dtype=np.uint32)
         ng = len(grp_off) - 1
         if cap is None:
             cap = int(4 * len(backbones.seq) + 4096) if backbones.mem == MEM_HOST else 1 << 24
         ooff = np.zeros(ng + 1, dtype=np.uint64); out = np.zeros(cap, dtype=np.uint8); needed = C.c_uint64(0); used = np.zeros(max(ng, 1), dtype=np.uint64)
-        rc = self._call("polish", C.byref(backbones.c), C.byref(rs.c), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(ooff), _p(out), C.c_uint64(cap), C.byref(needed), _p(used))
+        rc = self._call("polish", C.byref(backbones.c), C.byref(rs.c), _p(ro), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(ooff), _p(out), C.c_uint64(cap), C.byref(needed), _p(used))
         if rc: self._err(rc)
         return [out[int(ooff[g]):int(ooff[g + 1])].tobytes().decode() for g in range(ng)], used[:ng]

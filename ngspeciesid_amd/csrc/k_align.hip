@@ -206,8 +206,8 @@ static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen
     const uint32_t bnd_stride = (max_tlen + 15u) & ~15u;
     if (ctx->tb.n < nwaves * words) HIPCHK(ctx, ctx->tb.alloc(nwaves * words));
     if (ctx->bnd.n < nwaves * 2ull * bnd_stride) HIPCHK(ctx, ctx->bnd.alloc(nwaves * 2ull * bnd_stride));
-    hipLaunchKernelGGL((k_sg_align<RPL>), dim3((unsigned)blocks), dim3(64 * wpb), (size_t)wpb * lds_per_wave, ctx->stream,
-                       job, ctx->tb.p, words, ctx->bnd.p, bnd_stride, lds_per_wave);
+    { ProfScope ps_(ctx, "k_sg_align"); hipLaunchKernelGGL((k_sg_align<RPL>), dim3((unsigned)blocks), dim3(64 * wpb), (size_t)wpb * lds_per_wave, ctx->stream,
+                       job, ctx->tb.p, words, ctx->bnd.p, bnd_stride, lds_per_wave); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }

@@ -443,17 +443,17 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
                 const uint32_t want = ((S.R + 256 + 63) / 64) * 64;
                 if (want > stride || cnt.n < (uint64_t)BLK * stride) { stride = std::max(stride, want); HIPCHK(ctx, cnt.alloc((uint64_t)BLK * stride)); }
                 HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, 8ull * (uint64_t)(b1 - b0) * stride, ctx->stream));
-                hipLaunchKernelGGL(k_count_hits, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0,
-                                   S.dbc[S.cur].p, S.dbs[S.cur].p, 0u, S.n_db, cnt.p, stride);
+                { ProfScope ps_(ctx, "k_count_hits"); hipLaunchKernelGGL(k_count_hits, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0,
+                                   S.dbc[S.cur].p, S.dbs[S.cur].p, 0u, S.n_db, cnt.p, stride); }
                 HIPCHK(ctx, hipGetLastError());
                 need_full = false;
             }
-            hipLaunchKernelGGL(k_decide_map, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R);
+            { ProfScope ps_(ctx, "k_decide_map"); hipLaunchKernelGGL(k_decide_map, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R); }
             HIPCHK(ctx, hipGetLastError());
             for (;;) {      // alignment rounds: resolve from cache or request pairs, align, cache, repeat
                 HIPCHK(ctx, hipMemsetAsync(d_scal.p, 0, 4, ctx->stream));
-                hipLaunchKernelGGL(k_aln_next, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R,
-                                   req_q.p, req_t.p, req_slot.p, req_open.p, req_mid.p, d_scal.p);
+                { ProfScope ps_(ctx, "k_aln_next"); hipLaunchKernelGGL(k_aln_next, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R,
+                                   req_q.p, req_t.p, req_slot.p, req_open.p, req_mid.p, d_scal.p); }
                 HIPCHK(ctx, hipGetLastError());
                 uint32_t nreq = 0;
                 HIPCHK(ctx, hipMemcpyAsync(&nreq, d_scal.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -486,8 +486,8 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             if (S.R > stride) { need_full = true; }
             else {
                 // delta: hits of the later items against the new representative only
-                hipLaunchKernelGGL(k_count_hits, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0,
-                                   S.pool.p + S.h_pool_off[S.R - 1], (const uint32_t*)nullptr, S.R - 1, S.h_pool_off[S.R] - S.h_pool_off[S.R - 1], cnt.p, stride);
+                { ProfScope ps_(ctx, "k_count_hits"); hipLaunchKernelGGL(k_count_hits, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0,
+                                   S.pool.p + S.h_pool_off[S.R - 1], (const uint32_t*)nullptr, S.R - 1, S.h_pool_off[S.R] - S.h_pool_off[S.R - 1], cnt.p, stride); }
                 HIPCHK(ctx, hipGetLastError());
             }
             hipLaunchKernelGGL(k_reset_items, dim3((b1 - lo + 255) / 256), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1);

@@ -146,8 +146,8 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     size_t lds = 1024 + 64 + 272 * 4 + ncap * 8 + (size_t)R.maxlen + 16;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_hpc_minimizers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_hpc_minimizers, dim3((unsigned)R.n), dim3(256), lds, ctx->stream,
-                       R.seq, R.qual, R.off, R.n, k, w, d_codes, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag);
+    { ProfScope ps_(ctx, "k_hpc_minimizers"); hipLaunchKernelGGL(k_hpc_minimizers, dim3((unsigned)R.n), dim3(256), lds, ctx->stream,
+                       R.seq, R.qual, R.off, R.n, k, w, d_codes, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }

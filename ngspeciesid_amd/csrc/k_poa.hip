@@ -97,6 +97,12 @@ __device__ void tile_emit(const G& g, const uint32_t* cov, const PoaJobSet& J, u
         }
         int n = 0; for (int v = mx; v != NONE16; v = pred[v]) ++n;
         int i = n; for (int v = mx; v != NONE16; v = pred[v]) { --i; dst[i] = g.code[v]; if (dcov) { uint32_t c = cov[v]; for (int u = g.ring[v]; u != v; u = g.ring[u]) c += cov[u]; dcov[i] = c; } }
+        if (J.trim_tiles && dcov && n > 0) {   // oracle EMIT: coverage-trim the tile consensus ends
+            const uint32_t thr = (uint32_t)(st.cw_sum / 2); int b = 0, e = n - 1;
+            for (; b < n; ++b) if (dcov[b] >= thr) break;
+            for (; e >= 0; --e) if (dcov[e] >= thr) break;
+            if (b < e) { const int m2 = e - b + 1; if (b > 0) for (int x = 0; x < m2; ++x) { dst[x] = dst[b + x]; dcov[x] = dcov[b + x]; } n = m2; }
+        }
         J.out_len[slot] = n; J.out_cw[slot] = st.cw_sum;
     }
     __syncthreads();
@@ -405,9 +411,9 @@ int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
     if (ctx->poa_d.n < nwg * cells) HIPCHK(ctx, ctx->poa_d.alloc(nwg * cells));
     if (ctx->poa_cov.n < (size_t)nwg * J.Vcap) HIPCHK(ctx, ctx->poa_cov.alloc((size_t)nwg * J.Vcap));
     J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = ctx->poa_cov.p;
-    if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<1>, dim3(nwg), dim3(64), lds, ctx->stream, J); }
-    else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<2>, dim3(nwg), dim3(64), lds, ctx->stream, J); }
-    else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<4>, dim3(nwg), dim3(64), lds, ctx->stream, J); }
+    if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ProfScope ps_(ctx, "k_poa_tile"); hipLaunchKernelGGL(k_poa_tile<1>, dim3(nwg), dim3(64), lds, ctx->stream, J); }
+    else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ProfScope ps_(ctx, "k_poa_tile"); hipLaunchKernelGGL(k_poa_tile<2>, dim3(nwg), dim3(64), lds, ctx->stream, J); }
+    else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ProfScope ps_(ctx, "k_poa_tile"); hipLaunchKernelGGL(k_poa_tile<4>, dim3(nwg), dim3(64), lds, ctx->stream, J); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }

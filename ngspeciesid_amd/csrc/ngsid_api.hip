@@ -22,6 +22,7 @@ extern "C" int32_t ngsid_create(int32_t device_ordinal, uint32_t flags, ngsid_ct
     if (e != hipSuccess) { snprintf(g_static_err, sizeof g_static_err, "hipSetDevice: %s", hipGetErrorString(e)); return NGSID_ERR_HIP; }
     ngsid_ctx* c = new ngsid_ctx();
     c->device = device_ordinal;
+    c->debug_sync = getenv("NGSID_DEBUG_SYNC") != nullptr;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) {
         c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -233,5 +234,34 @@ extern "C" int32_t ngsid_score_reads(ngsid_ctx* ctx, const ngsid_reads_t* reads,
     HIPCHK(ctx, hipMemcpyAsync(err_rate, de.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(keep, dk.p, n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NGSID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- measurement hooks
+static void prof_collect(ngsid_ctx* ctx)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ctx->prof_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { auto& acc = ctx->prof_acc[e.name]; acc.first += ms; acc.second += 1; }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    ctx->prof_events.clear();
+}
+extern "C" int32_t ngsid_profile_enable(ngsid_ctx* ctx, int32_t on)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    prof_collect(ctx); ctx->prof_acc.clear(); ctx->prof = on != 0;
+    return NGSID_OK;
+}
+extern "C" int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap)
+{
+    if (!ctx || !buf || !cap) return NGSID_ERR_ARG;
+    prof_collect(ctx);
+    std::string out;
+    for (auto& kv : ctx->prof_acc) { char line[256]; snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.second, kv.second.first); out += line; }
+    ctx->prof_acc.clear();
+    if (out.size() + 1 > cap) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "profile buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
     return NGSID_OK;
 }

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string>
 #include <vector>
+#include <map>
 #include "../../include/ngsid.h"
 
 // RAII device buffer (freed at scope exit; all work is synchronised before return)
@@ -24,6 +25,8 @@ template <typename T> struct DevBuf {
     }
 };
 
+struct ProfEntry { const char* name; hipEvent_t a, b; };
+
 struct ngsid_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -32,12 +35,30 @@ struct ngsid_ctx {
     int n_cu = 256;
     DevBuf<uint64_t> tb;      // aligner traceback scratch (grow-only)
     DevBuf<int32_t> bnd;      // aligner strip boundary rows
+    bool debug_sync = false;
+    bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
 };
 
 #define NGSID_FAIL(ctx, code, ...) do { snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); return (code); } while (0)
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return NGSID_ERR_HIP; } } while (0)
+
+// brackets one kernel launch with HIP events on the ctx stream when profiling is enabled
+struct ProfScope {
+    ngsid_ctx* c; ProfEntry e; bool on;
+    const char* dbg_name;
+    ProfScope(ngsid_ctx* ctx, const char* name) : c(ctx), on(ctx->prof), dbg_name(name) {
+        if (c->debug_sync) { fprintf(stderr, "[ngsid] launch %s\n", name); fflush(stderr); }
+        if (!on) return; e.name = name;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(e.a, c->stream);
+    }
+    ~ProfScope() {
+        if (c->debug_sync) { hipError_t er = hipStreamSynchronize(c->stream); fprintf(stderr, "[ngsid] %s -> %s\n", dbg_name, hipGetErrorString(er)); fflush(stderr); }
+        if (!on) return; (void)hipEventRecord(e.b, c->stream); c->prof_events.push_back(e);
+    }
+};
 
 // A read set resident in HBM (+ host copy of the offsets, which every host-side planner needs)
 struct DevReads {

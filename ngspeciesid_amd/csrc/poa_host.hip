@@ -28,7 +28,7 @@ __global__ void k_make_pseq_reads(const uint8_t* seq, const uint8_t* qual, const
     out[i] = S;
 }
 
-struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; };
+struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; int trim_tiles; };
 
 // Runs all units to completion.  level0: device PSeq array (nseq0 entries) whose max length is maxlen0;
 // bbs: device backbone PSeqs (may be null), maxbb = longest backbone.
@@ -75,7 +75,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
             HIPCHK(ctx, hipMemsetAsync(d_flags.p, 0, 16, ctx->stream));
             PoaJobSet J{};
             J.seqs = cur; J.bbs = d_bbs; J.seq_idx = d_seq_idx.p; J.job_off = d_job_off.p; J.job_bb = d_job_bb.p; J.njobs = njobs;
-            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(2 * capV); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap;
+            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(2 * capV); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles;
             J.out = Lv->out.p; J.out_len = Lv->out_len.p; J.out_cw = Lv->out_cw.p; J.out_n = Lv->out_n.p; J.out_cov = hp.want_cov ? Lv->out_cov.p : nullptr;
             J.dropped = d_flags.p; J.slot_overflow = d_flags.p + 1;
             int32_t rc = poa_run_jobs(ctx, J, hp.band); if (rc) return rc;
@@ -131,19 +131,20 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- (a13,a14)
-extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint64_t* grp_off, uint64_t n_groups,
+extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                                        const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed)
 {
     if (!ctx) return NGSID_ERR_ARG;
     if (!reads || !grp_off || !prm || !cons_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
     DevReads RD; int32_t rc = ngsid_upload_reads(ctx, reads, &RD, false); if (rc) return rc;
-    if (grp_off[n_groups] > RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "group offsets exceed the read set");
+    if (!read_order && grp_off[n_groups] > RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "group offsets exceed the read set");
+    if (read_order) for (uint64_t x = 0; x < grp_off[n_groups]; ++x) if (read_order[x] >= RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "read_order[%llu] out of range", (unsigned long long)x);
     DevBuf<PSeq> d_seqs; HIPCHK(ctx, d_seqs.alloc(RD.n));
     if (RD.n) hipLaunchKernelGGL(k_make_pseq_reads, dim3((unsigned)((RD.n + 255) / 256)), dim3(256), 0, ctx->stream, RD.seq, RD.qual, RD.off, RD.n, prm->mode, d_seqs.p);
     HIPCHK(ctx, hipGetLastError());
     std::vector<Unit> units(n_groups);
-    for (uint64_t g = 0; g < n_groups; ++g) { units[g].seqs.reserve(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs.push_back((uint32_t)r); }
-    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, prm->mode, false};
+    for (uint64_t g = 0; g < n_groups; ++g) { units[g].seqs.reserve(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs.push_back(read_order ? read_order[r] : (uint32_t)r); }
+    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, prm->mode, false, 0};
     std::vector<int> nobb;
     rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;
     uint64_t total = 0; bool overflow = false; cons_off[0] = 0;
@@ -169,6 +170,7 @@ void k_strand(const uint64_t* __restrict__ off, const uint32_t* __restrict__ mzc
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= n) return;
     const uint32_t g = rgroup[r];
+    if (g == 0xffffffffu) { if (lane == 0) orient[r] = 255; return; }        // read belongs to no group
     const uint32_t M = hlen[r] >= (uint32_t)k ? mzcnt[r] : 0;
     const uint64_t* cf = bcodes + boff[g]; const uint32_t nf = (uint32_t)(boff[g + 1] - boff[g]);
     const uint64_t* cr = bcodes + boff[G + g]; const uint32_t nr = (uint32_t)(boff[G + g + 1] - boff[G + g]);
@@ -230,7 +232,7 @@ std::string revcomp(const std::string& s) { std::string r(s.size(), 'N'); for (s
 
 }  // namespace
 
-extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads,
+extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                                 const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                                 uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used)
 {
@@ -238,7 +240,8 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     if (!backbones || !reads || !grp_off || !prm || !out_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
     if (backbones->n != n_groups) NGSID_FAIL(ctx, NGSID_ERR_ARG, "one backbone per group expected");
     DevReads RD; int32_t rc = ngsid_upload_reads(ctx, reads, &RD, false); if (rc) return rc;
-    if (grp_off[n_groups] > RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "group offsets exceed the read set");
+    if (!read_order && grp_off[n_groups] > RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "group offsets exceed the read set");
+    if (read_order) for (uint64_t x = 0; x < grp_off[n_groups]; ++x) if (read_order[x] >= RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "read_order[%llu] out of range", (unsigned long long)x);
     const uint64_t N = RD.n; const uint32_t G = (uint32_t)n_groups;
     const int W = prm->window > 0 ? prm->window : 500;
     // backbones to host strings (they are tiny and are rebuilt on the host after every iteration)
@@ -260,7 +263,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     std::vector<uint32_t> h_rgroup(N, 0xffffffffu); std::vector<uint8_t> tgs(G, 0);
     for (uint32_t g = 0; g < G; ++g) {
         double tot = 0; const uint64_t ns = grp_off[g + 1] - grp_off[g];
-        for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) { h_rgroup[r] = g; tot += (double)(RD.h_off[r + 1] - RD.h_off[r]); }
+        for (uint64_t x = grp_off[g]; x < grp_off[g + 1]; ++x) { const uint64_t r = read_order ? read_order[x] : x; h_rgroup[r] = g; tot += (double)(RD.h_off[r + 1] - RD.h_off[r]); }
         tgs[g] = ns > 0 && (tot / (double)ns) > 1000.0;
     }
     // ---- strand detection (replaces minimap2's strand call): shared HPC minimizers with the initial backbone, fw vs rc
@@ -297,7 +300,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         DevBuf<uint64_t> d_lists, d_loff; HIPCHK(ctx, d_lists.alloc(lists.size() + 1)); HIPCHK(ctx, d_loff.alloc(loff.size()));
         if (!lists.empty()) HIPCHK(ctx, hipMemcpyAsync(d_lists.p, lists.data(), 8 * lists.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_loff.p, loff.data(), 8 * loff.size(), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_strand, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, RD.off, mzcnt.p, hlen.p, mzcode.p, prm->k, d_rgroup.p, d_lists.p, d_loff.p, G, N, d_orient.p);
+        { ProfScope ps_(ctx, "k_strand"); hipLaunchKernelGGL(k_strand, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, RD.off, mzcnt.p, hlen.p, mzcode.p, prm->k, d_rgroup.p, d_lists.p, d_loff.p, G, N, d_orient.p); }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -306,11 +309,11 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     (void)mzcode.alloc(0); (void)mzpos.alloc(0);
     // ---- oriented copies of the reads
     DevBuf<uint8_t> oseq, oqual; HIPCHK(ctx, oseq.alloc(RD.total + 16)); if (RD.qual) HIPCHK(ctx, oqual.alloc(RD.total + 16));
-    hipLaunchKernelGGL(k_orient, dim3((unsigned)N), dim3(128), 0, ctx->stream, RD.seq, RD.qual, RD.off, N, d_orient.p, oseq.p, RD.qual ? oqual.p : nullptr);
+    { ProfScope ps_(ctx, "k_orient"); hipLaunchKernelGGL(k_orient, dim3((unsigned)N), dim3(128), 0, ctx->stream, RD.seq, RD.qual, RD.off, N, d_orient.p, oseq.p, RD.qual ? oqual.p : nullptr); }
     HIPCHK(ctx, hipGetLastError());
     // ---- pairs (usable reads of reads that belong to a group), fixed over the iterations
     std::vector<uint32_t> pair_read, pair_group;
-    for (uint64_t r = 0; r < N; ++r) if (h_rgroup[r] != 0xffffffffu && h_orient[r] != 255) { pair_read.push_back((uint32_t)r); pair_group.push_back(h_rgroup[r]); }
+    for (uint64_t x = 0; x < grp_off[n_groups]; ++x) { const uint64_t r = read_order ? read_order[x] : x; if (h_orient[r] != 255) { pair_read.push_back((uint32_t)r); pair_group.push_back(h_rgroup[r]); } }
     const uint64_t NP = pair_read.size();
     DevBuf<uint32_t> d_pair_read, d_pair_group; DevBuf<int32_t> d_open, d_span, d_bp, d_blen; DevBuf<PSeq> d_lay; DevBuf<uint8_t> d_valid;
     HIPCHK(ctx, d_pair_read.alloc(NP)); HIPCHK(ctx, d_pair_group.alloc(NP)); HIPCHK(ctx, d_open.alloc(NP)); HIPCHK(ctx, d_span.alloc(NP * 4)); HIPCHK(ctx, d_blen.alloc(G));
@@ -338,8 +341,8 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             J.score = nullptr; J.ncols = nullptr; J.nmatch = nullptr; J.region = nullptr; J.bp = d_bp.p; J.bp_windows = nwinmax; J.window = W; J.span = d_span.p;
             rc = ngsid_launch_align(ctx, J, RD.maxlen, maxb); if (rc) return rc;
             const uint64_t T = NP * (uint64_t)nwinmax;
-            hipLaunchKernelGGL(k_layers, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, oseq.p, RD.qual ? oqual.p : nullptr, RD.off, d_pair_read.p, d_pair_group.p, NP, nwinmax,
-                               d_bp.p, d_span.p, d_blen.p, W, prm->quality_threshold, prm->error_threshold, d_lay.p, d_valid.p, flag.p);
+            { ProfScope ps_(ctx, "k_layers"); hipLaunchKernelGGL(k_layers, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, oseq.p, RD.qual ? oqual.p : nullptr, RD.off, d_pair_read.p, d_pair_group.p, NP, nwinmax,
+                               d_bp.p, d_span.p, d_blen.p, W, prm->quality_threshold, prm->error_threshold, d_lay.p, d_valid.p, flag.p); }
             HIPCHK(ctx, hipGetLastError());
             h_valid.resize(T);
             HIPCHK(ctx, hipMemcpyAsync(&max_layer, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -365,15 +368,15 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         }
         DevBuf<PSeq> d_bbs; HIPCHK(ctx, d_bbs.alloc(bbs.size()));
         if (!bbs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_bbs.p, bbs.data(), sizeof(PSeq) * bbs.size(), hipMemcpyHostToDevice, ctx->stream));
-        bool any_tgs = false; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
-        HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs};
+        bool any_tgs = prm->trim >= 2; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
+        HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, prm->trim >= 2 ? 1 : 0};
         rc = run_hierarchy(ctx, d_lay.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
         // ---- new backbones
         std::vector<std::string> NB(G);
         for (size_t u = 0; u < units.size(); ++u) {
             const uint32_t g = unit_gw[u].first; const int ws = unit_gw[u].second * W; const int wlen = std::min<int>(W, (int)B[g].size() - ws);
             std::string c = units[u].has_result ? units[u].result : std::string();
-            if (!c.empty() && tgs[g] && prm->trim && units[u].cov.size() == c.size()) {
+            if (!c.empty() && prm->trim && (tgs[g] || prm->trim >= 2) && units[u].cov.size() == c.size()) {
                 const uint32_t avg = (uint32_t)(nlayers[u] / 2); int b = 0, e = (int)c.size() - 1;
                 for (; b < (int)c.size(); ++b) if (units[u].cov[b] >= avg) break;
                 for (; e >= 0; --e) if (units[u].cov[e] >= avg) break;

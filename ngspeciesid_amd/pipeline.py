@@ -1,0 +1,122 @@
+"""The hot path end to end on one GPU: cluster -> draft consensus (spoa-style) -> rc merge -> polish (racon-style).
+
+Array-level driver used by bench.py and by the reference-shaped host layer (cluster.py / consensus.py of this
+package).  Everything heavy happens behind the C-ABI; this module only does the bookkeeping the reference does in
+Python dicts, with numpy on index arrays.
+"""
+from __future__ import annotations
+import time
+import numpy as np
+from ._capi import Api, ReadSet, cluster_params, poa_params, polish_params, POA_LOCAL
+
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMP[_a] = _b
+
+
+def revcomp_str(s: str) -> str:
+    return _COMP[np.frombuffer(s.encode(), dtype=np.uint8)[::-1]].tobytes().decode()
+
+
+def clusters_from_rep(rep_of: np.ndarray):
+    """-> (reps, order, grp_off): clusters keyed by representative read; order lists each cluster's reads with the
+    representative first and the members in processing order (cluster.py:338-345: the representative was processed
+    before any read that joined it, and reads are processed in index order)."""
+    order = np.argsort(rep_of, kind="stable").astype(np.uint32)
+    reps, start, counts = np.unique(rep_of[order], return_index=True, return_counts=True)
+    grp_off = np.concatenate((start, [len(order)])).astype(np.uint64)
+    return reps.astype(np.int64), order, grp_off, counts
+
+
+def select_centers(reps, counts, score, abundance_cutoff):
+    """clusters sorted by (size, representative score) descending, size >= cutoff   (consensus.py:254-256)."""
+    idx = np.lexsort((-score[reps], -counts))          # primary: size desc, secondary: score desc (stable)
+    return [int(i) for i in idx if counts[i] >= abundance_cutoff]
+
+
+def detect_reverse_complements(api: Api, centers, rc_identity_threshold):
+    """consensus.detect_reverse_complements (consensus.py:148-183): centers = [n_reads, c_id, seq, groups(list of cluster ids)].
+    Identity = matching columns / alignment columns of the semi-global alignment (open 3, ext 1, +2/-2), max over fw / rc."""
+    n = len(centers)
+    if n <= 1:
+        return [[c[0], c[1], c[2], list(c[3])] for c in centers]
+    seqs = [c[2] for c in centers]
+    rcs = [revcomp_str(s) for s in seqs]
+    q = ReadSet.from_strings(seqs); t = ReadSet.from_strings(seqs + rcs)
+    qi, ti = [], []
+    for i in range(n):
+        for j in range(i + 1, n):
+            qi += [i, i]; ti += [j, n + j]
+    score, ncols, nmatch, _ = api.sg_align_batch(q, t, qi, ti, 3, 1, 2, -2, 13, None)
+    ident = {}
+    p = 0
+    for i in range(n):
+        for j in range(i + 1, n):
+            fw = nmatch[p] / float(ncols[p]); rc = nmatch[p + 1] / float(ncols[p + 1]); p += 2
+            ident[(i, j)] = max(fw, rc)
+    out, removed = [], set()
+    for i in range(n):
+        nr, cid, seq, groups = centers[i]
+        if cid in removed:
+            continue
+        merged_n, allg = nr, list(groups)
+        if i < n - 1:
+            for j in range(i + 1, n):
+                if ident[(i, j)] >= rc_identity_threshold:          # NB the reference also re-merges already removed centres
+                    merged_n += centers[j][0]; removed.add(centers[j][1]); allg += list(centers[j][3])
+        out.append([merged_n, cid, seq, allg])
+    return out
+
+
+def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, w=20, abundance_ratio=0.1,
+                 rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=8, band=128, node_cap=0,
+                 p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2):
+    """Returns dict(rep_of, status, counters, hpc_err, centers=[(n_reads, c_id, draft, polished, groups)])."""
+    T = timings if timings is not None else {}
+    t0 = time.perf_counter()
+    prm = cluster_params(k=k, w=w, p_shared=p_shared, **(cluster_kwargs or {}))
+    rep_of, herr, status, counters = api.cluster_greedy(rs, prm, acc_rank=acc_rank)
+    T["cluster"] = T.get("cluster", 0.0) + time.perf_counter() - t0
+    res = dict(rep_of=rep_of, status=status, counters=counters, hpc_err=herr, centers=[])
+    if not do_consensus:
+        return res
+    t0 = time.perf_counter()
+    n = rs.n
+    reps, order, grp_off, counts = clusters_from_rep(rep_of)
+    cutoff = int(abundance_ratio * n)                                           # NGSpeciesID:65
+    sel = select_centers(reps, counts, score, cutoff)
+    T["host_group"] = T.get("host_group", 0.0) + time.perf_counter() - t0
+    if not sel:
+        return res
+    t0 = time.perf_counter()
+    sub_order, sub_off = [], [0]
+    for ci in sel:
+        a, b = int(grp_off[ci]), int(grp_off[ci + 1])
+        if max_seqs_for_consensus >= 0:
+            b = min(b, a + max_seqs_for_consensus)                              # consensus.py:260
+        sub_order.append(order[a:b]); sub_off.append(sub_off[-1] + (b - a))
+    sub_order = np.concatenate(sub_order) if sub_order else np.zeros(0, np.uint32)
+    drafts = api.poa_consensus(rs, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap),
+                               read_order=sub_order)
+    T["consensus"] = T.get("consensus", 0.0) + time.perf_counter() - t0
+    t0 = time.perf_counter()
+    centers = [[int(counts[ci]), int(reps[ci]), drafts[x], [ci]] for x, ci in enumerate(sel)]
+    merged = detect_reverse_complements(api, centers, rc_identity_threshold)
+    T["rc_merge"] = T.get("rc_merge", 0.0) + time.perf_counter() - t0
+    polished = [m[2] for m in merged]
+    if do_polish and racon_iter > 0:
+        t0 = time.perf_counter()
+        p_order, p_off = [], [0]
+        for m in merged:
+            for ci in m[3]:                                                     # pooled reads of the merged clusters (consensus.py:208-215)
+                a, b = int(grp_off[ci]), int(grp_off[ci + 1])
+                if max_seqs_for_consensus >= 0:
+                    b = min(b, a + max_seqs_for_consensus)                      # the pooled file is built from the truncated reads_c_id files
+                p_order.append(order[a:b])
+            p_off.append(sum(len(x) for x in p_order))
+        p_order = np.concatenate(p_order)
+        bb = ReadSet.from_strings([m[2] for m in merged])
+        polished, used = api.polish(bb, rs, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=polish_trim), read_order=p_order)
+        T["polish"] = T.get("polish", 0.0) + time.perf_counter() - t0
+    res["centers"] = [(m[0], m[1], m[2], polished[i], [int(reps[ci]) for ci in m[3]]) for i, m in enumerate(merged)]
+    return res

@@ -44,10 +44,10 @@ int32_t ongsid_sg_align_batch(const ngsid_reads_t* queries, const ngsid_reads_t*
 int32_t ongsid_sg_align_cigar(const uint8_t* q, int32_t n, const uint8_t* t, int32_t m,
                               int32_t match, int32_t mismatch, int32_t open, int32_t ext,
                               char* cigar, int32_t cigar_cap, int32_t* score);
-int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint64_t* grp_off, uint64_t n_groups,
+int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                              const ngsid_poa_params_t* prm,
                              uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed);
-int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads,
+int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                       const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                       uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used);
 

@@ -251,7 +251,7 @@ static int g_consensus(const graph* G, uint8_t* out, uint32_t* cov_out) {
 
 /* ---------------------------------------------------------------- tile engine: sequences in order -> one or more (consensus, cw) */
 typedef struct { uint8_t* s; uint32_t* cov; int len; uint64_t cw; } pout;
-typedef struct { int m, n, g, band, node_cap; } pprm;
+typedef struct { int m, n, g, band, node_cap, trim_tiles; } pprm;
 
 static int cap_for(int L0, int node_cap) { long c = (long)L0 * (node_cap > 0 ? node_cap : 32) / 16; if (c < L0 + 64) c = L0 + 64; return (int)c; }
 
@@ -264,7 +264,11 @@ static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* 
     graph G; g_init(&G, capV > maxlen + 1 ? capV : maxlen + 1);
     ppair* path = malloc(sizeof(ppair) * (size_t)(maxlen + G.capV + 4));
     int members = 0;
-#define EMIT() do { if (G.V > 0 && members > 0) { pout* o = &outs[nout++]; o->s = malloc((size_t)G.V + 1); o->cov = want_cov ? malloc(sizeof(uint32_t) * ((size_t)G.V + 1)) : NULL; o->len = g_consensus(&G, o->s, o->cov); o->cw = G.cw_sum; } } while (0)
+#define EMIT() do { if (G.V > 0 && members > 0) { pout* o = &outs[nout++]; o->s = malloc((size_t)G.V + 1); o->cov = (want_cov || P->trim_tiles) ? malloc(sizeof(uint32_t) * ((size_t)G.V + 1)) : NULL; o->len = g_consensus(&G, o->s, o->cov); o->cw = G.cw_sum; \
+        if (P->trim_tiles && o->len > 0) { /* coverage-trim the tile consensus ends: keeps unsupported backbone ends from propagating up the hierarchy */ \
+            uint32_t thr = (uint32_t)(G.cw_sum / 2); int b_ = 0, e_ = o->len - 1; for (; b_ < o->len; ++b_) if (o->cov[b_] >= thr) break; for (; e_ >= 0; --e_) if (o->cov[e_] >= thr) break; \
+            if (b_ < e_) { memmove(o->s, o->s + b_, (size_t)(e_ - b_ + 1)); memmove(o->cov, o->cov + b_, sizeof(uint32_t) * (size_t)(e_ - b_ + 1)); o->len = e_ - b_ + 1; } } \
+        if (!want_cov) { free(o->cov); o->cov = NULL; } } } while (0)
     for (int i = 0; i < ns; ++i) {
         const pseq* S = &seqs[i];
         if (S->len <= 0) continue;
@@ -319,15 +323,15 @@ static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P
     }
 }
 
-int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint64_t* grp_off, uint64_t n_groups,
+int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                              const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed) {
-    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap };
+    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, 0 };
     uint64_t total = 0; int overflow = 0; cons_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         int ns = (int)(grp_off[g + 1] - grp_off[g]);
         pseq* seqs = malloc(sizeof(pseq) * (size_t)(ns + 1));
         for (int i = 0; i < ns; ++i) {
-            uint64_t r = grp_off[g] + (uint64_t)i;
+            uint64_t r = read_order ? read_order[grp_off[g] + (uint64_t)i] : grp_off[g] + (uint64_t)i;
             seqs[i].s = reads->seq + reads->off[r]; seqs[i].q = reads->qual ? reads->qual + reads->off[r] : NULL; seqs[i].len = (int)(reads->off[r + 1] - reads->off[r]);
             seqs[i].uw = 1; seqs[i].cw = 1; seqs[i].mode = prm->mode; seqs[i].a0 = 0; seqs[i].a1 = -1;
         }
@@ -352,9 +356,9 @@ static uint8_t comp_base(uint8_t c) { switch (c) { case 'A': return 'T'; case 'C
 typedef struct { pseq* v; int n, cap; } layervec;
 static void lv_push(layervec* L, pseq s) { if (L->n == L->cap) { L->cap = L->cap ? L->cap * 2 : 16; L->v = realloc(L->v, sizeof(pseq) * (size_t)L->cap); } L->v[L->n++] = s; }
 
-int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint64_t* grp_off, uint64_t n_groups,
+int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                       const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used) {
-    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap };
+    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->trim >= 2 };
     const int W = prm->window > 0 ? prm->window : 500;
     uint64_t total = 0; int overflow = 0; out_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
@@ -370,7 +374,7 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
         int8_t* orient = malloc((size_t)ns + 1); uint8_t** rs = calloc((size_t)ns + 1, sizeof(uint8_t*)); uint8_t** rq = calloc((size_t)ns + 1, sizeof(uint8_t*)); int* rl = malloc(sizeof(int) * ((size_t)ns + 1));
         double totlen = 0.0; int rc_err = 0;
         for (int i = 0; i < ns; ++i) {
-            uint64_t r = grp_off[g] + (uint64_t)i; const uint8_t* s = reads->seq + reads->off[r]; const uint8_t* q = reads->qual ? reads->qual + reads->off[r] : NULL; int n = (int)(reads->off[r + 1] - reads->off[r]);
+            uint64_t r = read_order ? read_order[grp_off[g] + (uint64_t)i] : grp_off[g] + (uint64_t)i; const uint8_t* s = reads->seq + reads->off[r]; const uint8_t* q = reads->qual ? reads->qual + reads->off[r] : NULL; int n = (int)(reads->off[r + 1] - reads->off[r]);
             rl[i] = n; totlen += n;
             uint64_t* c = malloc(sizeof(uint64_t) * (size_t)(n + 1)); uint32_t* p = malloc(sizeof(uint32_t) * (size_t)(n + 1));
             int cnt = ongsid_i_hpc_minimizers(s, n, prm->k, prm->w, c, p);
@@ -434,7 +438,7 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
                 if (LV[wdx].n >= 2) {
                     pseq bb; bb.s = B + ws; bb.q = NULL; bb.len = wlen; bb.uw = 0; bb.cw = 0; bb.mode = NGSID_POA_GLOBAL; bb.a0 = 0; bb.a1 = -1;
                     len = run_hierarchy(LV[wdx].v, LV[wdx].n, &bb, &P, prm->tile_depth, NGSID_POA_GLOBAL, &c, &cov, 1);
-                    if (len > 0 && tgs && prm->trim && cov) {
+                    if (len > 0 && prm->trim && (tgs || prm->trim >= 2) && cov) {      /* racon trims TGS windows only; trim>=2 = every window (build choice) */
                         uint32_t avg = (uint32_t)(LV[wdx].n / 2); int b = 0, e = len - 1;
                         for (; b < len; ++b) if (cov[b] >= avg) break;
                         for (; e >= 0; --e) if (cov[e] >= avg) break;

@@ -48,17 +48,19 @@ def test_poa_small_capacity_splits(gpu_api, oracle):
     assert gpu_api.poa_consensus(rs, [0, rs.n], prm) == oracle.poa_consensus(rs, [0, rs.n], prm)
 
 
-@pytest.mark.parametrize("cfg", [dict(n=60, L=600, it=1, D=8, rc=0.5), dict(n=120, L=750, it=3, D=8, rc=0.0), dict(n=40, L=1300, it=2, D=8, rc=0.3, mu=25.0), dict(n=30, L=500, it=2, D=0, rc=0.5)])
+@pytest.mark.parametrize("cfg", [dict(n=60, L=600, it=1, D=8, rc=0.5), dict(n=120, L=750, it=3, D=8, rc=0.0), dict(n=40, L=1300, it=2, D=8, rc=0.3, mu=25.0), dict(n=30, L=500, it=2, D=0, rc=0.5), dict(n=200, L=750, it=3, D=8, rc=0.0, trim=2), dict(n=64, L=600, it=2, D=4, rc=0.5, trim=2)])
 def test_polish_vs_oracle(gpu_api, oracle, cfg):
     sp, rd, rs = make_set(cfg["n"], L=cfg["L"], mu=cfg.get("mu", 17.0), seed=11, rc_fraction=cfg["rc"])
     fw = int(np.nonzero(rd["strand"].numpy() == 0)[0][0])
     bb = ReadSet.from_strings([rs.get(fw)[0]])
-    prm = polish_params(iters=cfg["it"], tile_depth=cfg["D"], band=128)
+    prm = polish_params(iters=cfg["it"], tile_depth=cfg["D"], band=128, trim=cfg.get("trim", 1))
     got, gused = gpu_api.polish(bb, rs, [0, rs.n], prm)
     exp, eused = oracle.polish(bb, rs, [0, rs.n], prm)
     assert got == exp, "len got %d exp %d" % (len(got[0]), len(exp[0]))
     assert np.array_equal(gused, eused)
     assert interior_ed(got[0], sp[0].tobytes().decode()) <= 3
+    if cfg.get("trim", 1) == 2 and cfg["n"] >= 200:
+        assert got[0] == sp[0].tobytes().decode()          # trimmed tiles: the polished consensus IS the generating amplicon
 
 
 def test_polish_two_groups(gpu_api, oracle):
