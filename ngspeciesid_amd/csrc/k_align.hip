@@ -26,7 +26,10 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
     const int wib = threadIdx.x >> 6;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wib;
     const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    uint8_t* tgt = smem + (size_t)wib * lds_per_wave;
+    uint8_t* tgt = smem + (size_t)wib * lds_per_wave;                 // raw target, raw query, 4 KB traceback block
+    const uint32_t seq_lds = (lds_per_wave - 4096) / 2;
+    uint8_t* qry = tgt + seq_lds;
+    uint64_t* tbblk = (uint64_t*)(tgt + 2 * (size_t)seq_lds);
     uint64_t* mytb = tb + wave * tb_words_per_wave;
     int32_t* mybnd = bnd + wave * (uint64_t)bnd_stride * 2;
     const int STRIP = 64 * RPL;
@@ -46,7 +49,8 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
             if (J.bp) for (int x = lane; x < J.bp_windows * 4; x += 64) J.bp[p * (uint64_t)J.bp_windows * 4 + x] = -1;
             continue;
         }
-        for (int x = lane; x < m; x += 64) tgt[x] = (uint8_t)ngsid_bcode(t[x]);
+        for (int x = lane; x < m; x += 64) tgt[x] = t[x];
+        for (int x = lane; x < n; x += 64) qry[x] = q[x];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
 
@@ -59,14 +63,15 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
             const int i0 = sidx * STRIP + lane * RPL;
             int qc[RPL], hl[RPL], e[RPL];
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) { qc[r] = (i0 + r < n) ? ngsid_bcode(q[i0 + r]) : 4; hl[r] = 0; e[r] = NEGINF; }
+            for (int r = 0; r < RPL; ++r) { qc[r] = (i0 + r < n) ? ngsid_bcode(qry[i0 + r]) : 4; hl[r] = 0; e[r] = NEGINF; }
             const int rlast = (n - 1) - i0;            // row n-1 lives in this lane iff 0 <= rlast < RPL
             int hdiag_top = 0;                         // H[i0-1][j-1]
             int send_h = 0, send_f = NEGINF;
             uint64_t* stb = mytb + (uint64_t)sidx * steps * 64;
             for (int tau = 0; tau < steps; ++tau) {
                 const int j = tau - lane;
-                int hup = __shfl_up(send_h, 1), fup = __shfl_up(send_f, 1);
+                // lane l-1 -> lane l in one DPP move (wave_shr:1), no LDS crossbar round trip
+                int hup = __builtin_amdgcn_update_dpp(0, send_h, 0x138, 0xf, 0xf, false), fup = __builtin_amdgcn_update_dpp(0, send_f, 0x138, 0xf, 0xf, false);
                 if (lane == 0) {
                     if (sidx == 0) { hup = 0; fup = NEGINF; }
                     else if (j >= 0 && j < m) {
@@ -75,7 +80,7 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
                     }
                 }
                 if (j >= 0 && j < m) {
-                    const int tc = tgt[j];
+                    const int tc = ngsid_bcode(tgt[j]);
                     int hd = hdiag_top, hu = hup, f = fup;
                     uint64_t word = 0;
 #pragma unroll
@@ -130,16 +135,15 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-        // ---- traceback (lane 0), window statistic folded in
+        // ---- traceback: executed uniformly by the whole wave; traceback words are pulled 64 steps x 8 lanes (4 KB) at a time
+        //      into LDS (one HBM round trip per ~64 path steps instead of one per step), sequences are read from LDS.
         if (J.bp) for (int x = lane; x < J.bp_windows * 4; x += 64) J.bp[p * (uint64_t)J.bp_windows * 4 + x] = -1;
-        if (lane == 0) {
+        {
             const int K = J.k; const int mid = J.match_id ? J.match_id[p] : K;
             const uint64_t kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1);
             uint64_t win = 0; int cols = 0, nm = 0, region = 0;
-            // trailing end gaps (walked first)
-            const int tail = (n - 1 - ei) + (m - 1 - ej);
-            {
-                const int z = tail;
+            {   // trailing end gaps (walked first)
+                const int z = (n - 1 - ei) + (m - 1 - ej);
                 const int zl = z < K ? z : K;             // after K zeros the window is all zero
                 for (int x = 0; x < zl; ++x) { win <<= 1; ++cols; if (cols >= K) region += ((int)__popcll(win & kmask) >= mid); }
                 if (z > zl) { region += (0 >= mid) ? (z - zl) : 0; cols += z - zl; }
@@ -148,20 +152,35 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
             int q_end = -1, t_end = -1, q_beg = -1, t_beg = -1;
             int cw = -1, w_qf = 0, w_ql = 0, w_tf = 0, w_tl = 0;
             int32_t* bpp = J.bp ? J.bp + p * (uint64_t)J.bp_windows * 4 : nullptr;
+            int blk_s = -1, blk_g = -1, blk_hi = -1;       // loaded block: strip, 8-lane group, highest step
             while (i >= 0 && j >= 0) {
                 const int sidx = i / STRIP; const int il = i - sidx * STRIP; const int l = il / RPL; const int r = il - l * RPL;
-                const uint64_t word = mytb[((uint64_t)sidx * steps + (uint64_t)(j + l)) * 64 + l];
+                const int tau = j + l; const int grp = l >> 3;
+                if (sidx != blk_s || grp != blk_g || tau > blk_hi || tau < blk_hi - 63) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    blk_s = sidx; blk_g = grp; blk_hi = tau;
+                    const int tt = tau - lane;
+                    if (tt >= 0) {
+                        const uint4* src = (const uint4*)(mytb + ((uint64_t)sidx * steps + (uint64_t)tt) * 64 + grp * 8);
+                        ngsid_v4u* dstp = (ngsid_v4u*)(tbblk + lane * 8);
+                        // nt loads are served by L2: this wave rewrites the same scratch addresses for every pair, an L1 line may be stale
+                        dstp[0] = ngsid_load16_l2(src + 0); dstp[1] = ngsid_load16_l2(src + 1); dstp[2] = ngsid_load16_l2(src + 2); dstp[3] = ngsid_load16_l2(src + 3);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const uint64_t word = tbblk[(blk_hi - tau) * 8 + (l & 7)];
                 const int v = (int)((word >> (4 * r)) & 15);
                 int bit = 0, emit = 1;
                 if (state == 0) {
                     const int src = v & 3;
                     if (src == 0) {
-                        bit = (q[i] == t[j]);
+                        bit = (qry[i] == tgt[j]);
                         if (q_end < 0) { q_end = i; t_end = j; }
                         q_beg = i; t_beg = j;
                         if (bpp) {
                             const int wn = j / J.window;
-                            if (wn != cw) { if (cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = i; w_tl = j; }
+                            if (wn != cw) { if (lane == 0 && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = i; w_tl = j; }
                             w_qf = i; w_tf = j;
                         }
                         --i; --j;
@@ -170,7 +189,7 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
                 else { if (!((v >> 3) & 1)) state = 0; --i; }
                 if (emit) { win = (win << 1) | (uint64_t)bit; nm += bit; ++cols; if (cols >= K) region += ((int)__popcll(win & kmask) >= mid); }
             }
-            if (bpp && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
+            if (lane == 0 && bpp && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
             {   // leading end gaps
                 const int z = (i + 1) + (j + 1);
                 const int zl = z < K ? z : K;
@@ -178,11 +197,13 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
                 if (z > zl) { region += (0 >= mid) ? (z - zl) : 0; cols += z - zl; }
             }
             if (cols < K) region = (nm >= mid) ? 1 : 0;      // a single, shorter window (cluster.py:148-154)
-            if (J.score) J.score[p] = best;
-            if (J.ncols) J.ncols[p] = cols;
-            if (J.nmatch) J.nmatch[p] = nm;
-            if (J.region) J.region[p] = region;
-            if (J.span) { J.span[p * 4 + 0] = q_beg; J.span[p * 4 + 1] = q_end; J.span[p * 4 + 2] = t_beg; J.span[p * 4 + 3] = t_end; }
+            if (lane == 0) {
+                if (J.score) J.score[p] = best;
+                if (J.ncols) J.ncols[p] = cols;
+                if (J.nmatch) J.nmatch[p] = nm;
+                if (J.region) J.region[p] = region;
+                if (J.span) { J.span[p * 4 + 0] = q_beg; J.span[p * 4 + 1] = q_end; J.span[p * 4 + 2] = t_beg; J.span[p * 4 + 3] = t_end; }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -198,9 +219,10 @@ static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen
     const uint64_t by_mem = ctx->scratch_budget / (words * 8 + 1);
     if (want > by_mem) want = by_mem;
     if (want < 1) want = 1;
-    const uint32_t lds_per_wave = (max_tlen + 15u) & ~15u;
+    const uint32_t seq_lds = ((max_tlen > max_qlen ? max_tlen : max_qlen) + 15u) & ~15u;
+    const uint32_t lds_per_wave = 2 * seq_lds + 4096;
     int wpb = 4;
-    while (wpb > 1 && (uint64_t)wpb * lds_per_wave > 60 * 1024) wpb >>= 1;
+    while (wpb > 1 && (uint64_t)wpb * lds_per_wave > 40 * 1024) wpb >>= 1;
     const uint64_t blocks = (want + wpb - 1) / wpb;
     const uint64_t nwaves = blocks * wpb;
     const uint32_t bnd_stride = (max_tlen + 15u) & ~15u;

@@ -18,15 +18,37 @@
 #define PNEG (-(1 << 28))
 #define SRC_SLOT 63
 #define NONE16 0xFFFFu
-#define HR 16
+#define HR 8
 
+// Every graph array is an LDS (address space 3) pointer: with generic pointers the compiler emits FLAT loads, which count on
+// vmcnt and therefore wait for the row's outstanding HBM stores (measured: ~2 us per DP row instead of ~0.2).
+#define LDSP __attribute__((address_space(3)))
+typedef LDSP uint16_t* l16; typedef LDSP uint8_t* l8; typedef LDSP int32_t* l32; typedef LDSP long long* l64;
 struct G {   // LDS-resident graph of one tile + per-sequence scratch
-    uint16_t *anchor, *in_first, *in_last, *out_first, *out_last, *ring, *order, *rank, *lo, *tmpv;
-    uint8_t* code;
-    uint16_t *e_tail, *e_head, *e_next_in, *e_next_out; int32_t* e_w;
-    uint16_t *alnode, *nodeof, *ref; uint8_t* sq;
-    int32_t* hring; uint8_t* dirblk; long long* sc;
+    l16 anchor, in_first, in_last, out_first, out_last, ring, order, rank, lo, tmpv;
+    l8 code;
+    l16 e_tail, e_head, e_next_in, e_next_out; l32 e_w;
+    l16 alnode, nodeof, ref; l8 sq;
+    l32 hring; l8 dirblk; l64 sc;
+    l16 rp0, rp1; l8 rcode, rflag;      // per-rank row info for the forward pass (aliases dirblk: dead before the traceback)
 };
+
+// Single-wave workgroup: LDS instructions of one wave execute in issue order, so ordering LDS traffic between lanes only needs the
+// compiler not to reorder and the LDS queue to drain - no s_barrier and, crucially, no wait on outstanding HBM stores.
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+// inclusive max-scan over the 64 lanes: 4 DPP row shifts inside the 16-lane rows, row totals through readlane (SGPRs)
+__device__ __forceinline__ int wave_incl_max_scan(int v, int lane, int ident)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+    const int add = lane >= 48 ? max(r0, max(r1, r2)) : (lane >= 32 ? max(r0, r1) : (lane >= 16 ? r0 : ident));
+    return max(v, add);
+}
+
 struct TS { int V, E, L0, members, nout, capV, capE; unsigned long long cw_sum; };
 
 __device__ __forceinline__ int wtof(const PSeq& S, int i) { return S.q ? (int)S.q[i] - 33 : S.uw; }
@@ -65,7 +87,7 @@ __device__ void tile_emit(const G& g, const uint32_t* cov, const PoaJobSet& J, u
     __threadfence_block();
     __syncthreads();
     if (lane == 0) {
-        uint16_t* pred = g.lo;
+        l16 pred = g.lo;
         int mx = -1;
         for (int r = 0; r < V; ++r) {
             const int v = g.order[r]; long long sv = -1; int pv = NONE16;
@@ -115,30 +137,55 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
 {
     constexpr int BW = 64 * CPL;
     const int L = S.len, mode = S.mode, gp = J.g, V = st.V;
-    for (int r = lane; r < V; r += 64) g.lo[r] = (uint16_t)band_lo(g.anchor[g.order[r]], S, st.L0, BW);
+    // per-rank row info, built lane-parallel so that the serial row loop reads everything by rank (no pointer chasing):
+    // band start, node letter, ranks of the first two predecessors, flags (1 = no predecessor, 2 = more than two, 4 = sink)
+    for (int r = lane; r < V; r += 64) {
+        const int v = g.order[r];
+        g.lo[r] = (uint16_t)band_lo(g.anchor[v], S, st.L0, BW);
+        const int e0 = g.in_first[v]; int p0 = NONE16, p1 = NONE16, fl = 0;
+        if (e0 == NONE16) fl |= 1;
+        else { p0 = g.rank[g.e_tail[e0]]; const int e1 = g.e_next_in[e0]; if (e1 != NONE16) { p1 = g.rank[g.e_tail[e1]]; if (g.e_next_in[e1] != NONE16) fl |= 2; } }
+        if (g.out_first[v] == NONE16) fl |= 4;
+        g.rp0[r] = (uint16_t)p0; g.rp1[r] = (uint16_t)p1; g.rcode[r] = g.code[v]; g.rflag[r] = (uint8_t)fl;
+    }
     for (int i = lane; i < L; i += 64) { g.alnode[i] = NONE16; g.sq[i] = S.s[i]; }
     __syncthreads();
     // ---------- forward DP, one row per graph node in topological order
     int bestv = PNEG, bestr = -1, bestc = -1;
     for (int r = 0; r < V; ++r) {
-        const int v = g.order[r]; const int l0 = g.lo[r]; const uint8_t cv = g.code[v];
-        const int inf = g.in_first[v]; const bool nopred = inf == NONE16;
+        const int l0 = g.lo[r]; const uint8_t cv = g.rcode[r]; const int rfl = g.rflag[r];
+        const bool nopred = (rfl & 1) != 0;
         const bool use_src = nopred || mode == NGSID_POA_SEMI;
         const int jb = l0 + lane * CPL;
         int Xd[CPL], Dslot[CPL], Xu[CPL], Uslot[CPL], scj[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) { Xd[c] = PNEG; Xu[c] = PNEG; Dslot[c] = 0; Uslot[c] = 0; const int j = jb + c; scj[c] = (j >= 1 && j <= L) ? ((cv == g.sq[j - 1]) ? J.m : J.n) : 0; }
-        int slot = 0;
-        for (int e = inf; e != NONE16; e = g.e_next_in[e], ++slot) {
-            const int pr = g.rank[g.e_tail[e]]; const int plo = g.lo[pr];
-            const bool near = (r - pr) <= HR;
-            const int32_t* Hp = near ? (g.hring + (size_t)(pr % HR) * BW) : (Hg + (size_t)pr * BW);
+        // predecessors in in-edge order: the first two come from the row info, further ones (rare) by walking the in-edge list
+        int slot = 0, eit = NONE16;
+        if (rfl & 2) { eit = g.in_first[g.order[r]]; }
+        for (;; ++slot) {
+            int pr;
+            if (!(rfl & 2)) { pr = slot == 0 ? g.rp0[r] : (slot == 1 ? g.rp1[r] : NONE16); if (pr == NONE16) break; }
+            else { if (eit == NONE16) break; pr = g.rank[g.e_tail[eit]]; eit = g.e_next_in[eit]; }
+            const int plo = g.lo[pr];
+            // the lane needs predecessor columns j-1 .. j+CPL-1 : CPL+1 values starting at pc0-1
+            const int pc0 = jb - plo;
+            int hp[CPL + 1];
+            if ((r - pr) <= HR) {                       // LDS ring (the common case)
+                const l32 Hp = g.hring + (size_t)(pr % HR) * BW;
+#pragma unroll
+                for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : PNEG; }
+            } else {                                    // far predecessor: HBM copy of the row (written >= HR rows ago by this wave)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int32_t* Hq = Hg + (size_t)pr * BW;
+#pragma unroll
+                for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? __builtin_nontemporal_load(Hq + pc) : PNEG; }
+            }
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int j = jb + c; if (j > L) continue;
-                const int pc = j - plo;
-                if (pc >= 0 && pc < BW) { const int hv = Hp[pc]; if (hv > PNEG && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
-                if (j >= 1 && pc - 1 >= 0 && pc - 1 < BW) { const int hv = Hp[pc - 1]; if (hv > PNEG && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
+                { const int hv = hp[c + 1]; if (hv > PNEG && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
+                if (j >= 1) { const int hv = hp[c]; if (hv > PNEG && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
             }
         }
 #pragma unroll
@@ -159,10 +206,8 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
             const int y = (j <= L) ? xf - j * gp : PNEG * 2;
             exl[c] = run; run = max(run, y);
         }
-        int incl = run;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
-        int excl_lane = __shfl_up(incl, 1); if (lane == 0) excl_lane = PNEG * 2;
+        const int incl = wave_incl_max_scan(run, lane, PNEG * 2);
+        const int excl_lane = __builtin_amdgcn_update_dpp(PNEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1, lane 0 keeps the identity
         int hrow[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
@@ -178,17 +223,18 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
                 hv = val;
                 if (hv > PNEG) {
                     if (mode == NGSID_POA_LOCAL) { if (hv > bestv) { bestv = hv; bestr = r; bestc = lane * CPL + c; } }
-                    else if (j == L && (mode == NGSID_POA_SEMI || g.out_first[v] == NONE16)) { if (hv > bestv) { bestv = hv; bestr = r; bestc = lane * CPL + c; } }
+                    else if (j == L && (mode == NGSID_POA_SEMI || (rfl & 4))) { if (hv > bestv) { bestv = hv; bestr = r; bestc = lane * CPL + c; } }
                 }
             }
             hrow[c] = hv; Dd[c] = dd;
         }
-        int32_t* ring = g.hring + (size_t)(r % HR) * BW;
+        l32 ring = g.hring + (size_t)(r % HR) * BW;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) { ring[lane * CPL + c] = hrow[c]; Hg[(size_t)r * BW + lane * CPL + c] = hrow[c]; Dg[(size_t)r * BW + lane * CPL + c] = (uint8_t)Dd[c]; }
-        __threadfence_block();
-        __syncthreads();
+        lds_sync();                                   // next row reads this ring slot; HBM stores stay in flight
     }
+    __threadfence_block();                            // direction rows must have landed before the traceback pulls them back
+    __syncthreads();
     // ---------- best end cell: max value, ties -> lowest rank, then lowest column
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -209,7 +255,7 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
                 __syncthreads();
                 blk_hi = r; blk_lo = r - 63 < 0 ? 0 : r - 63;
                 const int rr = blk_hi - lane;
-                if (rr >= blk_lo) { const uint8_t* src = Dg + (size_t)rr * BW; uint8_t* dstp = g.dirblk + (size_t)lane * BW; for (int x = 0; x < BW; x += 16) *(uint4*)(dstp + x) = *(const uint4*)(src + x); }
+                if (rr >= blk_lo) { const uint8_t* src = Dg + (size_t)rr * BW; l8 dstp = g.dirblk + (size_t)lane * BW; for (int x = 0; x < BW; x += 16) *(LDSP ngsid_v4u*)(dstp + x) = ngsid_load16_l2(src + x); }   // L2-served: scratch rows are rewritten per sequence
                 __threadfence_block();
                 __syncthreads();
             }
@@ -280,7 +326,7 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
     __syncthreads();
     // ---------- D: ranks.  k-th new node -> tmpv[k] + k ; old node at rank p -> p + #{k : tmpv[k] <= p}
     {
-        uint16_t* neworder = g.lo;
+        l16 neworder = g.lo;
         for (int p = lane; p < V; p += 64) {
             int lo = 0, hi = nnew; while (lo < hi) { const int mid = (lo + hi) >> 1; if (g.tmpv[mid] <= p) lo = mid + 1; else hi = mid; }
             neworder[p + lo] = g.order[p];
@@ -314,8 +360,7 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
                 if (g.in_last[b] == NONE16) g.in_first[b] = (uint16_t)e; else g.e_next_in[g.in_last[b]] = (uint16_t)e; g.in_last[b] = (uint16_t)e;
             }
             ebase += __popcll(mn);
-            __threadfence_block();
-            __syncthreads();
+            lds_sync();
         }
         st.E = ebase;
     }
@@ -335,16 +380,19 @@ void k_poa_tile(PoaJobSet J)
     const int Vc = J.Vcap, Ec = J.Ecap, Lm = J.Lmax;
     G g;
     {
-        unsigned char* p = smem;
-        auto take = [&](size_t bytes) { unsigned char* q = p; p += (bytes + 15) & ~(size_t)15; return q; };
-        g.anchor = (uint16_t*)take(2 * Vc); g.in_first = (uint16_t*)take(2 * Vc); g.in_last = (uint16_t*)take(2 * Vc); g.out_first = (uint16_t*)take(2 * Vc);
-        g.out_last = (uint16_t*)take(2 * Vc); g.ring = (uint16_t*)take(2 * Vc); g.order = (uint16_t*)take(2 * Vc); g.rank = (uint16_t*)take(2 * Vc);
-        g.lo = (uint16_t*)take(2 * (Vc + 1)); g.tmpv = (uint16_t*)take(2 * (Vc + 1)); g.code = (uint8_t*)take(Vc);
-        g.e_tail = (uint16_t*)take(2 * Ec); g.e_head = (uint16_t*)take(2 * Ec); g.e_next_in = (uint16_t*)take(2 * Ec); g.e_next_out = (uint16_t*)take(2 * Ec); g.e_w = (int32_t*)take(4 * Ec);
-        g.alnode = (uint16_t*)take(2 * Lm); g.nodeof = (uint16_t*)take(2 * Lm); g.ref = (uint16_t*)take(2 * Lm); g.sq = (uint8_t*)take(Lm);
-        size_t dp = (size_t)HR * BW * 4 + (size_t)64 * BW; if (dp < (size_t)8 * Vc) dp = (size_t)8 * Vc;
-        unsigned char* dpr = take(dp);
-        g.hring = (int32_t*)dpr; g.dirblk = dpr + (size_t)HR * BW * 4; g.sc = (long long*)dpr;
+        LDSP unsigned char* base = (LDSP unsigned char*)smem;
+        size_t o = 0;
+        auto take = [&](size_t bytes) { LDSP unsigned char* q = base + o; o += (bytes + 15) & ~(size_t)15; return q; };
+        g.anchor = (l16)take(2 * Vc); g.in_first = (l16)take(2 * Vc); g.in_last = (l16)take(2 * Vc); g.out_first = (l16)take(2 * Vc);
+        g.out_last = (l16)take(2 * Vc); g.ring = (l16)take(2 * Vc); g.order = (l16)take(2 * Vc); g.rank = (l16)take(2 * Vc);
+        g.lo = (l16)take(2 * (Vc + 1)); g.tmpv = (l16)take(2 * (Vc + 1)); g.code = (l8)take(Vc);
+        g.e_tail = (l16)take(2 * Ec); g.e_head = (l16)take(2 * Ec); g.e_next_in = (l16)take(2 * Ec); g.e_next_out = (l16)take(2 * Ec); g.e_w = (l32)take(4 * Ec);
+        g.alnode = (l16)take(2 * Lm); g.nodeof = (l16)take(2 * Lm); g.ref = (l16)take(2 * Lm); g.sq = (l8)take(Lm);
+        size_t blk = (size_t)64 * BW; if (blk < (size_t)6 * Vc + 32) blk = ((size_t)6 * Vc + 32 + 15) & ~(size_t)15;
+        size_t dp = (size_t)HR * BW * 4 + blk; if (dp < (size_t)8 * Vc) dp = (size_t)8 * Vc;
+        LDSP unsigned char* dpr = take(dp);
+        g.hring = (l32)dpr; g.dirblk = (l8)(dpr + (size_t)HR * BW * 4); g.sc = (l64)dpr;
+        g.rp0 = (l16)g.dirblk; g.rp1 = g.rp0 + Vc; g.rcode = (l8)(g.rp1 + Vc); g.rflag = g.rcode + Vc;
     }
     int32_t* Hg = J.Hglob + (size_t)blockIdx.x * Vc * BW;
     uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW;
@@ -358,9 +406,9 @@ void k_poa_tile(PoaJobSet J)
         {   // per-job capacity = oracle run_tile: cap_for(L0) but at least the longest member + 1; edges 2x
             int maxlen = bbi >= 0 ? J.bbs[bbi].len : 0, first = bbi >= 0 ? J.bbs[bbi].len : 0;
             for (uint32_t si = s0; si < s1; ++si) { const int l = J.seqs[J.seq_idx ? J.seq_idx[si] : si].len; if (l > maxlen) maxlen = l; if (first == 0 && bbi < 0 && si == s0) first = l; }
-            long long c = (long long)(first > 0 ? first : 1) * (J.node_cap > 0 ? J.node_cap : 32) / 16; if (c < (first > 0 ? first : 1) + 64) c = (first > 0 ? first : 1) + 64;
+            long long c = (long long)(first > 0 ? first : 1) * (J.node_cap > 0 ? J.node_cap : 28) / 16; if (c < (first > 0 ? first : 1) + 64) c = (first > 0 ? first : 1) + 64;
             if (c < maxlen + 1) c = maxlen + 1;
-            st.capV = (int)(c < Vc ? c : Vc); st.capE = 2 * st.capV < Ec ? 2 * st.capV : Ec;
+            st.capV = (int)(c < Vc ? c : Vc); st.capE = 3 * st.capV / 2 < Ec ? 3 * st.capV / 2 : Ec;
         }
         for (uint32_t si = s0; si < s1; ++si) {
             const PSeq S = J.seqs[J.seq_idx ? J.seq_idx[si] : si];
@@ -392,7 +440,8 @@ size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW)
 {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     size_t t = 8 * al(2 * (size_t)Vc) + 2 * al(2 * ((size_t)Vc + 1)) + al(Vc) + 4 * al(2 * (size_t)Ec) + al(4 * (size_t)Ec) + 3 * al(2 * (size_t)Lm) + al(Lm);
-    size_t dp = (size_t)HR * BW * 4 + (size_t)64 * BW; if (dp < (size_t)8 * Vc) dp = (size_t)8 * Vc;
+    size_t blk = (size_t)64 * BW; if (blk < (size_t)6 * Vc + 32) blk = ((size_t)6 * Vc + 32 + 15) & ~(size_t)15;
+    size_t dp = (size_t)HR * BW * 4 + blk; if (dp < (size_t)8 * Vc) dp = (size_t)8 * Vc;
     return t + al(dp);
 }
 

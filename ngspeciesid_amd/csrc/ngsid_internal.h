@@ -85,6 +85,10 @@ struct AlignJob {            // device pointers
 };
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen);
 
+typedef unsigned int ngsid_v4u __attribute__((ext_vector_type(4)));
+// 16-byte load served by L2 (nt): for scratch that this wave rewrites between uses, where an L1 line could be stale
+__device__ __forceinline__ ngsid_v4u ngsid_load16_l2(const void* p) { return __builtin_nontemporal_load((const ngsid_v4u*)p); }
+
 __device__ __forceinline__ int ngsid_bcode(uint8_t c) {
     switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
 }

@@ -58,7 +58,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
         if (njobs == 0) break;
         if (any_nobb) maxL0 = std::max<int>(maxL0, (int)cur_maxlen);   // without a backbone the first member sets L0 (<= the longest member)
         // capacity (LDS sizing): the largest per-job capacity the oracle rule can produce
-        long long capV = (long long)maxL0 * (hp.node_cap > 0 ? hp.node_cap : 32) / 16; capV = std::max<long long>(capV, maxL0 + 64); capV = std::max<long long>(capV, (long long)cur_maxlen + 1);
+        long long capV = (long long)maxL0 * (hp.node_cap > 0 ? hp.node_cap : 28) / 16; capV = std::max<long long>(capV, maxL0 + 64); capV = std::max<long long>(capV, (long long)cur_maxlen + 1);
         capV = (capV + 7) & ~7ll;
         const int Lmax = (int)((std::max<uint32_t>(cur_maxlen, 1) + 15) & ~15u);
         DevBuf<uint32_t> d_job_off, d_seq_idx, d_flags; DevBuf<int32_t> d_job_bb;
@@ -75,7 +75,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
             HIPCHK(ctx, hipMemsetAsync(d_flags.p, 0, 16, ctx->stream));
             PoaJobSet J{};
             J.seqs = cur; J.bbs = d_bbs; J.seq_idx = d_seq_idx.p; J.job_off = d_job_off.p; J.job_bb = d_job_bb.p; J.njobs = njobs;
-            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(2 * capV); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles;
+            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles;
             J.out = Lv->out.p; J.out_len = Lv->out_len.p; J.out_cw = Lv->out_cw.p; J.out_n = Lv->out_n.p; J.out_cov = hp.want_cov ? Lv->out_cov.p : nullptr;
             J.dropped = d_flags.p; J.slot_overflow = d_flags.p + 1;
             int32_t rc = poa_run_jobs(ctx, J, hp.band); if (rc) return rc;

@@ -180,7 +180,7 @@ static int g_add_alignment(graph* G, const pseq* S, const ppair* path, int np) {
         if (v >= 0) { if (G->code[v] == S->s[i]) found = v; else for (int u = G->ring[v]; u != v; u = G->ring[u]) if (G->code[u] == S->s[i]) { found = u; break; } }
         nodeof[i] = found; if (found < 0) ++nnew;
     }
-    if (V0 + nnew > G->capV || G->E + L > 2 * G->capV) { free(alnode); free(nodeof); free(ref); return 0; }   /* node / edge (2x) capacity */
+    if (V0 + nnew > G->capV || G->E + L > 3 * G->capV / 2) { free(alnode); free(nodeof); free(ref); return 0; }   /* node / edge (1.5x) capacity */
     /* ref(i) = aligned node of the first aligned position >= i (insertion point: immediately before it), -1 = end */
     { int nx = -1; for (int i = L - 1; i >= 0; --i) { if (alnode[i] >= 0) nx = alnode[i]; ref[i] = nx; } }
     /* create nodes in sequence order; anchor from the nearest aligned position at or before i, else after, else a0 */
@@ -253,7 +253,7 @@ static int g_consensus(const graph* G, uint8_t* out, uint32_t* cov_out) {
 typedef struct { uint8_t* s; uint32_t* cov; int len; uint64_t cw; } pout;
 typedef struct { int m, n, g, band, node_cap, trim_tiles; } pprm;
 
-static int cap_for(int L0, int node_cap) { long c = (long)L0 * (node_cap > 0 ? node_cap : 32) / 16; if (c < L0 + 64) c = L0 + 64; return (int)c; }
+static int cap_for(int L0, int node_cap) { long c = (long)L0 * (node_cap > 0 ? node_cap : 28) / 16; if (c < L0 + 64) c = L0 + 64; return (int)c; }
 
 /* returns number of outputs appended to outs (caller frees .s/.cov) */
 static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* P, pout* outs, int want_cov) {

@@ -57,7 +57,7 @@ def _rand_pairs(rng, n, lmin, lmax, sim=True):
 
 
 @pytest.mark.parametrize("case", [("tiny", 40, 1, 40), ("rpl4", 60, 100, 256), ("rpl8", 40, 300, 512), ("rpl12", 60, 600, 768),
-                                  ("rpl16", 30, 800, 1024), ("strips", 12, 1100, 2600), ("random", 40, 50, 400)])
+                                  ("rpl16", 30, 800, 1024), ("strips", 12, 1100, 2600), ("random", 40, 50, 400), ("many", 9000, 60, 140)])
 def test_align_vs_oracle(gpu_api, oracle, case):
     name, n, lmin, lmax = case
     rng = np.random.default_rng(abs(hash(name)) % 1000)
