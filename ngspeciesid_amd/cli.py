@@ -1,0 +1,118 @@
+"""Command line of the reference (NGSpeciesID:187-287) over the MI355X hot path:  python -m ngspeciesid_amd --ont --fastq X --outfolder O --consensus --racon
+
+Same flags and defaults, same output files (sorted.fastq, logfile.txt, final_clusters.tsv, final_cluster_origins.tsv,
+consensus_reference_*.fasta, reads_to_consensus_*.fastq, racon_cl_id_*/consensus.fasta).  --medaka, --primer_file and
+--remove_universal_tails are outside the hot path and are refused.
+"""
+from __future__ import annotations
+import argparse, logging, os, random, shutil, sys, tempfile
+from time import time
+from . import get_sorted_fastq_for_cluster, parallelize, cluster, consensus, help_functions
+from .ptable import p_emp_probs_dict
+
+
+def single_clustering(read_array, p_emp_probs, args):
+    clusters, representatives = {}, {}
+    for i, b_i, acc, seq, qual, score in read_array:
+        clusters[i] = [acc]; representatives[i] = (i, b_i, acc, seq, qual, score)
+    res = cluster.reads_to_clusters(clusters, representatives, read_array, p_emp_probs, {}, 1, args)
+    clusters, representatives, _, _ = list(res.values())[0]
+    return clusters, representatives
+
+
+def main(args):
+    args.outfile = os.path.join(args.outfolder, "sorted.fastq")
+    sorted_reads_fastq_file = get_sorted_fastq_for_cluster.main(args)
+    with open(sorted_reads_fastq_file) as f:
+        read_array = [(i, 0, acc, seq, qual, float(acc.split("_")[-1])) for i, (acc, (seq, qual)) in enumerate(help_functions.readfq(f))]
+    if args.target_length > 0 and args.target_deviation > 0:
+        read_array = [r for r in read_array if args.target_length - args.target_deviation <= len(r[3]) <= args.target_length + args.target_deviation]
+    if args.top_reads:
+        read_array = read_array[:args.sample_size]
+    elif 0 < args.sample_size < len(read_array):
+        read_array = [read_array[i] for i in sorted(random.sample(range(len(read_array)), args.sample_size))]
+    abundance_cutoff = int(args.abundance_ratio * len(read_array))
+    p_emp_probs = p_emp_probs_dict(args.k, args.w)
+    logging.info(f"Starting Clustering: {len(read_array)} reads")
+    start = time()
+    if args.nr_cores > 1:
+        clusters, representatives = parallelize.parallel_clustering(read_array, p_emp_probs, args)
+    else:
+        clusters, representatives = single_clustering(read_array, p_emp_probs, args)
+    logging.debug(f"Time elapsed clustering: {time() - start}")
+    nontrivial, out_id = 0, 0
+    with open(os.path.join(args.outfolder, "final_clusters.tsv"), "w") as outfile, open(os.path.join(args.outfolder, "final_cluster_origins.tsv"), "w") as origins:
+        for c_id, all_read_acc in sorted(clusters.items(), key=lambda x: (len(x[1]), representatives[x[0]][5]), reverse=True):
+            tup = representatives[c_id]
+            read_cl_id, b_i, acc, c_seq, c_qual, score = tup[:6]
+            error_rate = tup[6] if len(tup) == 8 else ""
+            origins.write("{0}\t{1}\t{2}\t{3}\t{4}\t{5}\n".format(out_id, "_".join(acc.split("_")[:-1]), c_seq, c_qual, score, error_rate))
+            for r_acc in sorted(all_read_acc, key=lambda x: float(x.split("_")[-1]), reverse=True):
+                outfile.write("{0}\t{1}\n".format(out_id, "_".join(r_acc.split("_")[:-1])))
+            if len(all_read_acc) > 1:
+                nontrivial += 1
+            out_id += 1
+    logging.info(f"Finished Clustering: {nontrivial} clusters formed")
+    if args.consensus:
+        logging.info("Starting Consensus creation and polishing")
+        work_dir = tempfile.mkdtemp()
+        centers = consensus.form_draft_consensus(clusters, representatives, sorted_reads_fastq_file, work_dir, abundance_cutoff, args)
+        centers_filtered = consensus.detect_reverse_complements(centers, args.rc_identity_threshold)
+        consensus.polish_sequences(centers_filtered, args)
+        shutil.rmtree(work_dir)
+        logging.info(f"Finished Consensus creation: {len(centers_filtered)} created")
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Reference-free clustering and consensus forming of targeted ONT or PacBio reads (MI355X hot path)",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument('--version', action='version', version='%(prog)s 0.3.1-mi355x')
+    p.add_argument('--debug', action='store_true')
+    rf = p.add_mutually_exclusive_group(required=True)
+    rf.add_argument('--fastq', type=str)
+    rf.add_argument('--use_old_sorted_file', action='store_true')
+    p.add_argument('--t', dest="nr_cores", type=int, default=8, help='Number of score-ordered batches (the reference\'s cores); the cluster membership depends on it exactly like in the reference')
+    p.add_argument('--d', dest="print_output", type=int, default=10000)
+    p.add_argument('--q', dest="quality_threshold", type=float, default=7.0)
+    p.add_argument('--ont', action="store_true"); p.add_argument('--isoseq', action="store_true")
+    p.add_argument('--consensus', action="store_true")
+    p.add_argument('--abundance_ratio', type=float, default=0.1)
+    p.add_argument('--rc_identity_threshold', type=float, default=0.9)
+    p.add_argument('--max_seqs_for_consensus', type=int, default=-1)
+    g = p.add_mutually_exclusive_group()
+    g.add_argument('--medaka', action="store_true"); g.add_argument('--racon', action="store_true")
+    p.add_argument('--medaka_model', type=str, default=""); p.add_argument('--medaka_fastq', action="store_true")
+    p.add_argument('--racon_iter', type=int, default=2)
+    g2 = p.add_mutually_exclusive_group()
+    g2.add_argument('--remove_universal_tails', action="store_true"); g2.add_argument('--primer_file', type=str, default="")
+    p.add_argument('--primer_max_ed', type=int, default=2); p.add_argument('--trim_window', type=int, default=150)
+    p.add_argument('--m', dest="target_length", type=int, default=0); p.add_argument('--s', dest="target_deviation", type=int, default=0)
+    p.add_argument('--sample_size', type=int, default=0); p.add_argument('--top_reads', action='store_true')
+    p.add_argument('--k', type=int, default=13); p.add_argument('--w', type=int, default=20)
+    p.add_argument('--min_shared', type=int, default=5); p.add_argument('--mapped_threshold', type=float, default=0.7)
+    p.add_argument('--aligned_threshold', type=float, default=0.4); p.add_argument('--symmetric_map_align_thresholds', action='store_true')
+    p.add_argument('--batch_type', type=str, default='total_nt'); p.add_argument('--min_fraction', type=float, default=0.8)
+    p.add_argument('--min_prob_no_hits', type=float, default=0.1); p.add_argument('--outfolder', type=str, default=None)
+    return p
+
+
+def cli(argv=None):
+    args = build_parser().parse_args(argv)
+    logging.basicConfig(level=logging.DEBUG if args.debug else logging.INFO, format='%(message)s')
+    if args.ont and args.isoseq:
+        logging.error("Arguments mutually exclusive, specify either --isoseq or --ont. "); sys.exit()
+    elif args.isoseq:
+        args.k, args.w = 15, 50
+    elif args.ont:
+        args.k, args.w = 13, 20
+    if args.medaka or args.primer_file or args.remove_universal_tails:
+        logging.error("--medaka / --primer_file / --remove_universal_tails are outside the accelerated hot path (see DESIGN.md); not available."); sys.exit(1)
+    if 100 < args.w or args.w < args.k:
+        logging.error('Please specify a window of size larger or equal to k, and smaller than 100.'); sys.exit(1)
+    if args.outfolder and not os.path.exists(args.outfolder):
+        os.makedirs(args.outfolder)
+    main(args)
+
+
+if __name__ == "__main__":
+    cli()

@@ -1,0 +1,174 @@
+"""Host parallelism of the clustering stage: contiguous batches + pairwise tree merge (reference modules/parallelize.py).
+
+`--t N` of the reference = N score-ordered batches clustered independently, then merged pairwise in a binary tree where
+the lower batch's representatives keep their database and the higher batch's representatives are re-clustered against
+it (parallelize.py:107-217, cluster.py:221-223,243-248).  The same schedule is what shards the path over N GPUs: batch g
+lives on GPU g, the only exchange is the all-gather of the surviving representatives before the merge rounds
+(`distributed.py`).  Everything here is index-array bookkeeping; the clustering itself is ngsid_cluster_greedy.
+"""
+from __future__ import annotations
+import logging
+import numpy as np
+
+
+def batch_list_total_nt(lens, nr_cores):
+    """batch_list(lst, nr_cores, 'total_nt') (parallelize.py:54-67) on read lengths -> list of (start, end) slices.
+    Quirks kept: can yield fewer batches than cores, and a trailing EMPTY batch when the last read fills a chunk."""
+    lens = np.asarray(lens, dtype=np.int64)
+    tot = int(lens.sum())
+    chunk = int(tot / nr_cores) + 1
+    out, start, cur = [], 0, 0
+    for i, L in enumerate(lens):
+        cur += int(L)
+        if cur >= chunk:
+            out.append((start, i + 1)); start = i + 1; cur = 0
+    out.append((start, len(lens)))
+    return out
+
+
+def batch_list_nr_reads(n, nr_cores):
+    """batch_list(..., 'nr_reads') (parallelize.py:47-52)."""
+    chunk = int(n / nr_cores) + 1
+    return [(a, min(a + chunk, n)) for a in range(0, n, chunk)]
+
+
+def batch_merge_consecutive(prev_idx):
+    """batch_list(..., merge_consecutive=True) (parallelize.py:34-45) on the previous batch indices of the score-ordered
+    representatives -> list of index lists."""
+    batch_id, batch, out = 2, [], []
+    for i, b in enumerate(prev_idx):
+        if b <= batch_id:
+            batch.append(i)
+        else:
+            out.append(batch); batch_id += 2; batch = [i]
+    out.append(batch)
+    return out
+
+
+def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", first_round=None):
+    """The whole parallel_clustering schedule on index arrays.
+
+    cluster_fn(read_idx, prev_batch, known_err) -> (rep_local, herr, status, counters): clusters the reads `read_idx`
+      (global indices, processing order) and returns for each the LOCAL index of its representative.
+    first_round: optional precomputed round-1 result [(rep_global_for_batch_reads, herr_for_batch_reads)] per batch
+      (the multi-GPU path computes round 1 on the ranks and all-gathers it).
+    Returns (rep_of [N] global representative per read, herr [N] (NaN where unknown), merge_order)
+    where merge_order lists (joining_rep, new_rep) in the order the reference moves read lists (cluster.py:338-345).
+    """
+    N = len(lens)
+    rep_of = np.arange(N, dtype=np.int64)
+    herr = np.full(N, np.nan)
+    bidx = np.zeros(N, dtype=np.int64)
+    joins = []
+    if batch_type == "nr_reads":
+        batches = batch_list_nr_reads(N, nr_cores)
+    else:
+        batches = batch_list_total_nt(lens, nr_cores)
+    num_batches = nr_cores
+    # ---- round structure of parallelize.py:136-217
+    cur_batches = [np.arange(a, b, dtype=np.int64) for a, b in batches]
+    prev = None                                # previous batch index per read in cur_batches (None = all 0)
+    it = 1
+    while True:
+        single = len(cur_batches) == 1
+        alive_next = []
+        for bi, idx in enumerate(cur_batches):
+            new_index = 1 if single else bi + 1
+            if len(idx) == 0:
+                continue
+            if it == 1 and first_round is not None:
+                rep_g, he = first_round[bi]
+                rep_local = np.searchsorted(idx, rep_g)            # idx is a contiguous ascending slice
+                st = None
+            else:
+                pb = None if prev is None else bidx[idx].astype(np.int32)
+                ke = None if prev is None else herr[idx]
+                rep_local, he, st, _ = cluster_fn(idx, pb, ke)
+            rep_g = idx[np.asarray(rep_local, dtype=np.int64)]
+            moved = rep_g != idx
+            for a, b in zip(idx[moved], rep_g[moved]):             # processing order = cluster_to_new_cluster_id order
+                joins.append((int(a), int(b)))
+            rep_of[idx[moved]] = rep_g[moved]
+            surv = idx[~moved]
+            known = ~np.isnan(np.asarray(he)[~moved])
+            herr[surv[known]] = np.asarray(he)[~moved][known]
+            # batch index update (cluster.py:245,275,292): every surviving processed / seeded read gets new_index,
+            # except reads skipped for HPC length < k (status 3) which keep their old index
+            if st is not None:
+                keep_old = np.asarray(st)[~moved] == 3
+                bidx[surv[~keep_old]] = new_index
+            else:
+                bidx[surv] = new_index
+            alive_next.append(surv)
+        if single or num_batches == 1:
+            break
+        reps = np.concatenate(alive_next) if alive_next else np.zeros(0, dtype=np.int64)
+        # sorted(all_representatives, key=score, reverse=True): stable; dict order = batch order then read order
+        order = np.argsort(-score[reps], kind="stable")
+        reps = reps[order]
+        it += 1
+        groups = batch_merge_consecutive(bidx[reps])
+        cur_batches = [reps[np.asarray(g, dtype=np.int64)] if len(g) else np.zeros(0, dtype=np.int64) for g in groups]
+        num_batches = len(cur_batches)
+        prev = True
+        logging.debug("Batches after pairwise consecutive merge: %d", num_batches)
+    # path compression: a representative that joined later drags its reads (cluster.py:338-345)
+    for _ in range(64):
+        nxt = rep_of[rep_of]
+        if np.array_equal(nxt, rep_of):
+            break
+        rep_of = nxt
+    return rep_of, herr, joins
+
+
+def cluster_lists_from_joins(N, joins):
+    """Replay of clusters[new].append(...) / del clusters[old] (cluster.py:338-345) -> {rep: [member indices in the reference's list order]}."""
+    clusters = {i: [i] for i in range(N)}
+    for a, b in joins:
+        clusters[b].extend(clusters[a]); del clusters[a]
+    return clusters
+
+
+def parallel_clustering(read_array, p_emp_probs, args, api=None):
+    """parallelize.parallel_clustering(read_array, p_emp_probs, args) -> (clusters, representatives)  (parallelize.py:107-217).
+    Same batches, same merge rounds; batches of a round run one after the other on this process's GPU (or are spread over
+    the ranks of a torch.distributed job by distributed.py)."""
+    from . import cluster as _cluster
+    import math
+    nr = args.nr_cores
+    lens = [len(r[3]) for r in read_array]
+    if getattr(args, "batch_type", "total_nt") == "nr_reads":
+        sl = batch_list_nr_reads(len(read_array), nr)
+    else:
+        sl = batch_list_total_nt(lens, nr)
+    read_batches = [read_array[a:b] for a, b in sl]
+    cluster_batches, origin_batches, dbs = [], [], []
+    for batch in read_batches:
+        cluster_batches.append({i: [acc] for i, b_i, acc, seq, qual, score in batch})
+        origin_batches.append({i: (i, b_i, acc, seq, qual, score) for i, b_i, acc, seq, qual, score in batch})
+        dbs.append({})
+    num_batches = nr
+    it = 1
+    while True:
+        if len(read_batches) == 1:
+            res = _cluster.reads_to_clusters(cluster_batches[0], origin_batches[0], read_batches[0], p_emp_probs, dbs[0], 1, args, api=api)
+            c, o, _, _ = res[1]
+            return c, o
+        all_cl, all_repr, all_db = {}, {}, {}
+        for i in range(len(read_batches)):
+            res = _cluster.reads_to_clusters(cluster_batches[i], origin_batches[i], read_batches[i], p_emp_probs, dbs[i], i + 1, args, api=api)
+            c, o, db, bi = res[i + 1]
+            all_cl.update(c); all_repr.update(o); all_db[bi] = db
+        read_array = [(i, b_index, acc, seq, qual, score) for i, (i, b_index, acc, seq, qual, score, *_rest) in
+                      sorted(all_repr.items(), key=lambda x: x[1][5], reverse=True)]
+        if num_batches == 1:
+            return all_cl, all_repr
+        it += 1
+        groups = batch_merge_consecutive([r[1] for r in read_array])
+        read_batches = [[read_array[j] for j in g] for g in groups]
+        num_batches = len(read_batches)
+        cluster_batches, origin_batches, dbs = [], [], []
+        for batch in read_batches:
+            cluster_batches.append({i: all_cl[i] for i, *_ in batch})
+            origin_batches.append({i: all_repr[i] for i, *_ in batch})
+            dbs.append({})

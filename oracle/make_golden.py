@@ -289,5 +289,30 @@ def main():
     shutil.rmtree(tmp)
 
 
-if __name__ == "__main__":
+
+
+def golden_cli():
+    """final_clusters.tsv / final_cluster_origins.tsv / sorted.fastq of the reference CLI (--t 1, clustering only) on test/sample_h1.fastq."""
+    import importlib.machinery, importlib.util, hashlib
+    loader = importlib.machinery.SourceFileLoader("ngs_ref_cli", "/root/reference/NGSpeciesID")
+    spec = importlib.util.spec_from_loader("ngs_ref_cli", loader); mod = importlib.util.module_from_spec(spec)
+    sys.modules["parasail"] = parasail
+    loader.exec_module(mod)
+    tmp = tempfile.mkdtemp()
+    args = ref_args(k=13, w=20, nr_cores=1, fastq="/root/reference/test/sample_h1.fastq", outfolder=tmp, consensus=False, target_length=0, target_deviation=0,
+                    top_reads=False, sample_size=0, abundance_ratio=0.1, primer_file="", remove_universal_tails=False, ont=True, isoseq=False)
+    mod.main(args)
+    for name in ("final_clusters.tsv", "final_cluster_origins.tsv"):
+        shutil.copyfile(os.path.join(tmp, name), os.path.join(GOLD, "sample_h1_t1_" + name))
+    with open(os.path.join(GOLD, "sample_h1_t1_sorted.fastq.md5"), "w") as f:
+        f.write(hashlib.md5(open(os.path.join(tmp, "sorted.fastq"), "rb").read()).hexdigest() + "\n")
+    shutil.rmtree(tmp)
+    print("cli goldens written")
+
+
+if __name__ == "__main__" and "--cli-only" in sys.argv:
+    golden_cli()
+
+if __name__ == "__main__" and "--cli-only" not in sys.argv:
     main()
+    golden_cli()

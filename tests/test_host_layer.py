@@ -1,0 +1,47 @@
+"""CPU: the reference-shaped host layer (cluster.reads_to_clusters / parallelize.parallel_clustering dict API) with the oracle as
+the C-ABI backend, against the reference's own clusters dicts (tests/golden)."""
+import os, argparse
+import numpy as np
+import pytest
+from oracle_lib import GOLD
+from ngspeciesid_amd import cluster, parallelize
+from ngspeciesid_amd.ptable import p_emp_probs_dict
+
+
+def ref_args(**kw):
+    a = argparse.Namespace(k=13, w=20, min_shared=5, mapped_threshold=0.7, aligned_threshold=0.4, symmetric_map_align_thresholds=False,
+                           min_fraction=0.8, min_prob_no_hits=0.1, print_output=10 ** 9, nr_cores=1, batch_type="total_nt")
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def load_read_array(tag):
+    g = np.load(os.path.join(GOLD, "cluster_%s.npz" % tag), allow_pickle=False)
+    off = g["off"].astype(np.int64)
+    ra = []
+    for i in range(len(off) - 1):
+        ra.append((i, 0, str(g["acc"][i]), g["seq"][off[i]:off[i + 1]].tobytes().decode(), g["qual"][off[i]:off[i + 1]].tobytes().decode(), float(g["score"][i])))
+    return g, ra
+
+
+@pytest.mark.parametrize("tag,t", [("sample_h1", 1), ("sample_h1", 8), ("synth600_d10_q14", 4)])
+def test_dict_api_matches_reference(oracle, tag, t):
+    g, ra = load_read_array(tag)
+    args = ref_args(k=int(g["k"]), w=int(g["w"]), nr_cores=t)
+    pt = p_emp_probs_dict(args.k, args.w)
+    if t == 1:
+        clusters = {i: [acc] for i, _, acc, *_ in ra}; reps = {i: (i, b, acc, s, q, sc) for i, b, acc, s, q, sc in ra}
+        res = cluster.reads_to_clusters(clusters, reps, ra, pt, {}, 1, args, api=oracle)
+        clusters, reps, _, _ = res[1]
+    else:
+        clusters, reps = parallelize.parallel_clustering(ra, pt, args, api=oracle)
+    keys, off, order = g["t%d_cl_keys" % t], g["t%d_cl_off" % t], g["t%d_cl_order" % t]
+    assert sorted(clusters.keys()) == sorted(int(k) for k in keys)
+    for i, kk in enumerate(keys):
+        assert clusters[int(kk)] == [str(g["acc"][j]) for j in order[off[i]:off[i + 1]]]
+    for kk in keys:                                       # representatives carry the 8-tuple with the HPC error rate
+        tup = reps[int(kk)]
+        if len(tup) == 8:
+            ref = g["t%d_rep_err" % t][int(kk)]
+            assert abs(tup[6] - ref) <= 16 * np.spacing(ref)
