@@ -76,7 +76,13 @@ def main():
     kw = dict(k=13, w=20, abundance_ratio=0.02, racon_iter=3, tile_depth=args.tile_depth, band=128, p_shared=ptab)
 
     def step(T=None):
-        return pipeline.run_hot_path(api, rs, rd["score"], acc_rank=acc_rank, timings=T, **kw)
+        if dist is None:
+            return pipeline.run_hot_path(api, rs, rd["score"], acc_rank=acc_rank, timings=T, **kw)
+        from ngspeciesid_amd import distributed
+        r = distributed.sharded_hot_path(api, rs, rd["score"], acc_rank_local=acc_rank, timings=T, device=dev, **kw)
+        # same result shape as the single-GPU path for the checks below
+        r["rep_of"] = r["final_gid"]; r["centers"] = [(c[0], c[1], c[2], c[3], []) for c in r["centers"]]
+        return r
 
     def barrier():
         torch.cuda.synchronize()
@@ -158,6 +164,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "int32/u8 (f64 thresholds)", "data": "synthetic",
            "config": {"workload": "%d synthetic %d bp ONT-profile reads per GPU (mu=%.0f), %d species @15%% divergence, k=13 w=20, cluster + spoa-style POA + racon-style polish x3, abundance_ratio 0.02, POA tile depth %d band 128"
                       % (args.reads, args.length, args.mu, args.species, args.tile_depth),
+                      "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
                       "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()},
                       "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()},
                       "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed}},

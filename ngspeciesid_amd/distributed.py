@@ -1,0 +1,149 @@
+"""The hot path sharded over N GPUs of one node: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Shard g (rank g) = batch g+1 of the reference's `--t N` schedule.  Per rank, no collective: round-1 clustering of the
+shard, tile consensuses and window consensuses of the shard's own reads.  Collectives (all small, latency bound):
+  1. all-gather of the surviving REPRESENTATIVES (sequence, qualities, score, HPC error rate) after round 1 - the
+     reference's only exchange (parallelize.py:169-184) - then every rank replays the pairwise tree merge on them;
+  2. all-reduce of cluster sizes (which clusters reach the abundance cutoff);
+  3. all-gather of the per-shard partial consensuses (one string per selected cluster and rank), merged by a POA whose
+     per-base weights are proportional to the reads each partial stands for - once for the draft and once per polishing
+     iteration.
+Reads never move between GPUs.
+"""
+from __future__ import annotations
+import pickle
+import numpy as np
+import torch
+import torch.distributed as dist
+from . import parallelize, pipeline
+from ._capi import ReadSet, cluster_params, poa_params, polish_params, POA_LOCAL, ST_SHORT
+from .hostutil import subset_reads
+
+
+def all_gather_bytes(blob: bytes, device):
+    """variable-length all-gather: sizes first, then one padded uint8 all_gather (RCCL on GPU, gloo on CPU)."""
+    world = dist.get_world_size()
+    n = torch.tensor([len(blob)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    mx = int(max(int(s.item()) for s in sizes))
+    buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=device)
+    if len(blob):
+        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    outs = [torch.zeros(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return [bytes(o[:int(s.item())].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
+
+
+def all_gather_obj(obj, device):
+    return [pickle.loads(b) for b in all_gather_bytes(pickle.dumps(obj, protocol=4), device)]
+
+
+def _weighted_merge(api, partials, counts, tile_depth, band):
+    """POA of per-shard partial consensuses; the quality string carries the weight (reads represented, scaled to 1..93)."""
+    items = [(s, c) for s, c in zip(partials, counts) if s and c > 0]
+    if not items:
+        return ""
+    if len(items) == 1:
+        return items[0][0]
+    mx = max(c for _, c in items)
+    seqs = [s for s, _ in items]
+    quals = [chr(33 + max(1, min(93, int(round(93.0 * c / mx))))) * len(s) for s, c in items]
+    rs = ReadSet.from_strings(seqs, quals)
+    return api.poa_consensus(rs, [0, len(seqs)], poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=band))[0]
+
+
+def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k=13, w=20, abundance_ratio=0.1, rc_identity_threshold=0.9,
+                     racon_iter=3, tile_depth=8, band=128, p_shared=None, cluster_kwargs=None, do_consensus=True, polish_trim=2, device=None, timings=None):
+    """Runs on every rank; returns dict(final_rep=(rank, local idx) per local read as two arrays, centers=[(n, key, draft, polished)])."""
+    import time
+    T = timings if timings is not None else {}
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    prm = cluster_params(k=k, w=w, p_shared=p_shared, **(cluster_kwargs or {}))
+    n_local = rs_local.n
+    score_local = np.asarray(score_local, dtype=np.float64)
+    # ---- 1. round 1 on the shard (no communication)
+    t0 = time.perf_counter()
+    rep_local, herr, st, cnt = api.cluster_greedy(rs_local, prm, acc_rank=acc_rank_local)
+    T["cluster_local"] = T.get("cluster_local", 0.0) + time.perf_counter() - t0
+    # ---- 2. all-gather the representatives, replay the tree merge everywhere
+    t0 = time.perf_counter()
+    mine = np.nonzero(rep_local == np.arange(n_local))[0]
+    if rs_local.mem == 0:
+        sub = subset_reads(rs_local, mine)
+        payload = dict(idx=mine.astype(np.int64), seq=sub.seq, qual=sub.qual, off=sub.off, score=score_local[mine], herr=herr[mine],
+                       rank_key=None if acc_rank_local is None else np.asarray(acc_rank_local)[mine], n=n_local)
+    else:   # device resident shard: pull only the representatives to the host
+        seq_t, qual_t, off_t = rs_local.keep["seq"], rs_local.keep["qual"], rs_local.keep["off"]
+        offs = off_t.cpu().numpy()
+        lens = offs[mine + 1] - offs[mine]
+        noff = np.zeros(len(mine) + 1, dtype=np.uint64); noff[1:] = np.cumsum(lens)
+        gi = torch.from_numpy(np.repeat(offs[mine] - noff[:-1].astype(np.int64), lens) + np.arange(int(noff[-1]), dtype=np.int64)).to(seq_t.device)
+        payload = dict(idx=mine.astype(np.int64), seq=seq_t[gi].cpu().numpy(), qual=qual_t[gi].cpu().numpy(), off=noff, score=score_local[mine], herr=herr[mine],
+                       rank_key=None if acc_rank_local is None else np.asarray(acc_rank_local)[mine], n=n_local)
+    gathered = all_gather_obj(payload, device)
+    n_total = sum(g["n"] for g in gathered)
+    seqs = np.concatenate([g["seq"] for g in gathered]); quals = np.concatenate([g["qual"] for g in gathered])
+    lens_all = np.concatenate([np.diff(g["off"].astype(np.int64)) for g in gathered])
+    off_all = np.zeros(len(lens_all) + 1, dtype=np.uint64); off_all[1:] = np.cumsum(lens_all)
+    reps_rs = ReadSet(seqs, quals, off_all)
+    r_score = np.concatenate([g["score"] for g in gathered]); r_herr = np.concatenate([g["herr"] for g in gathered])
+    r_batch = np.concatenate([np.full(len(g["idx"]), b + 1, dtype=np.int64) for b, g in enumerate(gathered)])
+    r_owner = np.concatenate([np.full(len(g["idx"]), b, dtype=np.int64) for b, g in enumerate(gathered)])
+    r_lidx = np.concatenate([g["idx"] for g in gathered])
+    if gathered[0]["rank_key"] is not None:
+        # accession order across shards: (rank key within the shard, shard) - a total order consistent on every rank
+        key = np.concatenate([g["rank_key"].astype(np.int64) * world + b for b, g in enumerate(gathered)])
+        r_accrank = np.argsort(np.argsort(key, kind="stable"), kind="stable").astype(np.uint32)
+    else:
+        r_accrank = np.arange(len(r_lidx), dtype=np.uint32)
+
+    def cfn(read_idx, prev_batch, known_err):
+        s = subset_reads(reps_rs, read_idx)
+        return api.cluster_greedy(s, prm, acc_rank=r_accrank[np.asarray(read_idx, dtype=np.int64)], prev_batch=prev_batch, known_err=known_err)
+    rep_of_rep, _, joins = parallelize.tree_cluster(cfn, lens_all, r_score, world, state=(r_batch, r_herr))
+    base = np.concatenate(([0], np.cumsum([len(g["idx"]) for g in gathered])))
+    my_gid = np.full(n_local, -1, dtype=np.int64); my_gid[mine] = base[rank] + np.arange(len(mine))
+    final_gid = rep_of_rep[my_gid[rep_local]]                                 # global representative id of every local read
+    T["merge"] = T.get("merge", 0.0) + time.perf_counter() - t0
+    res = dict(final_owner=r_owner[final_gid], final_lidx=r_lidx[final_gid], final_gid=final_gid, counters=cnt, n_total=n_total, centers=[])
+    if not do_consensus:
+        return res
+    # ---- 3. cluster sizes over all shards
+    t0 = time.perf_counter()
+    sizes = torch.from_numpy(np.bincount(final_gid, minlength=len(r_lidx)).astype(np.int64)).to(device)
+    dist.all_reduce(sizes)
+    sizes = sizes.cpu().numpy()
+    cutoff = int(abundance_ratio * n_total)
+    cand = np.nonzero((sizes >= cutoff) & (sizes > 0))[0]
+    cand = cand[np.lexsort((-r_score[cand], -sizes[cand]))]
+    # ---- 4. per-shard partial consensus of every selected cluster, all-gather, weighted merge
+    order = np.argsort(final_gid, kind="stable").astype(np.uint32)
+    sorted_gid = final_gid[order]
+    lo = np.searchsorted(sorted_gid, cand, side="left"); hi = np.searchsorted(sorted_gid, cand, side="right")
+    sub_order = np.concatenate([order[a:b] for a, b in zip(lo, hi)]) if len(cand) else np.zeros(0, np.uint32)
+    sub_off = np.concatenate(([0], np.cumsum(hi - lo))).astype(np.uint64)
+    partial = api.poa_consensus(rs_local, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band), read_order=sub_order) if len(cand) else []
+    allp = all_gather_obj(dict(cons=partial, cnt=(hi - lo).tolist()), device)
+    drafts = [_weighted_merge(api, [p["cons"][c] for p in allp], [p["cnt"][c] for p in allp], tile_depth, band) for c in range(len(cand))]
+    T["consensus"] = T.get("consensus", 0.0) + time.perf_counter() - t0
+    # ---- 5. reverse-complement merge (identical on every rank), then polish: per iteration local window consensus + weighted merge
+    t0 = time.perf_counter()
+    centers = [[int(sizes[g]), int(g), drafts[c], [c]] for c, g in enumerate(cand)]
+    merged = pipeline.detect_reverse_complements(api, centers, rc_identity_threshold)
+    polished = [m[2] for m in merged]
+    for it in range(racon_iter):
+        p_order, p_off = [], [0]
+        for m in merged:
+            for c in m[3]:
+                p_order.append(order[lo[c]:hi[c]])
+            p_off.append(sum(len(x) for x in p_order))
+        p_order = np.concatenate(p_order) if p_order else np.zeros(0, np.uint32)
+        bb = ReadSet.from_strings(polished)
+        loc, used = api.polish(bb, rs_local, p_off, polish_params(iters=1, k=k, w=w, tile_depth=tile_depth, band=band, trim=polish_trim), read_order=p_order) if len(merged) else ([], [])
+        allq = all_gather_obj(dict(cons=loc, cnt=[int(u) for u in used]), device)
+        polished = [_weighted_merge(api, [q["cons"][c] for q in allq], [q["cnt"][c] for q in allq], tile_depth, band) or polished[c] for c in range(len(merged))]
+    T["polish"] = T.get("polish", 0.0) + time.perf_counter() - t0
+    res["centers"] = [(m[0], m[1], m[2], polished[i]) for i, m in enumerate(merged)]
+    return res

@@ -45,29 +45,42 @@ def batch_merge_consecutive(prev_idx):
     return out
 
 
-def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", first_round=None):
+def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state=None):
     """The whole parallel_clustering schedule on index arrays.
 
     cluster_fn(read_idx, prev_batch, known_err) -> (rep_local, herr, status, counters): clusters the reads `read_idx`
       (global indices, processing order) and returns for each the LOCAL index of its representative.
-    first_round: optional precomputed round-1 result [(rep_global_for_batch_reads, herr_for_batch_reads)] per batch
-      (the multi-GPU path computes round 1 on the ranks and all-gathers it).
-    Returns (rep_of [N] global representative per read, herr [N] (NaN where unknown), merge_order)
-    where merge_order lists (joining_rep, new_rep) in the order the reference moves read lists (cluster.py:338-345).
+    state: optional (bidx, herr) = the situation AFTER round 1 (every index is a surviving representative of batch
+      bidx[i] >= 1 with HPC error rate herr[i]); the multi-GPU path runs round 1 on the ranks, all-gathers the
+      representatives and enters here for the merge rounds only.
+    Returns (rep_of [N] global representative per read, herr [N] (NaN where unknown), joins)
+    where joins lists (joining_rep, new_rep) in the order the reference moves read lists (cluster.py:338-345).
     """
     N = len(lens)
     rep_of = np.arange(N, dtype=np.int64)
-    herr = np.full(N, np.nan)
-    bidx = np.zeros(N, dtype=np.int64)
     joins = []
-    if batch_type == "nr_reads":
-        batches = batch_list_nr_reads(N, nr_cores)
+    if state is None:
+        herr = np.full(N, np.nan)
+        bidx = np.zeros(N, dtype=np.int64)
+        if batch_type == "nr_reads":
+            batches = batch_list_nr_reads(N, nr_cores)
+        else:
+            batches = batch_list_total_nt(lens, nr_cores)
+        cur_batches = [np.arange(a, b, dtype=np.int64) for a, b in batches]
+        prev = None                                # previous batch index per read in cur_batches (None = all 0)
+        num_batches = nr_cores
     else:
-        batches = batch_list_total_nt(lens, nr_cores)
-    num_batches = nr_cores
+        bidx = np.asarray(state[0], dtype=np.int64).copy(); herr = np.asarray(state[1], dtype=np.float64).copy()
+        # parallelize.py:184 sorts by score; batches hold contiguous score ranges there, so (batch, score) is the same order
+        # and stays well defined when the shards of a multi-GPU run were scored independently
+        reps = np.lexsort((-np.asarray(score), bidx))
+        groups = batch_merge_consecutive(bidx[reps])
+        cur_batches = [reps[np.asarray(g, dtype=np.int64)] if len(g) else np.zeros(0, dtype=np.int64) for g in groups]
+        prev = True
+        num_batches = len(cur_batches)
+        if nr_cores == 1:
+            return rep_of, herr, joins
     # ---- round structure of parallelize.py:136-217
-    cur_batches = [np.arange(a, b, dtype=np.int64) for a, b in batches]
-    prev = None                                # previous batch index per read in cur_batches (None = all 0)
     it = 1
     while True:
         single = len(cur_batches) == 1
@@ -76,14 +89,9 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", first
             new_index = 1 if single else bi + 1
             if len(idx) == 0:
                 continue
-            if it == 1 and first_round is not None:
-                rep_g, he = first_round[bi]
-                rep_local = np.searchsorted(idx, rep_g)            # idx is a contiguous ascending slice
-                st = None
-            else:
-                pb = None if prev is None else bidx[idx].astype(np.int32)
-                ke = None if prev is None else herr[idx]
-                rep_local, he, st, _ = cluster_fn(idx, pb, ke)
+            pb = None if prev is None else bidx[idx].astype(np.int32)
+            ke = None if prev is None else herr[idx]
+            rep_local, he, st, _ = cluster_fn(idx, pb, ke)
             rep_g = idx[np.asarray(rep_local, dtype=np.int64)]
             moved = rep_g != idx
             for a, b in zip(idx[moved], rep_g[moved]):             # processing order = cluster_to_new_cluster_id order
@@ -94,17 +102,14 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", first
             herr[surv[known]] = np.asarray(he)[~moved][known]
             # batch index update (cluster.py:245,275,292): every surviving processed / seeded read gets new_index,
             # except reads skipped for HPC length < k (status 3) which keep their old index
-            if st is not None:
-                keep_old = np.asarray(st)[~moved] == 3
-                bidx[surv[~keep_old]] = new_index
-            else:
-                bidx[surv] = new_index
+            keep_old = np.asarray(st)[~moved] == 3
+            bidx[surv[~keep_old]] = new_index
             alive_next.append(surv)
         if single or num_batches == 1:
             break
         reps = np.concatenate(alive_next) if alive_next else np.zeros(0, dtype=np.int64)
         # sorted(all_representatives, key=score, reverse=True): stable; dict order = batch order then read order
-        order = np.argsort(-score[reps], kind="stable")
+        order = np.lexsort((-score[reps], bidx[reps]))                 # = sort by score on contiguous batches (see above)
         reps = reps[order]
         it += 1
         groups = batch_merge_consecutive(bidx[reps])

@@ -1,0 +1,58 @@
+"""CPU, world_size 2, gloo: the sharded path (ngspeciesid_amd.distributed) with the oracle as the C-ABI backend.
+Shards = the reference's own `--t 2` batches, so the merged membership must equal the reference's --t 2 result."""
+import os, sys, subprocess, tempfile, json
+import numpy as np
+import pytest
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+from oracle_lib import load_oracle, GOLD
+from ngspeciesid_amd import distributed, parallelize
+from ngspeciesid_amd._capi import ReadSet
+from ngspeciesid_amd.hostutil import acc_rank, subset_reads
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = np.load(os.path.join(GOLD, "cluster_%s.npz" % sys.argv[2]))
+rs = ReadSet(g["seq"], g["qual"], g["off"])
+lens = np.diff(g["off"].astype(np.int64))
+a, b = parallelize.batch_list_total_nt(lens, world)[rank]
+idx = np.arange(a, b)
+ar = acc_rank([str(x) for x in g["acc"]])
+res = distributed.sharded_hot_path(load_oracle(), subset_reads(rs, idx), g["score"][idx], acc_rank_local=ar[idx], k=int(g["k"]), w=int(g["w"]),
+                                   p_shared=g["p_table"], abundance_ratio=0.1, racon_iter=1, tile_depth=8, do_consensus=(sys.argv[4] == "1"))
+starts = [s for s, e in parallelize.batch_list_total_nt(lens, world)]
+final = np.array([starts[o] + l for o, l in zip(res["final_owner"], res["final_lidx"])])
+json.dump(dict(a=int(a), b=int(b), final=final.tolist(), centers=[(c[0], c[3]) for c in res["centers"]]), open(os.path.join(sys.argv[3], "r%d.json" % rank), "w"))
+dist.destroy_process_group()
+'''
+
+
+def _run(tag, consensus, world=2):
+    tmp = tempfile.mkdtemp()
+    wf = os.path.join(tmp, "worker.py"); open(wf, "w").write(WORKER)
+    env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", "29517",
+           wf, ROOT, tag, tmp, "1" if consensus else "0"]
+    subprocess.run(cmd, check=True, env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return [json.load(open(os.path.join(tmp, "r%d.json" % r))) for r in range(world)]
+
+
+def test_two_rank_membership_equals_reference_t2():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cluster_synth2k_d15.npz"))
+    outs = _run("synth2k_d15", consensus=False)
+    final = np.full(len(g["t2_rep_of"]), -1)
+    for o in outs:
+        final[o["a"]:o["b"]] = o["final"]
+    assert np.array_equal(final, g["t2_rep_of"])              # identical cluster membership to the reference's --t 2
+
+
+def test_two_rank_consensus_agrees_between_ranks():
+    outs = _run("synth2k_d15", consensus=True)
+    assert outs[0]["centers"] == outs[1]["centers"] and len(outs[0]["centers"]) == 5
+    sizes = sorted(c[0] for c in outs[0]["centers"])
+    assert sizes == [372, 393, 403, 411, 414]                 # the reference's cluster sizes for this fixture
+    for n, seq in outs[0]["centers"]:
+        assert 730 < len(seq) < 770
