@@ -30,7 +30,7 @@ struct G {   // LDS-resident graph of one tile + per-sequence scratch
     l16 e_tail, e_head, e_next_in, e_next_out; l32 e_w;
     l16 alnode, nodeof, ref; l8 sq;
     l32 hring; l8 dirblk; l64 sc;
-    l16 rp0, rp1; l8 rcode, rflag;      // per-rank row info for the forward pass (aliases dirblk: dead before the traceback)
+    l64 rinfo; l8 rneed;                // per-rank row info for the forward pass (aliases dirblk: dead before the traceback)
 };
 
 // Single-wave workgroup: LDS instructions of one wave execute in issue order, so ordering LDS traffic between lanes only needs the
@@ -137,110 +137,159 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
 {
     constexpr int BW = 64 * CPL;
     const int L = S.len, mode = S.mode, gp = J.g, V = st.V;
-    // per-rank row info, built lane-parallel so that the serial row loop reads everything by rank (no pointer chasing):
-    // band start, node letter, ranks of the first two predecessors, flags (1 = no predecessor, 2 = more than two, 4 = sink)
+    // ---------- per-rank row info, built lane-parallel so that the serial row loop reads ONE 8-byte LDS word per row:
+    //   lo:16 | first pred rank:16 | second pred rank:16 | letter:8 | flags:8
+    //   flags: 1 no predecessor, 2 more than two, 4 sink, 8 keep an HBM copy (a successor is > HR rows away),
+    //          16 chain row (single predecessor = previous row, band shift 0/1), 32 = that band shift
+    for (int r = lane; r < V; r += 64) g.rneed[r] = 0;
+    lds_sync();
     for (int r = lane; r < V; r += 64) {
         const int v = g.order[r];
-        g.lo[r] = (uint16_t)band_lo(g.anchor[v], S, st.L0, BW);
+        for (int e = g.in_first[v]; e != NONE16; e = g.e_next_in[e]) { const int pr = g.rank[g.e_tail[e]]; if (r - pr > HR) g.rneed[pr] = 1; }
+        const int l0 = band_lo(g.anchor[v], S, st.L0, BW);
+        g.lo[r] = (uint16_t)l0;
         const int e0 = g.in_first[v]; int p0 = NONE16, p1 = NONE16, fl = 0;
         if (e0 == NONE16) fl |= 1;
         else { p0 = g.rank[g.e_tail[e0]]; const int e1 = g.e_next_in[e0]; if (e1 != NONE16) { p1 = g.rank[g.e_tail[e1]]; if (g.e_next_in[e1] != NONE16) fl |= 2; } }
         if (g.out_first[v] == NONE16) fl |= 4;
-        g.rp0[r] = (uint16_t)p0; g.rp1[r] = (uint16_t)p1; g.rcode[r] = g.code[v]; g.rflag[r] = (uint8_t)fl;
+        if (r > 0 && !(fl & 3) && p0 == r - 1 && p1 == NONE16) {
+            const int d = l0 - band_lo(g.anchor[g.order[r - 1]], S, st.L0, BW);
+            if (d == 0 || d == 1) fl |= 16 | (d << 5);
+        }
+        g.rinfo[r] = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)p0 << 16) | ((unsigned long long)(unsigned)p1 << 32)
+                   | ((unsigned long long)g.code[v] << 48) | ((unsigned long long)(unsigned)fl << 56);
     }
     for (int i = lane; i < L; i += 64) { g.alnode[i] = NONE16; g.sq[i] = S.s[i]; }
+    lds_sync();
+    for (int r = lane; r < V; r += 64) if (g.rneed[r]) g.rinfo[r] |= 8ull << 56;
     __syncthreads();
     // ---------- forward DP, one row per graph node in topological order
-    int bestv = PNEG, bestr = -1, bestc = -1;
-    for (int r = 0; r < V; ++r) {
-        const int l0 = g.lo[r]; const uint8_t cv = g.rcode[r]; const int rfl = g.rflag[r];
-        const bool nopred = (rfl & 1) != 0;
-        const bool use_src = nopred || mode == NGSID_POA_SEMI;
+    const bool has_invalid = (L + 1 < BW);              // otherwise every band column is <= L (band_lo clamps)
+    const bool local = mode == NGSID_POA_LOCAL, semi = mode == NGSID_POA_SEMI;
+    const int sm = J.m, sn = J.n;
+    int bestv = PNEG, bestpk = 0x7fffffff;               // packed (rank << 8 | band column): ties -> lowest rank, then lowest column
+    int hprev[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) hprev[c] = PNEG;
+    unsigned long long ri_next = V > 0 ? g.rinfo[0] : 0ull;
+    uint8_t* dgp = Dg + lane * CPL;
+    for (int r = 0; r < V; ++r, dgp += BW) {
+        const unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)ri_next), rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri_next >> 32));
+        if (r + 1 < V) ri_next = g.rinfo[r + 1];          // prefetch: consumed one iteration later
+        const int l0 = rlo & 0xffff, p0r = rlo >> 16, p1r = rhi & 0xffff; const int cv = (rhi >> 16) & 0xff; const int rfl = rhi >> 24;
         const int jb = l0 + lane * CPL;
-        int Xd[CPL], Dslot[CPL], Xu[CPL], Uslot[CPL], scj[CPL];
+        int scj[CPL];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) { Xd[c] = PNEG; Xu[c] = PNEG; Dslot[c] = 0; Uslot[c] = 0; const int j = jb + c; scj[c] = (j >= 1 && j <= L) ? ((cv == g.sq[j - 1]) ? J.m : J.n) : 0; }
-        // predecessors in in-edge order: the first two come from the row info, further ones (rare) by walking the in-edge list
-        int slot = 0, eit = NONE16;
-        if (rfl & 2) { eit = g.in_first[g.order[r]]; }
-        for (;; ++slot) {
-            int pr;
-            if (!(rfl & 2)) { pr = slot == 0 ? g.rp0[r] : (slot == 1 ? g.rp1[r] : NONE16); if (pr == NONE16) break; }
-            else { if (eit == NONE16) break; pr = g.rank[g.e_tail[eit]]; eit = g.e_next_in[eit]; }
-            const int plo = g.lo[pr];
-            // the lane needs predecessor columns j-1 .. j+CPL-1 : CPL+1 values starting at pc0-1
-            const int pc0 = jb - plo;
-            int hp[CPL + 1];
-            if ((r - pr) <= HR) {                       // LDS ring (the common case)
-                const l32 Hp = g.hring + (size_t)(pr % HR) * BW;
+        for (int c = 0; c < CPL; ++c) { const int j = jb + c; const int ch = (j >= 1 && j <= L) ? (int)g.sq[j - 1] : 256; scj[c] = (ch == cv) ? sm : sn; }
+        int X[CPL], Dd[CPL];
+        if ((rfl & 16) && !semi) {
+            // chain row: the only predecessor is the previous row, still in registers; neighbours through one DPP move
+            const int lf = __builtin_amdgcn_update_dpp(PNEG, hprev[CPL - 1], 0x138, 0xf, 0xf, false);   // lane-1's last column
+            const int rt = __builtin_amdgcn_update_dpp(PNEG, hprev[0], 0x130, 0xf, 0xf, false);         // lane+1's first column
+            int ext[CPL + 2]; ext[0] = lf; ext[CPL + 1] = rt;
 #pragma unroll
-                for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : PNEG; }
-            } else {                                    // far predecessor: HBM copy of the row (written >= HR rows ago by this wave)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int32_t* Hq = Hg + (size_t)pr * BW;
+            for (int c = 0; c < CPL; ++c) ext[c + 1] = hprev[c];
+            const bool sh = (rfl & 32) != 0;
 #pragma unroll
-                for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? __builtin_nontemporal_load(Hq + pc) : PNEG; }
+            for (int c = 0; c < CPL; ++c) {
+                const int up = sh ? ext[c + 2] : ext[c + 1]; int dg = sh ? ext[c + 1] : ext[c];
+                if (jb + c < 1) dg = PNEG;
+                const int xu = up + gp, xd = dg + scj[c];
+                X[c] = xd >= xu ? xd : xu; Dd[c] = xd >= xu ? 0 : 1;
+            }
+        } else {
+            const bool nopred = (rfl & 1) != 0;
+            const bool use_src = nopred || semi;
+            int Xd[CPL], Dslot[CPL], Xu[CPL], Uslot[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) { Xd[c] = PNEG; Xu[c] = PNEG; Dslot[c] = 0; Uslot[c] = 0; }
+            int slot = 0, eit = NONE16;
+            if (rfl & 2) { eit = g.in_first[g.order[r]]; }
+            for (;; ++slot) {
+                int pr;
+                if (!(rfl & 2)) { pr = slot == 0 ? p0r : (slot == 1 ? p1r : NONE16); if (pr == NONE16) break; }
+                else { if (eit == NONE16) break; pr = g.rank[g.e_tail[eit]]; eit = g.e_next_in[eit]; }
+                const int plo = g.lo[pr];
+                const int pc0 = jb - plo;
+                int hp[CPL + 1];
+                if ((r - pr) <= HR) {                       // LDS ring
+                    const l32 Hp = g.hring + (size_t)(pr & (HR - 1)) * BW;
+#pragma unroll
+                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : PNEG; }
+                } else {                                    // far predecessor: HBM copy of the row (flag 8 made the producer store it)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const int32_t* Hq = Hg + (size_t)pr * BW;
+#pragma unroll
+                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? __builtin_nontemporal_load(Hq + pc) : PNEG; }
+                }
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int j = jb + c;
+                    { const int hv = hp[c + 1]; if (hv > PNEG && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
+                    if (j >= 1) { const int hv = hp[c]; if (hv > PNEG && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
+                }
             }
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-                const int j = jb + c; if (j > L) continue;
-                { const int hv = hp[c + 1]; if (hv > PNEG && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
-                if (j >= 1) { const int hv = hp[c]; if (hv > PNEG && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
+                const int j = jb + c;
+                if (use_src && j >= 1) { const int sv = local ? 0 : (j - 1) * gp; if (sv + scj[c] > Xd[c]) { Xd[c] = sv + scj[c]; Dslot[c] = SRC_SLOT; } }
+                if (nopred && !semi) { const int sv = local ? 0 : j * gp; if (sv + gp > Xu[c]) { Xu[c] = sv + gp; Uslot[c] = SRC_SLOT; } }
+                if (Xd[c] >= Xu[c]) { X[c] = Xd[c]; Dd[c] = 0 | (Dslot[c] << 2); } else { X[c] = Xu[c]; Dd[c] = 1 | (Uslot[c] << 2); }
             }
         }
+        // in-row gap chain H[j] = max(Xf[j], H[j-1]+g) as a max-plus prefix scan of y[j] = Xf[j] - j*g
+        int exl[CPL]; int run = PNEG * 2;
+        const int jg0 = jb * gp;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            const int j = jb + c; if (j > L) continue;
-            if (use_src && j >= 1) { const int sv = (mode == NGSID_POA_LOCAL) ? 0 : (j - 1) * gp; if (sv + scj[c] > Xd[c]) { Xd[c] = sv + scj[c]; Dslot[c] = SRC_SLOT; } }
-            if (nopred && mode != NGSID_POA_SEMI) { const int sv = (mode == NGSID_POA_LOCAL) ? 0 : j * gp; if (sv + gp > Xu[c]) { Xu[c] = sv + gp; Uslot[c] = SRC_SLOT; } }
-        }
-        // X = diag-first maximum; in-row gap chain H[j] = max(Xf[j], H[j-1]+g) as a max-plus prefix scan of y[j] = Xf[j] - j*g
-        int X[CPL], Dd[CPL], exl[CPL];
-        int run = PNEG * 2;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int j = jb + c;
-            if (Xd[c] >= Xu[c]) { X[c] = Xd[c]; Dd[c] = 0 | (Dslot[c] << 2); } else { X[c] = Xu[c]; Dd[c] = 1 | (Uslot[c] << 2); }
-            if (X[c] <= PNEG) { X[c] = PNEG; Dd[c] = 3; }
-            const int xf = (mode == NGSID_POA_LOCAL && X[c] < 0) ? 0 : X[c];
-            const int y = (j <= L) ? xf - j * gp : PNEG * 2;
+            if (X[c] < PNEG / 2) { X[c] = PNEG; Dd[c] = 3; }                   // unreachable (sentinel arithmetic may have drifted)
+            if (has_invalid && jb + c > L) { X[c] = PNEG; Dd[c] = 3; }
+            const int xf = (local && X[c] < 0) ? 0 : X[c];
+            int y = xf - (jg0 + c * gp);
+            if (has_invalid && jb + c > L) y = PNEG * 2;
             exl[c] = run; run = max(run, y);
         }
         const int incl = wave_incl_max_scan(run, lane, PNEG * 2);
         const int excl_lane = __builtin_amdgcn_update_dpp(PNEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1, lane 0 keeps the identity
-        int hrow[CPL];
+        int hrow[CPL]; unsigned dpack = 0;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            const int j = jb + c;
-            int hv = PNEG, dd = 3;
-            if (j <= L) {
-                const int ex = max(excl_lane, exl[c]);
-                int val = X[c]; dd = Dd[c];
-                const int lf = ex + j * gp;                      // best value reachable through the in-row gap chain
-                if (lf > val && lf > PNEG / 2) { val = lf; dd = 2; }
-                if (mode == NGSID_POA_LOCAL && val <= 0) { val = 0; dd = 3; }
-                if (val <= PNEG / 2) { val = PNEG; dd = 3; }
-                hv = val;
-                if (hv > PNEG) {
-                    if (mode == NGSID_POA_LOCAL) { if (hv > bestv) { bestv = hv; bestr = r; bestc = lane * CPL + c; } }
-                    else if (j == L && (mode == NGSID_POA_SEMI || (rfl & 4))) { if (hv > bestv) { bestv = hv; bestr = r; bestc = lane * CPL + c; } }
-                }
-            }
-            hrow[c] = hv; Dd[c] = dd;
+            const int ex = max(excl_lane, exl[c]);
+            int val = X[c], dd = Dd[c];
+            const int lfv = ex + jg0 + c * gp;                  // best value reachable through the in-row gap chain
+            if (lfv > val && lfv > PNEG / 2) { val = lfv; dd = 2; }
+            if (local && val <= 0) { val = 0; dd = 3; }
+            if (val <= PNEG / 2) { val = PNEG; dd = 3; }
+            if (has_invalid && jb + c > L) { val = PNEG; dd = 3; }
+            hrow[c] = val; hprev[c] = val; dpack |= (unsigned)(dd & 0xff) << (8 * c);
         }
-        l32 ring = g.hring + (size_t)(r % HR) * BW;
+        if (local) {
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) { ring[lane * CPL + c] = hrow[c]; Hg[(size_t)r * BW + lane * CPL + c] = hrow[c]; Dg[(size_t)r * BW + lane * CPL + c] = (uint8_t)Dd[c]; }
-        lds_sync();                                   // next row reads this ring slot; HBM stores stay in flight
+            for (int c = 0; c < CPL; ++c) if (hrow[c] > bestv) { bestv = hrow[c]; bestpk = (r << 8) | (lane * CPL + c); }
+        } else if (semi || (rfl & 4)) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) if (jb + c == L && hrow[c] > PNEG && hrow[c] > bestv) { bestv = hrow[c]; bestpk = (r << 8) | (lane * CPL + c); }
+        }
+        // publish the row: LDS ring for the next rows, HBM copy only where a far successor will ask for it, packed direction bytes
+        l32 ring = g.hring + (size_t)(r & (HR - 1)) * BW + lane * CPL;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) ring[c] = hrow[c];
+        if (rfl & 8) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) Hg[(size_t)r * BW + lane * CPL + c] = hrow[c];
+        }
+        if (CPL == 1) *dgp = (uint8_t)dpack; else if (CPL == 2) *(uint16_t*)dgp = (uint16_t)dpack; else *(unsigned int*)dgp = dpack;
+        lds_sync();                                   // next row may read this ring slot; HBM stores stay in flight
     }
     __threadfence_block();                            // direction rows must have landed before the traceback pulls them back
     __syncthreads();
     // ---------- best end cell: max value, ties -> lowest rank, then lowest column
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        const int ov = __shfl_xor(bestv, d), orr = __shfl_xor(bestr, d), oc = __shfl_xor(bestc, d);
-        if (orr >= 0 && (bestr < 0 || ov > bestv || (ov == bestv && (orr < bestr || (orr == bestr && oc < bestc))))) { bestv = ov; bestr = orr; bestc = oc; }
+        const int ov = __shfl_xor(bestv, d), opk = __shfl_xor(bestpk, d);
+        if (ov > bestv || (ov == bestv && opk < bestpk)) { bestv = ov; bestpk = opk; }
     }
+    const int bestr = bestpk == 0x7fffffff ? -1 : (bestpk >> 8), bestc = bestpk & 0xff;
     bool aligned_any = true;
     if (bestr < 0 || (mode == NGSID_POA_LOCAL && bestv <= 0)) {
         if (mode != NGSID_POA_LOCAL) return 0;
@@ -388,11 +437,11 @@ void k_poa_tile(PoaJobSet J)
         g.lo = (l16)take(2 * (Vc + 1)); g.tmpv = (l16)take(2 * (Vc + 1)); g.code = (l8)take(Vc);
         g.e_tail = (l16)take(2 * Ec); g.e_head = (l16)take(2 * Ec); g.e_next_in = (l16)take(2 * Ec); g.e_next_out = (l16)take(2 * Ec); g.e_w = (l32)take(4 * Ec);
         g.alnode = (l16)take(2 * Lm); g.nodeof = (l16)take(2 * Lm); g.ref = (l16)take(2 * Lm); g.sq = (l8)take(Lm);
-        size_t blk = (size_t)64 * BW; if (blk < (size_t)6 * Vc + 32) blk = ((size_t)6 * Vc + 32 + 15) & ~(size_t)15;
+        size_t blk = (size_t)64 * BW; if (blk < (size_t)9 * Vc + 32) blk = ((size_t)9 * Vc + 32 + 15) & ~(size_t)15;
         size_t dp = (size_t)HR * BW * 4 + blk; if (dp < (size_t)8 * Vc) dp = (size_t)8 * Vc;
         LDSP unsigned char* dpr = take(dp);
         g.hring = (l32)dpr; g.dirblk = (l8)(dpr + (size_t)HR * BW * 4); g.sc = (l64)dpr;
-        g.rp0 = (l16)g.dirblk; g.rp1 = g.rp0 + Vc; g.rcode = (l8)(g.rp1 + Vc); g.rflag = g.rcode + Vc;
+        g.rinfo = (l64)g.dirblk; g.rneed = (l8)(g.rinfo + Vc);
     }
     int32_t* Hg = J.Hglob + (size_t)blockIdx.x * Vc * BW;
     uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW;
@@ -440,7 +489,7 @@ size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW)
 {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
     size_t t = 8 * al(2 * (size_t)Vc) + 2 * al(2 * ((size_t)Vc + 1)) + al(Vc) + 4 * al(2 * (size_t)Ec) + al(4 * (size_t)Ec) + 3 * al(2 * (size_t)Lm) + al(Lm);
-    size_t blk = (size_t)64 * BW; if (blk < (size_t)6 * Vc + 32) blk = ((size_t)6 * Vc + 32 + 15) & ~(size_t)15;
+    size_t blk = (size_t)64 * BW; if (blk < (size_t)9 * Vc + 32) blk = ((size_t)9 * Vc + 32 + 15) & ~(size_t)15;
     size_t dp = (size_t)HR * BW * 4 + blk; if (dp < (size_t)8 * Vc) dp = (size_t)8 * Vc;
     return t + al(dp);
 }
