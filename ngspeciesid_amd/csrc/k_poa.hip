@@ -2,15 +2,20 @@
 // consensus on gfx950.  Semantics are defined (and mirrored bit for bit) by oracle/ngsid_oracle_poa.c; see its
 // header for what is restated from spoa/racon and what is this build's choice.
 //
-// One 64-lane workgroup owns one tile (an exact-order POA of <= D sequences).  The whole graph lives in LDS
-// (u16 node/edge indices: code, anchor, in/out edge lists, aligned ring, topological order+rank, edge
-// tail/head/next/weight), so the inherently serial steps (traceback, heaviest bundle) run at LDS latency, and
-// the data-parallel steps (banded DP row, node/edge creation, rank insertion) are lane-parallel with
-// ballot/prefix-sum id allocation.  The banded DP row of a node is BW = 64*CPL columns wide: each lane owns CPL
-// consecutive columns, predecessor rows come from a 16-row LDS ring (HBM copy as fallback for far predecessors),
-// the in-row gap chain is a max-plus prefix scan across the wave.  Direction bytes stream to HBM row by row
-// (coalesced BW-byte rows) and are pulled back 64 rows at a time into LDS for the traceback.
-// Integer work throughout; the bound is LDS/VALU latency per DP row, not HBM.
+// One 64-lane workgroup owns one tile (an exact-order POA of <= D sequences).
+//   * The GRAPH (node letters, anchors, in/out edge lists, aligned rings, topological order+rank, edge weights, coverage;
+//     u16 indices) lives in a per-workgroup HBM scratch that stays L2 resident; it is only touched by lane-parallel
+//     phases (row-info build, node matching, node/edge creation, rank insertion) where 64 independent requests hide
+//     the L2 latency.
+//   * The per-ALIGNMENT working set lives in LDS (~20-26 KB, so 6-8 tiles are resident per CU): one packed 8-byte
+//     "row info" word per topological rank (band start, ranks of the first two predecessors, letter, flags), an
+//     8-row ring of DP rows, the sequence, a 32-row block of direction bytes for the traceback, and the per-position
+//     alignment result.  The serial loops (DP rows, traceback, heaviest bundle) run entirely out of LDS/registers.
+//   * DP row of a node: BW = 64*CPL band columns, CPL per lane.  Chain rows (single predecessor = previous row, ~85 %)
+//     take their inputs from registers + one DPP lane shift; other rows read predecessor rows from the LDS ring
+//     (HBM copy for predecessors more than 8 rows back).  The in-row gap chain is a DPP max-plus prefix scan.
+//     Direction bytes stream to HBM (coalesced) and come back 32 rows at a time for the traceback.
+// Integer work throughout; the bound is instruction issue / LDS latency per DP row at one wave per tile, not HBM.
 #include "ngsid_internal.h"
 #include "k_poa.h"
 #include <algorithm>
@@ -18,24 +23,29 @@
 #define PNEG (-(1 << 28))
 #define SRC_SLOT 63
 #define NONE16 0xFFFFu
-#define HR 8
+#define HR 8           // DP rows kept in the LDS ring
+#define TBR 32         // direction rows per traceback block
 
-// Every graph array is an LDS (address space 3) pointer: with generic pointers the compiler emits FLAT loads, which count on
-// vmcnt and therefore wait for the row's outstanding HBM stores (measured: ~2 us per DP row instead of ~0.2).
 #define LDSP __attribute__((address_space(3)))
-typedef LDSP uint16_t* l16; typedef LDSP uint8_t* l8; typedef LDSP int32_t* l32; typedef LDSP long long* l64;
-struct G {   // LDS-resident graph of one tile + per-sequence scratch
-    l16 anchor, in_first, in_last, out_first, out_last, ring, order, rank, lo, tmpv;
-    l8 code;
-    l16 e_tail, e_head, e_next_in, e_next_out; l32 e_w;
-    l16 alnode, nodeof, ref; l8 sq;
-    l32 hring; l8 dirblk; l64 sc;
-    l64 rinfo; l8 rneed;                // per-rank row info for the forward pass (aliases dirblk: dead before the traceback)
+typedef LDSP uint16_t* l16; typedef LDSP uint8_t* l8; typedef LDSP int32_t* l32; typedef LDSP long long* l64; typedef LDSP unsigned long long* lu64;
+
+struct GG {   // graph arrays in the workgroup's HBM scratch
+    uint16_t *anchor, *in_first, *in_last, *out_first, *out_last, *ring, *order, *rank, *tmpo;
+    uint8_t *code, *need;
+    uint16_t *e_tail, *e_head, *e_next_in, *e_next_out; int32_t* e_w;
+    uint32_t* cov;
+};
+struct LL {   // LDS working set of one alignment (sc/epred/einfo/sinkbits alias the forward-pass region for the consensus)
+    lu64 rinfo; l32 hring; l8 dirblk;
+    l64 sc; l16 epred; LDSP unsigned int* einfo; LDSP unsigned int* sinkbits;
+    l16 alnode, nodeof, ref, tmpv; l8 sq;     // sq has one pad byte in front and BW behind
 };
 
 // Single-wave workgroup: LDS instructions of one wave execute in issue order, so ordering LDS traffic between lanes only needs the
-// compiler not to reorder and the LDS queue to drain - no s_barrier and, crucially, no wait on outstanding HBM stores.
+// compiler not to reorder and the LDS queue to drain - no s_barrier and no wait on outstanding HBM stores.
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+// HBM scratch written by some lanes and read by others of the same wave: drain the stores, then order.
+__device__ __forceinline__ void mem_sync() { __threadfence_block(); __syncthreads(); }
 
 // inclusive max-scan over the 64 lanes: 4 DPP row shifts inside the 16-lane rows, row totals through readlane (SGPRs)
 __device__ __forceinline__ int wave_incl_max_scan(int v, int lane, int ident)
@@ -48,6 +58,8 @@ __device__ __forceinline__ int wave_incl_max_scan(int v, int lane, int ident)
     const int add = lane >= 48 ? max(r0, max(r1, r2)) : (lane >= 32 ? max(r0, r1) : (lane >= 16 ? r0 : ident));
     return max(v, add);
 }
+
+#define PH(J, idx, t0) do { if ((J).phase_cycles && lane == 0) { const unsigned long long t1_ = __builtin_readcyclecounter(); atomicAdd(&(J).phase_cycles[idx], t1_ - (t0)); (t0) = t1_; } } while (0)
 
 struct TS { int V, E, L0, members, nout, capV, capE; unsigned long long cw_sum; };
 
@@ -62,21 +74,66 @@ __device__ __forceinline__ int band_lo(int anchor, const PSeq& S, int L0, int BW
     return (int)lo;
 }
 
-__device__ void tile_add_first(const G& g, uint32_t* cov, const PSeq& S, TS& st, int lane)
+__device__ void tile_add_first(const GG& g, const PSeq& S, TS& st, int lane)
 {
     for (int i = lane; i < S.len; i += 64) {
-        g.code[i] = S.s[i]; g.anchor[i] = (uint16_t)i; g.ring[i] = (uint16_t)i; g.order[i] = (uint16_t)i; g.rank[i] = (uint16_t)i; cov[i] = S.cw;
+        g.code[i] = S.s[i]; g.anchor[i] = (uint16_t)i; g.ring[i] = (uint16_t)i; g.order[i] = (uint16_t)i; g.rank[i] = (uint16_t)i; g.cov[i] = S.cw;
         g.in_first[i] = g.in_last[i] = (i > 0) ? (uint16_t)(i - 1) : (uint16_t)NONE16;
         g.out_first[i] = g.out_last[i] = (i + 1 < S.len) ? (uint16_t)i : (uint16_t)NONE16;
         if (i > 0) { const int e = i - 1; g.e_tail[e] = (uint16_t)(i - 1); g.e_head[e] = (uint16_t)i; g.e_next_in[e] = NONE16; g.e_next_out[e] = NONE16; g.e_w[e] = wtof(S, i - 1) + wtof(S, i); }
     }
     st.V = S.len; st.E = S.len > 0 ? S.len - 1 : 0; st.L0 = S.len; st.cw_sum += S.cw;
-    __threadfence_block();
-    __syncthreads();
+    mem_sync();
 }
 
-// heaviest bundle + branch completion (oracle g_consensus); lane 0, everything in LDS
-__device__ void tile_emit(const G& g, const uint32_t* cov, const PoaJobSet& J, uint32_t job, TS& st, int lane)
+// one pass of the heaviest-bundle recurrence over ranks [rb, V) in RANK space.  Per 64-rank chunk the lanes fetch the first two
+// in-edges (predecessor rank, weight) of their rank from HBM into LDS; lane 0 then runs the serial recurrence out of LDS.
+// completion = branch-completion pass (skip predecessors whose score is -1).  Returns the best rank (uniform) or -1.
+__device__ int bundle_pass(const GG& g, const LL& w, int V, int rb, int completion, int lane)
+{
+    int best = -1;
+    for (int r0 = rb; r0 < V; r0 += 64) {
+        const int r = r0 + lane;
+        if (r < V) {
+            const int v = g.order[r]; const int e0 = g.in_first[v];
+            unsigned t0 = NONE16, t1 = NONE16, fl = 0; int w0 = 0, w1 = 0;
+            if (e0 != NONE16) {
+                t0 = g.rank[g.e_tail[e0]]; w0 = g.e_w[e0];
+                const int e1 = g.e_next_in[e0];
+                if (e1 != NONE16) { t1 = g.rank[g.e_tail[e1]]; w1 = g.e_w[e1]; if (g.e_next_in[e1] != NONE16) fl = 1; }
+            }
+            w.einfo[lane * 4 + 0] = t0 | (t1 << 16); w.einfo[lane * 4 + 1] = (unsigned)w0; w.einfo[lane * 4 + 2] = (unsigned)w1; w.einfo[lane * 4 + 3] = fl;
+            if (!completion && g.out_first[v] == NONE16) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
+        }
+        lds_sync();
+        if (lane == 0) {
+            const int cnt = min(64, V - r0);
+            for (int x = 0; x < cnt; ++x) {
+                const int rr = r0 + x; long long sv = -1; int pv = NONE16;
+                const unsigned tt = w.einfo[x * 4 + 0]; const unsigned fl = w.einfo[x * 4 + 3];
+                if (!fl) {
+                    const int ta = tt & 0xffff, tb = tt >> 16;
+                    if (ta != NONE16 && !(completion && w.sc[ta] == -1)) { const long long ww = (int)w.einfo[x * 4 + 1]; if (sv < ww || (sv == ww && w.sc[pv] <= w.sc[ta])) { sv = ww; pv = ta; } }
+                    if (tb != NONE16 && !(completion && w.sc[tb] == -1)) { const long long ww = (int)w.einfo[x * 4 + 2]; if (sv < ww || (sv == ww && w.sc[pv] <= w.sc[tb])) { sv = ww; pv = tb; } }
+                } else {        // more than two in-edges: walk the list in HBM
+                    const int v = g.order[rr];
+                    for (int e = g.in_first[v]; e != NONE16; e = g.e_next_in[e]) {
+                        const int t = g.rank[g.e_tail[e]]; if (completion && w.sc[t] == -1) continue; const long long ww = g.e_w[e];
+                        if (sv < ww || (sv == ww && w.sc[pv] <= w.sc[t])) { sv = ww; pv = t; }
+                    }
+                }
+                if (pv != NONE16) sv += w.sc[pv];
+                w.sc[rr] = sv; w.epred[rr] = (uint16_t)pv;
+                if (best < 0 || w.sc[best] < sv) best = rr;
+            }
+        }
+        lds_sync();
+    }
+    return __builtin_amdgcn_readfirstlane(best);
+}
+
+// heaviest bundle + branch completion (oracle g_consensus)
+__device__ void tile_emit(const GG& g, const LL& w, const PoaJobSet& J, uint32_t job, TS& st, int lane)
 {
     if (st.V == 0 || st.members == 0) return;
     if (st.nout >= J.D) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow, 1u); return; }   // host retries with more output slots
@@ -84,70 +141,74 @@ __device__ void tile_emit(const G& g, const uint32_t* cov, const PoaJobSet& J, u
     uint8_t* dst = J.out + slot * (size_t)J.Vcap;
     uint32_t* dcov = J.out_cov ? J.out_cov + slot * (size_t)J.Vcap : nullptr;
     const int V = st.V;
-    __threadfence_block();
-    __syncthreads();
-    if (lane == 0) {
-        l16 pred = g.lo;
-        int mx = -1;
-        for (int r = 0; r < V; ++r) {
-            const int v = g.order[r]; long long sv = -1; int pv = NONE16;
-            for (int e = g.in_first[v]; e != NONE16; e = g.e_next_in[e]) {
-                const int t = g.e_tail[e]; const long long w = g.e_w[e];
-                if (sv < w || (sv == w && g.sc[pv] <= g.sc[t])) { sv = w; pv = t; }
-            }
-            if (pv != NONE16) sv += g.sc[pv];
-            g.sc[v] = sv; pred[v] = (uint16_t)pv;
-            if (mx < 0 || g.sc[mx] < sv) mx = v;
+    unsigned long long tph = J.phase_cycles ? __builtin_readcyclecounter() : 0;
+    mem_sync();
+    for (int x = lane; x < (V + 31) / 32; x += 64) w.sinkbits[x] = 0;
+    lds_sync();
+    int mx = bundle_pass(g, w, V, 0, 0, lane);
+    while (!((w.sinkbits[mx >> 5] >> (mx & 31)) & 1u)) {
+        const int start = mx;
+        if (lane == 0) {
+            const int sv = g.order[start];
+            for (int e = g.out_first[sv]; e != NONE16; e = g.e_next_out[e])
+                for (int f = g.in_first[g.e_head[e]]; f != NONE16; f = g.e_next_in[f]) if (g.e_tail[f] != sv) w.sc[g.rank[g.e_tail[f]]] = -1;
         }
-        while (g.out_first[mx] != NONE16) {
-            const int start = mx;
-            for (int e = g.out_first[start]; e != NONE16; e = g.e_next_out[e])
-                for (int f = g.in_first[g.e_head[e]]; f != NONE16; f = g.e_next_in[f]) if (g.e_tail[f] != start) g.sc[g.e_tail[f]] = -1;
-            int m2 = -1;
-            for (int r = g.rank[start] + 1; r < V; ++r) {
-                const int v = g.order[r]; long long sv = -1; int pv = NONE16;
-                for (int e = g.in_first[v]; e != NONE16; e = g.e_next_in[e]) {
-                    const int t = g.e_tail[e]; if (g.sc[t] == -1) continue; const long long w = g.e_w[e];
-                    if (sv < w || (sv == w && g.sc[pv] <= g.sc[t])) { sv = w; pv = t; }
-                }
-                if (pv != NONE16) sv += g.sc[pv];
-                g.sc[v] = sv; pred[v] = (uint16_t)pv;
-                if (m2 < 0 || g.sc[m2] < sv) m2 = v;
-            }
-            if (m2 < 0) break;
-            mx = m2;
-        }
-        int n = 0; for (int v = mx; v != NONE16; v = pred[v]) ++n;
-        int i = n; for (int v = mx; v != NONE16; v = pred[v]) { --i; dst[i] = g.code[v]; if (dcov) { uint32_t c = cov[v]; for (int u = g.ring[v]; u != v; u = g.ring[u]) c += cov[u]; dcov[i] = c; } }
-        if (J.trim_tiles && dcov && n > 0) {   // oracle EMIT: coverage-trim the tile consensus ends
-            const uint32_t thr = (uint32_t)(st.cw_sum / 2); int b = 0, e = n - 1;
-            for (; b < n; ++b) if (dcov[b] >= thr) break;
-            for (; e >= 0; --e) if (dcov[e] >= thr) break;
-            if (b < e) { const int m2 = e - b + 1; if (b > 0) for (int x = 0; x < m2; ++x) { dst[x] = dst[b + x]; dcov[x] = dcov[b + x]; } n = m2; }
-        }
-        J.out_len[slot] = n; J.out_cw[slot] = st.cw_sum;
+        lds_sync();
+        const int m2 = bundle_pass(g, w, V, start + 1, 1, lane);
+        if (m2 < 0) break;
+        mx = m2;
     }
-    __syncthreads();
+    // backtrack: lane 0 lists the ranks of the path (HBM scratch), then all lanes translate rank -> letter / coverage
+    int n = 0;
+    if (lane == 0) { for (int r = mx; r != NONE16; r = w.epred[r]) ++n; int i = n; for (int r = mx; r != NONE16; r = w.epred[r]) g.tmpo[--i] = (uint16_t)r; }
+    n = __builtin_amdgcn_readfirstlane(n);
+    mem_sync();
+    for (int i = lane; i < n; i += 64) {
+        const int v = g.order[g.tmpo[i]]; dst[i] = g.code[v];
+        if (dcov) { uint32_t c = g.cov[v]; for (int u = g.ring[v]; u != v; u = g.ring[u]) c += g.cov[u]; dcov[i] = c; }
+    }
+    mem_sync();
+    if (J.trim_tiles && dcov && n > 0) {     // oracle EMIT: coverage-trim the tile consensus ends
+        const uint32_t thr = (uint32_t)(st.cw_sum / 2);
+        int b = 0x7fffffff, e = -1;
+        for (int i = lane; i < n; i += 64) if (dcov[i] >= thr) { b = min(b, i); e = max(e, i); }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { b = min(b, __shfl_xor(b, d)); e = max(e, __shfl_xor(e, d)); }
+        if (b < e && b != 0x7fffffff) {
+            const int m2 = e - b + 1;
+            if (b > 0) for (int c0 = 0; c0 < m2; c0 += 64) {
+                const int x = c0 + lane; uint8_t ch = 0; uint32_t cv = 0;
+                if (x < m2) { ch = dst[b + x]; cv = dcov[b + x]; }
+                mem_sync();
+                if (x < m2) { dst[x] = ch; dcov[x] = cv; }
+                mem_sync();
+            }
+            n = m2;
+        }
+    }
+    if (lane == 0) { J.out_len[slot] = n; J.out_cw[slot] = st.cw_sum; }
+    mem_sync();
+    PH(J, 4, tph);
     st.nout += 1;
 }
 
 // align S to the graph and merge it.  returns 0 = dropped (no valid end cell), 1 = added, 2 = does not fit
 template <int CPL>
-__device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* Dg, const PoaJobSet& J, const PSeq& S, TS& st, int lane)
+__device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg, const PoaJobSet& J, const PSeq& S, TS& st, int lane)
 {
     constexpr int BW = 64 * CPL;
     const int L = S.len, mode = S.mode, gp = J.g, V = st.V;
+    unsigned long long tph = J.phase_cycles ? __builtin_readcyclecounter() : 0;
     // ---------- per-rank row info, built lane-parallel so that the serial row loop reads ONE 8-byte LDS word per row:
     //   lo:16 | first pred rank:16 | second pred rank:16 | letter:8 | flags:8
     //   flags: 1 no predecessor, 2 more than two, 4 sink, 8 keep an HBM copy (a successor is > HR rows away),
     //          16 chain row (single predecessor = previous row, band shift 0/1), 32 = that band shift
-    for (int r = lane; r < V; r += 64) g.rneed[r] = 0;
-    lds_sync();
+    for (int r = lane; r < V; r += 64) g.need[r] = 0;
+    mem_sync();
     for (int r = lane; r < V; r += 64) {
         const int v = g.order[r];
-        for (int e = g.in_first[v]; e != NONE16; e = g.e_next_in[e]) { const int pr = g.rank[g.e_tail[e]]; if (r - pr > HR) g.rneed[pr] = 1; }
+        for (int e = g.in_first[v]; e != NONE16; e = g.e_next_in[e]) { const int pr = g.rank[g.e_tail[e]]; if (r - pr > HR) g.need[pr] = 1; }
         const int l0 = band_lo(g.anchor[v], S, st.L0, BW);
-        g.lo[r] = (uint16_t)l0;
         const int e0 = g.in_first[v]; int p0 = NONE16, p1 = NONE16, fl = 0;
         if (e0 == NONE16) fl |= 1;
         else { p0 = g.rank[g.e_tail[e0]]; const int e1 = g.e_next_in[e0]; if (e1 != NONE16) { p1 = g.rank[g.e_tail[e1]]; if (g.e_next_in[e1] != NONE16) fl |= 2; } }
@@ -156,13 +217,16 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
             const int d = l0 - band_lo(g.anchor[g.order[r - 1]], S, st.L0, BW);
             if (d == 0 || d == 1) fl |= 16 | (d << 5);
         }
-        g.rinfo[r] = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)p0 << 16) | ((unsigned long long)(unsigned)p1 << 32)
+        w.rinfo[r] = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)p0 << 16) | ((unsigned long long)(unsigned)p1 << 32)
                    | ((unsigned long long)g.code[v] << 48) | ((unsigned long long)(unsigned)fl << 56);
     }
-    for (int i = lane; i < L; i += 64) { g.alnode[i] = NONE16; g.sq[i] = S.s[i]; }
+    for (int i = lane; i < L; i += 64) { w.alnode[i] = NONE16; w.sq[i] = S.s[i]; }
+    for (int i = lane; i < BW; i += 64) w.sq[L + i] = 0xFF;            // pad: columns past the end never match
+    if (lane == 0) w.sq[-1] = 0xFF;
+    mem_sync();
+    for (int r = lane; r < V; r += 64) if (g.need[r]) w.rinfo[r] |= 8ull << 56;
     lds_sync();
-    for (int r = lane; r < V; r += 64) if (g.rneed[r]) g.rinfo[r] |= 8ull << 56;
-    __syncthreads();
+    PH(J, 0, tph);
     // ---------- forward DP, one row per graph node in topological order
     const bool has_invalid = (L + 1 < BW);              // otherwise every band column is <= L (band_lo clamps)
     const bool local = mode == NGSID_POA_LOCAL, semi = mode == NGSID_POA_SEMI;
@@ -171,16 +235,16 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
     int hprev[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) hprev[c] = PNEG;
-    unsigned long long ri_next = V > 0 ? g.rinfo[0] : 0ull;
+    unsigned long long ri_next = V > 0 ? w.rinfo[0] : 0ull;
     uint8_t* dgp = Dg + lane * CPL;
     for (int r = 0; r < V; ++r, dgp += BW) {
         const unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)ri_next), rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri_next >> 32));
-        if (r + 1 < V) ri_next = g.rinfo[r + 1];          // prefetch: consumed one iteration later
+        if (r + 1 < V) ri_next = w.rinfo[r + 1];          // prefetch: consumed one iteration later
         const int l0 = rlo & 0xffff, p0r = rlo >> 16, p1r = rhi & 0xffff; const int cv = (rhi >> 16) & 0xff; const int rfl = rhi >> 24;
         const int jb = l0 + lane * CPL;
         int scj[CPL];
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) { const int j = jb + c; const int ch = (j >= 1 && j <= L) ? (int)g.sq[j - 1] : 256; scj[c] = (ch == cv) ? sm : sn; }
+        for (int c = 0; c < CPL; ++c) scj[c] = ((int)w.sq[jb + c - 1] == cv) ? sm : sn;      // sq is padded: no bounds branches
         int X[CPL], Dd[CPL];
         if ((rfl & 16) && !semi) {
             // chain row: the only predecessor is the previous row, still in registers; neighbours through one DPP move
@@ -209,11 +273,11 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
                 int pr;
                 if (!(rfl & 2)) { pr = slot == 0 ? p0r : (slot == 1 ? p1r : NONE16); if (pr == NONE16) break; }
                 else { if (eit == NONE16) break; pr = g.rank[g.e_tail[eit]]; eit = g.e_next_in[eit]; }
-                const int plo = g.lo[pr];
+                const int plo = (int)(w.rinfo[pr] & 0xffff);
                 const int pc0 = jb - plo;
                 int hp[CPL + 1];
                 if ((r - pr) <= HR) {                       // LDS ring
-                    const l32 Hp = g.hring + (size_t)(pr & (HR - 1)) * BW;
+                    const l32 Hp = w.hring + (size_t)(pr & (HR - 1)) * BW;
 #pragma unroll
                     for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : PNEG; }
                 } else {                                    // far predecessor: HBM copy of the row (flag 8 made the producer store it)
@@ -271,7 +335,7 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
             for (int c = 0; c < CPL; ++c) if (jb + c == L && hrow[c] > PNEG && hrow[c] > bestv) { bestv = hrow[c]; bestpk = (r << 8) | (lane * CPL + c); }
         }
         // publish the row: LDS ring for the next rows, HBM copy only where a far successor will ask for it, packed direction bytes
-        l32 ring = g.hring + (size_t)(r & (HR - 1)) * BW + lane * CPL;
+        l32 ring = w.hring + (size_t)(r & (HR - 1)) * BW + lane * CPL;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) ring[c] = hrow[c];
         if (rfl & 8) {
@@ -281,8 +345,8 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
         if (CPL == 1) *dgp = (uint8_t)dpack; else if (CPL == 2) *(uint16_t*)dgp = (uint16_t)dpack; else *(unsigned int*)dgp = dpack;
         lds_sync();                                   // next row may read this ring slot; HBM stores stay in flight
     }
-    __threadfence_block();                            // direction rows must have landed before the traceback pulls them back
-    __syncthreads();
+    mem_sync();                                       // direction rows must have landed before the traceback pulls them back
+    PH(J, 1, tph);
     // ---------- best end cell: max value, ties -> lowest rank, then lowest column
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -295,63 +359,71 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
         if (mode != NGSID_POA_LOCAL) return 0;
         aligned_any = false;                                   // nothing aligned: the whole read becomes a new branch
     }
-    // ---------- traceback (uniform across lanes; direction rows pulled 64 at a time into LDS)
+    // ---------- traceback in rank space (uniform across lanes): predecessors and band starts come from the row info in LDS,
+    //            direction rows are pulled TBR at a time from HBM into LDS.  alnode[] receives RANKS here.
     if (aligned_any) {
-        int r = bestr, c = bestc, j = g.lo[bestr] + bestc;
+        int r = bestr, c = bestc, j = (int)(w.rinfo[bestr] & 0xffff) + bestc;
         int blk_hi = -1, blk_lo = 0;
         for (;;) {
             if (r > blk_hi || r < blk_lo) {
-                __syncthreads();
-                blk_hi = r; blk_lo = r - 63 < 0 ? 0 : r - 63;
-                const int rr = blk_hi - lane;
-                if (rr >= blk_lo) { const uint8_t* src = Dg + (size_t)rr * BW; l8 dstp = g.dirblk + (size_t)lane * BW; for (int x = 0; x < BW; x += 16) *(LDSP ngsid_v4u*)(dstp + x) = ngsid_load16_l2(src + x); }   // L2-served: scratch rows are rewritten per sequence
-                __threadfence_block();
-                __syncthreads();
+                lds_sync();
+                blk_hi = r; blk_lo = r - (TBR - 1) < 0 ? 0 : r - (TBR - 1);
+                constexpr int LPR = 64 / TBR;                         // lanes per direction row
+                const int rr = blk_hi - lane / LPR;
+                if (rr >= blk_lo) {
+                    const uint8_t* src = Dg + (size_t)rr * BW; l8 dstp = w.dirblk + (size_t)(lane / LPR) * BW;
+                    for (int x = (lane % LPR) * 16; x < BW; x += 16 * LPR) *(LDSP ngsid_v4u*)(dstp + x) = ngsid_load16_l2(src + x);   // L2-served: rows are rewritten per sequence
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
-            const int v = g.order[r]; const int d = g.dirblk[(size_t)(blk_hi - r) * BW + c]; const int type = d & 3, slot = d >> 2;
+            const int d = w.dirblk[(size_t)(blk_hi - r) * BW + c]; const int type = d & 3, slot = d >> 2;
             if (type == 3) break;
             if (type == 2) { --j; --c; continue; }
-            if (type == 0) { if (lane == 0) g.alnode[j - 1] = (uint16_t)v; --j; }
+            if (type == 0) { if (lane == 0) w.alnode[j - 1] = (uint16_t)r; --j; }
             if (slot == SRC_SLOT) break;
-            int e = g.in_first[v]; for (int t = 0; t < slot; ++t) e = g.e_next_in[e];
-            r = g.rank[g.e_tail[e]]; c = j - g.lo[r];
+            const unsigned long long ri = w.rinfo[r];
+            int pr;
+            if (slot == 0) pr = (int)((ri >> 16) & 0xffff);
+            else if (slot == 1) pr = (int)((ri >> 32) & 0xffff);
+            else { int e = g.in_first[g.order[r]]; for (int t = 0; t < slot; ++t) e = g.e_next_in[e]; pr = g.rank[g.e_tail[e]]; }
+            r = pr; c = j - (int)(w.rinfo[r] & 0xffff);
         }
     }
-    __threadfence_block();
-    __syncthreads();
-    // ---------- A: existing node per position (same letter on the aligned node or one of its siblings)
+    lds_sync();
+    PH(J, 2, tph);
+    // ---------- A: rank -> node, then the existing node per position (same letter on the aligned node or one of its siblings)
     int nnew = 0;
     for (int i0 = 0; i0 < L; i0 += 64) {
         const int i = i0 + lane; bool isnew = false;
         if (i < L) {
-            const int v = g.alnode[i]; const uint8_t ch = g.sq[i]; int found = NONE16;
-            if (v != NONE16) { if (g.code[v] == ch) found = v; else for (int u = g.ring[v]; u != v; u = g.ring[u]) if (g.code[u] == ch) { found = u; break; } }
-            g.nodeof[i] = (uint16_t)found; isnew = found == NONE16;
+            const int ar = w.alnode[i]; const uint8_t ch = w.sq[i]; int found = NONE16, v = NONE16;
+            if (ar != NONE16) { v = g.order[ar]; if (g.code[v] == ch) found = v; else for (int u = g.ring[v]; u != v; u = g.ring[u]) if (g.code[u] == ch) { found = u; break; } }
+            w.alnode[i] = (uint16_t)v; w.nodeof[i] = (uint16_t)found; isnew = found == NONE16;
         }
         nnew += __popcll(__ballot(isnew));
     }
-    if (V + nnew > st.capV || st.E + L > st.capE) { __syncthreads(); return 2; }      // oracle g_add_alignment capacity rule
+    if (V + nnew > st.capV || st.E + L > st.capE) { lds_sync(); return 2; }      // oracle g_add_alignment capacity rule
     // ---------- B: ref(i) = aligned node of the first aligned position >= i (reverse carry scan)
     {
         int carry = NONE16;
         for (int i0 = ((L - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
-            const int i = i0 + lane; const int a = (i < L) ? g.alnode[i] : NONE16;
+            const int i = i0 + lane; const int a = (i < L) ? w.alnode[i] : NONE16;
             const unsigned long long m = __ballot(a != NONE16);
             const unsigned long long ge = m & (~0ull << lane);
             const int src = ge ? __ffsll((long long)ge) - 1 : 0;
             const int val = __shfl(a, src);
-            if (i < L) g.ref[i] = (uint16_t)(ge ? val : carry);
+            if (i < L) w.ref[i] = (uint16_t)(ge ? val : carry);
             if (m) { const int first = __ffsll((long long)m) - 1; carry = __shfl(a, first); }
         }
     }
-    __threadfence_block();
-    __syncthreads();
+    lds_sync();
     // ---------- C: create nodes (ids in sequence order).  anchor: nearest aligned position at or before i, else after, else a0.
     //             tmpv[k] = old rank the k-th new node is inserted before (V = end); non-decreasing in k.
     {
         int base = V, lastal = NONE16;
         for (int i0 = 0; i0 < L; i0 += 64) {
-            const int i = i0 + lane; const int a = (i < L) ? g.alnode[i] : NONE16; const bool isnew = (i < L) && g.nodeof[i] == NONE16;
+            const int i = i0 + lane; const int a = (i < L) ? w.alnode[i] : NONE16; const bool isnew = (i < L) && w.nodeof[i] == NONE16;
             const unsigned long long ma = __ballot(a != NONE16);
             const unsigned long long le = ma & (~0ull >> (63 - lane));
             const int src = le ? 63 - __clzll(le) : 0;
@@ -360,99 +432,117 @@ __device__ int tile_align_add(const G& g, uint32_t* cov, int32_t* Hg, uint8_t* D
             const unsigned long long mn = __ballot(isnew);
             const int before = __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
             if (isnew) {
-                const int y = base + before; const int rf = g.ref[i];
+                const int y = base + before; const int rf = w.ref[i];
                 const int anc = la != NONE16 ? g.anchor[la] : (rf != NONE16 ? g.anchor[rf] : (S.a1 < S.a0 ? 0 : S.a0));
-                g.code[y] = g.sq[i]; g.anchor[y] = (uint16_t)anc; g.in_first[y] = g.in_last[y] = g.out_first[y] = g.out_last[y] = NONE16; cov[y] = 0;
+                g.code[y] = w.sq[i]; g.anchor[y] = (uint16_t)anc; g.in_first[y] = g.in_last[y] = g.out_first[y] = g.out_last[y] = NONE16; g.cov[y] = 0;
                 if (a != NONE16) { g.ring[y] = g.ring[a]; g.ring[a] = (uint16_t)y; } else g.ring[y] = (uint16_t)y;
-                g.nodeof[i] = (uint16_t)y;
-                g.tmpv[y - V] = (uint16_t)(rf != NONE16 ? g.rank[rf] : V);
+                w.nodeof[i] = (uint16_t)y;
+                w.tmpv[y - V] = (uint16_t)(rf != NONE16 ? g.rank[rf] : V);
             }
             base += __popcll(mn);
             if (ma) { const int hl = 63 - __clzll(ma); lastal = __shfl(a, hl); }
         }
     }
-    __threadfence_block();
-    __syncthreads();
+    mem_sync();
     // ---------- D: ranks.  k-th new node -> tmpv[k] + k ; old node at rank p -> p + #{k : tmpv[k] <= p}
     {
-        l16 neworder = g.lo;
         for (int p = lane; p < V; p += 64) {
-            int lo = 0, hi = nnew; while (lo < hi) { const int mid = (lo + hi) >> 1; if (g.tmpv[mid] <= p) lo = mid + 1; else hi = mid; }
-            neworder[p + lo] = g.order[p];
+            int lo = 0, hi = nnew; while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.tmpv[mid] <= p) lo = mid + 1; else hi = mid; }
+            g.tmpo[p + lo] = g.order[p];
         }
-        for (int k = lane; k < nnew; k += 64) neworder[g.tmpv[k] + k] = (uint16_t)(V + k);
-        __threadfence_block();
-        __syncthreads();
-        for (int r = lane; r < V + nnew; r += 64) { const int v = neworder[r]; g.order[r] = (uint16_t)v; g.rank[v] = (uint16_t)r; }
+        for (int k = lane; k < nnew; k += 64) g.tmpo[w.tmpv[k] + k] = (uint16_t)(V + k);
+        mem_sync();
+        for (int r = lane; r < V + nnew; r += 64) { const int v = g.tmpo[r]; g.order[r] = (uint16_t)v; g.rank[v] = (uint16_t)r; }
     }
-    __threadfence_block();
-    __syncthreads();
+    mem_sync();
     // ---------- E: coverage and edges (edge ids in sequence order)
     {
         int ebase = st.E;
         for (int i0 = 0; i0 < L; i0 += 64) {
-            const int i = i0 + lane; bool newedge = false; int a = 0, b = 0, w = 0;
+            const int i = i0 + lane; bool newedge = false; int a = 0, b = 0, wgt = 0;
             if (i < L) {
-                b = g.nodeof[i]; cov[b] += S.cw;
+                b = w.nodeof[i]; g.cov[b] += S.cw;
                 if (i > 0) {
-                    a = g.nodeof[i - 1]; w = wtof(S, i - 1) + wtof(S, i);
+                    a = w.nodeof[i - 1]; wgt = wtof(S, i - 1) + wtof(S, i);
                     int e = g.out_first[a];
                     for (; e != NONE16; e = g.e_next_out[e]) if (g.e_head[e] == b) break;
-                    if (e != NONE16) g.e_w[e] += w; else newedge = true;
+                    if (e != NONE16) g.e_w[e] += wgt; else newedge = true;
                 }
             }
             const unsigned long long mn = __ballot(newedge);
             if (newedge) {
                 const int e = ebase + __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-                g.e_tail[e] = (uint16_t)a; g.e_head[e] = (uint16_t)b; g.e_w[e] = w; g.e_next_in[e] = NONE16; g.e_next_out[e] = NONE16;
+                g.e_tail[e] = (uint16_t)a; g.e_head[e] = (uint16_t)b; g.e_w[e] = wgt; g.e_next_in[e] = NONE16; g.e_next_out[e] = NONE16;
                 if (g.out_last[a] == NONE16) g.out_first[a] = (uint16_t)e; else g.e_next_out[g.out_last[a]] = (uint16_t)e; g.out_last[a] = (uint16_t)e;
                 if (g.in_last[b] == NONE16) g.in_first[b] = (uint16_t)e; else g.e_next_in[g.in_last[b]] = (uint16_t)e; g.in_last[b] = (uint16_t)e;
             }
             ebase += __popcll(mn);
-            lds_sync();
         }
         st.E = ebase;
     }
     st.V = V + nnew; st.cw_sum += S.cw;
-    __threadfence_block();
-    __syncthreads();
+    mem_sync();
+    PH(J, 3, tph);
     return 1;
+}
+
+// LDS bytes of one tile (must match the carve in k_poa_tile)
+size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW)
+{
+    (void)Ec;
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    size_t fwd = al((size_t)8 * Vc) + al((size_t)HR * BW * 4) + al((size_t)TBR * BW);
+    size_t cons = al((size_t)8 * Vc) + al((size_t)2 * Vc) + al(64 * 16) + al(((size_t)Vc + 31) / 32 * 4);
+    size_t region = fwd > cons ? fwd : cons;
+    return region + 4 * al(2 * (size_t)Lm) + al((size_t)Lm + BW + 32);
+}
+// HBM scratch bytes of one workgroup for the graph arrays
+static size_t poa_graph_bytes(int Vc, int Ec)
+{
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    return 9 * al(2 * ((size_t)Vc + 1)) + 2 * al(Vc) + 4 * al(2 * (size_t)Ec) + al(4 * (size_t)Ec) + al(4 * (size_t)Vc);
 }
 
 template <int CPL>
 __global__ __launch_bounds__(64)
-void k_poa_tile(PoaJobSet J)
+void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes)
 {
     constexpr int BW = 64 * CPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int Vc = J.Vcap, Ec = J.Ecap, Lm = J.Lmax;
-    G g;
+    LL w; GG g;
     {
         LDSP unsigned char* base = (LDSP unsigned char*)smem;
-        size_t o = 0;
-        auto take = [&](size_t bytes) { LDSP unsigned char* q = base + o; o += (bytes + 15) & ~(size_t)15; return q; };
-        g.anchor = (l16)take(2 * Vc); g.in_first = (l16)take(2 * Vc); g.in_last = (l16)take(2 * Vc); g.out_first = (l16)take(2 * Vc);
-        g.out_last = (l16)take(2 * Vc); g.ring = (l16)take(2 * Vc); g.order = (l16)take(2 * Vc); g.rank = (l16)take(2 * Vc);
-        g.lo = (l16)take(2 * (Vc + 1)); g.tmpv = (l16)take(2 * (Vc + 1)); g.code = (l8)take(Vc);
-        g.e_tail = (l16)take(2 * Ec); g.e_head = (l16)take(2 * Ec); g.e_next_in = (l16)take(2 * Ec); g.e_next_out = (l16)take(2 * Ec); g.e_w = (l32)take(4 * Ec);
-        g.alnode = (l16)take(2 * Lm); g.nodeof = (l16)take(2 * Lm); g.ref = (l16)take(2 * Lm); g.sq = (l8)take(Lm);
-        size_t blk = (size_t)64 * BW; if (blk < (size_t)9 * Vc + 32) blk = ((size_t)9 * Vc + 32 + 15) & ~(size_t)15;
-        size_t dp = (size_t)HR * BW * 4 + blk; if (dp < (size_t)8 * Vc) dp = (size_t)8 * Vc;
-        LDSP unsigned char* dpr = take(dp);
-        g.hring = (l32)dpr; g.dirblk = (l8)(dpr + (size_t)HR * BW * 4); g.sc = (l64)dpr;
-        g.rinfo = (l64)g.dirblk; g.rneed = (l8)(g.rinfo + Vc);
+        auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+        const size_t fwd = al((size_t)8 * Vc) + al((size_t)HR * BW * 4) + al((size_t)TBR * BW);
+        const size_t cons = al((size_t)8 * Vc) + al((size_t)2 * Vc) + al(64 * 16) + al(((size_t)Vc + 31) / 32 * 4);
+        const size_t region = fwd > cons ? fwd : cons;
+        w.rinfo = (lu64)base; w.hring = (l32)(base + al((size_t)8 * Vc)); w.dirblk = (l8)(base + al((size_t)8 * Vc) + al((size_t)HR * BW * 4));
+        w.sc = (l64)base; w.epred = (l16)(base + al((size_t)8 * Vc)); w.einfo = (LDSP unsigned int*)(base + al((size_t)8 * Vc) + al((size_t)2 * Vc));
+        w.sinkbits = (LDSP unsigned int*)(base + al((size_t)8 * Vc) + al((size_t)2 * Vc) + al(64 * 16));
+        size_t o = region;
+        w.alnode = (l16)(base + o); o += al(2 * (size_t)Lm); w.nodeof = (l16)(base + o); o += al(2 * (size_t)Lm);
+        w.ref = (l16)(base + o); o += al(2 * (size_t)Lm); w.tmpv = (l16)(base + o); o += al(2 * (size_t)Lm);
+        w.sq = (l8)(base + o + 16);                                   // one pad byte in front (sq[-1]), BW behind
+        uint8_t* p = gscratch + (size_t)blockIdx.x * gbytes;
+        auto take = [&](size_t bytes) { uint8_t* q = p; p += al(bytes); return q; };
+        g.anchor = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.in_first = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.in_last = (uint16_t*)take(2 * ((size_t)Vc + 1));
+        g.out_first = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.out_last = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.ring = (uint16_t*)take(2 * ((size_t)Vc + 1));
+        g.order = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.rank = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.tmpo = (uint16_t*)take(2 * ((size_t)Vc + 1));
+        g.code = take(Vc); g.need = take(Vc);
+        g.e_tail = (uint16_t*)take(2 * (size_t)Ec); g.e_head = (uint16_t*)take(2 * (size_t)Ec); g.e_next_in = (uint16_t*)take(2 * (size_t)Ec); g.e_next_out = (uint16_t*)take(2 * (size_t)Ec);
+        g.e_w = (int32_t*)take(4 * (size_t)Ec); g.cov = (uint32_t*)take(4 * (size_t)Vc);
     }
     int32_t* Hg = J.Hglob + (size_t)blockIdx.x * Vc * BW;
     uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW;
-    uint32_t* cov = J.covglob + (size_t)blockIdx.x * Vc;
 
     for (uint32_t job = blockIdx.x; job < J.njobs; job += gridDim.x) {
         const uint32_t s0 = J.job_off[job], s1 = J.job_off[job + 1];
         const int bbi = J.job_bb ? J.job_bb[job] : -1;
         TS st; st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.nout = 0; st.cw_sum = 0;
         uint32_t ndrop = 0;
-        {   // per-job capacity = oracle run_tile: cap_for(L0) but at least the longest member + 1; edges 2x
+        {   // per-job capacity = oracle run_tile: cap_for(L0) but at least the longest member + 1; edges 1.5x
             int maxlen = bbi >= 0 ? J.bbs[bbi].len : 0, first = bbi >= 0 ? J.bbs[bbi].len : 0;
             for (uint32_t si = s0; si < s1; ++si) { const int l = J.seqs[J.seq_idx ? J.seq_idx[si] : si].len; if (l > maxlen) maxlen = l; if (first == 0 && bbi < 0 && si == s0) first = l; }
             long long c = (long long)(first > 0 ? first : 1) * (J.node_cap > 0 ? J.node_cap : 28) / 16; if (c < (first > 0 ? first : 1) + 64) c = (first > 0 ? first : 1) + 64;
@@ -464,54 +554,47 @@ void k_poa_tile(PoaJobSet J)
             if (S.len <= 0) continue;
             if (S.len > Lm) { ++ndrop; continue; }
             if (st.V == 0) {
-                if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, cov, B, st, lane); }
-                else { if (S.len > st.capV) { ++ndrop; continue; } tile_add_first(g, cov, S, st, lane); st.members = 1; continue; }
+                if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, B, st, lane); }
+                else { if (S.len > st.capV) { ++ndrop; continue; } tile_add_first(g, S, st, lane); st.members = 1; continue; }
             }
-            int rcode = tile_align_add<CPL>(g, cov, Hg, Dg, J, S, st, lane);
+            int rcode = tile_align_add<CPL>(g, w, Hg, Dg, J, S, st, lane);
             if (rcode == 0) { ++ndrop; continue; }
             if (rcode == 2) {
-                tile_emit(g, cov, J, job, st, lane);
+                tile_emit(g, w, J, job, st, lane);
                 st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.cw_sum = 0;
-                if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, cov, B, st, lane); rcode = tile_align_add<CPL>(g, cov, Hg, Dg, J, S, st, lane); if (rcode == 1) st.members = 1; else ++ndrop; }
-                else if (S.len <= st.capV) { tile_add_first(g, cov, S, st, lane); st.members = 1; } else ++ndrop;
+                if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, B, st, lane); rcode = tile_align_add<CPL>(g, w, Hg, Dg, J, S, st, lane); if (rcode == 1) st.members = 1; else ++ndrop; }
+                else if (S.len <= st.capV) { tile_add_first(g, S, st, lane); st.members = 1; } else ++ndrop;
                 continue;
             }
             st.members += 1;
         }
-        tile_emit(g, cov, J, job, st, lane);
+        tile_emit(g, w, J, job, st, lane);
         if (lane == 0) { J.out_n[job] = (uint32_t)st.nout; if (ndrop && J.dropped) atomicAdd(J.dropped, ndrop); }
-        __syncthreads();
+        mem_sync();
     }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW)
-{
-    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    size_t t = 8 * al(2 * (size_t)Vc) + 2 * al(2 * ((size_t)Vc + 1)) + al(Vc) + 4 * al(2 * (size_t)Ec) + al(4 * (size_t)Ec) + 3 * al(2 * (size_t)Lm) + al(Lm);
-    size_t blk = (size_t)64 * BW; if (blk < (size_t)9 * Vc + 32) blk = ((size_t)9 * Vc + 32 + 15) & ~(size_t)15;
-    size_t dp = (size_t)HR * BW * 4 + blk; if (dp < (size_t)8 * Vc) dp = (size_t)8 * Vc;
-    return t + al(dp);
-}
-
 int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
 {
     if (J.njobs == 0) return NGSID_OK;
     const int BW = band <= 64 ? 64 : (band <= 128 ? 128 : 256);
     if (J.g >= 0) NGSID_FAIL(ctx, NGSID_ERR_ARG, "POA gap score must be negative");
-    if (J.Vcap > 0xFFF0 || J.Ecap > 0xFFF0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA graph capacity exceeds 16-bit indices (sequence too long for the LDS-resident tile)");
+    if (J.Vcap > 0xFFF0 || J.Ecap > 0xFFF0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA graph capacity exceeds 16-bit indices (sequence too long for the tile engine)");
     const size_t lds = poa_lds_bytes(J.Vcap, J.Ecap, J.Lmax, BW);
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);
-    const int per_cu = std::max<int>(1, (int)((160 * 1024) / lds));
-    uint32_t nwg = (uint32_t)std::min<uint64_t>(J.njobs, (uint64_t)ctx->n_cu * std::min(per_cu, 8));
+    const int per_cu = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / lds)));
+    uint32_t nwg = (uint32_t)std::min<uint64_t>(J.njobs, (uint64_t)ctx->n_cu * per_cu);
     const size_t cells = (size_t)J.Vcap * BW;
+    const size_t gbytes = poa_graph_bytes(J.Vcap, J.Ecap);
     if (ctx->poa_h.n < nwg * cells) HIPCHK(ctx, ctx->poa_h.alloc(nwg * cells));
     if (ctx->poa_d.n < nwg * cells) HIPCHK(ctx, ctx->poa_d.alloc(nwg * cells));
-    if (ctx->poa_cov.n < (size_t)nwg * J.Vcap) HIPCHK(ctx, ctx->poa_cov.alloc((size_t)nwg * J.Vcap));
-    J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = ctx->poa_cov.p;
-    if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ProfScope ps_(ctx, "k_poa_tile"); hipLaunchKernelGGL(k_poa_tile<1>, dim3(nwg), dim3(64), lds, ctx->stream, J); }
-    else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ProfScope ps_(ctx, "k_poa_tile"); hipLaunchKernelGGL(k_poa_tile<2>, dim3(nwg), dim3(64), lds, ctx->stream, J); }
-    else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ProfScope ps_(ctx, "k_poa_tile"); hipLaunchKernelGGL(k_poa_tile<4>, dim3(nwg), dim3(64), lds, ctx->stream, J); }
+    if (ctx->poa_g.n < nwg * gbytes) HIPCHK(ctx, ctx->poa_g.alloc(nwg * gbytes));
+    J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = nullptr;
+    ProfScope ps_(ctx, "k_poa_tile");
+    if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<1>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes); }
+    else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<2>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes); }
+    else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<4>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }

@@ -37,7 +37,7 @@ struct ngsid_ctx {
     DevBuf<int32_t> bnd;      // aligner strip boundary rows
     bool debug_sync = false;
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
-    DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
+    DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
 };
 
 #define NGSID_FAIL(ctx, code, ...) do { snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); return (code); } while (0)
