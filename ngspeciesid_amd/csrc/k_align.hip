@@ -18,7 +18,7 @@
 #define NEGINF (-(1 << 29))
 
 template <int RPL>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
 void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wave, int32_t* __restrict__ bnd, uint32_t bnd_stride, uint32_t lds_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -242,5 +242,7 @@ int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qle
     if (max_qlen <= 256) return launch_rpl<4>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 512) return launch_rpl<8>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 768) return launch_rpl<12>(ctx, job, max_qlen, max_tlen);
+    if (max_qlen <= 832) return launch_rpl<13>(ctx, job, max_qlen, max_tlen);     // tight fit: fewer idle lanes and rows per step
+    if (max_qlen <= 896) return launch_rpl<14>(ctx, job, max_qlen, max_tlen);
     return launch_rpl<16>(ctx, job, max_qlen, max_tlen);
 }

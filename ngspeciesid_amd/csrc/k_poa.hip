@@ -228,7 +228,7 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
     lds_sync();
     PH(J, 0, tph);
     // ---------- forward DP, one row per graph node in topological order
-    const bool has_invalid = (L + 1 < BW);              // otherwise every band column is <= L (band_lo clamps)
+    const int lane_jg = lane * CPL * gp;
     const bool local = mode == NGSID_POA_LOCAL, semi = mode == NGSID_POA_SEMI;
     const int sm = J.m, sn = J.n;
     int bestv = PNEG, bestpk = 0x7fffffff;               // packed (rank << 8 | band column): ties -> lowest rank, then lowest column
@@ -289,8 +289,8 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const int j = jb + c;
-                    { const int hv = hp[c + 1]; if (hv > PNEG && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
-                    if (j >= 1) { const int hv = hp[c]; if (hv > PNEG && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
+                    { const int hv = hp[c + 1]; if (hv > PNEG / 2 && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
+                    if (j >= 1) { const int hv = hp[c]; if (hv > PNEG / 2 && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
                 }
             }
 #pragma unroll
@@ -301,16 +301,16 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
                 if (Xd[c] >= Xu[c]) { X[c] = Xd[c]; Dd[c] = 0 | (Dslot[c] << 2); } else { X[c] = Xu[c]; Dd[c] = 1 | (Uslot[c] << 2); }
             }
         }
-        // in-row gap chain H[j] = max(Xf[j], H[j-1]+g) as a max-plus prefix scan of y[j] = Xf[j] - j*g
+        // in-row gap chain H[j] = max(Xf[j], H[j-1]+g) as a max-plus prefix scan of y[j] = Xf[j] - j*g.
+        // Unreachable cells are not normalised: they stay below -2^27 while reachable scores stay above -2^20, so every comparison
+        // that decides a reachable cell is unaffected (their own direction bytes are never read by the traceback).  Band columns
+        // past the end of the sequence (only when L+1 < BW) see the 0xFF padding and can never beat a real cell.
         int exl[CPL]; int run = PNEG * 2;
-        const int jg0 = jb * gp;
+        const int jg0 = l0 * gp + lane_jg;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            if (X[c] < PNEG / 2) { X[c] = PNEG; Dd[c] = 3; }                   // unreachable (sentinel arithmetic may have drifted)
-            if (has_invalid && jb + c > L) { X[c] = PNEG; Dd[c] = 3; }
             const int xf = (local && X[c] < 0) ? 0 : X[c];
-            int y = xf - (jg0 + c * gp);
-            if (has_invalid && jb + c > L) y = PNEG * 2;
+            const int y = xf - (jg0 + c * gp);
             exl[c] = run; run = max(run, y);
         }
         const int incl = wave_incl_max_scan(run, lane, PNEG * 2);
@@ -321,10 +321,8 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
             const int ex = max(excl_lane, exl[c]);
             int val = X[c], dd = Dd[c];
             const int lfv = ex + jg0 + c * gp;                  // best value reachable through the in-row gap chain
-            if (lfv > val && lfv > PNEG / 2) { val = lfv; dd = 2; }
+            if (lfv > val) { val = lfv; dd = 2; }
             if (local && val <= 0) { val = 0; dd = 3; }
-            if (val <= PNEG / 2) { val = PNEG; dd = 3; }
-            if (has_invalid && jb + c > L) { val = PNEG; dd = 3; }
             hrow[c] = val; hprev[c] = val; dpack |= (unsigned)(dd & 0xff) << (8 * c);
         }
         if (local) {
@@ -332,7 +330,7 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
             for (int c = 0; c < CPL; ++c) if (hrow[c] > bestv) { bestv = hrow[c]; bestpk = (r << 8) | (lane * CPL + c); }
         } else if (semi || (rfl & 4)) {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) if (jb + c == L && hrow[c] > PNEG && hrow[c] > bestv) { bestv = hrow[c]; bestpk = (r << 8) | (lane * CPL + c); }
+            for (int c = 0; c < CPL; ++c) if (jb + c == L && hrow[c] > PNEG / 2 && hrow[c] > bestv) { bestv = hrow[c]; bestpk = (r << 8) | (lane * CPL + c); }
         }
         // publish the row: LDS ring for the next rows, HBM copy only where a far successor will ask for it, packed direction bytes
         l32 ring = w.hring + (size_t)(r & (HR - 1)) * BW + lane * CPL;
