@@ -140,7 +140,14 @@ def main():
         alg_bytes_per_launch = units * per_read_bytes.get(dom[0], 2 * L) / max(cnt, 1)
         avg_s = ms / 1e3 / max(cnt, 1)
         ach = alg_bytes_per_launch / avg_s / 1e9
-        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": None,
+        traffic = None
+        try:    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), valid for the profiled workload size only
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            if tj.get("workload_reads") == args.reads and dom[0] in tj:
+                traffic = tj[dom[0]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic,
                 "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                 "note": "integer DP kernel: VALU/LDS-latency bound by construction, HBM fraction is small (DESIGN.md)"}
     # ---- CPU baseline: the oracle (port of the reference CPU path) on a bounded sample of the same workload, 1 core

@@ -1,0 +1,80 @@
+"""GPU: edge cases of the C-ABI - empty and ragged inputs, short reads, error codes - always against the oracle's behaviour."""
+import numpy as np
+import pytest
+from ngspeciesid_amd._capi import ReadSet, cluster_params, poa_params, polish_params, NgsidError, ST_SHORT, ST_NEWREP
+from ngspeciesid_amd.ptable import select_p_table
+from ngspeciesid_amd import synth
+
+pytestmark = pytest.mark.gpu
+PT = select_p_table(13, 20)
+
+
+def both(gpu_api, oracle, fn):
+    return fn(gpu_api), fn(oracle)
+
+
+def test_empty_read_set(gpu_api, oracle):
+    rs = ReadSet.from_strings([], [])
+    for api in (gpu_api, oracle):
+        rep, herr, st, cnt = api.cluster_greedy(rs, cluster_params(p_shared=PT))
+        assert len(rep) == 0 and cnt.tolist() == [0, 0, 0, 0]
+        assert api.poa_consensus(rs, [0], poa_params()) == []
+        sc, nc, nm, rg = api.sg_align_batch(rs, rs, [], [], [], 1)
+        assert len(sc) == 0
+
+
+def test_short_and_ragged_reads(gpu_api, oracle):
+    seqs = ["A", "ACGT", "ACGTACGTACGTA", "ACGTACGTACGTAC", "AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA", "ACGTTGCATGCAAGCTTAGCTAGGCTAGCTAGCATCGATCGATGGCATCGATGCATGCTAGCTAGTCGATCG" * 3,
+            "ACGTTGCATGCAAGCTTAGCTAGGCTAGCTAGCATCGATCGATGGCATCGATGCATGCTAGCTAGTCGATCG" * 3, "T" * 40 + "ACGATCGATCGTACGTAGCTAGCTAGCATGCATGCTAGCTAGCTAGCTAGCATGCATCGAT"]
+    quals = ["I" * len(s) for s in seqs]
+    rs = ReadSet.from_strings(seqs, quals)
+    g, o = both(gpu_api, oracle, lambda a: a.cluster_greedy(rs, cluster_params(p_shared=PT)))
+    for x, y in zip(g, o):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert g[2][0] == ST_SHORT and g[2][1] == ST_SHORT and g[2][4] == ST_SHORT       # HPC length < k (cluster.py:266-268)
+    assert g[0][6] == 5                                                              # identical read joins the first copy
+    gm, om = both(gpu_api, oracle, lambda a: a.hpc_minimizers(rs, 13, 20))
+    for x, y in zip(gm, om):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_error_codes(gpu_api, oracle):
+    rs = ReadSet.from_strings(["ACGTRYACGTACGTACGTACGTAGCTAGCTAGCTAGCATCGATCGATCG"], ["I" * 49])
+    for api in (gpu_api, oracle):
+        with pytest.raises(NgsidError) as e:
+            api.cluster_greedy(rs, cluster_params(p_shared=PT))
+        assert e.value.code == -3                                                    # NGSID_ERR_ALPHABET
+        with pytest.raises(NgsidError) as e:
+            api.cluster_greedy(ReadSet.from_strings(["ACGT" * 30], ["I" * 120]), cluster_params(k=22, w=30, p_shared=PT))
+        assert e.value.code == -2                                                    # k > 21
+    # a (k,w) without rows in the empirical table: KeyError in the reference (cluster.py:367) -> NGSID_ERR_NO_PTABLE
+    sp = synth.make_species(1, 300, 0.15, seed=2); rd = synth.make_reads(sp, 20, mu=20.0, seed=3)
+    rs2 = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    for api in (gpu_api, oracle):
+        with pytest.raises(NgsidError) as e:
+            api.cluster_greedy(rs2, cluster_params(p_shared=np.full(225, np.nan)))
+        assert e.value.code == -7
+    with pytest.raises(NgsidError) as e:
+        gpu_api.hpc_minimizers(rs2, 13, 20, cap=3)
+    assert e.value.code == -4                                                        # NGSID_ERR_CAPACITY
+
+
+def test_singletons_and_tiny_groups(gpu_api, oracle):
+    sp = synth.make_species(1, 200, 0.15, seed=4); rd = synth.make_reads(sp, 5, mu=20.0, seed=5)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    prm = poa_params(tile_depth=8, band=64)
+    goff = [0, 1, 1, 3, 5]                                                           # one read, empty, two reads, two reads
+    assert gpu_api.poa_consensus(rs, goff, prm) == oracle.poa_consensus(rs, goff, prm)
+    bb = ReadSet.from_strings([rs.get(0)[0], rs.get(3)[0]])
+    pp = polish_params(iters=2, tile_depth=8, band=64, trim=2)
+    g, o = both(gpu_api, oracle, lambda a: a.polish(bb, rs, [0, 1, 5], pp))           # group 0 has ONE read: < 2 layers -> backbone kept
+    assert g[0] == o[0] and np.array_equal(g[1], o[1]) and g[0][0] == rs.get(0)[0]
+
+
+def test_symmetric_thresholds(gpu_api, oracle):
+    g = np.load(__import__("os").path.join(__import__("oracle_lib").GOLD, "cluster_synth600_d10_q14.npz"))
+    rs = ReadSet(g["seq"], g["qual"], g["off"])
+    prm = cluster_params(k=13, w=20, p_shared=g["p_table"], symmetric=True, mapped_threshold=0.65, aligned_threshold=0.5, min_shared=4, min_fraction=0.7)
+    a, b = both(gpu_api, oracle, lambda api: api.cluster_greedy(rs, prm))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
