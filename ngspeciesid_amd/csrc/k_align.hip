@@ -19,13 +19,12 @@
 
 template <int RPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
-void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wave, int32_t* __restrict__ bnd, uint32_t bnd_stride, uint32_t lds_per_wave)
+void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wave, int32_t* __restrict__ bnd, uint32_t bnd_stride, uint32_t lds_per_wave, uint32_t* __restrict__ work_ctr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wib;
-    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     uint8_t* tgt = smem + (size_t)wib * lds_per_wave;                 // raw target, raw query, 4 KB traceback block
     const uint32_t seq_lds = (lds_per_wave - 4096) / 2;
     uint8_t* qry = tgt + seq_lds;
@@ -34,7 +33,11 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
     int32_t* mybnd = bnd + wave * (uint64_t)bnd_stride * 2;
     const int STRIP = 64 * RPL;
 
-    for (uint64_t p = wave; p < J.npairs; p += nwaves) {
+    for (;;) {
+        // persistent waves pull pairs from a queue: the grid is sized to what is resident, so there is no tail of idle SIMDs
+        uint32_t pq = 0; if (lane == 0) pq = atomicAdd(work_ctr, 1u);
+        const uint64_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)pq);
+        if (p >= J.npairs) break;
         const uint32_t qi = J.qidx[p], ti = J.tidx[p];
         const uint8_t* q = J.qseq + J.qoff[qi]; const int n = (int)(J.qoff[qi + 1] - J.qoff[qi]);
         const uint8_t* t = J.tseq + J.toff[ti]; const int m = (int)(J.toff[ti + 1] - J.toff[ti]);
@@ -215,7 +218,7 @@ static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen
     const uint64_t strip = 64ull * RPL;
     const uint64_t nstrips = (max_qlen + strip - 1) / strip;
     const uint64_t words = (nstrips ? nstrips : 1) * ((uint64_t)max_tlen + 63) * 64;
-    uint64_t want = job.npairs < (uint64_t)ctx->n_cu * 16 ? job.npairs : (uint64_t)ctx->n_cu * 16;
+    uint64_t want = job.npairs;
     const uint64_t by_mem = ctx->scratch_budget / (words * 8 + 1);
     if (want > by_mem) want = by_mem;
     if (want < 1) want = 1;
@@ -223,22 +226,31 @@ static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen
     const uint32_t lds_per_wave = 2 * seq_lds + 4096;
     int wpb = 4;
     while (wpb > 1 && (uint64_t)wpb * lds_per_wave > 40 * 1024) wpb >>= 1;
+    int occ = 0;
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_sg_align<RPL>, 64 * wpb, (size_t)wpb * lds_per_wave));
+    if (occ < 1) occ = 1;
+    const uint64_t resident = (uint64_t)occ * ctx->n_cu * wpb;          // waves that fit on the chip at once
+    if (want > resident) want = resident;
     const uint64_t blocks = (want + wpb - 1) / wpb;
     const uint64_t nwaves = blocks * wpb;
+    if (ctx->aln_ctr.n < 1) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
+    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t bnd_stride = (max_tlen + 15u) & ~15u;
     if (ctx->tb.n < nwaves * words) HIPCHK(ctx, ctx->tb.alloc(nwaves * words));
     if (ctx->bnd.n < nwaves * 2ull * bnd_stride) HIPCHK(ctx, ctx->bnd.alloc(nwaves * 2ull * bnd_stride));
     { ProfScope ps_(ctx, "k_sg_align"); hipLaunchKernelGGL((k_sg_align<RPL>), dim3((unsigned)blocks), dim3(64 * wpb), (size_t)wpb * lds_per_wave, ctx->stream,
-                       job, ctx->tb.p, words, ctx->bnd.p, bnd_stride, lds_per_wave); }
+                       job, ctx->tb.p, words, ctx->bnd.p, bnd_stride, lds_per_wave, ctx->aln_ctr.p); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }
 
-int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen)
+int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open)
 {
     if (job.npairs == 0) return NGSID_OK;
+    if (job.npairs > 0xf0000000ull) NGSID_FAIL(ctx, NGSID_ERR_ARG, "more than 2^32 pairs in one aligner call");
     if (max_tlen > NGSID_MAX_READ_LEN || max_qlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in aligner", NGSID_MAX_READ_LEN);
     if (job.k > 64) NGSID_FAIL(ctx, NGSID_ERR_ARG, "window k > 64 unsupported");
+    if (!getenv("NGSID_ALIGN32") && ngsid_align16_applicable(job, max_qlen, max_tlen, max_open)) return ngsid_launch_align16(ctx, job, max_qlen, max_tlen);   // packed int16 path (bit-identical)
     if (max_qlen <= 256) return launch_rpl<4>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 512) return launch_rpl<8>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 768) return launch_rpl<12>(ctx, job, max_qlen, max_tlen);

@@ -105,7 +105,8 @@ extern "C" int32_t ngsid_sg_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* que
     J.match = match; J.mismatch = mismatch; J.ext = ext; J.k = k; J.open = dopen.p; J.match_id = match_id ? dmid.p : nullptr;
     J.score = dout.p; J.ncols = dout.p + n_pairs; J.nmatch = dout.p + 2 * n_pairs; J.region = dout.p + 3 * n_pairs;
     J.bp = nullptr; J.bp_windows = 0; J.window = 1; J.span = nullptr;
-    rc = ngsid_launch_align(ctx, J, mq, mt); if (rc) return rc;
+    int mo = 0; for (uint64_t p = 0; p < n_pairs; ++p) { if (open[p] < 0) { mo = 1 << 20; break; } mo = std::max(mo, (int)open[p]); }
+    rc = ngsid_launch_align(ctx, J, mq, mt, mo); if (rc) return rc;
     std::vector<int32_t> h(n_pairs * 4);
     HIPCHK(ctx, hipMemcpyAsync(h.data(), dout.p, 16 * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -35,6 +35,7 @@ struct ngsid_ctx {
     int n_cu = 256;
     DevBuf<uint64_t> tb;      // aligner traceback scratch (grow-only)
     DevBuf<int32_t> bnd;      // aligner strip boundary rows
+    DevBuf<uint32_t> aln_ctr; // aligner work-queue counter (one pair index handed out per wave request)
     bool debug_sync = false;
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
@@ -83,7 +84,9 @@ struct AlignJob {            // device pointers
     // optional window break points (polish): per pair `bp_windows` records of 4 int32 {q_first,q_last,t_first,t_last}, -1 = none
     int32_t* bp; int bp_windows; int window; int32_t* span;  // span: per pair {q_begin,q_end,t_begin,t_end} of the aligned part
 };
-int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen);
+int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20);
+bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
+int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen);
 
 typedef unsigned int ngsid_v4u __attribute__((ext_vector_type(4)));
 // 16-byte load served by L2 (nt): for scratch that this wave rewrites between uses, where an L1 line could be stale
