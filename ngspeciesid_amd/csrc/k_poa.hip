@@ -47,16 +47,21 @@ __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)"
 // HBM scratch written by some lanes and read by others of the same wave: drain the stores, then order.
 __device__ __forceinline__ void mem_sync() { __threadfence_block(); __syncthreads(); }
 
-// inclusive max-scan over the 64 lanes: 4 DPP row shifts inside the 16-lane rows, row totals through readlane (SGPRs)
-__device__ __forceinline__ int wave_incl_max_scan(int v, int lane, int ident)
+// inclusive max-scan over the 64 lanes: the canonical GCN wave scan, six DPP-fused v_max (row_shr 1/2/4/8 inside the 16-lane rows,
+// then row_bcast:15 / row_bcast:31 carry the row totals).  In place: lanes without a DPP source keep their value (bound_ctrl off).
+// s_nop 1 = the two wait states a DPP read needs after the VALU write of the same register.
+__device__ __forceinline__ int wave_incl_max_scan(int v)
 {
-    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));
-    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
-    const int add = lane >= 48 ? max(r0, max(r1, r2)) : (lane >= 32 ? max(r0, r1) : (lane >= 16 ? r0 : ident));
-    return max(v, add);
+    asm volatile(
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "+v"(v));
+    return v;
 }
 
 #define PH(J, idx, t0) do { if ((J).phase_cycles && lane == 0) { const unsigned long long t1_ = __builtin_readcyclecounter(); atomicAdd(&(J).phase_cycles[idx], t1_ - (t0)); (t0) = t1_; } } while (0)
@@ -192,6 +197,147 @@ __device__ void tile_emit(const GG& g, const LL& w, const PoaJobSet& J, uint32_t
     st.nout += 1;
 }
 
+// Forward DP over the ranks of the graph (one row per node, topological order).  LOCAL is a template constant so the clamp / best-cell
+// bookkeeping of the other modes costs nothing.  Two kinds of rows:
+//   * chain rows (flag 16: the only predecessor is the previous row and the band start moves by 0 or 1; ~85 % of all rows): inputs come
+//     from the previous row's registers and ONE DPP lane shift; no LDS read apart from the row's own letters, no synchronisation;
+//   * everything else: predecessor rows from the LDS ring (HBM copy when further than HR rows back), slot bookkeeping for the traceback.
+// Out: the best end cell as (value, rank << 8 | band column), ties -> lowest rank, then lowest column.
+template <int CPL, bool LOCAL>
+__device__ __forceinline__ void poa_forward(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg, const PSeq& S, int V, int gp, int sm, int sn, int lane, int& bestv_out, int& bestpk_out)
+{
+    constexpr int BW = 64 * CPL;
+    const int L = S.len; const bool semi = S.mode == NGSID_POA_SEMI;
+    const int lane_jg = lane * CPL * gp;
+    int bestv = PNEG, bestpk = 0x7fffffff;      // !LOCAL
+    unsigned bkey[CPL];                         // LOCAL: (value << 16) | (0xFFFF - rank) per owned band column; values are >= 0 and < 2^16 (host check)
+    int hprev[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { hprev[c] = PNEG; bkey[c] = 0; }
+    unsigned long long ri_next = V > 0 ? w.rinfo[0] : 0ull;
+    uint8_t* dgp = Dg + lane * CPL;
+    for (int r = 0; r < V; ++r, dgp += BW) {
+        const unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)ri_next), rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri_next >> 32));
+        if (r + 1 < V) ri_next = w.rinfo[r + 1];          // prefetch: consumed one iteration later
+        const int l0 = rlo & 0xffff, p0r = rlo >> 16, p1r = rhi & 0xffff; const int cv = (rhi >> 16) & 0xff; const int rfl = rhi >> 24;
+        const int jb = l0 + lane * CPL;
+        int q[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) q[c] = w.sq[jb + c - 1];        // sq is padded: no bounds branches
+        int X[CPL], Dd[CPL];
+        if ((rfl & 16) && !semi) {
+            // chain row.  Band start moved by one (sh): diag = same register, up = next column; else diag = previous column, up = same.
+            // Lane 0 / 63 get PNEG from the DPP (no source lane), which is exactly the out-of-band value; column 0 never has a diagonal.
+            int up[CPL], dg[CPL];
+            if (rfl & 32) {
+                const int rt = __builtin_amdgcn_update_dpp(PNEG, hprev[0], 0x130, 0xf, 0xf, false);         // lane+1's first column
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) { up[c] = c + 1 < CPL ? hprev[c + 1] : rt; dg[c] = hprev[c]; }
+            } else {
+                const int lf = __builtin_amdgcn_update_dpp(PNEG, hprev[CPL - 1], 0x138, 0xf, 0xf, false);   // lane-1's last column
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) { up[c] = hprev[c]; dg[c] = c ? hprev[c - 1] : lf; }
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int xu = up[c] + gp, xd = dg[c] + (q[c] == cv ? sm : sn);
+                X[c] = max(xd, xu); Dd[c] = xu > xd ? 1 : 0;
+            }
+        } else {
+            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();     // ring rows of earlier iterations: LDS executes a wave's instructions in order
+            const bool nopred = (rfl & 1) != 0;
+            const bool use_src = nopred || semi;
+            int scj[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) scj[c] = (q[c] == cv) ? sm : sn;
+            int Xd[CPL], Dslot[CPL], Xu[CPL], Uslot[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) { Xd[c] = PNEG; Xu[c] = PNEG; Dslot[c] = 0; Uslot[c] = 0; }
+            int slot = 0, eit = NONE16;
+            if (rfl & 2) { eit = g.in_first[g.order[r]]; }
+            for (;; ++slot) {
+                int pr;
+                if (!(rfl & 2)) { pr = slot == 0 ? p0r : (slot == 1 ? p1r : NONE16); if (pr == NONE16) break; }
+                else { if (eit == NONE16) break; pr = g.rank[g.e_tail[eit]]; eit = g.e_next_in[eit]; }
+                const int plo = (int)(w.rinfo[pr] & 0xffff);
+                const int pc0 = jb - plo;
+                int hp[CPL + 1];
+                if ((r - pr) <= HR) {                       // LDS ring
+                    const l32 Hp = w.hring + (size_t)(pr & (HR - 1)) * BW;
+#pragma unroll
+                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : PNEG; }
+                } else {                                    // far predecessor: HBM copy of the row (flag 8 made the producer store it)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const int32_t* Hq = Hg + (size_t)pr * BW;
+#pragma unroll
+                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? __builtin_nontemporal_load(Hq + pc) : PNEG; }
+                }
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int j = jb + c;
+                    { const int hv = hp[c + 1]; if (hv > PNEG / 2 && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
+                    if (j >= 1) { const int hv = hp[c]; if (hv > PNEG / 2 && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = jb + c;
+                if (use_src && j >= 1) { const int sv = LOCAL ? 0 : (j - 1) * gp; if (sv + scj[c] > Xd[c]) { Xd[c] = sv + scj[c]; Dslot[c] = SRC_SLOT; } }
+                if (nopred && !semi) { const int sv = LOCAL ? 0 : j * gp; if (sv + gp > Xu[c]) { Xu[c] = sv + gp; Uslot[c] = SRC_SLOT; } }
+                if (Xd[c] >= Xu[c]) { X[c] = Xd[c]; Dd[c] = 0 | (Dslot[c] << 2); } else { X[c] = Xu[c]; Dd[c] = 1 | (Uslot[c] << 2); }
+            }
+        }
+        // in-row gap chain H[j] = max(Xf[j], H[j-1]+g) as a max-plus prefix scan of y[j] = Xf[j] - j*g.
+        // Unreachable cells are not normalised: they stay below -2^27 while reachable scores stay above -2^20, so every comparison
+        // that decides a reachable cell is unaffected (their own direction bytes are never read by the traceback).  Band columns
+        // past the end of the sequence (only when L+1 < BW) see the 0xFF padding and can never beat a real cell.
+        int exl[CPL]; int run = PNEG * 2;
+        const int jg0 = l0 * gp + lane_jg;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int xf = LOCAL ? max(X[c], 0) : X[c];
+            const int y = xf - (jg0 + c * gp);
+            exl[c] = run; run = c ? max(run, y) : y;
+        }
+        const int incl = wave_incl_max_scan(run);
+        const int excl_lane = __builtin_amdgcn_update_dpp(PNEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1, lane 0 keeps the identity
+        unsigned dpack = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int ex = c ? max(excl_lane, exl[c]) : excl_lane;
+            int val = X[c], dd = Dd[c];
+            const int lfv = ex + jg0 + c * gp;                  // best value reachable through the in-row gap chain
+            if (lfv > val) { val = lfv; dd = 2; }
+            if (LOCAL && val <= 0) { val = 0; dd = 3; }
+            hprev[c] = val; dpack |= (unsigned)(dd & 0xff) << (8 * c);
+        }
+        if (LOCAL) {
+            const unsigned rk = 0xFFFFu - (unsigned)r;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)hprev[c] << 16) | rk);
+        } else if (semi || (rfl & 4)) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) if (jb + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
+        }
+        // publish the row: LDS ring for later non-chain rows, HBM copy only where a far successor will ask for it, packed direction bytes
+        l32 ring = w.hring + (size_t)(r & (HR - 1)) * BW + lane * CPL;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) ring[c] = hprev[c];
+        if (rfl & 8) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) Hg[(size_t)r * BW + lane * CPL + c] = hprev[c];
+        }
+        if (CPL == 1) *dgp = (uint8_t)dpack; else if (CPL == 2) *(uint16_t*)dgp = (uint16_t)dpack; else *(unsigned int*)dgp = dpack;
+    }
+    if (LOCAL) {
+        unsigned k = bkey[0]; int cc = 0;
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) if (bkey[c] > k) { k = bkey[c]; cc = c; }
+        bestv = (int)(k >> 16); bestpk = (int)(((0xFFFFu - (k & 0xFFFFu)) << 8) | (unsigned)(lane * CPL + cc));
+    }
+    bestv_out = bestv; bestpk_out = bestpk;
+}
+
 // align S to the graph and merge it.  returns 0 = dropped (no valid end cell), 1 = added, 2 = does not fit
 template <int CPL>
 __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg, const PoaJobSet& J, const PSeq& S, TS& st, int lane)
@@ -228,121 +374,10 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
     lds_sync();
     PH(J, 0, tph);
     // ---------- forward DP, one row per graph node in topological order
-    const int lane_jg = lane * CPL * gp;
-    const bool local = mode == NGSID_POA_LOCAL, semi = mode == NGSID_POA_SEMI;
-    const int sm = J.m, sn = J.n;
-    int bestv = PNEG, bestpk = 0x7fffffff;               // packed (rank << 8 | band column): ties -> lowest rank, then lowest column
-    int hprev[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) hprev[c] = PNEG;
-    unsigned long long ri_next = V > 0 ? w.rinfo[0] : 0ull;
-    uint8_t* dgp = Dg + lane * CPL;
-    for (int r = 0; r < V; ++r, dgp += BW) {
-        const unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)ri_next), rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri_next >> 32));
-        if (r + 1 < V) ri_next = w.rinfo[r + 1];          // prefetch: consumed one iteration later
-        const int l0 = rlo & 0xffff, p0r = rlo >> 16, p1r = rhi & 0xffff; const int cv = (rhi >> 16) & 0xff; const int rfl = rhi >> 24;
-        const int jb = l0 + lane * CPL;
-        int scj[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) scj[c] = ((int)w.sq[jb + c - 1] == cv) ? sm : sn;      // sq is padded: no bounds branches
-        int X[CPL], Dd[CPL];
-        if ((rfl & 16) && !semi) {
-            // chain row: the only predecessor is the previous row, still in registers; neighbours through one DPP move
-            const int lf = __builtin_amdgcn_update_dpp(PNEG, hprev[CPL - 1], 0x138, 0xf, 0xf, false);   // lane-1's last column
-            const int rt = __builtin_amdgcn_update_dpp(PNEG, hprev[0], 0x130, 0xf, 0xf, false);         // lane+1's first column
-            int ext[CPL + 2]; ext[0] = lf; ext[CPL + 1] = rt;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) ext[c + 1] = hprev[c];
-            const bool sh = (rfl & 32) != 0;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int up = sh ? ext[c + 2] : ext[c + 1]; int dg = sh ? ext[c + 1] : ext[c];
-                if (jb + c < 1) dg = PNEG;
-                const int xu = up + gp, xd = dg + scj[c];
-                X[c] = xd >= xu ? xd : xu; Dd[c] = xd >= xu ? 0 : 1;
-            }
-        } else {
-            const bool nopred = (rfl & 1) != 0;
-            const bool use_src = nopred || semi;
-            int Xd[CPL], Dslot[CPL], Xu[CPL], Uslot[CPL];
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) { Xd[c] = PNEG; Xu[c] = PNEG; Dslot[c] = 0; Uslot[c] = 0; }
-            int slot = 0, eit = NONE16;
-            if (rfl & 2) { eit = g.in_first[g.order[r]]; }
-            for (;; ++slot) {
-                int pr;
-                if (!(rfl & 2)) { pr = slot == 0 ? p0r : (slot == 1 ? p1r : NONE16); if (pr == NONE16) break; }
-                else { if (eit == NONE16) break; pr = g.rank[g.e_tail[eit]]; eit = g.e_next_in[eit]; }
-                const int plo = (int)(w.rinfo[pr] & 0xffff);
-                const int pc0 = jb - plo;
-                int hp[CPL + 1];
-                if ((r - pr) <= HR) {                       // LDS ring
-                    const l32 Hp = w.hring + (size_t)(pr & (HR - 1)) * BW;
-#pragma unroll
-                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : PNEG; }
-                } else {                                    // far predecessor: HBM copy of the row (flag 8 made the producer store it)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const int32_t* Hq = Hg + (size_t)pr * BW;
-#pragma unroll
-                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? __builtin_nontemporal_load(Hq + pc) : PNEG; }
-                }
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const int j = jb + c;
-                    { const int hv = hp[c + 1]; if (hv > PNEG / 2 && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
-                    if (j >= 1) { const int hv = hp[c]; if (hv > PNEG / 2 && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int j = jb + c;
-                if (use_src && j >= 1) { const int sv = local ? 0 : (j - 1) * gp; if (sv + scj[c] > Xd[c]) { Xd[c] = sv + scj[c]; Dslot[c] = SRC_SLOT; } }
-                if (nopred && !semi) { const int sv = local ? 0 : j * gp; if (sv + gp > Xu[c]) { Xu[c] = sv + gp; Uslot[c] = SRC_SLOT; } }
-                if (Xd[c] >= Xu[c]) { X[c] = Xd[c]; Dd[c] = 0 | (Dslot[c] << 2); } else { X[c] = Xu[c]; Dd[c] = 1 | (Uslot[c] << 2); }
-            }
-        }
-        // in-row gap chain H[j] = max(Xf[j], H[j-1]+g) as a max-plus prefix scan of y[j] = Xf[j] - j*g.
-        // Unreachable cells are not normalised: they stay below -2^27 while reachable scores stay above -2^20, so every comparison
-        // that decides a reachable cell is unaffected (their own direction bytes are never read by the traceback).  Band columns
-        // past the end of the sequence (only when L+1 < BW) see the 0xFF padding and can never beat a real cell.
-        int exl[CPL]; int run = PNEG * 2;
-        const int jg0 = l0 * gp + lane_jg;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int xf = (local && X[c] < 0) ? 0 : X[c];
-            const int y = xf - (jg0 + c * gp);
-            exl[c] = run; run = max(run, y);
-        }
-        const int incl = wave_incl_max_scan(run, lane, PNEG * 2);
-        const int excl_lane = __builtin_amdgcn_update_dpp(PNEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1, lane 0 keeps the identity
-        int hrow[CPL]; unsigned dpack = 0;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int ex = max(excl_lane, exl[c]);
-            int val = X[c], dd = Dd[c];
-            const int lfv = ex + jg0 + c * gp;                  // best value reachable through the in-row gap chain
-            if (lfv > val) { val = lfv; dd = 2; }
-            if (local && val <= 0) { val = 0; dd = 3; }
-            hrow[c] = val; hprev[c] = val; dpack |= (unsigned)(dd & 0xff) << (8 * c);
-        }
-        if (local) {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) if (hrow[c] > bestv) { bestv = hrow[c]; bestpk = (r << 8) | (lane * CPL + c); }
-        } else if (semi || (rfl & 4)) {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) if (jb + c == L && hrow[c] > PNEG / 2 && hrow[c] > bestv) { bestv = hrow[c]; bestpk = (r << 8) | (lane * CPL + c); }
-        }
-        // publish the row: LDS ring for the next rows, HBM copy only where a far successor will ask for it, packed direction bytes
-        l32 ring = w.hring + (size_t)(r & (HR - 1)) * BW + lane * CPL;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) ring[c] = hrow[c];
-        if (rfl & 8) {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) Hg[(size_t)r * BW + lane * CPL + c] = hrow[c];
-        }
-        if (CPL == 1) *dgp = (uint8_t)dpack; else if (CPL == 2) *(uint16_t*)dgp = (uint16_t)dpack; else *(unsigned int*)dgp = dpack;
-        lds_sync();                                   // next row may read this ring slot; HBM stores stay in flight
-    }
+    const bool local = mode == NGSID_POA_LOCAL;
+    int bestv, bestpk;
+    if (local) poa_forward<CPL, true>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk);
+    else poa_forward<CPL, false>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk);
     mem_sync();                                       // direction rows must have landed before the traceback pulls them back
     PH(J, 1, tph);
     // ---------- best end cell: max value, ties -> lowest rank, then lowest column
@@ -578,6 +613,7 @@ int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
     if (J.njobs == 0) return NGSID_OK;
     const int BW = band <= 64 ? 64 : (band <= 128 ? 128 : 256);
     if (J.g >= 0) NGSID_FAIL(ctx, NGSID_ERR_ARG, "POA gap score must be negative");
+    if ((long long)J.m * J.Lmax >= 65536 || J.m < 0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA local score range exceeds 16 bits (match %d x length %d)", J.m, J.Lmax);
     if (J.Vcap > 0xFFF0 || J.Ecap > 0xFFF0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA graph capacity exceeds 16-bit indices (sequence too long for the tile engine)");
     const size_t lds = poa_lds_bytes(J.Vcap, J.Ecap, J.Lmax, BW);
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);
