@@ -57,12 +57,19 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
+    ndev = torch.cuda.device_count()
+    local = local % ndev                      # (dev aid: more ranks than GPUs only with NGSID_DIST_BACKEND=gloo, e.g. 2 ranks on a 1-GPU box)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    backend = os.environ.get("NGSID_DIST_BACKEND", "nccl")
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from ngspeciesid_amd import runtime, pipeline
     from ngspeciesid_amd._capi import ReadSet
     from ngspeciesid_amd.ptable import select_p_table
@@ -79,7 +86,7 @@ def main():
         if dist is None:
             return pipeline.run_hot_path(api, rs, rd["score"], acc_rank=acc_rank, timings=T, **kw)
         from ngspeciesid_amd import distributed
-        r = distributed.sharded_hot_path(api, rs, rd["score"], acc_rank_local=acc_rank, timings=T, device=dev, **kw)
+        r = distributed.sharded_hot_path(api, rs, rd["score"], acc_rank_local=acc_rank, timings=T, device=comm_dev, **kw)
         # same result shape as the single-GPU path for the checks below
         r["rep_of"] = r["final_gid"]; r["centers"] = [(c[0], c[1], c[2], c[3], []) for c in r["centers"]]
         return r
@@ -106,8 +113,8 @@ def main():
     for line in buf.value.decode().splitlines():
         nm, cnt, ms = line.split(); kern[nm] = (int(cnt), float(ms))
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        tn = torch.tensor([n], device=dev, dtype=torch.float64); dist.all_reduce(tn); n_total = int(tn.item())
+        t = torch.tensor([dt], device=comm_dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        tn = torch.tensor([n], device=comm_dev, dtype=torch.float64); dist.all_reduce(tn); n_total = int(tn.item())
     else:
         n_total = n
     if rank != 0:

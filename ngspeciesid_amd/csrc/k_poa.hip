@@ -29,17 +29,45 @@
 #define LDSP __attribute__((address_space(3)))
 typedef LDSP uint16_t* l16; typedef LDSP uint8_t* l8; typedef LDSP int32_t* l32; typedef LDSP long long* l64; typedef LDSP unsigned long long* lu64;
 
-struct GG {   // graph arrays in the workgroup's HBM scratch
-    uint16_t *anchor, *in_first, *in_last, *out_first, *out_last, *ring, *order, *rank, *tmpo;
-    uint8_t *code, *need;
-    uint16_t *e_tail, *e_head, *e_next_in, *e_next_out; int32_t* e_w;
-    uint32_t* cov;
+struct GG {   // graph arrays in the workgroup's HBM scratch: ONE base pointer + 32-bit byte offsets derived from three strides, so the
+              // arrays cost 2+3 SGPRs instead of 34 and every access is a saddr+voffset global instruction
+    uint8_t* base; uint32_t s16, s8, se;      // bytes of one u16[Vc+1] array, one u8[Vc] array, one u16[Ec] array (16-byte multiples)
+#define GG_U16(name, k) __device__ __forceinline__ uint16_t& name(uint32_t i) const { return *(uint16_t*)(base + ((k) * s16 + 2u * i)); }
+    GG_U16(anchor, 0) GG_U16(in_first, 1) GG_U16(in_last, 2) GG_U16(out_first, 3) GG_U16(out_last, 4) GG_U16(ring, 5) GG_U16(order, 6) GG_U16(rank, 7) GG_U16(tmpo, 8)
+#undef GG_U16
+    __device__ __forceinline__ uint8_t& code(uint32_t i) const { return *(base + (9u * s16 + i)); }
+    __device__ __forceinline__ uint8_t& need(uint32_t i) const { return *(base + (9u * s16 + s8 + i)); }
+#define GG_E16(name, k) __device__ __forceinline__ uint16_t& name(uint32_t i) const { return *(uint16_t*)(base + (9u * s16 + 2u * s8 + (k) * se + 2u * i)); }
+    GG_E16(e_tail, 0) GG_E16(e_head, 1) GG_E16(e_next_in, 2) GG_E16(e_next_out, 3)
+#undef GG_E16
+    __device__ __forceinline__ int32_t& e_w(uint32_t i) const { return *(int32_t*)(base + (9u * s16 + 2u * s8 + 4u * se + 4u * i)); }
+    __device__ __forceinline__ uint32_t& cov(uint32_t i) const { return *(uint32_t*)(base + (9u * s16 + 2u * s8 + 6u * se + 4u * i)); }
 };
-struct LL {   // LDS working set of one alignment (sc/epred/einfo/sinkbits alias the forward-pass region for the consensus)
-    lu64 rinfo; l32 hring; l8 dirblk;
-    l64 sc; l16 epred; LDSP unsigned int* einfo; LDSP unsigned int* sinkbits;
-    l16 alnode, nodeof, ref, tmpv; l8 sq;     // sq has one pad byte in front and BW behind
+// LDS working set of one alignment.  The hot arrays sit at COMPILE-TIME offsets (hring, dirblk, rinfo) so the row loop spends no SGPRs
+// on them; the rest follows at offsets derived from Vcap / Lmax.  Layout (BW = band width):
+//   [0, HR*BW*4)            hring   ring of DP rows
+//   [.., + TBR*BW)          dirblk  direction rows of the traceback block
+//   [C0, C0 + 8*Vc)         rinfo   (forward)  |  sc (consensus scores, 8 bytes per rank)
+//   [C1, C1 + X)            alnode, nodeof, ref, tmpv (per alignment)  |  epred, einfo, sinkbits (consensus);  X = max of the two
+//   [C2, ..)                sq      (one pad byte in front, BW behind)
+extern __shared__ __attribute__((aligned(16))) unsigned char poa_smem[];     // dynamic LDS of k_poa_tile (starts at LDS address 0)
+#define POA_LDS(T, off) ((T)((LDSP unsigned char*)poa_smem + (off)))
+template <int BW>
+struct LLT {
+    static constexpr unsigned HRING = 0, DIRBLK = HR * BW * 4, C0 = HR * BW * 4 + TBR * BW;
+    static __device__ __forceinline__ l32 hring() { return POA_LDS(l32, HRING); }
+    static __device__ __forceinline__ l8 dirblk() { return POA_LDS(l8, DIRBLK); }
+    static __device__ __forceinline__ lu64 rinfo() { return POA_LDS(lu64, C0); }
+    static __device__ __forceinline__ l64 sc() { return POA_LDS(l64, C0); }
+    l16 alnode, nodeof, ref, tmpv; l8 sq;
+    l16 epred; LDSP unsigned int* einfo; LDSP unsigned int* sinkbits;
 };
+__host__ __device__ inline size_t poa_al16(size_t b) { return (b + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t poa_lds_mid(int Vc, int Lm)      // bytes of the [C1, C2) area
+{
+    const size_t a = 4 * poa_al16(2 * (size_t)Lm), c = poa_al16((size_t)2 * Vc) + poa_al16(64 * 16) + poa_al16(((size_t)Vc + 31) / 32 * 4);
+    return a > c ? a : c;
+}
 
 // Single-wave workgroup: LDS instructions of one wave execute in issue order, so ordering LDS traffic between lanes only needs the
 // compiler not to reorder and the LDS queue to drain - no s_barrier and no wait on outstanding HBM stores.
@@ -82,10 +110,10 @@ __device__ __forceinline__ int band_lo(int anchor, const PSeq& S, int L0, int BW
 __device__ void tile_add_first(const GG& g, const PSeq& S, TS& st, int lane)
 {
     for (int i = lane; i < S.len; i += 64) {
-        g.code[i] = S.s[i]; g.anchor[i] = (uint16_t)i; g.ring[i] = (uint16_t)i; g.order[i] = (uint16_t)i; g.rank[i] = (uint16_t)i; g.cov[i] = S.cw;
-        g.in_first[i] = g.in_last[i] = (i > 0) ? (uint16_t)(i - 1) : (uint16_t)NONE16;
-        g.out_first[i] = g.out_last[i] = (i + 1 < S.len) ? (uint16_t)i : (uint16_t)NONE16;
-        if (i > 0) { const int e = i - 1; g.e_tail[e] = (uint16_t)(i - 1); g.e_head[e] = (uint16_t)i; g.e_next_in[e] = NONE16; g.e_next_out[e] = NONE16; g.e_w[e] = wtof(S, i - 1) + wtof(S, i); }
+        g.code(i) = S.s[i]; g.anchor(i) = (uint16_t)i; g.ring(i) = (uint16_t)i; g.order(i) = (uint16_t)i; g.rank(i) = (uint16_t)i; g.cov(i) = S.cw;
+        g.in_first(i) = g.in_last(i) = (i > 0) ? (uint16_t)(i - 1) : (uint16_t)NONE16;
+        g.out_first(i) = g.out_last(i) = (i + 1 < S.len) ? (uint16_t)i : (uint16_t)NONE16;
+        if (i > 0) { const int e = i - 1; g.e_tail(e) = (uint16_t)(i - 1); g.e_head(e) = (uint16_t)i; g.e_next_in(e) = NONE16; g.e_next_out(e) = NONE16; g.e_w(e) = wtof(S, i - 1) + wtof(S, i); }
     }
     st.V = S.len; st.E = S.len > 0 ? S.len - 1 : 0; st.L0 = S.len; st.cw_sum += S.cw;
     mem_sync();
@@ -94,21 +122,22 @@ __device__ void tile_add_first(const GG& g, const PSeq& S, TS& st, int lane)
 // one pass of the heaviest-bundle recurrence over ranks [rb, V) in RANK space.  Per 64-rank chunk the lanes fetch the first two
 // in-edges (predecessor rank, weight) of their rank from HBM into LDS; lane 0 then runs the serial recurrence out of LDS.
 // completion = branch-completion pass (skip predecessors whose score is -1).  Returns the best rank (uniform) or -1.
-__device__ int bundle_pass(const GG& g, const LL& w, int V, int rb, int completion, int lane)
+template <int BW>
+__device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int completion, int lane)
 {
     int best = -1;
     for (int r0 = rb; r0 < V; r0 += 64) {
         const int r = r0 + lane;
         if (r < V) {
-            const int v = g.order[r]; const int e0 = g.in_first[v];
+            const int v = g.order(r); const int e0 = g.in_first(v);
             unsigned t0 = NONE16, t1 = NONE16, fl = 0; int w0 = 0, w1 = 0;
             if (e0 != NONE16) {
-                t0 = g.rank[g.e_tail[e0]]; w0 = g.e_w[e0];
-                const int e1 = g.e_next_in[e0];
-                if (e1 != NONE16) { t1 = g.rank[g.e_tail[e1]]; w1 = g.e_w[e1]; if (g.e_next_in[e1] != NONE16) fl = 1; }
+                t0 = g.rank(g.e_tail(e0)); w0 = g.e_w(e0);
+                const int e1 = g.e_next_in(e0);
+                if (e1 != NONE16) { t1 = g.rank(g.e_tail(e1)); w1 = g.e_w(e1); if (g.e_next_in(e1) != NONE16) fl = 1; }
             }
             w.einfo[lane * 4 + 0] = t0 | (t1 << 16); w.einfo[lane * 4 + 1] = (unsigned)w0; w.einfo[lane * 4 + 2] = (unsigned)w1; w.einfo[lane * 4 + 3] = fl;
-            if (!completion && g.out_first[v] == NONE16) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
+            if (!completion && g.out_first(v) == NONE16) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
         }
         lds_sync();
         if (lane == 0) {
@@ -118,18 +147,18 @@ __device__ int bundle_pass(const GG& g, const LL& w, int V, int rb, int completi
                 const unsigned tt = w.einfo[x * 4 + 0]; const unsigned fl = w.einfo[x * 4 + 3];
                 if (!fl) {
                     const int ta = tt & 0xffff, tb = tt >> 16;
-                    if (ta != NONE16 && !(completion && w.sc[ta] == -1)) { const long long ww = (int)w.einfo[x * 4 + 1]; if (sv < ww || (sv == ww && w.sc[pv] <= w.sc[ta])) { sv = ww; pv = ta; } }
-                    if (tb != NONE16 && !(completion && w.sc[tb] == -1)) { const long long ww = (int)w.einfo[x * 4 + 2]; if (sv < ww || (sv == ww && w.sc[pv] <= w.sc[tb])) { sv = ww; pv = tb; } }
+                    if (ta != NONE16 && !(completion && w.sc()[ta] == -1)) { const long long ww = (int)w.einfo[x * 4 + 1]; if (sv < ww || (sv == ww && w.sc()[pv] <= w.sc()[ta])) { sv = ww; pv = ta; } }
+                    if (tb != NONE16 && !(completion && w.sc()[tb] == -1)) { const long long ww = (int)w.einfo[x * 4 + 2]; if (sv < ww || (sv == ww && w.sc()[pv] <= w.sc()[tb])) { sv = ww; pv = tb; } }
                 } else {        // more than two in-edges: walk the list in HBM
-                    const int v = g.order[rr];
-                    for (int e = g.in_first[v]; e != NONE16; e = g.e_next_in[e]) {
-                        const int t = g.rank[g.e_tail[e]]; if (completion && w.sc[t] == -1) continue; const long long ww = g.e_w[e];
-                        if (sv < ww || (sv == ww && w.sc[pv] <= w.sc[t])) { sv = ww; pv = t; }
+                    const int v = g.order(rr);
+                    for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) {
+                        const int t = g.rank(g.e_tail(e)); if (completion && w.sc()[t] == -1) continue; const long long ww = g.e_w(e);
+                        if (sv < ww || (sv == ww && w.sc()[pv] <= w.sc()[t])) { sv = ww; pv = t; }
                     }
                 }
-                if (pv != NONE16) sv += w.sc[pv];
-                w.sc[rr] = sv; w.epred[rr] = (uint16_t)pv;
-                if (best < 0 || w.sc[best] < sv) best = rr;
+                if (pv != NONE16) sv += w.sc()[pv];
+                w.sc()[rr] = sv; w.epred[rr] = (uint16_t)pv;
+                if (best < 0 || w.sc()[best] < sv) best = rr;
             }
         }
         lds_sync();
@@ -138,7 +167,8 @@ __device__ int bundle_pass(const GG& g, const LL& w, int V, int rb, int completi
 }
 
 // heaviest bundle + branch completion (oracle g_consensus)
-__device__ void tile_emit(const GG& g, const LL& w, const PoaJobSet& J, uint32_t job, TS& st, int lane)
+template <int BW>
+__device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uint32_t job, TS& st, int lane)
 {
     if (st.V == 0 || st.members == 0) return;
     if (st.nout >= J.D) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow, 1u); return; }   // host retries with more output slots
@@ -154,9 +184,9 @@ __device__ void tile_emit(const GG& g, const LL& w, const PoaJobSet& J, uint32_t
     while (!((w.sinkbits[mx >> 5] >> (mx & 31)) & 1u)) {
         const int start = mx;
         if (lane == 0) {
-            const int sv = g.order[start];
-            for (int e = g.out_first[sv]; e != NONE16; e = g.e_next_out[e])
-                for (int f = g.in_first[g.e_head[e]]; f != NONE16; f = g.e_next_in[f]) if (g.e_tail[f] != sv) w.sc[g.rank[g.e_tail[f]]] = -1;
+            const int sv = g.order(start);
+            for (int e = g.out_first(sv); e != NONE16; e = g.e_next_out(e))
+                for (int f = g.in_first(g.e_head(e)); f != NONE16; f = g.e_next_in(f)) if (g.e_tail(f) != sv) w.sc()[g.rank(g.e_tail(f))] = -1;
         }
         lds_sync();
         const int m2 = bundle_pass(g, w, V, start + 1, 1, lane);
@@ -165,12 +195,12 @@ __device__ void tile_emit(const GG& g, const LL& w, const PoaJobSet& J, uint32_t
     }
     // backtrack: lane 0 lists the ranks of the path (HBM scratch), then all lanes translate rank -> letter / coverage
     int n = 0;
-    if (lane == 0) { for (int r = mx; r != NONE16; r = w.epred[r]) ++n; int i = n; for (int r = mx; r != NONE16; r = w.epred[r]) g.tmpo[--i] = (uint16_t)r; }
+    if (lane == 0) { for (int r = mx; r != NONE16; r = w.epred[r]) ++n; int i = n; for (int r = mx; r != NONE16; r = w.epred[r]) g.tmpo(--i) = (uint16_t)r; }
     n = __builtin_amdgcn_readfirstlane(n);
     mem_sync();
     for (int i = lane; i < n; i += 64) {
-        const int v = g.order[g.tmpo[i]]; dst[i] = g.code[v];
-        if (dcov) { uint32_t c = g.cov[v]; for (int u = g.ring[v]; u != v; u = g.ring[u]) c += g.cov[u]; dcov[i] = c; }
+        const int v = g.order(g.tmpo(i)); dst[i] = g.code(v);
+        if (dcov) { uint32_t c = g.cov(v); for (int u = g.ring(v); u != v; u = g.ring(u)) c += g.cov(u); dcov[i] = c; }
     }
     mem_sync();
     if (J.trim_tiles && dcov && n > 0) {     // oracle EMIT: coverage-trim the tile consensus ends
@@ -200,70 +230,146 @@ __device__ void tile_emit(const GG& g, const LL& w, const PoaJobSet& J, uint32_t
 // Forward DP over the ranks of the graph (one row per node, topological order).  LOCAL is a template constant so the clamp / best-cell
 // bookkeeping of the other modes costs nothing.  Two kinds of rows:
 //   * chain rows (flag 16: the only predecessor is the previous row and the band start moves by 0 or 1; ~85 % of all rows): inputs come
-//     from the previous row's registers and ONE DPP lane shift; no LDS read apart from the row's own letters, no synchronisation;
+//     from the previous row's registers and ONE DPP lane shift.  Runs of chain rows execute in an inner loop that contains no HBM
+//     instruction at all (so the compiler's waitcnt model has nothing to wait for) and no synchronisation;
 //   * everything else: predecessor rows from the LDS ring (HBM copy when further than HR rows back), slot bookkeeping for the traceback.
+// Direction bytes are staged in the LDS block the traceback will use later (aligned blocks of TBR rows) and flushed to HBM with 16-byte
+// stores when a block fills; the final (partial) block stays in LDS for the traceback.
 // Out: the best end cell as (value, rank << 8 | band column), ties -> lowest rank, then lowest column.
+template <int CPL>
+__device__ __forceinline__ void poa_row_tail_store(l32 ringrow, LDSP uint8_t* dst, const int (&h)[CPL], unsigned dpack)
+{
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) ringrow[c] = h[c];
+    if (CPL == 1) *dst = (uint8_t)dpack; else if (CPL == 2) *(LDSP uint16_t*)dst = (uint16_t)dpack; else *(LDSP unsigned int*)dst = dpack;
+}
+
+// in-row gap chain H[j] = max(Xf[j], H[j-1]+g) as a max-plus prefix scan of y[j] = Xf[j] - j*g, then the final cell values / directions.
+// Unreachable cells are not normalised: they stay below -2^27 while reachable scores stay above -2^20, so every comparison
+// that decides a reachable cell is unaffected (their own direction bytes are never read by the traceback).  Band columns
+// past the end of the sequence (only when L+1 < BW) see the 0xFF padding and can never beat a real cell.
 template <int CPL, bool LOCAL>
-__device__ __forceinline__ void poa_forward(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg, const PSeq& S, int V, int gp, int sm, int sn, int lane, int& bestv_out, int& bestpk_out)
+__device__ __forceinline__ unsigned poa_row_finish(const int (&X)[CPL], const int (&Dd)[CPL], int jg0, int gp, int (&hout)[CPL])
+{
+    int exl[CPL]; int run = PNEG * 2;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int xf = LOCAL ? max(X[c], 0) : X[c];
+        const int y = xf - (jg0 + c * gp);
+        exl[c] = run; run = c ? max(run, y) : y;
+    }
+    const int incl = wave_incl_max_scan(run);
+    const int excl_lane = __builtin_amdgcn_update_dpp(PNEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1, lane 0 keeps the identity
+    unsigned dpack = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int ex = c ? max(excl_lane, exl[c]) : excl_lane;
+        int val = X[c], dd = Dd[c];
+        const int lfv = ex + jg0 + c * gp;                  // best value reachable through the in-row gap chain
+        if (lfv > val) { val = lfv; dd = 2; }
+        if (LOCAL && val <= 0) { val = 0; dd = 3; }
+        hout[c] = val; dpack |= (unsigned)(dd & 0xff) << (8 * c);
+    }
+    return dpack;
+}
+
+template <int CPL, bool LOCAL>
+__device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, const PSeq& S, int V, int gp_, int sm_, int sn_, int lane, int& bestv_out, int& bestpk_out, int& nslow_out)
 {
     constexpr int BW = 64 * CPL;
-    const int L = S.len; const bool semi = S.mode == NGSID_POA_SEMI;
-    const int lane_jg = lane * CPL * gp;
+    int nslow = 0;
+    const int L = __builtin_amdgcn_readfirstlane(S.len); const bool semi = __builtin_amdgcn_readfirstlane(S.mode) == NGSID_POA_SEMI;
+    int gp = gp_, sm = sm_, sn = sn_;
+    const int lane_jg = lane * CPL * gp_;
+    asm volatile("" : "+v"(gp), "+v"(sm), "+v"(sn));      // keep the three score constants in VGPRs (SGPRs are the scarce resource of this kernel);
+                                                          // gp_ stays scalar for the per-row l0 * gap product
     int bestv = PNEG, bestpk = 0x7fffffff;      // !LOCAL
     unsigned bkey[CPL];                         // LOCAL: (value << 16) | (0xFFFF - rank) per owned band column; values are >= 0 and < 2^16 (host check)
     int hprev[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) { hprev[c] = PNEG; bkey[c] = 0; }
-    unsigned long long ri_next = V > 0 ? w.rinfo[0] : 0ull;
-    uint8_t* dgp = Dg + lane * CPL;
-    for (int r = 0; r < V; ++r, dgp += BW) {
-        const unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)ri_next), rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri_next >> 32));
-        if (r + 1 < V) ri_next = w.rinfo[r + 1];          // prefetch: consumed one iteration later
-        const int l0 = rlo & 0xffff, p0r = rlo >> 16, p1r = rhi & 0xffff; const int cv = (rhi >> 16) & 0xff; const int rfl = rhi >> 24;
-        const int jb = l0 + lane * CPL;
-        int q[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) q[c] = w.sq[jb + c - 1];        // sq is padded: no bounds branches
-        int X[CPL], Dd[CPL];
+    const l32 ring0 = w.hring() + lane * CPL;
+    const l8 stage0 = w.dirblk() + lane * CPL;
+    const l8 sq0 = w.sq + lane * CPL - 1;
+    unsigned long long ri = V > 0 ? w.rinfo()[0] : 0ull;
+    int r = 0;
+    while (r < V) {
+        unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)ri), rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri >> 32));
+        int rfl = rhi >> 24;
         if ((rfl & 16) && !semi) {
-            // chain row.  Band start moved by one (sh): diag = same register, up = next column; else diag = previous column, up = same.
-            // Lane 0 / 63 get PNEG from the DPP (no source lane), which is exactly the out-of-band value; column 0 never has a diagonal.
-            int up[CPL], dg[CPL];
-            if (rfl & 32) {
-                const int rt = __builtin_amdgcn_update_dpp(PNEG, hprev[0], 0x130, 0xf, 0xf, false);         // lane+1's first column
+            // ---- run of chain rows: registers + one DPP per row, LDS only for letters / ring / staged directions
+            for (;;) {
+#ifdef POA_EXP2
+                ri += 1ull | (1ull << 16);
+#else
+                if (r + 1 < V) ri = w.rinfo()[r + 1];                  // prefetch: consumed one iteration later
+#endif
+                const int l0 = rlo & 0xffff; const int cv = (rhi >> 16) & 0xff;
+                int q[CPL];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) { up[c] = c + 1 < CPL ? hprev[c + 1] : rt; dg[c] = hprev[c]; }
-            } else {
-                const int lf = __builtin_amdgcn_update_dpp(PNEG, hprev[CPL - 1], 0x138, 0xf, 0xf, false);   // lane-1's last column
+#ifdef POA_EXP1
+                for (int c = 0; c < CPL; ++c) q[c] = 1 + c + (lane & 1);
+#else
+                for (int c = 0; c < CPL; ++c) q[c] = sq0[l0 + c];          // sq is padded: no bounds branches
+#endif
+                // Band start moved by one: diag = same register, up = next column; else diag = previous column, up = same.
+                // Lane 0 / 63 get PNEG from the DPP (no source lane), which is exactly the out-of-band value; column 0 never has a diagonal.
+                int up[CPL], dg[CPL];
+                if (rfl & 32) {
+                    const int rt = __builtin_amdgcn_update_dpp(PNEG, hprev[0], 0x130, 0xf, 0xf, false);         // lane+1's first column
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) { up[c] = hprev[c]; dg[c] = c ? hprev[c - 1] : lf; }
-            }
+                    for (int c = 0; c < CPL; ++c) { up[c] = c + 1 < CPL ? hprev[c + 1] : rt; dg[c] = hprev[c]; }
+                } else {
+                    const int lf = __builtin_amdgcn_update_dpp(PNEG, hprev[CPL - 1], 0x138, 0xf, 0xf, false);   // lane-1's last column
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int xu = up[c] + gp, xd = dg[c] + (q[c] == cv ? sm : sn);
-                X[c] = max(xd, xu); Dd[c] = xu > xd ? 1 : 0;
+                    for (int c = 0; c < CPL; ++c) { up[c] = hprev[c]; dg[c] = c ? hprev[c - 1] : lf; }
+                }
+                int X[CPL], Dd[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int xu = up[c] + gp, xd = dg[c] + (q[c] == cv ? sm : sn);
+                    X[c] = max(xd, xu); Dd[c] = xu > xd ? 1 : 0;
+                }
+                const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, l0 * gp_ + lane_jg, gp, hprev);
+                poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * BW, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
+                if (LOCAL) {
+                    const unsigned rk = 0xFFFFu - (unsigned)r;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)hprev[c] << 16) | rk);
+                } else if (rfl & 4) {
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) if (l0 + lane * CPL + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
+                }
+                ++r;
+                if ((rfl & 8) || (r & (TBR - 1)) == 0 || r >= V) break;       // HBM copy / block flush / end: handled below
+                rlo = __builtin_amdgcn_readfirstlane((unsigned)ri); rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri >> 32)); rfl = rhi >> 24;
+                if (!(rfl & 16)) { rfl = 0; break; }                           // next row is not a chain row (nothing pending for the row just done)
             }
         } else {
+            ++nslow;
+            if (r + 1 < V) ri = w.rinfo()[r + 1];
+            const int l0 = rlo & 0xffff, p0r = rlo >> 16, p1r = rhi & 0xffff; const int cv = (rhi >> 16) & 0xff;
+            const int jb = l0 + lane * CPL;
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();     // ring rows of earlier iterations: LDS executes a wave's instructions in order
             const bool nopred = (rfl & 1) != 0;
             const bool use_src = nopred || semi;
             int scj[CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) scj[c] = (q[c] == cv) ? sm : sn;
+            for (int c = 0; c < CPL; ++c) scj[c] = ((int)sq0[l0 + c] == cv) ? sm : sn;
             int Xd[CPL], Dslot[CPL], Xu[CPL], Uslot[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; ++c) { Xd[c] = PNEG; Xu[c] = PNEG; Dslot[c] = 0; Uslot[c] = 0; }
             int slot = 0, eit = NONE16;
-            if (rfl & 2) { eit = g.in_first[g.order[r]]; }
+            if (rfl & 2) { eit = g.in_first(g.order(r)); }
             for (;; ++slot) {
                 int pr;
                 if (!(rfl & 2)) { pr = slot == 0 ? p0r : (slot == 1 ? p1r : NONE16); if (pr == NONE16) break; }
-                else { if (eit == NONE16) break; pr = g.rank[g.e_tail[eit]]; eit = g.e_next_in[eit]; }
-                const int plo = (int)(w.rinfo[pr] & 0xffff);
+                else { if (eit == NONE16) break; pr = g.rank(g.e_tail(eit)); eit = g.e_next_in(eit); }
+                const int plo = (int)(w.rinfo()[pr] & 0xffff);
                 const int pc0 = jb - plo;
                 int hp[CPL + 1];
                 if ((r - pr) <= HR) {                       // LDS ring
-                    const l32 Hp = w.hring + (size_t)(pr & (HR - 1)) * BW;
+                    const l32 Hp = w.hring() + (size_t)(pr & (HR - 1)) * BW;
 #pragma unroll
                     for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : PNEG; }
                 } else {                                    // far predecessor: HBM copy of the row (flag 8 made the producer store it)
@@ -279,6 +385,7 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LL& w, int32_t* H
                     if (j >= 1) { const int hv = hp[c]; if (hv > PNEG / 2 && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
                 }
             }
+            int X[CPL], Dd[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int j = jb + c;
@@ -286,48 +393,30 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LL& w, int32_t* H
                 if (nopred && !semi) { const int sv = LOCAL ? 0 : j * gp; if (sv + gp > Xu[c]) { Xu[c] = sv + gp; Uslot[c] = SRC_SLOT; } }
                 if (Xd[c] >= Xu[c]) { X[c] = Xd[c]; Dd[c] = 0 | (Dslot[c] << 2); } else { X[c] = Xu[c]; Dd[c] = 1 | (Uslot[c] << 2); }
             }
+            const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, l0 * gp_ + lane_jg, gp, hprev);
+            poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * BW, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
+            if (LOCAL) {
+                const unsigned rk = 0xFFFFu - (unsigned)r;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)hprev[c] << 16) | rk);
+            } else if (semi || (rfl & 4)) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) if (jb + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
+            }
+            ++r;
         }
-        // in-row gap chain H[j] = max(Xf[j], H[j-1]+g) as a max-plus prefix scan of y[j] = Xf[j] - j*g.
-        // Unreachable cells are not normalised: they stay below -2^27 while reachable scores stay above -2^20, so every comparison
-        // that decides a reachable cell is unaffected (their own direction bytes are never read by the traceback).  Band columns
-        // past the end of the sequence (only when L+1 < BW) see the 0xFF padding and can never beat a real cell.
-        int exl[CPL]; int run = PNEG * 2;
-        const int jg0 = l0 * gp + lane_jg;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int xf = LOCAL ? max(X[c], 0) : X[c];
-            const int y = xf - (jg0 + c * gp);
-            exl[c] = run; run = c ? max(run, y) : y;
-        }
-        const int incl = wave_incl_max_scan(run);
-        const int excl_lane = __builtin_amdgcn_update_dpp(PNEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1, lane 0 keeps the identity
-        unsigned dpack = 0;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int ex = c ? max(excl_lane, exl[c]) : excl_lane;
-            int val = X[c], dd = Dd[c];
-            const int lfv = ex + jg0 + c * gp;                  // best value reachable through the in-row gap chain
-            if (lfv > val) { val = lfv; dd = 2; }
-            if (LOCAL && val <= 0) { val = 0; dd = 3; }
-            hprev[c] = val; dpack |= (unsigned)(dd & 0xff) << (8 * c);
-        }
-        if (LOCAL) {
-            const unsigned rk = 0xFFFFu - (unsigned)r;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)hprev[c] << 16) | rk);
-        } else if (semi || (rfl & 4)) {
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) if (jb + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
-        }
-        // publish the row: LDS ring for later non-chain rows, HBM copy only where a far successor will ask for it, packed direction bytes
-        l32 ring = w.hring + (size_t)(r & (HR - 1)) * BW + lane * CPL;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) ring[c] = hprev[c];
+        // ---- after the row(s): HBM copy of row r-1 where a far successor will ask for it; flush a completed block of direction rows
         if (rfl & 8) {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) Hg[(size_t)r * BW + lane * CPL + c] = hprev[c];
+            for (int c = 0; c < CPL; ++c) Hg[(size_t)(r - 1) * BW + lane * CPL + c] = hprev[c];
         }
-        if (CPL == 1) *dgp = (uint8_t)dpack; else if (CPL == 2) *(uint16_t*)dgp = (uint16_t)dpack; else *(unsigned int*)dgp = dpack;
+        if ((r & (TBR - 1)) == 0) {
+            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
+            uint8_t* dstb = Dg + (size_t)(r - TBR) * BW;
+#pragma unroll
+            for (int x = 0; x < TBR * BW / 16 / 64; ++x) { const int piece = lane + 64 * x; *(ngsid_v4u*)(dstb + piece * 16) = *(LDSP ngsid_v4u*)(w.dirblk() + piece * 16); }
+            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
+        }
     }
     if (LOCAL) {
         unsigned k = bkey[0]; int cc = 0;
@@ -335,49 +424,51 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LL& w, int32_t* H
         for (int c = 1; c < CPL; ++c) if (bkey[c] > k) { k = bkey[c]; cc = c; }
         bestv = (int)(k >> 16); bestpk = (int)(((0xFFFFu - (k & 0xFFFFu)) << 8) | (unsigned)(lane * CPL + cc));
     }
-    bestv_out = bestv; bestpk_out = bestpk;
+    bestv_out = bestv; bestpk_out = bestpk; nslow_out = nslow;
 }
 
 // align S to the graph and merge it.  returns 0 = dropped (no valid end cell), 1 = added, 2 = does not fit
 template <int CPL>
-__device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg, const PoaJobSet& J, const PSeq& S, TS& st, int lane)
+__device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, const PoaJobSet& J, const PSeq& S, TS& st, int lane)
 {
     constexpr int BW = 64 * CPL;
-    const int L = S.len, mode = S.mode, gp = J.g, V = st.V;
+    // wave-uniform by construction; tell the compiler so the row loops get scalar control flow
+    const int L = __builtin_amdgcn_readfirstlane(S.len), mode = __builtin_amdgcn_readfirstlane(S.mode), gp = __builtin_amdgcn_readfirstlane(J.g), V = __builtin_amdgcn_readfirstlane(st.V);
     unsigned long long tph = J.phase_cycles ? __builtin_readcyclecounter() : 0;
     // ---------- per-rank row info, built lane-parallel so that the serial row loop reads ONE 8-byte LDS word per row:
     //   lo:16 | first pred rank:16 | second pred rank:16 | letter:8 | flags:8
     //   flags: 1 no predecessor, 2 more than two, 4 sink, 8 keep an HBM copy (a successor is > HR rows away),
     //          16 chain row (single predecessor = previous row, band shift 0/1), 32 = that band shift
-    for (int r = lane; r < V; r += 64) g.need[r] = 0;
+    for (int r = lane; r < V; r += 64) g.need(r) = 0;
     mem_sync();
     for (int r = lane; r < V; r += 64) {
-        const int v = g.order[r];
-        for (int e = g.in_first[v]; e != NONE16; e = g.e_next_in[e]) { const int pr = g.rank[g.e_tail[e]]; if (r - pr > HR) g.need[pr] = 1; }
-        const int l0 = band_lo(g.anchor[v], S, st.L0, BW);
-        const int e0 = g.in_first[v]; int p0 = NONE16, p1 = NONE16, fl = 0;
+        const int v = g.order(r);
+        for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) g.need(pr) = 1; }
+        const int l0 = band_lo(g.anchor(v), S, st.L0, BW);
+        const int e0 = g.in_first(v); int p0 = NONE16, p1 = NONE16, fl = 0;
         if (e0 == NONE16) fl |= 1;
-        else { p0 = g.rank[g.e_tail[e0]]; const int e1 = g.e_next_in[e0]; if (e1 != NONE16) { p1 = g.rank[g.e_tail[e1]]; if (g.e_next_in[e1] != NONE16) fl |= 2; } }
-        if (g.out_first[v] == NONE16) fl |= 4;
+        else { p0 = g.rank(g.e_tail(e0)); const int e1 = g.e_next_in(e0); if (e1 != NONE16) { p1 = g.rank(g.e_tail(e1)); if (g.e_next_in(e1) != NONE16) fl |= 2; } }
+        if (g.out_first(v) == NONE16) fl |= 4;
         if (r > 0 && !(fl & 3) && p0 == r - 1 && p1 == NONE16) {
-            const int d = l0 - band_lo(g.anchor[g.order[r - 1]], S, st.L0, BW);
+            const int d = l0 - band_lo(g.anchor(g.order(r - 1)), S, st.L0, BW);
             if (d == 0 || d == 1) fl |= 16 | (d << 5);
         }
-        w.rinfo[r] = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)p0 << 16) | ((unsigned long long)(unsigned)p1 << 32)
-                   | ((unsigned long long)g.code[v] << 48) | ((unsigned long long)(unsigned)fl << 56);
+        w.rinfo()[r] = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)p0 << 16) | ((unsigned long long)(unsigned)p1 << 32)
+                   | ((unsigned long long)g.code(v) << 48) | ((unsigned long long)(unsigned)fl << 56);
     }
     for (int i = lane; i < L; i += 64) { w.alnode[i] = NONE16; w.sq[i] = S.s[i]; }
     for (int i = lane; i < BW; i += 64) w.sq[L + i] = 0xFF;            // pad: columns past the end never match
     if (lane == 0) w.sq[-1] = 0xFF;
     mem_sync();
-    for (int r = lane; r < V; r += 64) if (g.need[r]) w.rinfo[r] |= 8ull << 56;
+    for (int r = lane; r < V; r += 64) if (g.need(r)) w.rinfo()[r] |= 8ull << 56;
     lds_sync();
     PH(J, 0, tph);
     // ---------- forward DP, one row per graph node in topological order
     const bool local = mode == NGSID_POA_LOCAL;
-    int bestv, bestpk;
-    if (local) poa_forward<CPL, true>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk);
-    else poa_forward<CPL, false>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk);
+    int bestv, bestpk, nslow;
+    if (local) poa_forward<CPL, true>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    else poa_forward<CPL, false>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[5], (unsigned long long)V); atomicAdd(&J.phase_cycles[6], (unsigned long long)nslow); }
     mem_sync();                                       // direction rows must have landed before the traceback pulls them back
     PH(J, 1, tph);
     // ---------- best end cell: max value, ties -> lowest rank, then lowest column
@@ -395,32 +486,32 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
     // ---------- traceback in rank space (uniform across lanes): predecessors and band starts come from the row info in LDS,
     //            direction rows are pulled TBR at a time from HBM into LDS.  alnode[] receives RANKS here.
     if (aligned_any) {
-        int r = bestr, c = bestc, j = (int)(w.rinfo[bestr] & 0xffff) + bestc;
-        int blk_hi = -1, blk_lo = 0;
+        int r = bestr, c = bestc, j = (int)(w.rinfo()[bestr] & 0xffff) + bestc;
+        int blk_lo = (V - 1) & ~(TBR - 1);                 // the forward pass left the last (partial) block of direction rows in LDS
         for (;;) {
-            if (r > blk_hi || r < blk_lo) {
+            if (r < blk_lo) {
                 lds_sync();
-                blk_hi = r; blk_lo = r - (TBR - 1) < 0 ? 0 : r - (TBR - 1);
+                blk_lo = r & ~(TBR - 1);                    // aligned blocks of TBR rows, same layout as the forward pass staged them
                 constexpr int LPR = 64 / TBR;                         // lanes per direction row
-                const int rr = blk_hi - lane / LPR;
-                if (rr >= blk_lo) {
-                    const uint8_t* src = Dg + (size_t)rr * BW; l8 dstp = w.dirblk + (size_t)(lane / LPR) * BW;
+                const int rr = blk_lo + lane / LPR;
+                {
+                    const uint8_t* src = Dg + (size_t)rr * BW; l8 dstp = w.dirblk() + (size_t)(lane / LPR) * BW;
                     for (int x = (lane % LPR) * 16; x < BW; x += 16 * LPR) *(LDSP ngsid_v4u*)(dstp + x) = ngsid_load16_l2(src + x);   // L2-served: rows are rewritten per sequence
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-            const int d = w.dirblk[(size_t)(blk_hi - r) * BW + c]; const int type = d & 3, slot = d >> 2;
+            const int d = w.dirblk()[(size_t)(r - blk_lo) * BW + c]; const int type = d & 3, slot = d >> 2;
             if (type == 3) break;
             if (type == 2) { --j; --c; continue; }
             if (type == 0) { if (lane == 0) w.alnode[j - 1] = (uint16_t)r; --j; }
             if (slot == SRC_SLOT) break;
-            const unsigned long long ri = w.rinfo[r];
+            const unsigned long long ri = w.rinfo()[r];
             int pr;
             if (slot == 0) pr = (int)((ri >> 16) & 0xffff);
             else if (slot == 1) pr = (int)((ri >> 32) & 0xffff);
-            else { int e = g.in_first[g.order[r]]; for (int t = 0; t < slot; ++t) e = g.e_next_in[e]; pr = g.rank[g.e_tail[e]]; }
-            r = pr; c = j - (int)(w.rinfo[r] & 0xffff);
+            else { int e = g.in_first(g.order(r)); for (int t = 0; t < slot; ++t) e = g.e_next_in(e); pr = g.rank(g.e_tail(e)); }
+            r = pr; c = j - (int)(w.rinfo()[r] & 0xffff);
         }
     }
     lds_sync();
@@ -431,7 +522,7 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
         const int i = i0 + lane; bool isnew = false;
         if (i < L) {
             const int ar = w.alnode[i]; const uint8_t ch = w.sq[i]; int found = NONE16, v = NONE16;
-            if (ar != NONE16) { v = g.order[ar]; if (g.code[v] == ch) found = v; else for (int u = g.ring[v]; u != v; u = g.ring[u]) if (g.code[u] == ch) { found = u; break; } }
+            if (ar != NONE16) { v = g.order(ar); if (g.code(v) == ch) found = v; else for (int u = g.ring(v); u != v; u = g.ring(u)) if (g.code(u) == ch) { found = u; break; } }
             w.alnode[i] = (uint16_t)v; w.nodeof[i] = (uint16_t)found; isnew = found == NONE16;
         }
         nnew += __popcll(__ballot(isnew));
@@ -466,11 +557,11 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
             const int before = __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
             if (isnew) {
                 const int y = base + before; const int rf = w.ref[i];
-                const int anc = la != NONE16 ? g.anchor[la] : (rf != NONE16 ? g.anchor[rf] : (S.a1 < S.a0 ? 0 : S.a0));
-                g.code[y] = w.sq[i]; g.anchor[y] = (uint16_t)anc; g.in_first[y] = g.in_last[y] = g.out_first[y] = g.out_last[y] = NONE16; g.cov[y] = 0;
-                if (a != NONE16) { g.ring[y] = g.ring[a]; g.ring[a] = (uint16_t)y; } else g.ring[y] = (uint16_t)y;
+                const int anc = la != NONE16 ? g.anchor(la) : (rf != NONE16 ? g.anchor(rf) : (S.a1 < S.a0 ? 0 : S.a0));
+                g.code(y) = w.sq[i]; g.anchor(y) = (uint16_t)anc; g.in_first(y) = g.in_last(y) = g.out_first(y) = g.out_last(y) = NONE16; g.cov(y) = 0;
+                if (a != NONE16) { g.ring(y) = g.ring(a); g.ring(a) = (uint16_t)y; } else g.ring(y) = (uint16_t)y;
                 w.nodeof[i] = (uint16_t)y;
-                w.tmpv[y - V] = (uint16_t)(rf != NONE16 ? g.rank[rf] : V);
+                w.tmpv[y - V] = (uint16_t)(rf != NONE16 ? g.rank(rf) : V);
             }
             base += __popcll(mn);
             if (ma) { const int hl = 63 - __clzll(ma); lastal = __shfl(a, hl); }
@@ -481,11 +572,11 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
     {
         for (int p = lane; p < V; p += 64) {
             int lo = 0, hi = nnew; while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.tmpv[mid] <= p) lo = mid + 1; else hi = mid; }
-            g.tmpo[p + lo] = g.order[p];
+            g.tmpo(p + lo) = g.order(p);
         }
-        for (int k = lane; k < nnew; k += 64) g.tmpo[w.tmpv[k] + k] = (uint16_t)(V + k);
+        for (int k = lane; k < nnew; k += 64) g.tmpo(w.tmpv[k] + k) = (uint16_t)(V + k);
         mem_sync();
-        for (int r = lane; r < V + nnew; r += 64) { const int v = g.tmpo[r]; g.order[r] = (uint16_t)v; g.rank[v] = (uint16_t)r; }
+        for (int r = lane; r < V + nnew; r += 64) { const int v = g.tmpo(r); g.order(r) = (uint16_t)v; g.rank(v) = (uint16_t)r; }
     }
     mem_sync();
     // ---------- E: coverage and edges (edge ids in sequence order)
@@ -494,20 +585,20 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
         for (int i0 = 0; i0 < L; i0 += 64) {
             const int i = i0 + lane; bool newedge = false; int a = 0, b = 0, wgt = 0;
             if (i < L) {
-                b = w.nodeof[i]; g.cov[b] += S.cw;
+                b = w.nodeof[i]; g.cov(b) += S.cw;
                 if (i > 0) {
                     a = w.nodeof[i - 1]; wgt = wtof(S, i - 1) + wtof(S, i);
-                    int e = g.out_first[a];
-                    for (; e != NONE16; e = g.e_next_out[e]) if (g.e_head[e] == b) break;
-                    if (e != NONE16) g.e_w[e] += wgt; else newedge = true;
+                    int e = g.out_first(a);
+                    for (; e != NONE16; e = g.e_next_out(e)) if (g.e_head(e) == b) break;
+                    if (e != NONE16) g.e_w(e) += wgt; else newedge = true;
                 }
             }
             const unsigned long long mn = __ballot(newedge);
             if (newedge) {
                 const int e = ebase + __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-                g.e_tail[e] = (uint16_t)a; g.e_head[e] = (uint16_t)b; g.e_w[e] = wgt; g.e_next_in[e] = NONE16; g.e_next_out[e] = NONE16;
-                if (g.out_last[a] == NONE16) g.out_first[a] = (uint16_t)e; else g.e_next_out[g.out_last[a]] = (uint16_t)e; g.out_last[a] = (uint16_t)e;
-                if (g.in_last[b] == NONE16) g.in_first[b] = (uint16_t)e; else g.e_next_in[g.in_last[b]] = (uint16_t)e; g.in_last[b] = (uint16_t)e;
+                g.e_tail(e) = (uint16_t)a; g.e_head(e) = (uint16_t)b; g.e_w(e) = wgt; g.e_next_in(e) = NONE16; g.e_next_out(e) = NONE16;
+                if (g.out_last(a) == NONE16) g.out_first(a) = (uint16_t)e; else g.e_next_out(g.out_last(a)) = (uint16_t)e; g.out_last(a) = (uint16_t)e;
+                if (g.in_last(b) == NONE16) g.in_first(b) = (uint16_t)e; else g.e_next_in(g.in_last(b)) = (uint16_t)e; g.in_last(b) = (uint16_t)e;
             }
             ebase += __popcll(mn);
         }
@@ -523,17 +614,13 @@ __device__ int tile_align_add(const GG& g, const LL& w, int32_t* Hg, uint8_t* Dg
 size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW)
 {
     (void)Ec;
-    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    size_t fwd = al((size_t)8 * Vc) + al((size_t)HR * BW * 4) + al((size_t)TBR * BW);
-    size_t cons = al((size_t)8 * Vc) + al((size_t)2 * Vc) + al(64 * 16) + al(((size_t)Vc + 31) / 32 * 4);
-    size_t region = fwd > cons ? fwd : cons;
-    return region + 4 * al(2 * (size_t)Lm) + al((size_t)Lm + BW + 32);
+    return (size_t)HR * BW * 4 + (size_t)TBR * BW + poa_al16((size_t)8 * Vc) + poa_lds_mid(Vc, Lm) + poa_al16((size_t)Lm + BW + 32);
 }
 // HBM scratch bytes of one workgroup for the graph arrays
 static size_t poa_graph_bytes(int Vc, int Ec)
 {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    return 9 * al(2 * ((size_t)Vc + 1)) + 2 * al(Vc) + 4 * al(2 * (size_t)Ec) + al(4 * (size_t)Ec) + al(4 * (size_t)Vc);
+    return 9 * al(2 * ((size_t)Vc + 1)) + 2 * al(Vc) + 6 * al(2 * (size_t)Ec) + al(4 * (size_t)Vc);
 }
 
 template <int CPL>
@@ -541,31 +628,17 @@ __global__ __launch_bounds__(64)
 void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes)
 {
     constexpr int BW = 64 * CPL;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int Vc = J.Vcap, Ec = J.Ecap, Lm = J.Lmax;
-    LL w; GG g;
+    LLT<BW> w; GG g;
     {
-        LDSP unsigned char* base = (LDSP unsigned char*)smem;
         auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-        const size_t fwd = al((size_t)8 * Vc) + al((size_t)HR * BW * 4) + al((size_t)TBR * BW);
-        const size_t cons = al((size_t)8 * Vc) + al((size_t)2 * Vc) + al(64 * 16) + al(((size_t)Vc + 31) / 32 * 4);
-        const size_t region = fwd > cons ? fwd : cons;
-        w.rinfo = (lu64)base; w.hring = (l32)(base + al((size_t)8 * Vc)); w.dirblk = (l8)(base + al((size_t)8 * Vc) + al((size_t)HR * BW * 4));
-        w.sc = (l64)base; w.epred = (l16)(base + al((size_t)8 * Vc)); w.einfo = (LDSP unsigned int*)(base + al((size_t)8 * Vc) + al((size_t)2 * Vc));
-        w.sinkbits = (LDSP unsigned int*)(base + al((size_t)8 * Vc) + al((size_t)2 * Vc) + al(64 * 16));
-        size_t o = region;
-        w.alnode = (l16)(base + o); o += al(2 * (size_t)Lm); w.nodeof = (l16)(base + o); o += al(2 * (size_t)Lm);
-        w.ref = (l16)(base + o); o += al(2 * (size_t)Lm); w.tmpv = (l16)(base + o); o += al(2 * (size_t)Lm);
-        w.sq = (l8)(base + o + 16);                                   // one pad byte in front (sq[-1]), BW behind
-        uint8_t* p = gscratch + (size_t)blockIdx.x * gbytes;
-        auto take = [&](size_t bytes) { uint8_t* q = p; p += al(bytes); return q; };
-        g.anchor = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.in_first = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.in_last = (uint16_t*)take(2 * ((size_t)Vc + 1));
-        g.out_first = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.out_last = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.ring = (uint16_t*)take(2 * ((size_t)Vc + 1));
-        g.order = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.rank = (uint16_t*)take(2 * ((size_t)Vc + 1)); g.tmpo = (uint16_t*)take(2 * ((size_t)Vc + 1));
-        g.code = take(Vc); g.need = take(Vc);
-        g.e_tail = (uint16_t*)take(2 * (size_t)Ec); g.e_head = (uint16_t*)take(2 * (size_t)Ec); g.e_next_in = (uint16_t*)take(2 * (size_t)Ec); g.e_next_out = (uint16_t*)take(2 * (size_t)Ec);
-        g.e_w = (int32_t*)take(4 * (size_t)Ec); g.cov = (uint32_t*)take(4 * (size_t)Vc);
+        LDSP unsigned char* base = POA_LDS(LDSP unsigned char*, LLT<BW>::C0 + (unsigned)al((size_t)8 * Vc));      // C1
+        w.alnode = (l16)base; w.nodeof = (l16)(base + al(2 * (size_t)Lm)); w.ref = (l16)(base + 2 * al(2 * (size_t)Lm)); w.tmpv = (l16)(base + 3 * al(2 * (size_t)Lm));
+        w.epred = (l16)base; w.einfo = (LDSP unsigned int*)(base + al((size_t)2 * Vc)); w.sinkbits = (LDSP unsigned int*)(base + al((size_t)2 * Vc) + al(64 * 16));
+        w.sq = (l8)(base + poa_lds_mid(Vc, Lm) + 16);                 // one pad byte in front (sq[-1]), BW behind
+        g.base = gscratch + (size_t)blockIdx.x * gbytes;
+        g.s16 = (uint32_t)al(2 * ((size_t)Vc + 1)); g.s8 = (uint32_t)al(Vc); g.se = (uint32_t)al(2 * (size_t)Ec);
     }
     int32_t* Hg = J.Hglob + (size_t)blockIdx.x * Vc * BW;
     uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW;
@@ -586,20 +659,18 @@ void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes)
             const PSeq S = J.seqs[J.seq_idx ? J.seq_idx[si] : si];
             if (S.len <= 0) continue;
             if (S.len > Lm) { ++ndrop; continue; }
-            if (st.V == 0) {
-                if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, B, st, lane); }
-                else { if (S.len > st.capV) { ++ndrop; continue; } tile_add_first(g, S, st, lane); st.members = 1; continue; }
-            }
-            int rcode = tile_align_add<CPL>(g, w, Hg, Dg, J, S, st, lane);
-            if (rcode == 0) { ++ndrop; continue; }
-            if (rcode == 2) {
+            // at most two attempts: when the graph is full (code 2) the tile is emitted and the sequence starts / joins a fresh one
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if (st.V == 0) {
+                    if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, B, st, lane); }
+                    else { if (S.len > st.capV) ++ndrop; else { tile_add_first(g, S, st, lane); st.members = 1; } break; }
+                }
+                const int rcode = tile_align_add<CPL>(g, w, Hg, Dg, J, S, st, lane);
+                if (rcode == 1) { st.members += 1; break; }
+                if (rcode == 0 || attempt == 1) { ++ndrop; break; }
                 tile_emit(g, w, J, job, st, lane);
                 st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.cw_sum = 0;
-                if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, B, st, lane); rcode = tile_align_add<CPL>(g, w, Hg, Dg, J, S, st, lane); if (rcode == 1) st.members = 1; else ++ndrop; }
-                else if (S.len <= st.capV) { tile_add_first(g, S, st, lane); st.members = 1; } else ++ndrop;
-                continue;
             }
-            st.members += 1;
         }
         tile_emit(g, w, J, job, st, lane);
         if (lane == 0) { J.out_n[job] = (uint32_t)st.nout; if (ndrop && J.dropped) atomicAdd(J.dropped, ndrop); }
