@@ -24,6 +24,11 @@
 #define SRC_SLOT 63
 #define NONE16 0xFFFFu
 #define HR 8           // DP rows kept in the LDS ring
+#ifndef RPADL
+#define RPADL 4        // ring row: RPADL guard cells (PNEG) | BW cells | RPADR guard cells, so neighbour reads need no bounds checks
+#define RPADR 12
+#endif
+#define DLO_MAX 11     // largest band-start difference to a predecessor a 'near' row may have (<= RPADR - 1)
 #define TBR 32         // direction rows per traceback block
 
 #define LDSP __attribute__((address_space(3)))
@@ -45,7 +50,7 @@ struct GG {   // graph arrays in the workgroup's HBM scratch: ONE base pointer +
 };
 // LDS working set of one alignment.  The hot arrays sit at COMPILE-TIME offsets (hring, dirblk, rinfo) so the row loop spends no SGPRs
 // on them; the rest follows at offsets derived from Vcap / Lmax.  Layout (BW = band width):
-//   [0, HR*BW*4)            hring   ring of DP rows
+//   [0, HR*RS*4)            hring   ring of DP rows, RS = RPADL + BW + RPADR ints each (guard cells hold PNEG)
 //   [.., + TBR*BW)          dirblk  direction rows of the traceback block
 //   [C0, C0 + 8*Vc)         rinfo   (forward)  |  sc (consensus scores, 8 bytes per rank)
 //   [C1, C1 + X)            alnode, nodeof, ref, tmpv (per alignment)  |  epred, einfo, sinkbits (consensus);  X = max of the two
@@ -54,7 +59,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char poa_smem[];     // 
 #define POA_LDS(T, off) ((T)((LDSP unsigned char*)poa_smem + (off)))
 template <int BW>
 struct LLT {
-    static constexpr unsigned HRING = 0, DIRBLK = HR * BW * 4, C0 = HR * BW * 4 + TBR * BW;
+    static constexpr unsigned RS = BW + RPADL + RPADR;      // ring row stride (ints)
+    static constexpr unsigned HRING = 0, DIRBLK = HR * RS * 4, C0 = HR * RS * 4 + TBR * BW;
     static __device__ __forceinline__ l32 hring() { return POA_LDS(l32, HRING); }
     static __device__ __forceinline__ l8 dirblk() { return POA_LDS(l8, DIRBLK); }
     static __device__ __forceinline__ lu64 rinfo() { return POA_LDS(lu64, C0); }
@@ -119,9 +125,17 @@ __device__ void tile_add_first(const GG& g, const PSeq& S, TS& st, int lane)
     mem_sync();
 }
 
-// one pass of the heaviest-bundle recurrence over ranks [rb, V) in RANK space.  Per 64-rank chunk the lanes fetch the first two
-// in-edges (predecessor rank, weight) of their rank from HBM into LDS; lane 0 then runs the serial recurrence out of LDS.
+// one pass of the heaviest-bundle recurrence over ranks [rb, V) in RANK space.  Per 64-rank chunk every lane fetches the first two
+// in-edges (predecessor rank, weight) of its rank from HBM into registers; the serial recurrence then runs UNIFORMLY on the whole
+// wave: edge data comes through v_readlane, the running scores live in LDS (sc) with the previous rank's score kept in registers,
+// so the common case (single predecessor = previous rank) touches no memory on its dependent path.
 // completion = branch-completion pass (skip predecessors whose score is -1).  Returns the best rank (uniform) or -1.
+__device__ __forceinline__ long long uniform64(long long v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+#ifdef POA_OLD_BUNDLE
 template <int BW>
 __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int completion, int lane)
 {
@@ -149,7 +163,7 @@ __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int com
                     const int ta = tt & 0xffff, tb = tt >> 16;
                     if (ta != NONE16 && !(completion && w.sc()[ta] == -1)) { const long long ww = (int)w.einfo[x * 4 + 1]; if (sv < ww || (sv == ww && w.sc()[pv] <= w.sc()[ta])) { sv = ww; pv = ta; } }
                     if (tb != NONE16 && !(completion && w.sc()[tb] == -1)) { const long long ww = (int)w.einfo[x * 4 + 2]; if (sv < ww || (sv == ww && w.sc()[pv] <= w.sc()[tb])) { sv = ww; pv = tb; } }
-                } else {        // more than two in-edges: walk the list in HBM
+                } else {
                     const int v = g.order(rr);
                     for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) {
                         const int t = g.rank(g.e_tail(e)); if (completion && w.sc()[t] == -1) continue; const long long ww = g.e_w(e);
@@ -165,6 +179,71 @@ __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int com
     }
     return __builtin_amdgcn_readfirstlane(best);
 }
+#else
+template <int BW>
+__device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int completion, int lane)
+{
+    int best = -1; long long best_sv = 0;
+    int prev_r = -2; long long prev_sv = 0;                   // score of the rank handled last (register copy of sc[prev_r])
+    auto SC = [&](int t) -> long long { return t == prev_r ? prev_sv : uniform64(w.sc()[t]); };
+    for (int r0 = rb; r0 < V; r0 += 64) {
+        const int r = r0 + lane;
+        unsigned tt = NONE16 | (NONE16 << 16), fl = 0; int w0 = 0, w1 = 0;
+        if (r < V) {
+            const int v = g.order(r); const int e0 = g.in_first(v);
+            unsigned t0 = NONE16, t1 = NONE16;
+            if (e0 != NONE16) {
+                t0 = g.rank(g.e_tail(e0)); w0 = g.e_w(e0);
+                const int e1 = g.e_next_in(e0);
+                if (e1 != NONE16) { t1 = g.rank(g.e_tail(e1)); w1 = g.e_w(e1); if (g.e_next_in(e1) != NONE16) fl = 1; }
+            }
+            tt = t0 | (t1 << 16);
+            if (!completion && g.out_first(v) == NONE16) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
+        }
+        const int cnt = min(64, V - r0);
+        for (int x = 0; x < cnt; ++x) {
+            const int rr = r0 + x; long long sv = -1; int pv = NONE16;
+            const unsigned tx = __builtin_amdgcn_readlane(tt, x);
+            if (!__builtin_amdgcn_readlane(fl, x)) {
+                const int ta = tx & 0xffff, tb = tx >> 16;
+                const long long wa = (int)__builtin_amdgcn_readlane(w0, x), wb = (int)__builtin_amdgcn_readlane(w1, x);
+                bool ha = ta != NONE16, hb = tb != NONE16, ka = false, kb = false; long long sa = 0, sb = 0;
+                if (completion) {
+                    if (ha) { sa = SC(ta); ka = true; if (sa == -1) ha = false; }
+                    if (hb) { sb = SC(tb); kb = true; if (sb == -1) hb = false; }
+                }
+                if (ha) { sv = wa; pv = ta; }
+                if (hb) {
+                    bool take = sv < wb;
+                    if (!take && sv == wb && ha) {                 // equal weights: the later edge wins unless its tail scores lower
+                        if (!ka) { sa = SC(ta); ka = true; }
+                        if (!kb) { sb = SC(tb); kb = true; }
+                        take = sa <= sb;
+                    }
+                    if (take) { sv = wb; pv = tb; }
+                }
+                if (pv != NONE16) sv += (pv == ta) ? (ka ? sa : SC(ta)) : (kb ? sb : SC(tb));
+            } else {        // more than two in-edges: walk the list in HBM
+                const int v = g.order(rr);
+                long long spv = 0;
+                for (int e = __builtin_amdgcn_readfirstlane((int)g.in_first(v)); e != NONE16; e = __builtin_amdgcn_readfirstlane((int)g.e_next_in(e))) {
+                    const int t = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(e))); const long long st_ = SC(t);
+                    if (completion && st_ == -1) continue;
+                    const long long ww = __builtin_amdgcn_readfirstlane(g.e_w(e));
+                    if (sv < ww || (sv == ww && pv != NONE16 && spv <= st_)) { sv = ww; pv = t; spv = st_; }
+                }
+                if (pv != NONE16) sv += spv;
+            }
+            if (lane == 0) { w.sc()[rr] = sv; w.epred[rr] = (uint16_t)pv; }
+            prev_r = rr; prev_sv = sv;
+            if (best < 0 || best_sv < sv) { best = rr; best_sv = sv; }
+        }
+    }
+    lds_sync();
+    return best;
+}
+
+#endif
 
 // heaviest bundle + branch completion (oracle g_consensus)
 template <int BW>
@@ -181,7 +260,8 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     for (int x = lane; x < (V + 31) / 32; x += 64) w.sinkbits[x] = 0;
     lds_sync();
     int mx = bundle_pass(g, w, V, 0, 0, lane);
-    while (!((w.sinkbits[mx >> 5] >> (mx & 31)) & 1u)) {
+    for (int guard = 0; !((w.sinkbits[mx >> 5] >> (mx & 31)) & 1u); ++guard) {
+        if (guard > V) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow + 1, 2u); break; }   // cannot happen: each completion pass starts further down
         const int start = mx;
         if (lane == 0) {
             const int sv = g.order(start);
@@ -222,6 +302,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
         }
     }
     if (lane == 0) { J.out_len[slot] = n; J.out_cw[slot] = st.cw_sum; }
+    if (J.phase_cycles && lane == 0) atomicAdd(&J.phase_cycles[12], (unsigned long long)n);
     mem_sync();
     PH(J, 4, tph);
     st.nout += 1;
@@ -273,12 +354,13 @@ __device__ __forceinline__ unsigned poa_row_finish(const int (&X)[CPL], const in
     return dpack;
 }
 
-template <int CPL, bool LOCAL>
+template <int CPL, int MODE>
 __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, const PSeq& S, int V, int gp_, int sm_, int sn_, int lane, int& bestv_out, int& bestpk_out, int& nslow_out)
 {
     constexpr int BW = 64 * CPL;
     int nslow = 0;
-    const int L = __builtin_amdgcn_readfirstlane(S.len); const bool semi = __builtin_amdgcn_readfirstlane(S.mode) == NGSID_POA_SEMI;
+    constexpr bool LOCAL = MODE == NGSID_POA_LOCAL, semi = MODE == NGSID_POA_SEMI;
+    const int L = __builtin_amdgcn_readfirstlane(S.len);
     int gp = gp_, sm = sm_, sn = sn_;
     const int lane_jg = lane * CPL * gp_;
     asm volatile("" : "+v"(gp), "+v"(sm), "+v"(sn));      // keep the three score constants in VGPRs (SGPRs are the scarce resource of this kernel);
@@ -288,7 +370,8 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
     int hprev[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) { hprev[c] = PNEG; bkey[c] = 0; }
-    const l32 ring0 = w.hring() + lane * CPL;
+    constexpr int RS = BW + RPADL + RPADR;
+    const l32 ring0 = w.hring() + RPADL + lane * CPL;
     const l8 stage0 = w.dirblk() + lane * CPL;
     const l8 sq0 = w.sq + lane * CPL - 1;
     unsigned long long ri = V > 0 ? w.rinfo()[0] : 0ull;
@@ -296,7 +379,7 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
     while (r < V) {
         unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)ri), rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri >> 32));
         int rfl = rhi >> 24;
-        if ((rfl & 16) && !semi) {
+        if (rfl & 16) {
             // ---- run of chain rows: registers + one DPP per row, LDS only for letters / ring / staged directions
             for (;;) {
 #ifdef POA_EXP2
@@ -325,18 +408,21 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                     for (int c = 0; c < CPL; ++c) { up[c] = hprev[c]; dg[c] = c ? hprev[c - 1] : lf; }
                 }
                 int X[CPL], Dd[CPL];
+                const int jg0 = l0 * gp_ + lane_jg;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
-                    const int xu = up[c] + gp, xd = dg[c] + (q[c] == cv ? sm : sn);
-                    X[c] = max(xd, xu); Dd[c] = xu > xd ? 1 : 0;
+                    const int sc = q[c] == cv ? sm : sn;
+                    const int xu = up[c] + gp; int xd = dg[c] + sc, ds = 0;
+                    if (semi) { const int sv = jg0 + (c - 1) * gp + sc; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT << 2; } }   // free start in the graph
+                    X[c] = max(xd, xu); Dd[c] = xu > xd ? 1 : ds;
                 }
-                const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, l0 * gp_ + lane_jg, gp, hprev);
-                poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * BW, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
+                const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, jg0, gp, hprev);
+                poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * RS, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
                 if (LOCAL) {
                     const unsigned rk = 0xFFFFu - (unsigned)r;
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)hprev[c] << 16) | rk);
-                } else if (rfl & 4) {
+                } else if ((semi || (rfl & 4)) && (unsigned)(L - l0) < (unsigned)BW) {     // end cells: last column, on sinks (any row in semi-global mode)
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) if (l0 + lane * CPL + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
                 }
@@ -345,12 +431,53 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                 rlo = __builtin_amdgcn_readfirstlane((unsigned)ri); rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri >> 32)); rfl = rhi >> 24;
                 if (!(rfl & 16)) { rfl = 0; break; }                           // next row is not a chain row (nothing pending for the row just done)
             }
+        } else if (rfl & 64) {
+            // ---- near row: one or two predecessors, both still in the LDS ring; all reads issue at once, guard cells replace bounds checks
+            if (r + 1 < V) ri = w.rinfo()[r + 1];
+            const int l0 = rlo & 0xffff; const int cv = (rhi >> 16) & 0xff;
+            const int dist0 = (rlo >> 16) & 0xff, dist1 = rlo >> 24, dlo0 = rhi & 0xff, dlo1 = (rhi >> 8) & 0xff;
+            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();     // ring rows of earlier iterations: LDS executes a wave's instructions in order
+            const l32 H0 = ring0 + ((r - dist0) & (HR - 1)) * RS + (dlo0 - 1);
+            int h0[CPL + 1], h1[CPL + 1];
+#pragma unroll
+            for (int c = 0; c <= CPL; ++c) h0[c] = H0[c];
+            if (dist1) {
+                const l32 H1 = ring0 + ((r - dist1) & (HR - 1)) * RS + (dlo1 - 1);
+#pragma unroll
+                for (int c = 0; c <= CPL; ++c) h1[c] = H1[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c <= CPL; ++c) h1[c] = PNEG;
+            }
+            int X[CPL], Dd[CPL];
+            const int jg0 = l0 * gp_ + lane_jg;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int sc = ((int)sq0[l0 + c] == cv) ? sm : sn;
+                // first predecessor wins ties (the oracle walks the edge list in order and replaces on strictly greater)
+                const int xu = max(h0[c + 1], h1[c + 1]) + gp, us = h1[c + 1] > h0[c + 1] ? 1 : 0;
+                int xd = max(h0[c], h1[c]) + sc, ds = h1[c] > h0[c] ? 1 : 0;
+                if (semi) { const int sv = jg0 + (c - 1) * gp + sc; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT; } }       // free start in the graph
+                if (xd >= xu) { X[c] = xd; Dd[c] = 0 | (ds << 2); } else { X[c] = xu; Dd[c] = 1 | (us << 2); }
+            }
+            const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, jg0, gp, hprev);
+            poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * RS, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
+            if (LOCAL) {
+                const unsigned rk = 0xFFFFu - (unsigned)r;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)hprev[c] << 16) | rk);
+            } else if ((semi || (rfl & 4)) && (unsigned)(L - l0) < (unsigned)BW) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) if (l0 + lane * CPL + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
+            }
+            ++r;
         } else {
+            // ---- generic row (no predecessor, semi-global mode, far or many predecessors): walk the in-edge list in HBM
             ++nslow;
             if (r + 1 < V) ri = w.rinfo()[r + 1];
-            const int l0 = rlo & 0xffff, p0r = rlo >> 16, p1r = rhi & 0xffff; const int cv = (rhi >> 16) & 0xff;
+            const int l0 = rlo & 0xffff; const int cv = (rhi >> 16) & 0xff;
             const int jb = l0 + lane * CPL;
-            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();     // ring rows of earlier iterations: LDS executes a wave's instructions in order
+            asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
             const bool nopred = (rfl & 1) != 0;
             const bool use_src = nopred || semi;
             int scj[CPL];
@@ -359,17 +486,14 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
             int Xd[CPL], Dslot[CPL], Xu[CPL], Uslot[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; ++c) { Xd[c] = PNEG; Xu[c] = PNEG; Dslot[c] = 0; Uslot[c] = 0; }
-            int slot = 0, eit = NONE16;
-            if (rfl & 2) { eit = g.in_first(g.order(r)); }
-            for (;; ++slot) {
-                int pr;
-                if (!(rfl & 2)) { pr = slot == 0 ? p0r : (slot == 1 ? p1r : NONE16); if (pr == NONE16) break; }
-                else { if (eit == NONE16) break; pr = g.rank(g.e_tail(eit)); eit = g.e_next_in(eit); }
+            int slot = 0;
+            for (int eit = nopred ? NONE16 : __builtin_amdgcn_readfirstlane((int)g.in_first(g.order(r))); eit != NONE16; eit = __builtin_amdgcn_readfirstlane((int)g.e_next_in(eit)), ++slot) {
+                const int pr = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(eit)));
                 const int plo = (int)(w.rinfo()[pr] & 0xffff);
                 const int pc0 = jb - plo;
                 int hp[CPL + 1];
                 if ((r - pr) <= HR) {                       // LDS ring
-                    const l32 Hp = w.hring() + (size_t)(pr & (HR - 1)) * BW;
+                    const l32 Hp = w.hring() + (size_t)(pr & (HR - 1)) * RS + RPADL;
 #pragma unroll
                     for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : PNEG; }
                 } else {                                    // far predecessor: HBM copy of the row (flag 8 made the producer store it)
@@ -394,7 +518,7 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                 if (Xd[c] >= Xu[c]) { X[c] = Xd[c]; Dd[c] = 0 | (Dslot[c] << 2); } else { X[c] = Xu[c]; Dd[c] = 1 | (Uslot[c] << 2); }
             }
             const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, l0 * gp_ + lane_jg, gp, hprev);
-            poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * BW, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
+            poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * RS, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
             if (LOCAL) {
                 const unsigned rk = 0xFFFFu - (unsigned)r;
 #pragma unroll
@@ -436,25 +560,43 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     const int L = __builtin_amdgcn_readfirstlane(S.len), mode = __builtin_amdgcn_readfirstlane(S.mode), gp = __builtin_amdgcn_readfirstlane(J.g), V = __builtin_amdgcn_readfirstlane(st.V);
     unsigned long long tph = J.phase_cycles ? __builtin_readcyclecounter() : 0;
     // ---------- per-rank row info, built lane-parallel so that the serial row loop reads ONE 8-byte LDS word per row:
-    //   lo:16 | first pred rank:16 | second pred rank:16 | letter:8 | flags:8
-    //   flags: 1 no predecessor, 2 more than two, 4 sink, 8 keep an HBM copy (a successor is > HR rows away),
-    //          16 chain row (single predecessor = previous row, band shift 0/1), 32 = that band shift
+    //   lo:16 | dist0:8 | dist1:8 | dlo0:8 | dlo1:8 | letter:8 | flags:8
+    //   dist = rank distance to the first / second predecessor (0 = none), dlo = band start of this row minus that of the predecessor
+    //   flags: 1 no predecessor, 2 irregular (more than two predecessors, or a distance / band shift that does not fit): walk the
+    //          edge list in HBM, 4 sink, 8 keep an HBM copy (a successor is > HR rows away),
+    //          16 chain row (single predecessor = previous row, band shift 0/1), 32 = that band shift,
+    //          64 near row (one or two predecessors, all within the LDS ring, band shifts 0..DLO_MAX)
     for (int r = lane; r < V; r += 64) g.need(r) = 0;
     mem_sync();
     for (int r = lane; r < V; r += 64) {
         const int v = g.order(r);
         for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) g.need(pr) = 1; }
         const int l0 = band_lo(g.anchor(v), S, st.L0, BW);
-        const int e0 = g.in_first(v); int p0 = NONE16, p1 = NONE16, fl = 0;
+        const int e0 = g.in_first(v); int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
         if (e0 == NONE16) fl |= 1;
-        else { p0 = g.rank(g.e_tail(e0)); const int e1 = g.e_next_in(e0); if (e1 != NONE16) { p1 = g.rank(g.e_tail(e1)); if (g.e_next_in(e1) != NONE16) fl |= 2; } }
-        if (g.out_first(v) == NONE16) fl |= 4;
-        if (r > 0 && !(fl & 3) && p0 == r - 1 && p1 == NONE16) {
-            const int d = l0 - band_lo(g.anchor(g.order(r - 1)), S, st.L0, BW);
-            if (d == 0 || d == 1) fl |= 16 | (d << 5);
+        else {
+            const int t0 = g.e_tail(e0); d0 = r - (int)g.rank(t0); dl0 = l0 - band_lo(g.anchor(t0), S, st.L0, BW);
+            const int e1 = g.e_next_in(e0);
+            if (e1 != NONE16) {
+                const int t1 = g.e_tail(e1); d1 = r - (int)g.rank(t1); dl1 = l0 - band_lo(g.anchor(t1), S, st.L0, BW);
+                if (g.e_next_in(e1) != NONE16) fl |= 2;
+            }
+            if (d0 > 255 || d1 > 255 || dl0 < 0 || dl0 > 255 || dl1 < 0 || dl1 > 255) { fl |= 2; d0 = d1 = dl0 = dl1 = 0; }
         }
-        w.rinfo()[r] = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)p0 << 16) | ((unsigned long long)(unsigned)p1 << 32)
+        if (g.out_first(v) == NONE16) fl |= 4;
+        if (!(fl & 3)) {
+            if (d0 == 1 && d1 == 0 && dl0 <= 1) fl |= 16 | (dl0 << 5);
+#ifndef POA_NO_NEAR
+            else if (d0 <= HR && d1 <= HR && dl0 <= DLO_MAX && dl1 <= DLO_MAX) fl |= 64;
+#endif
+        }
+        w.rinfo()[r] = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)d0 << 16) | ((unsigned long long)(unsigned)d1 << 24)
+                   | ((unsigned long long)(unsigned)dl0 << 32) | ((unsigned long long)(unsigned)dl1 << 40)
                    | ((unsigned long long)g.code(v) << 48) | ((unsigned long long)(unsigned)fl << 56);
+    }
+    for (int i = lane; i < HR * (RPADL + RPADR); i += 64) {       // guard cells of the ring rows
+        const int row = i / (RPADL + RPADR), k = i % (RPADL + RPADR);
+        w.hring()[row * (BW + RPADL + RPADR) + (k < RPADL ? k : BW + k)] = PNEG;
     }
     for (int i = lane; i < L; i += 64) { w.alnode[i] = NONE16; w.sq[i] = S.s[i]; }
     for (int i = lane; i < BW; i += 64) w.sq[L + i] = 0xFF;            // pad: columns past the end never match
@@ -466,8 +608,9 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     // ---------- forward DP, one row per graph node in topological order
     const bool local = mode == NGSID_POA_LOCAL;
     int bestv, bestpk, nslow;
-    if (local) poa_forward<CPL, true>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
-    else poa_forward<CPL, false>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    if (local) poa_forward<CPL, NGSID_POA_LOCAL>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    else if (mode == NGSID_POA_SEMI) poa_forward<CPL, NGSID_POA_SEMI>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    else poa_forward<CPL, NGSID_POA_GLOBAL>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[5], (unsigned long long)V); atomicAdd(&J.phase_cycles[6], (unsigned long long)nslow); }
     mem_sync();                                       // direction rows must have landed before the traceback pulls them back
     PH(J, 1, tph);
@@ -478,17 +621,21 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         if (ov > bestv || (ov == bestv && opk < bestpk)) { bestv = ov; bestpk = opk; }
     }
     const int bestr = bestpk == 0x7fffffff ? -1 : (bestpk >> 8), bestc = bestpk & 0xff;
+    if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[8], (unsigned long long)(unsigned)bestv); atomicAdd(&J.phase_cycles[9], (unsigned long long)(unsigned)bestpk); }
     bool aligned_any = true;
     if (bestr < 0 || (mode == NGSID_POA_LOCAL && bestv <= 0)) {
         if (mode != NGSID_POA_LOCAL) return 0;
         aligned_any = false;                                   // nothing aligned: the whole read becomes a new branch
     }
-    // ---------- traceback in rank space (uniform across lanes): predecessors and band starts come from the row info in LDS,
-    //            direction rows are pulled TBR at a time from HBM into LDS.  alnode[] receives RANKS here.
+    // ---------- traceback in rank space: predecessors and band starts come from the row info in LDS, direction rows are pulled TBR at
+    //            a time from HBM into LDS.  alnode[] receives RANKS here.  The walk is serial, but most of it is runs of plain
+    //            diagonal moves through chain rows (predecessor = previous rank): lane k speculatively inspects the cell k such moves
+    //            ahead, the wave takes the whole leading run at once, and the first other move is decoded from that lane's data.
     if (aligned_any) {
-        int r = bestr, c = bestc, j = (int)(w.rinfo()[bestr] & 0xffff) + bestc;
+        int r = bestr, j = (int)(w.rinfo()[bestr] & 0xffff) + bestc;
         int blk_lo = (V - 1) & ~(TBR - 1);                 // the forward pass left the last (partial) block of direction rows in LDS
-        for (;;) {
+        for (int guard = 0;; ++guard) {
+            if (guard > 2 * (V + L) + 64) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow + 1, 1u); break; }   // cannot happen: every iteration consumes a move (reported by the host as an internal error)
             if (r < blk_lo) {
                 lds_sync();
                 blk_lo = r & ~(TBR - 1);                    // aligned blocks of TBR rows, same layout as the forward pass staged them
@@ -501,38 +648,72 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-            const int d = w.dirblk()[(size_t)(r - blk_lo) * BW + c]; const int type = d & 3, slot = d >> 2;
+            const int rk = r - lane, jk = j - lane;
+            bool loaded = false, good = false; int dk = 0; unsigned long long rik = 0;
+            if (rk >= blk_lo) {
+                rik = w.rinfo()[rk];
+                const int ck = jk - (int)(rik & 0xffff);
+                if (ck >= 0 && ck < BW) { dk = w.dirblk()[(size_t)(rk - blk_lo) * BW + ck]; loaded = true; good = dk == 0 && ((rik >> 56) & 16) && jk >= 1; }
+            }
+            const unsigned long long gm = __ballot(good), lm = __ballot(loaded);
+#ifdef POA_NO_SPEC
+            const int run = 0;
+#else
+            const int run = (~gm) ? __builtin_ctzll(~gm) : 64;
+#endif
+            if (lane < run) w.alnode[jk - 1] = (uint16_t)rk;            // `run` diagonal moves, each to the previous rank
+            r -= run; j -= run;
+            if (run == 64 || !((lm >> run) & 1)) { if (run == 0) break; continue; }   // next cell not inspected (block edge): go round again (run == 0 cannot happen: the current cell is always inside its band)
+            const int d = __builtin_amdgcn_readlane(dk, run);
+            const unsigned rlo = __builtin_amdgcn_readlane((unsigned)rik, run), rhi = __builtin_amdgcn_readlane((unsigned)(rik >> 32), run);
+            const int type = d & 3, slot = d >> 2;
             if (type == 3) break;
-            if (type == 2) { --j; --c; continue; }
+            if (type == 2) { --j; continue; }
             if (type == 0) { if (lane == 0) w.alnode[j - 1] = (uint16_t)r; --j; }
             if (slot == SRC_SLOT) break;
-            const unsigned long long ri = w.rinfo()[r];
             int pr;
-            if (slot == 0) pr = (int)((ri >> 16) & 0xffff);
-            else if (slot == 1) pr = (int)((ri >> 32) & 0xffff);
-            else { int e = g.in_first(g.order(r)); for (int t = 0; t < slot; ++t) e = g.e_next_in(e); pr = g.rank(g.e_tail(e)); }
-            r = pr; c = j - (int)(w.rinfo()[r] & 0xffff);
+            if (!((rhi >> 24) & 2) && slot <= 1) pr = r - (int)(slot == 0 ? ((rlo >> 16) & 0xff) : (rlo >> 24));
+            else { int e = g.in_first(g.order(r)); for (int t = 0; t < slot; ++t) e = g.e_next_in(e); pr = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(e))); }
+            r = pr;
         }
     }
     lds_sync();
     PH(J, 2, tph);
-    // ---------- A: rank -> node, then the existing node per position (same letter on the aligned node or one of its siblings)
+    // ---------- A: rank -> node, then the existing node per position: the aligned node if the letter matches, else a sibling (same column)
+    //             with that letter whose rank lies strictly between the previous aligned position's node and this one (oracle
+    //             g_add_alignment: keeps the order topological without a re-sort)
     int nnew = 0;
-    for (int i0 = 0; i0 < L; i0 += 64) {
-        const int i = i0 + lane; bool isnew = false;
-        if (i < L) {
-            const int ar = w.alnode[i]; const uint8_t ch = w.sq[i]; int found = NONE16, v = NONE16;
-            if (ar != NONE16) { v = g.order(ar); if (g.code(v) == ch) found = v; else for (int u = g.ring(v); u != v; u = g.ring(u)) if (g.code(u) == ch) { found = u; break; } }
-            w.alnode[i] = (uint16_t)v; w.nodeof[i] = (uint16_t)found; isnew = found == NONE16;
+    {
+        int carry = -1;                                   // rank of the aligned node of the nearest aligned position before the chunk
+        for (int i0 = 0; i0 < L; i0 += 64) {
+            const int i = i0 + lane; bool isnew = false;
+            const int ar = (i < L) ? (int)w.alnode[i] : NONE16;
+            const unsigned long long ma = __ballot(ar != NONE16);
+            const unsigned long long lt = ma & ((1ull << lane) - 1);
+            const int psrc = lt ? 63 - __clzll(lt) : 0;
+            const int pv = __shfl(ar, psrc);
+            const int prev_rank = lt ? pv : carry;
+            if (i < L) {
+                const uint8_t ch = w.sq[i]; int found = NONE16, v = NONE16;
+                if (ar != NONE16) {
+                    v = g.order(ar);
+                    if (g.code(v) == ch) found = v;
+                    else for (int u = g.ring(v); u != v; u = g.ring(u)) if (g.code(u) == ch) { const int ru = g.rank(u); if (ru > prev_rank && ru < ar) { found = u; break; } }
+                }
+                w.alnode[i] = (uint16_t)v; w.nodeof[i] = (uint16_t)found; isnew = found == NONE16;
+            }
+            nnew += __popcll(__ballot(isnew));
+            if (ma) { const int hl = 63 - __clzll(ma); carry = __shfl(ar, hl); }
         }
-        nnew += __popcll(__ballot(isnew));
     }
+    if (J.phase_cycles) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(w.alnode[i] + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&J.phase_cycles[10], (unsigned long long)nnew); atomicAdd(&J.phase_cycles[11], sm_); } }
     if (V + nnew > st.capV || st.E + L > st.capE) { lds_sync(); return 2; }      // oracle g_add_alignment capacity rule
-    // ---------- B: ref(i) = aligned node of the first aligned position >= i (reverse carry scan)
+    // ---------- B: ref(i) = node chosen for the first aligned position >= i (reverse carry scan); new nodes go immediately before it
     {
         int carry = NONE16;
         for (int i0 = ((L - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
-            const int i = i0 + lane; const int a = (i < L) ? w.alnode[i] : NONE16;
+            const int i = i0 + lane; int a = (i < L) ? w.alnode[i] : NONE16;
+            if (a != NONE16 && w.nodeof[i] != NONE16) a = w.nodeof[i];          // the node chosen for an aligned position (reused sibling or the aligned node)
             const unsigned long long m = __ballot(a != NONE16);
             const unsigned long long ge = m & (~0ull << lane);
             const int src = ge ? __ffsll((long long)ge) - 1 : 0;
@@ -614,7 +795,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
 size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW)
 {
     (void)Ec;
-    return (size_t)HR * BW * 4 + (size_t)TBR * BW + poa_al16((size_t)8 * Vc) + poa_lds_mid(Vc, Lm) + poa_al16((size_t)Lm + BW + 32);
+    return (size_t)HR * (BW + RPADL + RPADR) * 4 + (size_t)TBR * BW + poa_al16((size_t)8 * Vc) + poa_lds_mid(Vc, Lm) + poa_al16((size_t)Lm + BW + 32);
 }
 // HBM scratch bytes of one workgroup for the graph arrays
 static size_t poa_graph_bytes(int Vc, int Ec)

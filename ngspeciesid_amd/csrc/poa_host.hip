@@ -79,7 +79,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
             J.out = Lv->out.p; J.out_len = Lv->out_len.p; J.out_cw = Lv->out_cw.p; J.out_n = Lv->out_n.p; J.out_cov = hp.want_cov ? Lv->out_cov.p : nullptr;
             J.dropped = d_flags.p; J.slot_overflow = d_flags.p + 1;
             DevBuf<unsigned long long> d_ph; static const bool want_ph = getenv("NGSID_POA_PHASES") != nullptr;
-            if (want_ph) { HIPCHK(ctx, d_ph.alloc(8)); HIPCHK(ctx, hipMemsetAsync(d_ph.p, 0, 64, ctx->stream)); J.phase_cycles = d_ph.p; }
+            if (want_ph) { HIPCHK(ctx, d_ph.alloc(16)); HIPCHK(ctx, hipMemsetAsync(d_ph.p, 0, 128, ctx->stream)); J.phase_cycles = d_ph.p; }
             int32_t rc = poa_run_jobs(ctx, J, hp.band); if (rc) return rc;
             uint32_t h_flags[4];
             h_out_n.resize(njobs); h_out_len.resize((size_t)njobs * slots); h_out_cw.resize((size_t)njobs * slots);
@@ -88,7 +88,8 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
             HIPCHK(ctx, hipMemcpyAsync(h_out_len.data(), Lv->out_len.p, 4ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(h_out_cw.data(), Lv->out_cw.p, 8ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            if (want_ph) { unsigned long long h[8]; HIPCHK(ctx, hipMemcpy(h, d_ph.p, 64, hipMemcpyDeviceToHost)); fprintf(stderr, "[ngsid poa phases, Mcycles] jobs %u prepass %.1f forward %.1f traceback %.1f update %.1f emit %.1f | rows %llu non-chain %llu\n", njobs, h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5], h[6]); }
+            if (want_ph) { unsigned long long h[16]; HIPCHK(ctx, hipMemcpy(h, d_ph.p, 128, hipMemcpyDeviceToHost)); fprintf(stderr, "[ngsid poa phases, Mcycles] jobs %u prepass %.1f forward %.1f traceback %.1f update %.1f emit %.1f | rows %llu non-chain %llu | sums: bestv %llu bestpk %llu nnew %llu alnsum %llu outlen %llu\n", njobs, h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5], h[6], h[8], h[9], h[10], h[11], h[12]); }
+            if (h_flags[2]) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA tile kernel loop guard tripped (code %u)", h_flags[2]);
             if (!h_flags[1]) break;
             if (slots >= (int)maxD) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA output slot overflow at full depth");
             slots = (int)std::min<uint32_t>(maxD, (uint32_t)slots * 4); slots_cap = slots;

@@ -114,6 +114,7 @@ static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW,
                 const int sc = (G->code[v] == S->s[j - 1]) ? m : n;
                 for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e], ++slot) {
                     const int pr = G->rank[G->e_tail[e]]; const int pc = j - 1 - lo[pr];
+                    if (pr >= r) { fprintf(stderr, "ngsid oracle: topological order violated (pred rank %d >= %d)\n", pr, r); abort(); }
                     if (pc < 0 || pc >= BW) continue;
                     const int hv = H[(size_t)pr * BW + pc]; if (hv <= PNEG) continue;
                     if (hv + sc > bestv) { bestv = hv + sc; bd = 0 | (slot << 2); }
@@ -174,15 +175,24 @@ static int g_add_alignment(graph* G, const pseq* S, const ppair* path, int np) {
     for (int i = 0; i < L; ++i) alnode[i] = -1;
     for (int p = 0; p < np; ++p) if (path[p].pos >= 0 && path[p].node >= 0) alnode[path[p].pos] = path[p].node;
     /* existing node per position, count new */
-    int nnew = 0;
+    /* A sibling (node aligned to the same column) is reused only if its rank lies strictly between the rank of the previous aligned
+       position's node and that of this position's aligned node.  With new nodes inserted immediately before the CHOSEN node of the
+       next aligned position this keeps `order` a valid topological order without a re-sort (spoa re-sorts instead); a sibling outside
+       that window gets a duplicate node, which only splits its weight. */
+    int nnew = 0, prev_rank = -1;
     for (int i = 0; i < L; ++i) {
         int v = alnode[i], found = -1;
-        if (v >= 0) { if (G->code[v] == S->s[i]) found = v; else for (int u = G->ring[v]; u != v; u = G->ring[u]) if (G->code[u] == S->s[i]) { found = u; break; } }
+        if (v >= 0) {
+            if (G->code[v] == S->s[i]) found = v;
+            else for (int u = G->ring[v]; u != v; u = G->ring[u]) if (G->code[u] == S->s[i] && G->rank[u] > prev_rank && G->rank[u] < G->rank[v]) { found = u; break; }
+            prev_rank = G->rank[v];
+        }
         nodeof[i] = found; if (found < 0) ++nnew;
     }
     if (V0 + nnew > G->capV || G->E + L > 3 * G->capV / 2) { free(alnode); free(nodeof); free(ref); return 0; }   /* node / edge (1.5x) capacity */
-    /* ref(i) = aligned node of the first aligned position >= i (insertion point: immediately before it), -1 = end */
-    { int nx = -1; for (int i = L - 1; i >= 0; --i) { if (alnode[i] >= 0) nx = alnode[i]; ref[i] = nx; } }
+    /* ref(i) = node chosen for the first aligned position >= i (the reused node, else the aligned node itself); new nodes are inserted
+       immediately before it, -1 = end */
+    { int nx = -1; for (int i = L - 1; i >= 0; --i) { if (alnode[i] >= 0) nx = nodeof[i] >= 0 ? nodeof[i] : alnode[i]; ref[i] = nx; } }
     /* create nodes in sequence order; anchor from the nearest aligned position at or before i, else after, else a0 */
     int lastal = -1;
     int* newlist = malloc(sizeof(int) * (size_t)(nnew + 1)); int* newref = malloc(sizeof(int) * (size_t)(nnew + 1)); int nn = 0;
