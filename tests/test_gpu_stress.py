@@ -8,10 +8,11 @@ import os, subprocess, sys
 import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, "tools", "stress_poa.py")
+TOOL_ALN = os.path.join(ROOT, "tools", "stress_align.py")
 
 
-def _run(*args):
-    p = subprocess.run([sys.executable, TOOL] + [str(a) for a in args], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+def _run(*args, tool=TOOL):
+    p = subprocess.run([sys.executable, tool] + [str(a) for a in args], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     tail = "\n".join(p.stdout.splitlines()[-8:])
     assert p.returncode == 0, tail
 
@@ -26,3 +27,37 @@ def test_spoa_groups_match_oracle(groups, depth, seed):
 @pytest.mark.parametrize("groups,depth,seed", [(80, 24, 11), (20, 90, 7)])
 def test_polish_groups_match_oracle(groups, depth, seed):
     _run(groups, depth, "polish", seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pairs,maxlen,seed", [(2500, 1100, 1), (300, 4400, 2)])
+def test_aligner_pairs_match_oracle(pairs, maxlen, seed):
+    """16-bit packed kernel (<= 4000 bases) and the 32-bit kernel, incl. wildcards, lower case, empty and unrelated sequences"""
+    _run(pairs, maxlen, seed, tool=TOOL_ALN)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_reads,n_species,div,mu,seed", [(5000, 6, 0.15, 17.0, 3), (3000, 12, 0.06, 14.0, 4)])
+def test_cluster_volume_matches_oracle(gpu_api, oracle, n_reads, n_species, div, mu, seed):
+    """greedy clustering at a size where speculative blocks, cache hits and database merges all occur; closely related species
+    (6 % divergence) force many aligner decisions"""
+    import numpy as np
+    from ngspeciesid_amd import synth
+    from ngspeciesid_amd._capi import ReadSet, cluster_params
+    from ngspeciesid_amd.ptable import select_p_table
+    sp = synth.make_species(n_species, 700, div, seed=seed)
+    rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed + 1, rc_fraction=0.3)
+    rs0 = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    score, err, keep = gpu_api.score_reads(rs0, 13, 7.0)
+    oscore, oerr, okeep = oracle.score_reads(rs0, 13, 7.0)
+    assert np.array_equal(score, oscore) and np.array_equal(keep, okeep)
+    from ngspeciesid_amd.hostutil import subset_reads
+    idx = np.nonzero(keep)[0]; idx = idx[np.argsort(-score[idx], kind="stable")]
+    rs = subset_reads(rs0, idx)
+    prm = cluster_params(k=13, w=20, p_shared=select_p_table(13, 20))
+    ar = np.arange(rs.n, dtype=np.uint32)
+    rep, herr, st, cnt = gpu_api.cluster_greedy(rs, prm, acc_rank=ar)
+    orep, oherr, ost, ocnt = oracle.cluster_greedy(rs, prm, acc_rank=ar)
+    bad = np.nonzero((rep != orep) | (st != ost))[0]
+    assert len(bad) == 0, "cluster: %d reads differ, first %s got %s exp %s" % (len(bad), bad[:8], rep[bad[:8]], orep[bad[:8]])
+    assert np.array_equal(cnt, ocnt)
