@@ -47,33 +47,29 @@ struct GG {   // graph arrays in the workgroup's HBM scratch: ONE base pointer +
 #undef GG_E16
     __device__ __forceinline__ int32_t& e_w(uint32_t i) const { return *(int32_t*)(base + (9u * s16 + 2u * s8 + 4u * se + 4u * i)); }
     __device__ __forceinline__ uint32_t& cov(uint32_t i) const { return *(uint32_t*)(base + (9u * s16 + 2u * s8 + 6u * se + 4u * i)); }
+    __device__ __forceinline__ unsigned long long& ri(uint32_t i) const { return *(unsigned long long*)(base + (9u * s16 + 6u * s8 + 6u * se + 8u * i)); }   // per-rank row info of the current alignment
 };
-// LDS working set of one alignment.  The hot arrays sit at COMPILE-TIME offsets (hring, dirblk, rinfo) so the row loop spends no SGPRs
-// on them; the rest follows at offsets derived from Vcap / Lmax.  Layout (BW = band width):
-//   [0, HR*RS*4)            hring   ring of DP rows, RS = RPADL + BW + RPADR ints each (guard cells hold PNEG)
-//   [.., + TBR*BW)          dirblk  direction rows of the traceback block
-//   [C0, C0 + 8*Vc)         rinfo   (forward)  |  sc (consensus scores, 8 bytes per rank)
-//   [C1, C1 + X)            alnode, nodeof, ref, tmpv (per alignment)  |  epred, einfo, sinkbits (consensus);  X = max of the two
+// LDS working set.  ~16 KB per tile for 750-base reads, so ten tiles are resident per CU.  The hot arrays sit at COMPILE-TIME offsets so the
+// row loop spends no SGPRs on them.  Layout (BW = band width), alignment phases | consensus phase:
+//   [0, HR*RS*4)            hring   ring of DP rows, RS = RPADL + BW + RPADR ints each (guard cells hold PNEG)      | sc (8 bytes per rank)
+//   [.., + TBR*BW)          dirblk  direction rows: staged by the forward pass, block by block for the traceback      | .. epred, sinkbits
+//   [.., + TBR*8)           rblk    row info of the rows in dirblk (the full per-rank row info lives in HBM: GG::ri)
+//   [C1, ..)                alnode, nodeof, ref, tmpv (2 bytes per sequence position each)
 //   [C2, ..)                sq      (one pad byte in front, BW behind)
 extern __shared__ __attribute__((aligned(16))) unsigned char poa_smem[];     // dynamic LDS of k_poa_tile (starts at LDS address 0)
 #define POA_LDS(T, off) ((T)((LDSP unsigned char*)poa_smem + (off)))
 template <int BW>
 struct LLT {
     static constexpr unsigned RS = BW + RPADL + RPADR;      // ring row stride (ints)
-    static constexpr unsigned HRING = 0, DIRBLK = HR * RS * 4, C0 = HR * RS * 4 + TBR * BW;
+    static constexpr unsigned HRING = 0, DIRBLK = HR * RS * 4, RBLK = DIRBLK + TBR * BW, C1 = RBLK + TBR * 8;
     static __device__ __forceinline__ l32 hring() { return POA_LDS(l32, HRING); }
     static __device__ __forceinline__ l8 dirblk() { return POA_LDS(l8, DIRBLK); }
-    static __device__ __forceinline__ lu64 rinfo() { return POA_LDS(lu64, C0); }
-    static __device__ __forceinline__ l64 sc() { return POA_LDS(l64, C0); }
+    static __device__ __forceinline__ lu64 rblk() { return POA_LDS(lu64, RBLK); }
+    static __device__ __forceinline__ l64 sc() { return POA_LDS(l64, 0); }
     l16 alnode, nodeof, ref, tmpv; l8 sq;
-    l16 epred; LDSP unsigned int* einfo; LDSP unsigned int* sinkbits;
+    l16 epred; LDSP unsigned int* sinkbits;
 };
 __host__ __device__ inline size_t poa_al16(size_t b) { return (b + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t poa_lds_mid(int Vc, int Lm)      // bytes of the [C1, C2) area
-{
-    const size_t a = 4 * poa_al16(2 * (size_t)Lm), c = poa_al16((size_t)2 * Vc) + poa_al16(64 * 16) + poa_al16(((size_t)Vc + 31) / 32 * 4);
-    return a > c ? a : c;
-}
 
 // Single-wave workgroup: LDS instructions of one wave execute in issue order, so ordering LDS traffic between lanes only needs the
 // compiler not to reorder and the LDS queue to drain - no s_barrier and no wait on outstanding HBM stores.
@@ -135,51 +131,6 @@ __device__ __forceinline__ long long uniform64(long long v)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
-#ifdef POA_OLD_BUNDLE
-template <int BW>
-__device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int completion, int lane)
-{
-    int best = -1;
-    for (int r0 = rb; r0 < V; r0 += 64) {
-        const int r = r0 + lane;
-        if (r < V) {
-            const int v = g.order(r); const int e0 = g.in_first(v);
-            unsigned t0 = NONE16, t1 = NONE16, fl = 0; int w0 = 0, w1 = 0;
-            if (e0 != NONE16) {
-                t0 = g.rank(g.e_tail(e0)); w0 = g.e_w(e0);
-                const int e1 = g.e_next_in(e0);
-                if (e1 != NONE16) { t1 = g.rank(g.e_tail(e1)); w1 = g.e_w(e1); if (g.e_next_in(e1) != NONE16) fl = 1; }
-            }
-            w.einfo[lane * 4 + 0] = t0 | (t1 << 16); w.einfo[lane * 4 + 1] = (unsigned)w0; w.einfo[lane * 4 + 2] = (unsigned)w1; w.einfo[lane * 4 + 3] = fl;
-            if (!completion && g.out_first(v) == NONE16) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
-        }
-        lds_sync();
-        if (lane == 0) {
-            const int cnt = min(64, V - r0);
-            for (int x = 0; x < cnt; ++x) {
-                const int rr = r0 + x; long long sv = -1; int pv = NONE16;
-                const unsigned tt = w.einfo[x * 4 + 0]; const unsigned fl = w.einfo[x * 4 + 3];
-                if (!fl) {
-                    const int ta = tt & 0xffff, tb = tt >> 16;
-                    if (ta != NONE16 && !(completion && w.sc()[ta] == -1)) { const long long ww = (int)w.einfo[x * 4 + 1]; if (sv < ww || (sv == ww && w.sc()[pv] <= w.sc()[ta])) { sv = ww; pv = ta; } }
-                    if (tb != NONE16 && !(completion && w.sc()[tb] == -1)) { const long long ww = (int)w.einfo[x * 4 + 2]; if (sv < ww || (sv == ww && w.sc()[pv] <= w.sc()[tb])) { sv = ww; pv = tb; } }
-                } else {
-                    const int v = g.order(rr);
-                    for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) {
-                        const int t = g.rank(g.e_tail(e)); if (completion && w.sc()[t] == -1) continue; const long long ww = g.e_w(e);
-                        if (sv < ww || (sv == ww && w.sc()[pv] <= w.sc()[t])) { sv = ww; pv = t; }
-                    }
-                }
-                if (pv != NONE16) sv += w.sc()[pv];
-                w.sc()[rr] = sv; w.epred[rr] = (uint16_t)pv;
-                if (best < 0 || w.sc()[best] < sv) best = rr;
-            }
-        }
-        lds_sync();
-    }
-    return __builtin_amdgcn_readfirstlane(best);
-}
-#else
 template <int BW>
 __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int completion, int lane)
 {
@@ -243,8 +194,6 @@ __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int com
     return best;
 }
 
-#endif
-
 // heaviest bundle + branch completion (oracle g_consensus)
 template <int BW>
 __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uint32_t job, TS& st, int lane)
@@ -260,6 +209,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     for (int x = lane; x < (V + 31) / 32; x += 64) w.sinkbits[x] = 0;
     lds_sync();
     int mx = bundle_pass(g, w, V, 0, 0, lane);
+    unsigned long long tph2 = tph; PH(J, 13, tph2);
     for (int guard = 0; !((w.sinkbits[mx >> 5] >> (mx & 31)) & 1u); ++guard) {
         if (guard > V) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow + 1, 2u); break; }   // cannot happen: each completion pass starts further down
         const int start = mx;
@@ -273,11 +223,13 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
         if (m2 < 0) break;
         mx = m2;
     }
+    PH(J, 14, tph2);
     // backtrack: lane 0 lists the ranks of the path (HBM scratch), then all lanes translate rank -> letter / coverage
     int n = 0;
     if (lane == 0) { for (int r = mx; r != NONE16; r = w.epred[r]) ++n; int i = n; for (int r = mx; r != NONE16; r = w.epred[r]) g.tmpo(--i) = (uint16_t)r; }
     n = __builtin_amdgcn_readfirstlane(n);
     mem_sync();
+    PH(J, 15, tph2);
     for (int i = lane; i < n; i += 64) {
         const int v = g.order(g.tmpo(i)); dst[i] = g.code(v);
         if (dcov) { uint32_t c = g.cov(v); for (int u = g.ring(v); u != v; u = g.ring(u)) c += g.cov(u); dcov[i] = c; }
@@ -374,27 +326,21 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
     const l32 ring0 = w.hring() + RPADL + lane * CPL;
     const l8 stage0 = w.dirblk() + lane * CPL;
     const l8 sq0 = w.sq + lane * CPL - 1;
-    unsigned long long ri = V > 0 ? w.rinfo()[0] : 0ull;
+    // row info of ranks [r & ~63, +64) in lane order (one v_readlane pair per row, no LDS on the row's critical path); the next 64 are
+    // prefetched from HBM a whole chunk ahead
+    unsigned clo, chi, nlo, nhi;
+    { const unsigned long long a = lane < V ? g.ri(lane) : 0ull, b = 64 + lane < V ? g.ri(64 + lane) : 0ull; clo = (unsigned)a; chi = (unsigned)(a >> 32); nlo = (unsigned)b; nhi = (unsigned)(b >> 32); }
     int r = 0;
     while (r < V) {
-        unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)ri), rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri >> 32));
+        unsigned rlo = __builtin_amdgcn_readlane(clo, r & 63), rhi = __builtin_amdgcn_readlane(chi, r & 63);
         int rfl = rhi >> 24;
         if (rfl & 16) {
             // ---- run of chain rows: registers + one DPP per row, LDS only for letters / ring / staged directions
             for (;;) {
-#ifdef POA_EXP2
-                ri += 1ull | (1ull << 16);
-#else
-                if (r + 1 < V) ri = w.rinfo()[r + 1];                  // prefetch: consumed one iteration later
-#endif
                 const int l0 = rlo & 0xffff; const int cv = (rhi >> 16) & 0xff;
                 int q[CPL];
 #pragma unroll
-#ifdef POA_EXP1
-                for (int c = 0; c < CPL; ++c) q[c] = 1 + c + (lane & 1);
-#else
                 for (int c = 0; c < CPL; ++c) q[c] = sq0[l0 + c];          // sq is padded: no bounds branches
-#endif
                 // Band start moved by one: diag = same register, up = next column; else diag = previous column, up = same.
                 // Lane 0 / 63 get PNEG from the DPP (no source lane), which is exactly the out-of-band value; column 0 never has a diagonal.
                 int up[CPL], dg[CPL];
@@ -427,13 +373,12 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                     for (int c = 0; c < CPL; ++c) if (l0 + lane * CPL + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
                 }
                 ++r;
-                if ((rfl & 8) || (r & (TBR - 1)) == 0 || r >= V) break;       // HBM copy / block flush / end: handled below
-                rlo = __builtin_amdgcn_readfirstlane((unsigned)ri); rhi = __builtin_amdgcn_readfirstlane((unsigned)(ri >> 32)); rfl = rhi >> 24;
+                if ((rfl & 8) || (r & (TBR - 1)) == 0 || r >= V) break;       // HBM copy / block flush / chunk switch / end: handled below
+                rlo = __builtin_amdgcn_readlane(clo, r & 63); rhi = __builtin_amdgcn_readlane(chi, r & 63); rfl = rhi >> 24;
                 if (!(rfl & 16)) { rfl = 0; break; }                           // next row is not a chain row (nothing pending for the row just done)
             }
         } else if (rfl & 64) {
             // ---- near row: one or two predecessors, both still in the LDS ring; all reads issue at once, guard cells replace bounds checks
-            if (r + 1 < V) ri = w.rinfo()[r + 1];
             const int l0 = rlo & 0xffff; const int cv = (rhi >> 16) & 0xff;
             const int dist0 = (rlo >> 16) & 0xff, dist1 = rlo >> 24, dlo0 = rhi & 0xff, dlo1 = (rhi >> 8) & 0xff;
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();     // ring rows of earlier iterations: LDS executes a wave's instructions in order
@@ -474,7 +419,6 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
         } else {
             // ---- generic row (no predecessor, semi-global mode, far or many predecessors): walk the in-edge list in HBM
             ++nslow;
-            if (r + 1 < V) ri = w.rinfo()[r + 1];
             const int l0 = rlo & 0xffff; const int cv = (rhi >> 16) & 0xff;
             const int jb = l0 + lane * CPL;
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
@@ -489,7 +433,7 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
             int slot = 0;
             for (int eit = nopred ? NONE16 : __builtin_amdgcn_readfirstlane((int)g.in_first(g.order(r))); eit != NONE16; eit = __builtin_amdgcn_readfirstlane((int)g.e_next_in(eit)), ++slot) {
                 const int pr = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(eit)));
-                const int plo = (int)(w.rinfo()[pr] & 0xffff);
+                const int plo = (int)(__builtin_amdgcn_readfirstlane((unsigned)g.ri(pr)) & 0xffff);
                 const int pc0 = jb - plo;
                 int hp[CPL + 1];
                 if ((r - pr) <= HR) {                       // LDS ring
@@ -541,6 +485,14 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
             for (int x = 0; x < TBR * BW / 16 / 64; ++x) { const int piece = lane + 64 * x; *(ngsid_v4u*)(dstb + piece * 16) = *(LDSP ngsid_v4u*)(w.dirblk() + piece * 16); }
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
         }
+        if ((r & 63) == 0 && r < V) {          // next chunk of row info; prefetch the one after
+            clo = nlo; chi = nhi;
+            const unsigned long long b = r + 64 + lane < V ? g.ri(r + 64 + lane) : 0ull; nlo = (unsigned)b; nhi = (unsigned)(b >> 32);
+        }
+    }
+    {   // the traceback starts in the last (still staged) block of direction rows: give it the row info of those rows
+        const int cb = (V - 1) & ~63, blk = (V - 1) & ~(TBR - 1), x = cb + lane;
+        if (x >= blk && x < V) w.rblk()[x - blk] = (unsigned long long)clo | ((unsigned long long)chi << 32);
     }
     if (LOCAL) {
         unsigned k = bkey[0]; int cc = 0;
@@ -590,7 +542,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             else if (d0 <= HR && d1 <= HR && dl0 <= DLO_MAX && dl1 <= DLO_MAX) fl |= 64;
 #endif
         }
-        w.rinfo()[r] = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)d0 << 16) | ((unsigned long long)(unsigned)d1 << 24)
+        g.ri(r) = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)d0 << 16) | ((unsigned long long)(unsigned)d1 << 24)
                    | ((unsigned long long)(unsigned)dl0 << 32) | ((unsigned long long)(unsigned)dl1 << 40)
                    | ((unsigned long long)g.code(v) << 48) | ((unsigned long long)(unsigned)fl << 56);
     }
@@ -602,8 +554,8 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     for (int i = lane; i < BW; i += 64) w.sq[L + i] = 0xFF;            // pad: columns past the end never match
     if (lane == 0) w.sq[-1] = 0xFF;
     mem_sync();
-    for (int r = lane; r < V; r += 64) if (g.need(r)) w.rinfo()[r] |= 8ull << 56;
-    lds_sync();
+    for (int r = lane; r < V; r += 64) if (g.need(r)) g.ri(r) |= 8ull << 56;
+    mem_sync();
     PH(J, 0, tph);
     // ---------- forward DP, one row per graph node in topological order
     const bool local = mode == NGSID_POA_LOCAL;
@@ -632,7 +584,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     //            diagonal moves through chain rows (predecessor = previous rank): lane k speculatively inspects the cell k such moves
     //            ahead, the wave takes the whole leading run at once, and the first other move is decoded from that lane's data.
     if (aligned_any) {
-        int r = bestr, j = (int)(w.rinfo()[bestr] & 0xffff) + bestc;
+        int r = bestr, j = (int)(__builtin_amdgcn_readfirstlane((unsigned)g.ri(bestr)) & 0xffff) + bestc;
         int blk_lo = (V - 1) & ~(TBR - 1);                 // the forward pass left the last (partial) block of direction rows in LDS
         for (int guard = 0;; ++guard) {
             if (guard > 2 * (V + L) + 64) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow + 1, 1u); break; }   // cannot happen: every iteration consumes a move (reported by the host as an internal error)
@@ -644,6 +596,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 {
                     const uint8_t* src = Dg + (size_t)rr * BW; l8 dstp = w.dirblk() + (size_t)(lane / LPR) * BW;
                     for (int x = (lane % LPR) * 16; x < BW; x += 16 * LPR) *(LDSP ngsid_v4u*)(dstp + x) = ngsid_load16_l2(src + x);   // L2-served: rows are rewritten per sequence
+                    if (lane < TBR) w.rblk()[lane] = g.ri(blk_lo + lane);
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -651,7 +604,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             const int rk = r - lane, jk = j - lane;
             bool loaded = false, good = false; int dk = 0; unsigned long long rik = 0;
             if (rk >= blk_lo) {
-                rik = w.rinfo()[rk];
+                rik = w.rblk()[rk - blk_lo];
                 const int ck = jk - (int)(rik & 0xffff);
                 if (ck >= 0 && ck < BW) { dk = w.dirblk()[(size_t)(rk - blk_lo) * BW + ck]; loaded = true; good = dk == 0 && ((rik >> 56) & 16) && jk >= 1; }
             }
@@ -795,18 +748,20 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
 size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW)
 {
     (void)Ec;
-    return (size_t)HR * (BW + RPADL + RPADR) * 4 + (size_t)TBR * BW + poa_al16((size_t)8 * Vc) + poa_lds_mid(Vc, Lm) + poa_al16((size_t)Lm + BW + 32);
+    const size_t aln = (size_t)HR * (BW + RPADL + RPADR) * 4 + (size_t)TBR * BW + (size_t)TBR * 8 + 4 * poa_al16(2 * (size_t)Lm) + poa_al16((size_t)Lm + BW + 32);
+    const size_t cons = poa_al16((size_t)8 * Vc) + poa_al16((size_t)2 * Vc) + poa_al16(((size_t)Vc + 31) / 32 * 4);
+    return aln > cons ? aln : cons;
 }
 // HBM scratch bytes of one workgroup for the graph arrays
 static size_t poa_graph_bytes(int Vc, int Ec)
 {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    return 9 * al(2 * ((size_t)Vc + 1)) + 2 * al(Vc) + 6 * al(2 * (size_t)Ec) + al(4 * (size_t)Vc);
+    return 9 * al(2 * ((size_t)Vc + 1)) + 6 * al(Vc) + 6 * al(2 * (size_t)Ec) + al(8 * (size_t)Vc);
 }
 
 template <int CPL>
-__global__ __launch_bounds__(64)
-void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))      // <= 168 VGPRs: three single-wave tiles per SIMD (the LDS budget allows ten per CU)
+void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restrict__ work_ctr)
 {
     constexpr int BW = 64 * CPL;
     const int lane = threadIdx.x;
@@ -814,17 +769,21 @@ void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes)
     LLT<BW> w; GG g;
     {
         auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-        LDSP unsigned char* base = POA_LDS(LDSP unsigned char*, LLT<BW>::C0 + (unsigned)al((size_t)8 * Vc));      // C1
+        LDSP unsigned char* base = POA_LDS(LDSP unsigned char*, LLT<BW>::C1);
         w.alnode = (l16)base; w.nodeof = (l16)(base + al(2 * (size_t)Lm)); w.ref = (l16)(base + 2 * al(2 * (size_t)Lm)); w.tmpv = (l16)(base + 3 * al(2 * (size_t)Lm));
-        w.epred = (l16)base; w.einfo = (LDSP unsigned int*)(base + al((size_t)2 * Vc)); w.sinkbits = (LDSP unsigned int*)(base + al((size_t)2 * Vc) + al(64 * 16));
-        w.sq = (l8)(base + poa_lds_mid(Vc, Lm) + 16);                 // one pad byte in front (sq[-1]), BW behind
+        w.sq = (l8)(base + 4 * al(2 * (size_t)Lm) + 16);              // one pad byte in front (sq[-1]), BW behind
+        w.epred = POA_LDS(l16, (unsigned)al((size_t)8 * Vc)); w.sinkbits = POA_LDS(LDSP unsigned int*, (unsigned)(al((size_t)8 * Vc) + al((size_t)2 * Vc)));
         g.base = gscratch + (size_t)blockIdx.x * gbytes;
         g.s16 = (uint32_t)al(2 * ((size_t)Vc + 1)); g.s8 = (uint32_t)al(Vc); g.se = (uint32_t)al(2 * (size_t)Ec);
     }
     int32_t* Hg = J.Hglob + (size_t)blockIdx.x * Vc * BW;
     uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW;
 
-    for (uint32_t job = blockIdx.x; job < J.njobs; job += gridDim.x) {
+    for (;;) {
+        // persistent workgroups pull tiles from a queue (tiles differ a lot in cost: depth, graph growth, splits)
+        uint32_t jq = 0; if (lane == 0) jq = atomicAdd(work_ctr, 1u);
+        const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)jq);
+        if (job >= J.njobs) break;
         const uint32_t s0 = J.job_off[job], s1 = J.job_off[job + 1];
         const int bbi = J.job_bb ? J.job_bb[job] : -1;
         TS st; st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.nout = 0; st.cw_sum = 0;
@@ -869,7 +828,8 @@ int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
     if (J.Vcap > 0xFFF0 || J.Ecap > 0xFFF0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA graph capacity exceeds 16-bit indices (sequence too long for the tile engine)");
     const size_t lds = poa_lds_bytes(J.Vcap, J.Ecap, J.Lmax, BW);
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);
-    const int per_cu = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / lds)));
+    int per_cu = std::max<int>(1, std::min<int>(12, (int)((160 * 1024) / lds)));      // 12 = three waves per SIMD, the VGPR budget of the kernel
+    if (const char* e = getenv("NGSID_POA_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));      // dev knob
     uint32_t nwg = (uint32_t)std::min<uint64_t>(J.njobs, (uint64_t)ctx->n_cu * per_cu);
     const size_t cells = (size_t)J.Vcap * BW;
     const size_t gbytes = poa_graph_bytes(J.Vcap, J.Ecap);
@@ -877,10 +837,12 @@ int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
     if (ctx->poa_d.n < nwg * cells) HIPCHK(ctx, ctx->poa_d.alloc(nwg * cells));
     if (ctx->poa_g.n < nwg * gbytes) HIPCHK(ctx, ctx->poa_g.alloc(nwg * gbytes));
     J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = nullptr;
+    if (ctx->poa_ctr.n < 1) HIPCHK(ctx, ctx->poa_ctr.alloc(16));
+    HIPCHK(ctx, hipMemsetAsync(ctx->poa_ctr.p, 0, sizeof(uint32_t), ctx->stream));
     ProfScope ps_(ctx, "k_poa_tile");
-    if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<1>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes); }
-    else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<2>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes); }
-    else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<4>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes); }
+    if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<1>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
+    else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<2>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
+    else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<4>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }

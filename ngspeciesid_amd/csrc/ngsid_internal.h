@@ -36,6 +36,7 @@ struct ngsid_ctx {
     DevBuf<uint64_t> tb;      // aligner traceback scratch (grow-only)
     DevBuf<int32_t> bnd;      // aligner strip boundary rows
     DevBuf<uint32_t> aln_ctr; // aligner work-queue counter (one pair index handed out per wave request)
+    DevBuf<uint32_t> poa_ctr; // POA tile work-queue counter
     bool debug_sync = false;
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
