@@ -196,34 +196,79 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
             int cw = -1, w_qf = 0, w_ql = 0, w_tf = 0, w_tl = 0;
             int32_t* bpp = J.bp ? J.bp + p * (uint64_t)J.bp_windows * 4 : nullptr;
             int blk_s = -1, blk_g = -1, blk_hi = -1;
+            // polishing window of the current column, tracked incrementally (no divisions in the loop): [ws, ws + window), index wsn
+            int wsn = bpp ? j / J.window : 0, ws = bpp ? wsn * J.window : 0;
             while (i >= 0 && j >= 0) {
-                const int sidx = i / STRIP; const int il = i - sidx * STRIP; const int l = il / RPL; const int rr = il - l * RPL;
-                const int half = rr / RP, r = rr - half * RP;
-                const int tau = j + 2 * l + half; const int grp = l >> 3;
-                if (sidx != blk_s || grp != blk_g || tau > blk_hi || tau < blk_hi - 63) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    blk_s = sidx; blk_g = grp; blk_hi = tau;
-                    const int tt = tau - lane;
-                    if (tt >= 0) {
-                        const uint4* src = (const uint4*)(mytb + ((uint64_t)sidx * steps + (uint64_t)tt) * 64 + grp * 8);
-                        ngsid_v4u* dstp = (ngsid_v4u*)(tbblk + lane * 8);
-                        dstp[0] = ngsid_load16_l2(src + 0); dstp[1] = ngsid_load16_l2(src + 1); dstp[2] = ngsid_load16_l2(src + 2); dstp[3] = ngsid_load16_l2(src + 3);
+                if (bpp) while (j < ws) { ws -= J.window; --wsn; }
+                {   // make sure the block of traceback words around the current cell is in LDS (64 steps x one group of 8 lanes)
+                    const int sidx = i / STRIP; const int il = i - sidx * STRIP; const int l = il / RPL; const int rr = il - l * RPL;
+                    const int tau = j + 2 * l + rr / RP; const int grp = l >> 3;
+                    if (sidx != blk_s || grp != blk_g || tau > blk_hi || tau < blk_hi - 63) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        blk_s = sidx; blk_g = grp; blk_hi = tau;
+                        const int tt = tau - lane;
+                        if (tt >= 0) {
+                            const uint4* src = (const uint4*)(mytb + ((uint64_t)sidx * steps + (uint64_t)tt) * 64 + grp * 8);
+                            ngsid_v4u* dstp = (ngsid_v4u*)(tbblk + lane * 8);
+                            dstp[0] = ngsid_load16_l2(src + 0); dstp[1] = ngsid_load16_l2(src + 1); dstp[2] = ngsid_load16_l2(src + 2); dstp[3] = ngsid_load16_l2(src + 3);
+                        }
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
                 }
-                const uint64_t word = tbblk[(blk_hi - tau) * 8 + (l & 7)];
-                const unsigned w32 = half ? (unsigned)(word >> 32) : (unsigned)word;
-                const int sh = r < C0 ? 4 * (C0 - 1 - r) : 16 + 4 * (C1 - 1 - (r - C0));
-                const int v = (int)((~(w32 >> sh)) & 15);       // stored complemented -> bit0 diag, bit1 E>=F, bit2 E extends, bit3 F extends
+                // lane k decodes the cell k diagonal steps back; in state 0 the wave takes the whole leading run of diagonal moves at once
+                // (most of an alignment of similar sequences), then the first other cell is handled by the serial state machine below
+                const int ik = i - lane, jk = j - lane;
+                bool inb = false; int vk = 0;
+                if (ik >= 0 && jk >= 0) {
+                    const int sidx = ik / STRIP; const int il = ik - sidx * STRIP; const int l = il / RPL; const int rr = il - l * RPL;
+                    const int half = rr / RP, r = rr - half * RP;
+                    const int tau = jk + 2 * l + half;
+                    if (sidx == blk_s && (l >> 3) == blk_g && tau <= blk_hi && tau >= blk_hi - 63) {
+                        const uint64_t word = tbblk[(blk_hi - tau) * 8 + (l & 7)];
+                        const unsigned w32 = half ? (unsigned)(word >> 32) : (unsigned)word;
+                        const int sh = r < C0 ? 4 * (C0 - 1 - r) : 16 + 4 * (C1 - 1 - (r - C0));
+                        vk = (int)((~(w32 >> sh)) & 15);        // stored complemented -> bit0 diag, bit1 E>=F, bit2 E extends, bit3 F extends
+                        inb = true;
+                    }
+                }
+                int run = 0;
+                if (state == 0) {
+                    const bool good = inb && (vk & 1) && jk >= ws;          // a run never crosses a polishing-window boundary
+                    const unsigned long long gm = __ballot(good);
+                    run = (~gm) ? __builtin_ctzll(~gm) : 64;
+                }
+                if (run > 0) {
+                    const unsigned long long mb = __ballot(ik >= 0 && jk >= 0 && qry[ik >= 0 ? ik : 0] == tgt[jk >= 0 ? jk : 0]);      // match bit of step k
+                    const unsigned long long rmask = run == 64 ? ~0ull : ((1ull << run) - 1);
+                    // window after step k: the k+1 new bits enter in step order (step 0 ends up highest)
+                    const uint64_t wk = (lane == 63 ? 0ull : (win << (lane + 1))) | (__brevll(mb) >> (63 - lane));
+                    const bool cnt = (cols + lane + 1 >= K) && ((int)__popcll(wk & kmask) >= mid);
+                    region += (int)__popcll(__ballot(cnt) & rmask);
+                    nm += (int)__popcll(mb & rmask);
+                    { const int last = run - 1; const unsigned lo_ = __builtin_amdgcn_readlane((unsigned)wk, last), hi_ = __builtin_amdgcn_readlane((unsigned)(wk >> 32), last); win = ((uint64_t)hi_ << 32) | lo_; }
+                    cols += run;
+                    if (q_end < 0) { q_end = i; t_end = j; }
+                    q_beg = i - run + 1; t_beg = j - run + 1;
+                    if (bpp) {
+                        const int wn = wsn;
+                        if (wn != cw) { if (lane == 0 && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = i; w_tl = j; }
+                        w_qf = i - run + 1; w_tf = j - run + 1;
+                    }
+                    i -= run; j -= run;
+                    if (i < 0 || j < 0) break;
+                    if (bpp) while (j < ws) { ws -= J.window; --wsn; }
+                }
+                if (run == 64 || !((__ballot(inb) >> run) & 1)) continue;     // next cell outside the loaded block: go round (reloads)
+                const int v = __builtin_amdgcn_readlane(vk, run);
                 int bit = 0, emit = 1;
                 if (state == 0) {
-                    if (v & 1) {
+                    if (v & 1) {                                       // (a diagonal move the run could not take: window boundary)
                         bit = (qry[i] == tgt[j]);
                         if (q_end < 0) { q_end = i; t_end = j; }
                         q_beg = i; t_beg = j;
                         if (bpp) {
-                            const int wn = j / J.window;
+                            const int wn = wsn;
                             if (wn != cw) { if (lane == 0 && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = i; w_tl = j; }
                             w_qf = i; w_tf = j;
                         }
