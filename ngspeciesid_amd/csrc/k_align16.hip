@@ -9,6 +9,7 @@
 // 8-byte word (4 bits per cell, A cells in the low dword, B cells in the high dword).
 // The systolic skew is two columns per lane: steps = m + 127 per strip.
 #include "ngsid_internal.h"
+#include <algorithm>
 
 #define NEG16 (-20000)
 // Packed 16-bit VALU ops through inline asm: with plain vector types the compiler "simplifies" the flag arithmetic back into
@@ -58,8 +59,9 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
     for (;;) {
         // persistent waves pull pairs from a queue: the grid is sized to what is resident, so there is no tail of idle SIMDs
         uint32_t pq = 0; if (lane == 0) pq = atomicAdd(work_ctr, 1u);
-        const uint64_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)pq);
-        if (p >= J.npairs) break;
+        const uint32_t kq = (uint32_t)__builtin_amdgcn_readfirstlane((int)pq);
+        if (kq >= (J.npairs_dev ? *J.npairs_dev : (uint32_t)J.npairs)) break;
+        const uint64_t p = J.pair_list ? J.pair_list[kq] : kq;
         const uint32_t qi = J.qidx[p], ti = J.tidx[p];
         const uint8_t* q = J.qseq + J.qoff[qi]; const int n = sgpr((int)(J.qoff[qi + 1] - J.qoff[qi]));     // wave-uniform by construction
         const uint8_t* t = J.tseq + J.toff[ti]; const int m = sgpr((int)(J.toff[ti + 1] - J.toff[ti]));
@@ -298,34 +300,67 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
     }
 }
 
+#define NCLS 5
+static inline uint32_t k_cls_bound_host(int c) { static const uint32_t b[NCLS] = {256, 512, 768, 896, 0xffffffffu}; return b[c]; }
+__constant__ const uint32_t k_cls_bound[NCLS] = {256, 512, 768, 896, 0xffffffffu};     // query-length classes = the RP instances below
+
+// pairs -> per-class index lists (order inside a class is irrelevant: results are written by pair index)
+__global__ __launch_bounds__(256)
+void k_pair_classes(AlignJob J, uint32_t* __restrict__ lists, uint32_t* __restrict__ counts)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int cls = -1;
+    if (p < J.npairs) { const uint32_t qi = J.qidx[p]; const uint32_t ql = (uint32_t)(J.qoff[qi + 1] - J.qoff[qi]); cls = 0; while (ql > k_cls_bound[cls]) ++cls; }
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {                      // one atomic per wave and class
+        const unsigned long long m = __ballot(cls == c);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0; if (lane == leader) base = atomicAdd(&counts[c], (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (cls == c) lists[(size_t)c * J.npairs + base + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)p;
+    }
+}
+
+struct Launch16 { uint64_t words, blocks, nwaves; uint32_t lds_per_wave, bnd_stride; int wpb; };
+
 template <int RP>
-static int32_t launch16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen)
+static int32_t plan16(ngsid_ctx* ctx, uint64_t npairs, uint32_t max_qlen, uint32_t max_tlen, Launch16* L)
 {
     const uint64_t strip = 128ull * RP;
     const uint64_t nstrips = (max_qlen + strip - 1) / strip;
-    const uint64_t words = (nstrips ? nstrips : 1) * ((uint64_t)max_tlen + 127) * 64;
-    uint64_t want = job.npairs;
-    const uint64_t by_mem = ctx->scratch_budget / (words * 8 + 1);
+    L->words = (nstrips ? nstrips : 1) * ((uint64_t)max_tlen + 127) * 64;
+    uint64_t want = npairs;
+    const uint64_t by_mem = ctx->scratch_budget / (L->words * 8 + 1);
     if (want > by_mem) want = by_mem;
     if (want < 1) want = 1;
     const uint32_t seq_lds = ((max_tlen > max_qlen ? max_tlen : max_qlen) + 15u) & ~15u;
-    const uint32_t lds_per_wave = 2 * seq_lds + 4096;
+    L->lds_per_wave = 2 * seq_lds + 4096;
     int wpb = 4;
-    while (wpb > 1 && (uint64_t)wpb * lds_per_wave > 40 * 1024) wpb >>= 1;
+    while (wpb > 1 && (uint64_t)wpb * L->lds_per_wave > 40 * 1024) wpb >>= 1;
     int occ = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_sg_align16<RP>, 64 * wpb, (size_t)wpb * lds_per_wave));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_sg_align16<RP>, 64 * wpb, (size_t)wpb * L->lds_per_wave));
     if (occ < 1) occ = 1;
     const uint64_t resident = (uint64_t)occ * ctx->n_cu * wpb;          // waves that fit on the chip at once
     if (want > resident) want = resident;
-    const uint64_t blocks = (want + wpb - 1) / wpb;
-    const uint64_t nwaves = blocks * wpb;
-    if (ctx->aln_ctr.n < 1) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
-    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p, 0, sizeof(uint32_t), ctx->stream));
-    const uint32_t bnd_stride = (max_tlen + 15u) & ~15u;
-    if (ctx->tb.n < nwaves * words) HIPCHK(ctx, ctx->tb.alloc(nwaves * words));
-    if (ctx->bnd.n < nwaves * 2ull * bnd_stride) HIPCHK(ctx, ctx->bnd.alloc(nwaves * 2ull * bnd_stride));
-    { ProfScope ps_(ctx, "k_sg_align"); hipLaunchKernelGGL((k_sg_align16<RP>), dim3((unsigned)blocks), dim3(64 * wpb), (size_t)wpb * lds_per_wave, ctx->stream,
-                       job, ctx->tb.p, words, ctx->bnd.p, bnd_stride, lds_per_wave, ctx->aln_ctr.p); }
+    L->wpb = wpb; L->blocks = (want + wpb - 1) / wpb; L->nwaves = L->blocks * wpb;
+    L->bnd_stride = (max_tlen + 15u) & ~15u;
+    return NGSID_OK;
+}
+
+template <int RP>
+static int32_t launch16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t ctr_slot = 0)
+{
+    Launch16 L; int32_t rc = plan16<RP>(ctx, job.npairs, max_qlen, max_tlen, &L); if (rc) return rc;
+    if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
+    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), ctx->stream));
+    // scratch is grow-only and sized by the caller for all launches of a call BEFORE the first one (a reallocation frees memory
+    // that an earlier, still running launch uses)
+    if (ctx->tb.n < L.nwaves * L.words) HIPCHK(ctx, ctx->tb.alloc(L.nwaves * L.words));
+    if (ctx->bnd.n < L.nwaves * 2ull * L.bnd_stride) HIPCHK(ctx, ctx->bnd.alloc(L.nwaves * 2ull * L.bnd_stride));
+    { ProfScope ps_(ctx, "k_sg_align"); hipLaunchKernelGGL((k_sg_align16<RP>), dim3((unsigned)L.blocks), dim3(64 * L.wpb), (size_t)L.wpb * L.lds_per_wave, ctx->stream,
+                       job, ctx->tb.p, L.words, ctx->bnd.p, L.bnd_stride, L.lds_per_wave, ctx->aln_ctr.p + ctr_slot); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }
@@ -337,8 +372,44 @@ bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t m
            job.ext >= 0 && job.ext <= 4 && max_open >= 0 && max_open <= 16;
 }
 
+template <int RP>
+static int32_t launch_class(ngsid_ctx* ctx, AlignJob job, int cls, uint32_t max_qlen, uint32_t max_tlen)
+{
+    const uint64_t n = job.npairs;
+    job.pair_list = ctx->aln_cls.p + (size_t)cls * n; job.npairs_dev = ctx->aln_ctr.p + 8 + cls;
+    // waves serialise on the scratch of the launches before them only through the stream: every class launch uses its own slice
+    return launch16<RP>(ctx, job, max_qlen < k_cls_bound_host(cls) ? max_qlen : k_cls_bound_host(cls), max_tlen, (uint32_t)(1 + cls));
+}
+
 int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen)
 {
+    // Large batches with mixed query lengths: split the pairs by query-length class so that every pair runs in the instance with the
+    // fewest idle rows (a lane owns 2*RP rows; 750-base reads with a few 800-base ones would otherwise all run with RP = 7).
+    if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !getenv("NGSID_ALIGN_NOCLASS")) {
+        const uint64_t n = job.npairs;
+        if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
+        if (ctx->aln_cls.n < (size_t)NCLS * n) HIPCHK(ctx, ctx->aln_cls.alloc((size_t)NCLS * n));
+        HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p, 0, 16 * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_pair_classes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, job, ctx->aln_cls.p, ctx->aln_ctr.p + 8);
+        HIPCHK(ctx, hipGetLastError());
+        {   // size the scratch once for the most demanding class launch
+            Launch16 L; uint64_t tbw = 0, bw = 0;
+            plan16<2>(ctx, n, 256, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
+            plan16<4>(ctx, n, 512, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
+            plan16<6>(ctx, n, 768, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
+            plan16<7>(ctx, n, 896, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
+            plan16<8>(ctx, n, max_qlen, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
+            if (ctx->tb.n < tbw) HIPCHK(ctx, ctx->tb.alloc(tbw));
+            if (ctx->bnd.n < bw) HIPCHK(ctx, ctx->bnd.alloc(bw));
+        }
+        int32_t rc;
+        if ((rc = launch_class<2>(ctx, job, 0, max_qlen, max_tlen))) return rc;
+        if (max_qlen > 256 && (rc = launch_class<4>(ctx, job, 1, max_qlen, max_tlen))) return rc;
+        if (max_qlen > 512 && (rc = launch_class<6>(ctx, job, 2, max_qlen, max_tlen))) return rc;
+        if (max_qlen > 768 && (rc = launch_class<7>(ctx, job, 3, max_qlen, max_tlen))) return rc;
+        if (max_qlen > 896 && (rc = launch_class<8>(ctx, job, 4, max_qlen, max_tlen))) return rc;
+        return NGSID_OK;
+    }
     if (max_qlen <= 256) return launch16<2>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 512) return launch16<4>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 768) return launch16<6>(ctx, job, max_qlen, max_tlen);

@@ -35,7 +35,8 @@ struct ngsid_ctx {
     int n_cu = 256;
     DevBuf<uint64_t> tb;      // aligner traceback scratch (grow-only)
     DevBuf<int32_t> bnd;      // aligner strip boundary rows
-    DevBuf<uint32_t> aln_ctr; // aligner work-queue counter (one pair index handed out per wave request)
+    DevBuf<uint32_t> aln_ctr; // aligner work-queue counters (one per launch in flight) + length-class counts
+    DevBuf<uint32_t> aln_cls; // pair lists of the length classes
     DevBuf<uint32_t> poa_ctr; // POA tile work-queue counter
     bool debug_sync = false;
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
@@ -84,6 +85,8 @@ struct AlignJob {            // device pointers
     int32_t* score; int32_t* ncols; int32_t* nmatch; int32_t* region;
     // optional window break points (polish): per pair `bp_windows` records of 4 int32 {q_first,q_last,t_first,t_last}, -1 = none
     int32_t* bp; int bp_windows; int window; int32_t* span;  // span: per pair {q_begin,q_end,t_begin,t_end} of the aligned part
+    // optional indirection (length classes): the k-th work item is pair pair_list[k], and the item count is read from device memory
+    const uint32_t* pair_list; const uint32_t* npairs_dev;
 };
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20);
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
