@@ -150,13 +150,21 @@ def main():
         traffic = None
         try:    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), valid for the profiled workload size only
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            if tj.get("workload_reads") == args.reads and dom[0] in tj:
-                traffic = tj[dom[0]]["hbm_bytes_per_launch"]
+            if tj.get("workload_reads") == args.reads and dom[0] in tj and world == 1:
+                traffic = int(tj[dom[0]]["hbm_bytes_per_step"] * args.steps / max(cnt, 1))      # per launch, like `achieved`
         except Exception:
             traffic = None
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic,
                 "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-                "note": "integer DP kernel: VALU/LDS-latency bound by construction, HBM fraction is small (DESIGN.md)"}
+                "note": "integer DP kernel: VALU-issue bound by construction, HBM fraction is small (DESIGN.md section 4)"}
+        if dom[0] == "k_sg_align":      # what actually bounds it: VALU issue.  17.7 VALU instructions per DP cell and lane (ISA count, k_align16.hip), 64 cells per wave instruction
+            prop = torch.cuda.get_device_properties(dev)
+            clk = float(getattr(prop, "clock_rate", 2400000)) * 1e3
+            peak_issue = prop.multi_processor_count * 4 * clk / 4.0
+            cells = units * L * L
+            wi = cells / 64.0 * 17.7 / (ms / 1e3)
+            roof["valu_issue"] = {"achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4),
+                                  "dp_cells_per_s": round(cells / (ms / 1e3), 0)}
     # ---- CPU baseline: the oracle (port of the reference CPU path) on a bounded sample of the same workload, 1 core
     cpu = None
     if not args.no_cpu_baseline and world == 1:
