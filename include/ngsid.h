@@ -122,6 +122,16 @@ int32_t ngsid_sg_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const
                              int32_t k, const int32_t* match_id,
                              int32_t* score, int32_t* n_cols, int32_t* n_match, int32_t* region);
 
+/* (a17) the read->backbone alignment of the polisher in edit-distance mode (ngsid_polish_params_t.aln_mode = 1; racon obtains the
+ * same thing from edlib, racon src/overlap.cpp find_breaking_points): pair p aligns all of query q_idx[p] inside target t_idx[p]
+ * with unit costs (target ends free).  Rules as in ngsid_polish_params_t.aln_mode.  Outputs per pair (any may be NULL):
+ * distance; span = {q_first, q_last, t_first, t_last} of the aligned (match/mismatch) columns, -1 if none; and, per polishing
+ * window w of `window` target bases (w < bp_windows), bp[(p*bp_windows+w)*4..] = {q_first, q_last, t_first, t_last} of the aligned
+ * columns whose target position falls in the window, -1 if none.  Queries longer than 1 024 bases -> NGSID_ERR_TOO_LONG. */
+int32_t ngsid_ed_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const ngsid_reads_t* targets,
+                             const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                             int32_t window, int32_t bp_windows, int32_t* distance, int32_t* span, int32_t* bp);
+
 /* POA modes */
 #define NGSID_POA_LOCAL   0   /* spoa -l 0 */
 #define NGSID_POA_GLOBAL  1   /* spoa -l 1 (racon windows) */
@@ -154,6 +164,11 @@ typedef struct {
     int32_t tile_depth, band, node_cap;
     int32_t aln_match, aln_mismatch, aln_open, aln_ext;  /* read->backbone aligner (replaces the edlib NW path of racon) */
     int32_t trim;             /* 0 none; 1 = racon: coverage-trim the consensus of TGS windows (mean read length > 1000); 2 = trim every window */
+    int32_t aln_mode;         /* read->backbone aligner: 0 = semi-global affine (aln_* scores, all end gaps free);
+                                 1 = unit-cost edit distance, read end to end, backbone ends free (what racon gets from edlib inside the
+                                 minimap2 span); traceback prefers match/mismatch, then a read-only column, then a backbone-only column;
+                                 end column = leftmost minimum of the last row; non-ACGT letters match nothing (reads <= 1 024 bases);
+                                 2 = automatic: mode 1 if the longest read of the read set has <= 1 024 bases, else mode 0 */
 } ngsid_polish_params_t;
 
 /* (a16,a17) replaces run_racon's (minimap2 -> racon) x racon_iter chain (consensus.py:107-126).

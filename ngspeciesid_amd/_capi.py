@@ -40,7 +40,7 @@ class PolishParams(C.Structure):
     _fields_ = [("iters", C.c_int32), ("window", C.c_int32), ("quality_threshold", C.c_double), ("error_threshold", C.c_double),
                 ("match", C.c_int32), ("mismatch", C.c_int32), ("gap", C.c_int32), ("k", C.c_int32), ("w", C.c_int32),
                 ("tile_depth", C.c_int32), ("band", C.c_int32), ("node_cap", C.c_int32),
-                ("aln_match", C.c_int32), ("aln_mismatch", C.c_int32), ("aln_open", C.c_int32), ("aln_ext", C.c_int32), ("trim", C.c_int32)]
+                ("aln_match", C.c_int32), ("aln_mismatch", C.c_int32), ("aln_open", C.c_int32), ("aln_ext", C.c_int32), ("trim", C.c_int32), ("aln_mode", C.c_int32)]
 
 
 def cluster_params(k=13, w=20, min_shared=5, min_fraction=0.8, mapped_threshold=0.7, aligned_threshold=0.4,
@@ -60,10 +60,10 @@ def poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=
 
 
 def polish_params(iters=2, window=500, quality_threshold=10.0, error_threshold=0.3, match=3, mismatch=-5, gap=-4,
-                  k=13, w=20, tile_depth=0, band=0, node_cap=0, aln_match=2, aln_mismatch=-2, aln_open=3, aln_ext=1, trim=1):
+                  k=13, w=20, tile_depth=0, band=0, node_cap=0, aln_match=2, aln_mismatch=-2, aln_open=3, aln_ext=1, trim=1, aln_mode=2):
     """Defaults = racon 1.4.x (-w 500 -q 10 -e 0.3 -m 3 -x -5 -g -4), iters = --racon_iter (NGSpeciesID:212)."""
     return PolishParams(int(iters), int(window), float(quality_threshold), float(error_threshold), int(match), int(mismatch), int(gap),
-                        int(k), int(w), int(tile_depth), int(band), int(node_cap), int(aln_match), int(aln_mismatch), int(aln_open), int(aln_ext), int(trim))
+                        int(k), int(w), int(tile_depth), int(band), int(node_cap), int(aln_match), int(aln_mismatch), int(aln_open), int(aln_ext), int(trim), int(aln_mode))
 
 
 class ReadSet:
@@ -175,6 +175,16 @@ class Api:
                         _p(open_), C.c_int32(ext), C.c_int32(k), _p(mid), _p(score), _p(ncols), _p(nmatch), _p(region))
         if rc: self._err(rc)
         return score, ncols, nmatch, region
+
+    def ed_align_batch(self, q: ReadSet, t: ReadSet, q_idx, t_idx, window=500, bp_windows=0):
+        """edit-distance (read inside backbone) alignment of the polisher: distance, span[n,4], bp[n,bp_windows,4]"""
+        q_idx = np.ascontiguousarray(q_idx, dtype=np.uint32); t_idx = np.ascontiguousarray(t_idx, dtype=np.uint32)
+        n = len(q_idx)
+        dist = np.zeros(n, dtype=np.int32); span = np.zeros((n, 4), dtype=np.int32); bp = np.zeros((n, max(bp_windows, 1), 4), dtype=np.int32)
+        rc = self._call("ed_align_batch", C.byref(q.c), C.byref(t.c), _p(q_idx), _p(t_idx), C.c_uint64(n), C.c_int32(window), C.c_int32(bp_windows),
+                        _p(dist), _p(span), _p(bp) if bp_windows else None)
+        if rc: self._err(rc)
+        return dist, span, bp[:, :bp_windows]
 
     # ---- (a13,a14)
     def poa_consensus(self, rs: ReadSet, grp_off, prm: PoaParams, cap=None, read_order=None):

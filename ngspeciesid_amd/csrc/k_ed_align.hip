@@ -1,0 +1,163 @@
+// k_ed_align.hip - (a17) read -> backbone alignment of the polisher in edit-distance mode (ngsid_polish_params_t.aln_mode = 1).
+//
+// racon finds its window break points with edlib (unit-cost alignment, Myers' bit-vector algorithm); this is the same recurrence on
+// gfx950.  Semantics = oracle ongsid_i_ed_ops (plain O(nm) DP): the whole query inside the target, target ends free, end column =
+// leftmost minimum of the last row, traceback prefers diagonal, then up (query only), then left (target only).
+//
+// Mapping: ONE PAIR PER LANE - the recurrence has no cross-lane dependency, so a wave advances 64 alignments and every VALU
+// instruction updates 64 x 64 DP cells (one 64-row block of 64 pairs).  Per target column the lane walks its query blocks top to
+// bottom (Hyyro/edlib block step with a horizontal carry); the block states Pv/Mv live in registers (template BMAX blocks, queries up
+// to 64*BMAX bases), the query as three bit planes per block in LDS (letter bit 0, bit 1, "is A/C/G/T").  For the traceback every
+// (block, column) stores two 64-bit vectors: DIAG (a diagonal move is optimal) and UP (vertical delta +1) - one coalesced 1 KB store
+// per instruction - and each lane then walks its own path, one 16-byte L2 load per step, recording the window break points.
+// ~55 VALU instructions per (block, column) for 64 pairs: ~8 k wave instructions per 750 x 750 pair instead of ~190 k in k_sg_align16.
+#include "ngsid_internal.h"
+#include <algorithm>
+
+typedef unsigned long long u64;
+#define LDSP __attribute__((address_space(3)))
+
+template <int BMAX>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-byte units */, uint32_t mstride, uint32_t* __restrict__ work_ctr, int32_t* __restrict__ dist_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    LDSP u64* planes = (LDSP u64*)smem;                     // [block][3][lane]
+    ngsid_v4u* mytb = tb + (u64)blockIdx.x * tb_per_wave;
+    const u64 nbundles = (J.npairs + 63) / 64;
+    for (;;) {
+        uint32_t kq = 0; if (lane == 0) kq = atomicAdd(work_ctr, 1u);
+        kq = (uint32_t)__builtin_amdgcn_readfirstlane((int)kq);
+        if (kq >= nbundles) break;
+        const u64 p = (u64)kq * 64 + lane;
+        const bool have = p < J.npairs;
+        const uint8_t* q = nullptr; const uint8_t* t = nullptr; int n = 0, m = 0;
+        if (have) { const uint32_t qi = J.qidx[p], ti = J.tidx[p]; q = J.qseq + J.qoff[qi]; n = (int)(J.qoff[qi + 1] - J.qoff[qi]); t = J.tseq + J.toff[ti]; m = (int)(J.toff[ti + 1] - J.toff[ti]); }
+        int nmax = n, mmax = m;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { nmax = max(nmax, __shfl_xor(nmax, d)); mmax = max(mmax, __shfl_xor(mmax, d)); }
+        nmax = __builtin_amdgcn_readfirstlane(nmax); mmax = __builtin_amdgcn_readfirstlane(mmax);
+        const int B = (nmax + 63) >> 6;                     // blocks the wave walks (<= BMAX, guaranteed by the launcher)
+        // ---- query bit planes -> LDS
+        for (int b = 0; b < B; ++b) {
+            u64 lo = 0, hi = 0, ok = 0;
+            const int base = b * 64;
+            for (int r = 0; r < 64; ++r) {
+                const int i = base + r;
+                const int c = i < n ? ngsid_bcode(q[i]) : 4;
+                lo |= (u64)(c & 1) << r; hi |= (u64)((c >> 1) & 1) << r; ok |= (u64)(c < 4) << r;
+            }
+            planes[(b * 3 + 0) * 64 + lane] = lo; planes[(b * 3 + 1) * 64 + lane] = hi; planes[(b * 3 + 2) * 64 + lane] = ok;
+        }
+        u64 Pv[BMAX], Mv[BMAX];
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
+        const int bl = n > 0 ? (n - 1) >> 6 : 0, lastbit = n > 0 ? (n - 1) & 63 : 0;
+        int score = n, best = n, bestj = 0;                 // D[n][0] = n
+        // ---- forward: column by column, blocks top to bottom
+        for (int j = 0; j < mmax; ++j) {
+            const int tc = j < m ? ngsid_bcode(t[j]) : 4;
+            const u64 Tlo = (tc & 1) ? ~0ull : 0ull, Thi = (tc & 2) ? ~0ull : 0ull, Tok = tc < 4 ? ~0ull : 0ull;
+            int hin = 0;                                    // top row of the matrix is all zeros (target prefix free)
+            ngsid_v4u* col = mytb + ((u64)j * 64 + lane);
+#pragma unroll
+            for (int b = 0; b < BMAX; ++b) {
+                if (b < B) {
+                    const u64 lo = planes[(b * 3 + 0) * 64 + lane], hi = planes[(b * 3 + 1) * 64 + lane], ok = planes[(b * 3 + 2) * 64 + lane];
+                    const u64 Eq = ~(lo ^ Tlo) & ~(hi ^ Thi) & ok & Tok;
+                    const u64 pv = Pv[b], mv = Mv[b];
+                    const u64 Xv = Eq | mv;
+                    const u64 Eqh = Eq | (hin < 0 ? 1ull : 0ull);
+                    const u64 Xh = (((Eqh & pv) + pv) ^ pv) | Eqh;
+                    u64 Ph = mv | ~(Xh | pv), Mh = pv & Xh;
+                    // moves (oracle: diagonal if D[i-1][j-1] + neq == D[i][j]): a match always qualifies; a mismatch iff the diagonal delta
+                    // h(i,j) + v(i,j-1) is +1, i.e. (h,v) = (+1,0) or (0,+1)
+                    const u64 diag = Eq | (Ph & ~(pv | mv)) | (~(Ph | Mh) & pv);
+                    const int hout63 = (int)((Ph >> 63) & 1) - (int)((Mh >> 63) & 1);
+                    if (b == bl && j < m) {
+                        score += (int)((Ph >> lastbit) & 1) - (int)((Mh >> lastbit) & 1);
+                        if (score < best) { best = score; bestj = j + 1; }
+                    }
+                    Ph <<= 1; Mh <<= 1;
+                    if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+                    const u64 npv = Mh | ~(Xv | Ph);
+                    Pv[b] = npv; Mv[b] = Ph & Xv;
+                    ngsid_v4u w; w.x = (unsigned)diag; w.y = (unsigned)(diag >> 32); w.z = (unsigned)npv; w.w = (unsigned)(npv >> 32);
+                    col[(u64)b * mstride * 64] = w;
+                    hin = hout63;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- traceback, every lane on its own path
+        int i = n, j = bestj;
+        int q_end = -1, t_end = -1, q_beg = -1, t_beg = -1;
+        int32_t* bpp = (J.bp && have) ? J.bp + p * (u64)J.bp_windows * 4 : nullptr;
+        if (bpp) for (int x = 0; x < J.bp_windows * 4; ++x) bpp[x] = -1;
+        const int W = J.window > 0 ? J.window : 0x7fffffff;
+        int cw = -1, w_qf = 0, w_ql = 0, w_tf = 0, w_tl = 0;
+        int wsn = j > 0 ? (j - 1) / W : 0, ws = wsn * W;       // window of the current target position, tracked without divisions
+        while (i > 0) {
+            bool diag = false, up = true;
+            if (j > 0) {
+                const ngsid_v4u w = __builtin_nontemporal_load(mytb + (((u64)((i - 1) >> 6) * mstride + (u64)(j - 1)) * 64 + lane));
+                const int bit = (i - 1) & 63;
+                const u64 dv = ((u64)w.y << 32) | w.x, uv = ((u64)w.w << 32) | w.z;
+                diag = (dv >> bit) & 1; up = (uv >> bit) & 1;
+            }
+            if (diag) {
+                const int qi = i - 1, ti = j - 1;
+                if (q_end < 0) { q_end = qi; t_end = ti; }
+                q_beg = qi; t_beg = ti;
+                if (bpp) {
+                    while (ti < ws) { ws -= W; --wsn; }
+                    const int wn = wsn;
+                    if (wn != cw) { if (cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = qi; w_tl = ti; }
+                    w_qf = qi; w_tf = ti;
+                }
+                --i; --j;
+            } else if (up) --i;
+            else --j;
+        }
+        if (bpp && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
+        if (have) {
+            if (dist_out) dist_out[p] = best;
+            if (J.span) { J.span[p * 4 + 0] = q_beg; J.span[p * 4 + 1] = q_end; J.span[p * 4 + 2] = t_beg; J.span[p * 4 + 3] = t_end; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int BMAX>
+static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_tlen, int32_t* dist_out)
+{
+    const u64 nbundles = (job.npairs + 63) / 64;
+    const uint32_t mstride = max_tlen ? max_tlen : 1;
+    const u64 per_wave = (u64)BMAX * mstride * 64;                         // 16-byte units
+    const size_t lds = (size_t)BMAX * 3 * 64 * 8;
+    int occ = 0;
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ed_align<BMAX>, 64, lds));
+    if (occ < 1) occ = 1;
+    u64 want = std::min<u64>(nbundles, (u64)occ * ctx->n_cu);
+    const u64 by_mem = std::max<u64>(1, ((size_t)12 << 30) / (per_wave * 16));
+    want = std::max<u64>(1, std::min(want, by_mem));
+    if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.alloc(want * per_wave));
+    if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
+    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + 14, 0, sizeof(uint32_t), ctx->stream));
+    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + 14, dist_out); }
+    HIPCHK(ctx, hipGetLastError());
+    return NGSID_OK;
+}
+
+int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out)
+{
+    if (job.npairs == 0) return NGSID_OK;
+    if (max_qlen > 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "edit-distance polisher alignment supports reads up to 1024 bases (got %u): use aln_mode 0", max_qlen);
+    if (max_tlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "backbone longer than %d", NGSID_MAX_READ_LEN);
+    if (max_qlen <= 256) return launch_ed<4>(ctx, job, max_tlen, dist_out);
+    if (max_qlen <= 512) return launch_ed<8>(ctx, job, max_tlen, dist_out);
+    if (max_qlen <= 768) return launch_ed<12>(ctx, job, max_tlen, dist_out);
+    return launch_ed<16>(ctx, job, max_tlen, dist_out);
+}

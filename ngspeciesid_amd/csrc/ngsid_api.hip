@@ -117,6 +117,40 @@ extern "C" int32_t ngsid_sg_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* que
     return NGSID_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- (a17, edit-distance mode)
+extern "C" int32_t ngsid_ed_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const ngsid_reads_t* targets,
+                                        const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                                        int32_t window, int32_t bp_windows, int32_t* distance, int32_t* span, int32_t* bp)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!queries || !targets || (n_pairs && (!q_idx || !t_idx))) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    if (bp && (bp_windows <= 0 || window <= 0)) NGSID_FAIL(ctx, NGSID_ERR_ARG, "bp needs window > 0 and bp_windows > 0");
+    DevReads Q, T;
+    int32_t rc = ngsid_upload_reads(ctx, queries, &Q, false); if (rc) return rc;
+    rc = ngsid_upload_reads(ctx, targets, &T, false); if (rc) return rc;
+    if (n_pairs == 0) return NGSID_OK;
+    uint32_t mq = 0, mt = 0;
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        if (q_idx[p] >= Q.n || t_idx[p] >= T.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "pair %llu out of range", (unsigned long long)p);
+        mq = std::max<uint32_t>(mq, (uint32_t)(Q.h_off[q_idx[p] + 1] - Q.h_off[q_idx[p]]));
+        mt = std::max<uint32_t>(mt, (uint32_t)(T.h_off[t_idx[p] + 1] - T.h_off[t_idx[p]]));
+    }
+    DevBuf<uint32_t> dq, dt; DevBuf<int32_t> ddist, dspan, dbp;
+    HIPCHK(ctx, dq.alloc(n_pairs)); HIPCHK(ctx, dt.alloc(n_pairs)); HIPCHK(ctx, ddist.alloc(n_pairs)); HIPCHK(ctx, dspan.alloc(n_pairs * 4));
+    if (bp) HIPCHK(ctx, dbp.alloc(n_pairs * (uint64_t)bp_windows * 4));
+    HIPCHK(ctx, hipMemcpyAsync(dq.p, q_idx, 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dt.p, t_idx, 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    AlignJob J{};
+    J.qseq = Q.seq; J.qoff = Q.off; J.tseq = T.seq; J.toff = T.off; J.qidx = dq.p; J.tidx = dt.p; J.npairs = n_pairs;
+    J.bp = bp ? dbp.p : nullptr; J.bp_windows = bp ? bp_windows : 0; J.window = window; J.span = dspan.p;
+    rc = ngsid_launch_ed_align(ctx, J, mq, mt, ddist.p); if (rc) return rc;
+    if (distance) HIPCHK(ctx, hipMemcpyAsync(distance, ddist.p, 4 * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    if (span) HIPCHK(ctx, hipMemcpyAsync(span, dspan.p, 16 * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    if (bp) HIPCHK(ctx, hipMemcpyAsync(bp, dbp.p, 16ull * n_pairs * bp_windows, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NGSID_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- (a1-a3)
 __global__ void k_csr_gather(const uint64_t* __restrict__ roff, const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ moff,
                              const uint64_t* __restrict__ scodes, const uint32_t* __restrict__ spos, uint64_t n,

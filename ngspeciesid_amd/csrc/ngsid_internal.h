@@ -27,6 +27,7 @@ template <typename T> struct DevBuf {
 
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 
+typedef unsigned int ngsid_v4u_t __attribute__((ext_vector_type(4)));
 struct ngsid_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -37,6 +38,7 @@ struct ngsid_ctx {
     DevBuf<int32_t> bnd;      // aligner strip boundary rows
     DevBuf<uint32_t> aln_ctr; // aligner work-queue counters (one per launch in flight) + length-class counts
     DevBuf<uint32_t> aln_cls; // pair lists of the length classes
+    DevBuf<ngsid_v4u_t> ed_tb; // traceback vectors of the edit-distance aligner
     DevBuf<uint32_t> poa_ctr; // POA tile work-queue counter
     bool debug_sync = false;
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
@@ -91,6 +93,7 @@ struct AlignJob {            // device pointers
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20);
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
 int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen);
+int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out);   // k_ed_align.hip (uses qseq..npairs, bp, bp_windows, window, span)
 
 typedef unsigned int ngsid_v4u __attribute__((ext_vector_type(4)));
 // 16-byte load served by L2 (nt): for scratch that this wave rewrites between uses, where an L1 line could be stale

@@ -343,7 +343,10 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             J.qseq = oseq.p; J.qoff = RD.off; J.tseq = BB.seq; J.toff = BB.off; J.qidx = d_pair_read.p; J.tidx = d_pair_group.p; J.npairs = NP;
             J.match = prm->aln_match; J.mismatch = prm->aln_mismatch; J.ext = prm->aln_ext; J.k = 1; J.open = d_open.p; J.match_id = nullptr;
             J.score = nullptr; J.ncols = nullptr; J.nmatch = nullptr; J.region = nullptr; J.bp = d_bp.p; J.bp_windows = nwinmax; J.window = W; J.span = d_span.p;
-            rc = ngsid_launch_align(ctx, J, RD.maxlen, maxb, prm->aln_open); if (rc) return rc;
+            const int aln_mode = prm->aln_mode == 2 ? (RD.maxlen <= 1024 ? 1 : 0) : prm->aln_mode;
+            if (aln_mode == 1) rc = ngsid_launch_ed_align(ctx, J, RD.maxlen, maxb, nullptr);          // unit-cost, bit-parallel (k_ed_align.hip)
+            else rc = ngsid_launch_align(ctx, J, RD.maxlen, maxb, prm->aln_open);
+            if (rc) return rc;
             const uint64_t T = NP * (uint64_t)nwinmax;
             { ProfScope ps_(ctx, "k_layers"); hipLaunchKernelGGL(k_layers, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, oseq.p, RD.qual ? oqual.p : nullptr, RD.off, d_pair_read.p, d_pair_group.p, NP, nwinmax,
                                d_bp.p, d_span.p, d_blen.p, W, prm->quality_threshold, prm->error_threshold, d_lay.p, d_valid.p, flag.p); }

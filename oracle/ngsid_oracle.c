@@ -212,6 +212,34 @@ int32_t ongsid_sg_align_batch(const ngsid_reads_t* Q, const ngsid_reads_t* T,
     return NGSID_OK;
 }
 
+
+int ongsid_i_ed_ops(const uint8_t* q, int n, const uint8_t* t, int m, uint8_t* ops);
+/* twin of ngsid_ed_align_batch */
+int32_t ongsid_ed_align_batch(const ngsid_reads_t* Q, const ngsid_reads_t* T, const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                              int32_t window, int32_t bp_windows, int32_t* distance, int32_t* span, int32_t* bp) {
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        uint32_t qi = q_idx[p], ti = t_idx[p];
+        const uint8_t* q = Q->seq + Q->off[qi]; int n = (int)(Q->off[qi + 1] - Q->off[qi]);
+        const uint8_t* t = T->seq + T->off[ti]; int m = (int)(T->off[ti + 1] - T->off[ti]);
+        uint8_t* ops = (uint8_t*)malloc((size_t)(n + m + 2));
+        int c = ongsid_i_ed_ops(q, n, t, m, ops);
+        int d = 0, a = 0, b = 0, qb = -1, qe = -1, tb = -1, te = -1;
+        if (bp) for (int x = 0; x < bp_windows * 4; ++x) bp[p * (uint64_t)bp_windows * 4 + x] = -1;
+        for (int x = 0; x < c; ++x) {
+            if (ops[x] <= 1) {
+                d += ops[x];
+                if (qb < 0) { qb = a; tb = b; } qe = a; te = b;
+                if (bp && window > 0) { int w = b / window; if (w < bp_windows) { int32_t* r = bp + (p * (uint64_t)bp_windows + w) * 4; if (r[0] < 0) { r[0] = a; r[2] = b; } r[1] = a; r[3] = b; } }
+                ++a; ++b;
+            } else if (ops[x] == 2) { ++d; ++a; } else { if (a > 0 && a < n) ++d; ++b; }
+        }
+        if (distance) distance[p] = d;
+        if (span) { span[p * 4 + 0] = qb; span[p * 4 + 1] = qe; span[p * 4 + 2] = tb; span[p * 4 + 3] = te; }
+        free(ops);
+    }
+    return NGSID_OK;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * (f1) read scoring                                              get_sorted_fastq_for_cluster.py:23-33,124-155
  * ---------------------------------------------------------------------------------------------- */
@@ -486,6 +514,41 @@ int ongsid_i_hpc_minimizers(const uint8_t* s, int n, int k, int w, uint64_t* cod
     if (hl >= k) cnt = minimizers(hs, hl, k, w, codes, pos);
     free(hs);
     return cnt;       /* -1 = alphabet error */
+}
+
+/* forward-order op list of the unit-cost (edit distance) alignment of the whole query inside the target (target ends free; the
+   skipped target prefix is emitted as 'D' ops so that positions stay absolute).  Plain O(nm) DP = the definition; the HIP kernel
+   computes the same matrix bit-parallel.  Letters match only if both are A/C/G/T (any case) and equal.  End column = leftmost minimum
+   of the last row; traceback prefers diagonal, then up (query only), then left (target only). */
+static inline int ed_code(uint8_t c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+int ongsid_i_ed_ops(const uint8_t* q, int n, const uint8_t* t, int m, uint8_t* ops) {
+    if (n <= 0) { int c = 0; for (int j = 0; j < m; ++j) ops[c++] = 3; return c; }
+    const size_t W = (size_t)m + 1;
+    int* D = malloc(sizeof(int) * ((size_t)n + 1) * W);
+    for (int j = 0; j <= m; ++j) D[j] = 0;
+    for (int i = 1; i <= n; ++i) {
+        int* Dr = D + (size_t)i * W; const int* Dp = Dr - W; const int qc = ed_code(q[i - 1]);
+        Dr[0] = i;
+        for (int j = 1; j <= m; ++j) {
+            const int tc = ed_code(t[j - 1]); const int neq = !(qc < 4 && qc == tc);
+            int v = Dp[j - 1] + neq; if (Dp[j] + 1 < v) v = Dp[j] + 1; if (Dr[j - 1] + 1 < v) v = Dr[j - 1] + 1;
+            Dr[j] = v;
+        }
+    }
+    int je = 0; { const int* Dl = D + (size_t)n * W; for (int j = 1; j <= m; ++j) if (Dl[j] < Dl[je]) je = j; }
+    int c = 0, i = n, j = je;
+    for (int x = m; x > je; --x) ops[c++] = 3;                       /* free target suffix */
+    while (i > 0) {
+        const int* Dr = D + (size_t)i * W; const int* Dp = Dr - W;
+        if (j > 0) { const int qc = ed_code(q[i - 1]), tc = ed_code(t[j - 1]); const int neq = !(qc < 4 && qc == tc);
+                     if (Dp[j - 1] + neq == Dr[j]) { ops[c++] = (uint8_t)neq; --i; --j; continue; } }
+        if (Dp[j] + 1 == Dr[j]) { ops[c++] = 2; --i; continue; }
+        ops[c++] = 3; --j;
+    }
+    for (; j > 0; --j) ops[c++] = 3;                                /* free target prefix */
+    for (int a = 0, b = c - 1; a < b; ++a, --b) { uint8_t x = ops[a]; ops[a] = ops[b]; ops[b] = x; }
+    free(D);
+    return c;
 }
 /* forward-order op list (0 '=',1 'X',2 'I' query only,3 'D' target only) of the semi-global alignment; returns #ops */
 int ongsid_i_sg_ops(const uint8_t* q, int n, const uint8_t* t, int m, int match, int mismatch, int open, int ext, uint8_t* ops) {

@@ -35,6 +35,8 @@ int32_t ongsid_hpc_minimizers(const ngsid_reads_t* reads, int32_t k, int32_t w,
 int32_t ongsid_cluster_greedy(const ngsid_reads_t* reads, const ngsid_cluster_params_t* prm,
                               const uint32_t* acc_rank, const int32_t* prev_batch, const double* known_err,
                               int32_t* rep_of_read, double* hpc_err_out, uint8_t* status_out, uint64_t counters[4]);
+int32_t ongsid_ed_align_batch(const ngsid_reads_t* queries, const ngsid_reads_t* targets, const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                              int32_t window, int32_t bp_windows, int32_t* distance, int32_t* span, int32_t* bp);
 int32_t ongsid_sg_align_batch(const ngsid_reads_t* queries, const ngsid_reads_t* targets,
                               const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
                               int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,

@@ -358,6 +358,7 @@ int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_or
 /* ---------------------------------------------------------------- racon-style polishing (consensus.py:107-126) */
 int ongsid_i_hpc_minimizers(const uint8_t* s, int n, int k, int w, uint64_t* codes, uint32_t* pos);
 int ongsid_i_sg_ops(const uint8_t* q, int n, const uint8_t* t, int m, int match, int mismatch, int open, int ext, uint8_t* ops);
+int ongsid_i_ed_ops(const uint8_t* q, int n, const uint8_t* t, int m, uint8_t* ops);
 
 static int cmp_u64(const void* a, const void* b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : (x > y); }
 static int in_sorted(const uint64_t* a, int n, uint64_t key) { int lo = 0, hi = n; while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; } return lo < n && a[lo] == key; }
@@ -370,6 +371,8 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
                       const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used) {
     pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->trim >= 2 };
     const int W = prm->window > 0 ? prm->window : 500;
+    int aln_mode = prm->aln_mode;
+    if (aln_mode == 2) { uint64_t mx = 0; for (uint64_t r = 0; r < reads->n; ++r) { uint64_t l = reads->off[r + 1] - reads->off[r]; if (l > mx) mx = l; } aln_mode = mx <= 1024 ? 1 : 0; }
     uint64_t total = 0; int overflow = 0; out_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         int Blen = (int)(backbones->off[g + 1] - backbones->off[g]);
@@ -409,7 +412,8 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
                 if (orient[i] < 0) continue;
                 const int n = rl[i];
                 uint8_t* ops = malloc((size_t)(n + Blen + 2));
-                int c = ongsid_i_sg_ops(rs[i], n, B, Blen, prm->aln_match, prm->aln_mismatch, prm->aln_open, prm->aln_ext, ops);
+                int c = aln_mode == 1 ? ongsid_i_ed_ops(rs[i], n, B, Blen, ops)
+                                           : ongsid_i_sg_ops(rs[i], n, B, Blen, prm->aln_match, prm->aln_mismatch, prm->aln_open, prm->aln_ext, ops);
                 int qi = 0, ti = 0, qb = -1, tb = -1, qe = -1, te = -1;
                 int* wf = malloc(sizeof(int) * 4 * ((size_t)nwin + 1)); for (int x = 0; x < 4 * nwin; ++x) wf[x] = -1;
                 for (int x = 0; x < c; ++x) {

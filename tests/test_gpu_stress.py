@@ -61,3 +61,14 @@ def test_cluster_volume_matches_oracle(gpu_api, oracle, n_reads, n_species, div,
     bad = np.nonzero((rep != orep) | (st != ost))[0]
     assert len(bad) == 0, "cluster: %d reads differ, first %s got %s exp %s" % (len(bad), bad[:8], rep[bad[:8]], orep[bad[:8]])
     assert np.array_equal(cnt, ocnt)
+
+
+TOOL_ED = os.path.join(ROOT, "tools", "stress_ed.py")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pairs,maxq,seed", [(6000, 1024, 3), (3000, 300, 5), (2500, 770, 4)])
+def test_edit_distance_aligner_matches_oracle(pairs, maxq, seed):
+    """bit-parallel polisher aligner (k_ed_align): distance, span and window break points vs the oracle's plain DP; every block-count
+    instance (queries up to 256 / 512 / 768 / 1024), partial last blocks, wildcards, lower case, empty and unrelated sequences"""
+    _run(pairs, maxq, seed, tool=TOOL_ED)
