@@ -134,14 +134,14 @@ template <int BMAX>
 static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_tlen, int32_t* dist_out)
 {
     const u64 nbundles = (job.npairs + 63) / 64;
-    const uint32_t mstride = max_tlen ? max_tlen : 1;
+    const uint32_t mstride = (max_tlen + 63u) & ~63u;                     // rounded so that backbones growing by a few bases between iterations reuse the scratch
     const u64 per_wave = (u64)BMAX * mstride * 64;                         // 16-byte units
     const size_t lds = (size_t)BMAX * 3 * 64 * 8;
     int occ = 0;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ed_align<BMAX>, 64, lds));
     if (occ < 1) occ = 1;
     u64 want = std::min<u64>(nbundles, (u64)occ * ctx->n_cu);
-    const u64 by_mem = std::max<u64>(1, ((size_t)12 << 30) / (per_wave * 16));
+    const u64 by_mem = std::max<u64>(1, ((size_t)24 << 30) / (per_wave * 16));
     want = std::max<u64>(1, std::min(want, by_mem));
     if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.alloc(want * per_wave));
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));

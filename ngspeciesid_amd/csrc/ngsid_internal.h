@@ -16,7 +16,10 @@ template <typename T> struct DevBuf {
     DevBuf() {}
     DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; if (!count) count = 1; return hipMalloc((void**)&p, count * sizeof(T)); }
+    size_t cap = 0;
+    hipError_t alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; if (!count) count = 1; cap = count; return hipMalloc((void**)&p, count * sizeof(T)); }
+    // grow-only, contents not kept: for scratch that is reused call after call (hipMalloc/hipFree of GB-sized buffers cost milliseconds and synchronise)
+    hipError_t reserve(size_t count) { if (p && count <= cap) { n = count; return hipSuccess; } return alloc(count + count / 8); }
     hipError_t grow(size_t count, hipStream_t s) {   // keeps contents
         if (count <= n) return hipSuccess;
         T* q = nullptr; hipError_t e = hipMalloc((void**)&q, count * sizeof(T)); if (e != hipSuccess) return e;
@@ -40,6 +43,9 @@ struct ngsid_ctx {
     DevBuf<uint32_t> aln_cls; // pair lists of the length classes
     DevBuf<ngsid_v4u_t> ed_tb; // traceback vectors of the edit-distance aligner
     DevBuf<uint32_t> poa_ctr; // POA tile work-queue counter
+    struct PoaLevelBufs { DevBuf<uint8_t> out, seqs /* PSeq[] */; DevBuf<int32_t> out_len, job_bb; DevBuf<uint64_t> out_cw; DevBuf<uint32_t> out_n, out_cov, job_off, seq_idx, flags; };
+    PoaLevelBufs poa_lv[2];   // hierarchy levels ping-pong between two buffer sets (level L+1 reads what level L wrote)
+    DevBuf<uint64_t> pol_mzcode; DevBuf<uint32_t> pol_mzpos; DevBuf<uint8_t> pol_oseq, pol_oqual, pol_valid; DevBuf<int32_t> pol_bp; DevBuf<uint8_t> pol_lay;   // polisher scratch (grow-only)
     bool debug_sync = false;
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)

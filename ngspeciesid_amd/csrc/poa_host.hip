@@ -2,12 +2,20 @@
 // and ngsid_polish (a16,a17).  Mirrors oracle/ngsid_oracle_poa.c: run_hierarchy / ongsid_poa_consensus / ongsid_polish.
 #include "ngsid_internal.h"
 #include "k_poa.h"
+#include <chrono>
 #include <algorithm>
 #include <vector>
 #include <string>
 #include <memory>
 
 namespace {
+// dev aid: NGSID_HOST_TIMERS=1 prints host-side wall time per section (stream synchronised at each mark)
+struct HostTimer {
+    bool on; hipStream_t st; std::chrono::steady_clock::time_point t0; const char* what;
+    HostTimer(hipStream_t s, const char* w) : on(getenv("NGSID_HOST_TIMERS") != nullptr), st(s), what(w) { if (on) { (void)hipStreamSynchronize(st); t0 = std::chrono::steady_clock::now(); } }
+    void mark(const char* label) { if (!on) return; (void)hipStreamSynchronize(st); auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[ngsid host] %s: %s %.2f ms\n", what, label, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
+};
+#define HT_INIT
 
 struct Unit {                       // one consensus problem: a cluster (spoa stage) or a backbone window (polish)
     std::vector<uint32_t> seqs;     // indices into the CURRENT level's PSeq array, in order
@@ -35,7 +43,6 @@ struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; i
 int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
                       std::vector<Unit>& units, const HierParams& hp)
 {
-    std::vector<std::unique_ptr<Level>> keep;
     const PSeq* cur = d_level0; uint32_t cur_maxlen = maxlen0;
     int slots_cap = 0;
     for (int level = 0;; ++level) {
@@ -61,17 +68,17 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
         long long capV = (long long)maxL0 * (hp.node_cap > 0 ? hp.node_cap : 28) / 16; capV = std::max<long long>(capV, maxL0 + 64); capV = std::max<long long>(capV, (long long)cur_maxlen + 1);
         capV = (capV + 7) & ~7ll;
         const int Lmax = (int)((std::max<uint32_t>(cur_maxlen, 1) + 15) & ~15u);
-        DevBuf<uint32_t> d_job_off, d_seq_idx, d_flags; DevBuf<int32_t> d_job_bb;
-        HIPCHK(ctx, d_job_off.alloc(job_off.size())); HIPCHK(ctx, d_seq_idx.alloc(seq_idx.size())); HIPCHK(ctx, d_job_bb.alloc(job_bb.size())); HIPCHK(ctx, d_flags.alloc(4));
+        ngsid_ctx::PoaLevelBufs* Lv = &ctx->poa_lv[level & 1];      // level L+1 reads what level L wrote: two alternating, grow-only buffer sets
+        DevBuf<uint32_t>& d_job_off = Lv->job_off; DevBuf<uint32_t>& d_seq_idx = Lv->seq_idx; DevBuf<uint32_t>& d_flags = Lv->flags; DevBuf<int32_t>& d_job_bb = Lv->job_bb;
+        HIPCHK(ctx, d_job_off.reserve(job_off.size())); HIPCHK(ctx, d_seq_idx.reserve(seq_idx.size())); HIPCHK(ctx, d_job_bb.reserve(job_bb.size())); HIPCHK(ctx, d_flags.reserve(4));
         HIPCHK(ctx, hipMemcpyAsync(d_job_off.p, job_off.data(), 4 * job_off.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_seq_idx.p, seq_idx.data(), 4 * seq_idx.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_job_bb.p, job_bb.data(), 4 * job_bb.size(), hipMemcpyHostToDevice, ctx->stream));
         int slots = slots_cap ? slots_cap : (int)std::min<uint32_t>(maxD, 4);
-        std::unique_ptr<Level> Lv(new Level());
         std::vector<uint32_t> h_out_n; std::vector<int32_t> h_out_len; std::vector<uint64_t> h_out_cw;
         for (;;) {      // retry with more output slots if a tile had to split more often than `slots`
-            HIPCHK(ctx, Lv->out.alloc((size_t)njobs * slots * capV)); HIPCHK(ctx, Lv->out_len.alloc((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_cw.alloc((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_n.alloc(njobs));
-            if (hp.want_cov) HIPCHK(ctx, Lv->out_cov.alloc((size_t)njobs * slots * capV));
+            HIPCHK(ctx, Lv->out.reserve((size_t)njobs * slots * capV)); HIPCHK(ctx, Lv->out_len.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_cw.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_n.reserve(njobs));
+            if (hp.want_cov) HIPCHK(ctx, Lv->out_cov.reserve((size_t)njobs * slots * capV));
             HIPCHK(ctx, hipMemsetAsync(d_flags.p, 0, 16, ctx->stream));
             PoaJobSet J{};
             J.seqs = cur; J.bbs = d_bbs; J.seq_idx = d_seq_idx.p; J.job_off = d_job_off.p; J.job_bb = d_job_bb.p; J.njobs = njobs;
@@ -122,12 +129,11 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
                 U.seqs.push_back((uint32_t)next.size()); next.push_back(S); next_maxlen = std::max<uint32_t>(next_maxlen, (uint32_t)S.len);
             }
         }
-        if (next.empty()) { keep.push_back(std::move(Lv)); break; }
-        HIPCHK(ctx, Lv->seqs.alloc(next.size()));
+        if (next.empty()) break;
+        HIPCHK(ctx, Lv->seqs.reserve(sizeof(PSeq) * next.size()));
         HIPCHK(ctx, hipMemcpyAsync(Lv->seqs.p, next.data(), sizeof(PSeq) * next.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        cur = Lv->seqs.p; cur_maxlen = next_maxlen;
-        keep.push_back(std::move(Lv));
+        cur = (const PSeq*)Lv->seqs.p; cur_maxlen = next_maxlen;
     }
     return NGSID_OK;
 }
@@ -243,11 +249,13 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     if (!ctx) return NGSID_ERR_ARG;
     if (!backbones || !reads || !grp_off || !prm || !out_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
     if (backbones->n != n_groups) NGSID_FAIL(ctx, NGSID_ERR_ARG, "one backbone per group expected");
+    HostTimer ht(ctx->stream, "polish");
     DevReads RD; int32_t rc = ngsid_upload_reads(ctx, reads, &RD, false); if (rc) return rc;
     if (!read_order && grp_off[n_groups] > RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "group offsets exceed the read set");
     if (read_order) for (uint64_t x = 0; x < grp_off[n_groups]; ++x) if (read_order[x] >= RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "read_order[%llu] out of range", (unsigned long long)x);
     const uint64_t N = RD.n; const uint32_t G = (uint32_t)n_groups;
     const int W = prm->window > 0 ? prm->window : 500;
+    ht.mark("upload + checks");
     // backbones to host strings (they are tiny and are rebuilt on the host after every iteration)
     std::vector<std::string> B(G);
     {
@@ -270,9 +278,10 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         for (uint64_t x = grp_off[g]; x < grp_off[g + 1]; ++x) { const uint64_t r = read_order ? read_order[x] : x; h_rgroup[r] = g; tot += (double)(RD.h_off[r + 1] - RD.h_off[r]); }
         tgs[g] = ns > 0 && (tot / (double)ns) > 1000.0;
     }
+    ht.mark("group map");
     // ---- strand detection (replaces minimap2's strand call): shared HPC minimizers with the initial backbone, fw vs rc
-    DevBuf<uint64_t> mzcode; DevBuf<uint32_t> mzpos, mzcnt, hlen, d_rgroup; DevBuf<double> herr, rawerr; DevBuf<int> flag; DevBuf<uint8_t> d_orient;
-    HIPCHK(ctx, mzcode.alloc(RD.total + 1)); HIPCHK(ctx, mzpos.alloc(RD.total + 1)); HIPCHK(ctx, mzcnt.alloc(N)); HIPCHK(ctx, hlen.alloc(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N));
+    DevBuf<uint64_t>& mzcode = ctx->pol_mzcode; DevBuf<uint32_t>& mzpos = ctx->pol_mzpos; DevBuf<uint32_t> mzcnt, hlen, d_rgroup; DevBuf<double> herr, rawerr; DevBuf<int> flag; DevBuf<uint8_t> d_orient;
+    HIPCHK(ctx, mzcode.reserve(RD.total + 1)); HIPCHK(ctx, mzpos.reserve(RD.total + 1)); HIPCHK(ctx, mzcnt.alloc(N)); HIPCHK(ctx, hlen.alloc(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N));
     HIPCHK(ctx, flag.alloc(1)); HIPCHK(ctx, d_rgroup.alloc(N)); HIPCHK(ctx, d_orient.alloc(N));
     HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_rgroup.p, h_rgroup.data(), 4 * N, hipMemcpyHostToDevice, ctx->stream));
@@ -310,21 +319,22 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     }
     std::vector<uint8_t> h_orient(N);
     HIPCHK(ctx, hipMemcpy(h_orient.data(), d_orient.p, N, hipMemcpyDeviceToHost));
-    (void)mzcode.alloc(0); (void)mzpos.alloc(0);
+    ht.mark("minimizers + strand");
     // ---- oriented copies of the reads
-    DevBuf<uint8_t> oseq, oqual; HIPCHK(ctx, oseq.alloc(RD.total + 16)); if (RD.qual) HIPCHK(ctx, oqual.alloc(RD.total + 16));
+    DevBuf<uint8_t>& oseq = ctx->pol_oseq; DevBuf<uint8_t>& oqual = ctx->pol_oqual; HIPCHK(ctx, oseq.reserve(RD.total + 16)); if (RD.qual) HIPCHK(ctx, oqual.reserve(RD.total + 16));
     { ProfScope ps_(ctx, "k_orient"); hipLaunchKernelGGL(k_orient, dim3((unsigned)N), dim3(128), 0, ctx->stream, RD.seq, RD.qual, RD.off, N, d_orient.p, oseq.p, RD.qual ? oqual.p : nullptr); }
     HIPCHK(ctx, hipGetLastError());
     // ---- pairs (usable reads of reads that belong to a group), fixed over the iterations
     std::vector<uint32_t> pair_read, pair_group;
     for (uint64_t x = 0; x < grp_off[n_groups]; ++x) { const uint64_t r = read_order ? read_order[x] : x; if (h_orient[r] != 255) { pair_read.push_back((uint32_t)r); pair_group.push_back(h_rgroup[r]); } }
     const uint64_t NP = pair_read.size();
-    DevBuf<uint32_t> d_pair_read, d_pair_group; DevBuf<int32_t> d_open, d_span, d_bp, d_blen; DevBuf<PSeq> d_lay; DevBuf<uint8_t> d_valid;
+    DevBuf<uint32_t> d_pair_read, d_pair_group; DevBuf<int32_t> d_open, d_span, d_blen; DevBuf<int32_t>& d_bp = ctx->pol_bp; DevBuf<uint8_t>& d_lay_raw = ctx->pol_lay; DevBuf<uint8_t>& d_valid = ctx->pol_valid;
     HIPCHK(ctx, d_pair_read.alloc(NP)); HIPCHK(ctx, d_pair_group.alloc(NP)); HIPCHK(ctx, d_open.alloc(NP)); HIPCHK(ctx, d_span.alloc(NP * 4)); HIPCHK(ctx, d_blen.alloc(G));
     if (NP) { HIPCHK(ctx, hipMemcpyAsync(d_pair_read.p, pair_read.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d_pair_group.p, pair_group.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream));
               HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)d_open.p, prm->aln_open, NP, ctx->stream)); }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<uint64_t> used(G, 0);
+    ht.mark("orient + pairs");
 
     for (int it = 0; it < prm->iters; ++it) {
         // upload the current backbones
@@ -338,7 +348,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         std::vector<uint8_t> h_valid; int max_layer = 1;
         HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
         if (NP) {
-            HIPCHK(ctx, d_bp.alloc(NP * (uint64_t)nwinmax * 4)); HIPCHK(ctx, d_lay.alloc(NP * (uint64_t)nwinmax)); HIPCHK(ctx, d_valid.alloc(NP * (uint64_t)nwinmax));
+            HIPCHK(ctx, d_bp.reserve(NP * (uint64_t)nwinmax * 4)); HIPCHK(ctx, d_lay_raw.reserve(sizeof(PSeq) * NP * (uint64_t)nwinmax)); HIPCHK(ctx, d_valid.reserve(NP * (uint64_t)nwinmax));
             AlignJob J{};
             J.qseq = oseq.p; J.qoff = RD.off; J.tseq = BB.seq; J.toff = BB.off; J.qidx = d_pair_read.p; J.tidx = d_pair_group.p; J.npairs = NP;
             J.match = prm->aln_match; J.mismatch = prm->aln_mismatch; J.ext = prm->aln_ext; J.k = 1; J.open = d_open.p; J.match_id = nullptr;
@@ -349,13 +359,14 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             if (rc) return rc;
             const uint64_t T = NP * (uint64_t)nwinmax;
             { ProfScope ps_(ctx, "k_layers"); hipLaunchKernelGGL(k_layers, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, oseq.p, RD.qual ? oqual.p : nullptr, RD.off, d_pair_read.p, d_pair_group.p, NP, nwinmax,
-                               d_bp.p, d_span.p, d_blen.p, W, prm->quality_threshold, prm->error_threshold, d_lay.p, d_valid.p, flag.p); }
+                               d_bp.p, d_span.p, d_blen.p, W, prm->quality_threshold, prm->error_threshold, (PSeq*)d_lay_raw.p, d_valid.p, flag.p); }
             HIPCHK(ctx, hipGetLastError());
             h_valid.resize(T);
             HIPCHK(ctx, hipMemcpyAsync(&max_layer, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(h_valid.data(), d_valid.p, T, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
+        ht.mark("align + layers + valid copy");
         // ---- units = (group, window) with their layers in read order
         std::vector<std::vector<int>> unit_of(G);
         for (uint32_t g = 0; g < G; ++g) { const int nw = (int)((B[g].size() + W - 1) / W); unit_of[g].assign(nw, -1);
@@ -377,7 +388,9 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         if (!bbs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_bbs.p, bbs.data(), sizeof(PSeq) * bbs.size(), hipMemcpyHostToDevice, ctx->stream));
         bool any_tgs = prm->trim >= 2; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
         HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, prm->trim >= 2 ? 1 : 0};
-        rc = run_hierarchy(ctx, d_lay.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
+        ht.mark("unit lists");
+        rc = run_hierarchy(ctx, (const PSeq*)d_lay_raw.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
+        ht.mark("hierarchy");
         // ---- new backbones
         std::vector<std::string> NB(G);
         for (size_t u = 0; u < units.size(); ++u) {
