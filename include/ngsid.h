@@ -127,7 +127,7 @@ int32_t ngsid_sg_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const
  * with unit costs (target ends free).  Rules as in ngsid_polish_params_t.aln_mode.  Outputs per pair (any may be NULL):
  * distance; span = {q_first, q_last, t_first, t_last} of the aligned (match/mismatch) columns, -1 if none; and, per polishing
  * window w of `window` target bases (w < bp_windows), bp[(p*bp_windows+w)*4..] = {q_first, q_last, t_first, t_last} of the aligned
- * columns whose target position falls in the window, -1 if none.  Queries longer than 1 024 bases -> NGSID_ERR_TOO_LONG. */
+ * columns whose target position falls in the window, -1 if none. */
 int32_t ngsid_ed_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const ngsid_reads_t* targets,
                              const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
                              int32_t window, int32_t bp_windows, int32_t* distance, int32_t* span, int32_t* bp);
@@ -167,8 +167,8 @@ typedef struct {
     int32_t aln_mode;         /* read->backbone aligner: 0 = semi-global affine (aln_* scores, all end gaps free);
                                  1 = unit-cost edit distance, read end to end, backbone ends free (what racon gets from edlib inside the
                                  minimap2 span); traceback prefers match/mismatch, then a read-only column, then a backbone-only column;
-                                 end column = leftmost minimum of the last row; non-ACGT letters match nothing (reads <= 1 024 bases);
-                                 2 = automatic: mode 1 if the longest read of the read set has <= 1 024 bases, else mode 0 */
+                                 end column = leftmost minimum of the last row; non-ACGT letters match nothing;
+                                 2 = the library's default (currently mode 1) */
 } ngsid_polish_params_t;
 
 /* (a16,a17) replaces run_racon's (minimap2 -> racon) x racon_iter chain (consensus.py:107-126).

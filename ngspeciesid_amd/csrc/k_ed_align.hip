@@ -6,8 +6,8 @@
 //
 // Mapping: ONE PAIR PER LANE - the recurrence has no cross-lane dependency, so a wave advances 64 alignments and every VALU
 // instruction updates 64 x 64 DP cells (one 64-row block of 64 pairs).  Per target column the lane walks its query blocks top to
-// bottom (Hyyro/edlib block step with a horizontal carry); the block states Pv/Mv live in registers (template BMAX blocks, queries up
-// to 64*BMAX bases), the query as three bit planes per block in LDS (letter bit 0, bit 1, "is A/C/G/T").  For the traceback every
+// bottom (Hyyro/edlib block step with a horizontal carry); the block states Pv/Mv live in registers (template BMAX blocks; longer queries
+// run in groups of BMAX blocks with the horizontal deltas below a group carried through HBM), the query as three bit planes per block in LDS (letter bit 0, bit 1, "is A/C/G/T").  For the traceback every
 // (block, column) stores two 64-bit vectors: DIAG (a diagonal move is optimal) and UP (vertical delta +1) - one coalesced 1 KB store
 // per instruction - and each lane then walks its own path, one 16-byte L2 load per step, recording the window break points.
 // ~55 VALU instructions per (block, column) for 64 pairs: ~8 k wave instructions per 750 x 750 pair instead of ~190 k in k_sg_align16.
@@ -19,12 +19,14 @@ typedef unsigned long long u64;
 
 template <int BMAX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
-void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-byte units */, uint32_t mstride, uint32_t* __restrict__ work_ctr, int32_t* __restrict__ dist_out)
+void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-byte units */, uint32_t mstride, uint32_t* __restrict__ work_ctr, int32_t* __restrict__ dist_out,
+                int8_t* __restrict__ hcar /* per wave mstride x 64: horizontal delta below the last block of a block group */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     LDSP u64* planes = (LDSP u64*)smem;                     // [block][3][lane]
     ngsid_v4u* mytb = tb + (u64)blockIdx.x * tb_per_wave;
+    int8_t* myh = hcar + (u64)blockIdx.x * mstride * 64;
     const u64 nbundles = (J.npairs + 63) / 64;
     for (;;) {
         uint32_t kq = 0; if (lane == 0) kq = atomicAdd(work_ctr, 1u);
@@ -38,56 +40,62 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { nmax = max(nmax, __shfl_xor(nmax, d)); mmax = max(mmax, __shfl_xor(mmax, d)); }
         nmax = __builtin_amdgcn_readfirstlane(nmax); mmax = __builtin_amdgcn_readfirstlane(mmax);
-        const int B = (nmax + 63) >> 6;                     // blocks the wave walks (<= BMAX, guaranteed by the launcher)
-        // ---- query bit planes -> LDS
-        for (int b = 0; b < B; ++b) {
-            u64 lo = 0, hi = 0, ok = 0;
-            const int base = b * 64;
-            for (int r = 0; r < 64; ++r) {
-                const int i = base + r;
-                const int c = i < n ? ngsid_bcode(q[i]) : 4;
-                lo |= (u64)(c & 1) << r; hi |= (u64)((c >> 1) & 1) << r; ok |= (u64)(c < 4) << r;
-            }
-            planes[(b * 3 + 0) * 64 + lane] = lo; planes[(b * 3 + 1) * 64 + lane] = hi; planes[(b * 3 + 2) * 64 + lane] = ok;
-        }
-        u64 Pv[BMAX], Mv[BMAX];
-#pragma unroll
-        for (int b = 0; b < BMAX; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
+        const int B = (nmax + 63) >> 6;                     // 64-row blocks the wave walks, in groups of BMAX (register-resident states)
         const int bl = n > 0 ? (n - 1) >> 6 : 0, lastbit = n > 0 ? (n - 1) & 63 : 0;
         int score = n, best = n, bestj = 0;                 // D[n][0] = n
-        // ---- forward: column by column, blocks top to bottom
-        for (int j = 0; j < mmax; ++j) {
-            const int tc = j < m ? ngsid_bcode(t[j]) : 4;
-            const u64 Tlo = (tc & 1) ? ~0ull : 0ull, Thi = (tc & 2) ? ~0ull : 0ull, Tok = tc < 4 ? ~0ull : 0ull;
-            int hin = 0;                                    // top row of the matrix is all zeros (target prefix free)
-            ngsid_v4u* col = mytb + ((u64)j * 64 + lane);
-#pragma unroll
-            for (int b = 0; b < BMAX; ++b) {
-                if (b < B) {
-                    const u64 lo = planes[(b * 3 + 0) * 64 + lane], hi = planes[(b * 3 + 1) * 64 + lane], ok = planes[(b * 3 + 2) * 64 + lane];
-                    const u64 Eq = ~(lo ^ Tlo) & ~(hi ^ Thi) & ok & Tok;
-                    const u64 pv = Pv[b], mv = Mv[b];
-                    const u64 Xv = Eq | mv;
-                    const u64 Eqh = Eq | (hin < 0 ? 1ull : 0ull);
-                    const u64 Xh = (((Eqh & pv) + pv) ^ pv) | Eqh;
-                    u64 Ph = mv | ~(Xh | pv), Mh = pv & Xh;
-                    // moves (oracle: diagonal if D[i-1][j-1] + neq == D[i][j]): a match always qualifies; a mismatch iff the diagonal delta
-                    // h(i,j) + v(i,j-1) is +1, i.e. (h,v) = (+1,0) or (0,+1)
-                    const u64 diag = Eq | (Ph & ~(pv | mv)) | (~(Ph | Mh) & pv);
-                    const int hout63 = (int)((Ph >> 63) & 1) - (int)((Mh >> 63) & 1);
-                    if (b == bl && j < m) {
-                        score += (int)((Ph >> lastbit) & 1) - (int)((Mh >> lastbit) & 1);
-                        if (score < best) { best = score; bestj = j + 1; }
-                    }
-                    Ph <<= 1; Mh <<= 1;
-                    if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
-                    const u64 npv = Mh | ~(Xv | Ph);
-                    Pv[b] = npv; Mv[b] = Ph & Xv;
-                    ngsid_v4u w; w.x = (unsigned)diag; w.y = (unsigned)(diag >> 32); w.z = (unsigned)npv; w.w = (unsigned)(npv >> 32);
-                    col[(u64)b * mstride * 64] = w;
-                    hin = hout63;
+        for (int g0 = 0; g0 < B; g0 += BMAX) {
+            const int Bg = min(BMAX, B - g0);
+            // ---- query bit planes of the group -> LDS
+            for (int b = 0; b < Bg; ++b) {
+                u64 lo = 0, hi = 0, ok = 0;
+                const int base = (g0 + b) * 64;
+                for (int r = 0; r < 64; ++r) {
+                    const int i = base + r;
+                    const int c = i < n ? ngsid_bcode(q[i]) : 4;
+                    lo |= (u64)(c & 1) << r; hi |= (u64)((c >> 1) & 1) << r; ok |= (u64)(c < 4) << r;
                 }
+                planes[(b * 3 + 0) * 64 + lane] = lo; planes[(b * 3 + 1) * 64 + lane] = hi; planes[(b * 3 + 2) * 64 + lane] = ok;
             }
+            u64 Pv[BMAX], Mv[BMAX];
+#pragma unroll
+            for (int b = 0; b < BMAX; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
+            const bool more = g0 + BMAX < B;                // a further group follows: keep the horizontal deltas of this group's last row
+            // ---- forward: column by column, blocks top to bottom
+            for (int j = 0; j < mmax; ++j) {
+                const int tc = j < m ? ngsid_bcode(t[j]) : 4;
+                const u64 Tlo = (tc & 1) ? ~0ull : 0ull, Thi = (tc & 2) ? ~0ull : 0ull, Tok = tc < 4 ? ~0ull : 0ull;
+                int hin = g0 ? (int)myh[(u64)j * 64 + lane] : 0;      // top row of the matrix is all zeros (target prefix free)
+                ngsid_v4u* col = mytb + ((u64)j * 64 + lane);
+#pragma unroll
+                for (int b = 0; b < BMAX; ++b) {
+                    if (b < Bg) {
+                        const u64 lo = planes[(b * 3 + 0) * 64 + lane], hi = planes[(b * 3 + 1) * 64 + lane], ok = planes[(b * 3 + 2) * 64 + lane];
+                        const u64 Eq = ~(lo ^ Tlo) & ~(hi ^ Thi) & ok & Tok;
+                        const u64 pv = Pv[b], mv = Mv[b];
+                        const u64 Xv = Eq | mv;
+                        const u64 Eqh = Eq | (hin < 0 ? 1ull : 0ull);
+                        const u64 Xh = (((Eqh & pv) + pv) ^ pv) | Eqh;
+                        u64 Ph = mv | ~(Xh | pv), Mh = pv & Xh;
+                        // moves (oracle: diagonal if D[i-1][j-1] + neq == D[i][j]): a match always qualifies; a mismatch iff the diagonal delta
+                        // h(i,j) + v(i,j-1) is +1, i.e. (h,v) = (+1,0) or (0,+1)
+                        const u64 diag = Eq | (Ph & ~(pv | mv)) | (~(Ph | Mh) & pv);
+                        const int hout63 = (int)((Ph >> 63) & 1) - (int)((Mh >> 63) & 1);
+                        if (g0 + b == bl && j < m) {
+                            score += (int)((Ph >> lastbit) & 1) - (int)((Mh >> lastbit) & 1);
+                            if (score < best) { best = score; bestj = j + 1; }
+                        }
+                        Ph <<= 1; Mh <<= 1;
+                        if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+                        const u64 npv = Mh | ~(Xv | Ph);
+                        Pv[b] = npv; Mv[b] = Ph & Xv;
+                        ngsid_v4u w; w.x = (unsigned)diag; w.y = (unsigned)(diag >> 32); w.z = (unsigned)npv; w.w = (unsigned)(npv >> 32);
+                        col[(u64)(g0 + b) * mstride * 64] = w;
+                        hin = hout63;
+                    }
+                }
+                if (more) myh[(u64)j * 64 + lane] = (int8_t)hin;
+            }
+            if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -131,11 +139,12 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
 }
 
 template <int BMAX>
-static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_tlen, int32_t* dist_out)
+static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out)
 {
     const u64 nbundles = (job.npairs + 63) / 64;
     const uint32_t mstride = (max_tlen + 63u) & ~63u;                     // rounded so that backbones growing by a few bases between iterations reuse the scratch
-    const u64 per_wave = (u64)BMAX * mstride * 64;                         // 16-byte units
+    const u64 nblocks = std::max<u64>(1, ((u64)max_qlen + 63) / 64);
+    const u64 per_wave = nblocks * mstride * 64;                           // 16-byte units
     const size_t lds = (size_t)BMAX * 3 * 64 * 8;
     int occ = 0;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ed_align<BMAX>, 64, lds));
@@ -143,10 +152,11 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_tlen,
     u64 want = std::min<u64>(nbundles, (u64)occ * ctx->n_cu);
     const u64 by_mem = std::max<u64>(1, ((size_t)24 << 30) / (per_wave * 16));
     want = std::max<u64>(1, std::min(want, by_mem));
-    if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.alloc(want * per_wave));
+    if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.reserve(want * per_wave));
+    if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
     HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + 14, 0, sizeof(uint32_t), ctx->stream));
-    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + 14, dist_out); }
+    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + 14, dist_out, ctx->ed_h.p); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }
@@ -154,10 +164,9 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_tlen,
 int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out)
 {
     if (job.npairs == 0) return NGSID_OK;
-    if (max_qlen > 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "edit-distance polisher alignment supports reads up to 1024 bases (got %u): use aln_mode 0", max_qlen);
-    if (max_tlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "backbone longer than %d", NGSID_MAX_READ_LEN);
-    if (max_qlen <= 256) return launch_ed<4>(ctx, job, max_tlen, dist_out);
-    if (max_qlen <= 512) return launch_ed<8>(ctx, job, max_tlen, dist_out);
-    if (max_qlen <= 768) return launch_ed<12>(ctx, job, max_tlen, dist_out);
-    return launch_ed<16>(ctx, job, max_tlen, dist_out);
+    if (max_qlen > NGSID_MAX_READ_LEN || max_tlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in the edit-distance aligner", NGSID_MAX_READ_LEN);
+    if (max_qlen <= 256) return launch_ed<4>(ctx, job, max_qlen, max_tlen, dist_out);
+    if (max_qlen <= 512) return launch_ed<8>(ctx, job, max_qlen, max_tlen, dist_out);
+    if (max_qlen <= 768) return launch_ed<12>(ctx, job, max_qlen, max_tlen, dist_out);
+    return launch_ed<16>(ctx, job, max_qlen, max_tlen, dist_out);          // longer queries: groups of 16 blocks, horizontal deltas carried through HBM
 }

@@ -353,7 +353,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             J.qseq = oseq.p; J.qoff = RD.off; J.tseq = BB.seq; J.toff = BB.off; J.qidx = d_pair_read.p; J.tidx = d_pair_group.p; J.npairs = NP;
             J.match = prm->aln_match; J.mismatch = prm->aln_mismatch; J.ext = prm->aln_ext; J.k = 1; J.open = d_open.p; J.match_id = nullptr;
             J.score = nullptr; J.ncols = nullptr; J.nmatch = nullptr; J.region = nullptr; J.bp = d_bp.p; J.bp_windows = nwinmax; J.window = W; J.span = d_span.p;
-            const int aln_mode = prm->aln_mode == 2 ? (RD.maxlen <= 1024 ? 1 : 0) : prm->aln_mode;
+            const int aln_mode = prm->aln_mode == 2 ? 1 : prm->aln_mode;
             if (aln_mode == 1) rc = ngsid_launch_ed_align(ctx, J, RD.maxlen, maxb, nullptr);          // unit-cost, bit-parallel (k_ed_align.hip)
             else rc = ngsid_launch_align(ctx, J, RD.maxlen, maxb, prm->aln_open);
             if (rc) return rc;

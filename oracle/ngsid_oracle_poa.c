@@ -372,7 +372,7 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
     pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->trim >= 2 };
     const int W = prm->window > 0 ? prm->window : 500;
     int aln_mode = prm->aln_mode;
-    if (aln_mode == 2) { uint64_t mx = 0; for (uint64_t r = 0; r < reads->n; ++r) { uint64_t l = reads->off[r + 1] - reads->off[r]; if (l > mx) mx = l; } aln_mode = mx <= 1024 ? 1 : 0; }
+    if (aln_mode == 2) aln_mode = 1;
     uint64_t total = 0; int overflow = 0; out_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         int Blen = (int)(backbones->off[g + 1] - backbones->off[g]);

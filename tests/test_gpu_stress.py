@@ -67,8 +67,8 @@ TOOL_ED = os.path.join(ROOT, "tools", "stress_ed.py")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pairs,maxq,seed", [(6000, 1024, 3), (3000, 300, 5), (2500, 770, 4)])
+@pytest.mark.parametrize("pairs,maxq,seed", [(6000, 1024, 3), (3000, 300, 5), (2500, 770, 4), (900, 2600, 7)])
 def test_edit_distance_aligner_matches_oracle(pairs, maxq, seed):
     """bit-parallel polisher aligner (k_ed_align): distance, span and window break points vs the oracle's plain DP; every block-count
-    instance (queries up to 256 / 512 / 768 / 1024), partial last blocks, wildcards, lower case, empty and unrelated sequences"""
+    instance (queries up to 256 / 512 / 768 / 1024 and block groups beyond), partial last blocks, wildcards, lower case, empty and unrelated sequences"""
     _run(pairs, maxq, seed, tool=TOOL_ED)

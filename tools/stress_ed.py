@@ -1,6 +1,6 @@
 """dev tool / stress parity of the edit-distance polisher aligner (HIP bit-parallel kernel vs the oracle's plain DP).
 
-    python tools/stress_ed.py [n_pairs] [max_qlen<=1024] [seed]
+    python tools/stress_ed.py [n_pairs] [max_qlen] [seed]
 Exit code 1 on any difference in distance, span or window break points.
 """
 import sys, os, time
