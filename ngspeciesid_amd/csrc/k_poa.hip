@@ -194,6 +194,76 @@ __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int com
     return best;
 }
 
+// First (complete) pass of the heaviest-bundle recurrence, data-parallel.  The predecessor of a rank is chosen by edge weight alone
+// unless two in-edges tie or there are more than two of them ("hard" ranks, a fraction of a percent), so for up to 64 consecutive ranks
+// every lane knows its predecessor immediately and the scores sc[r] = w + sc[pred] are path sums: pointer jumping inside the chunk
+// (6 rounds of lane shuffles), predecessors before the chunk come from LDS.  A chunk ends in front of the first hard rank whose
+// candidates lie inside it; that rank opens the next chunk with all its candidates final.  Same results as bundle_pass(.., 0, 0, ..).
+template <int BW>
+__device__ int bundle_pass_parallel(const GG& g, const LLT<BW>& w, int V, int lane)
+{
+    int best = -1; long long best_sv = 0;
+    int r0 = 0;
+    while (r0 < V) {
+        const int r = r0 + lane; const bool valid = r < V;
+        int t0 = NONE16, t1 = NONE16, w0 = 0, w1 = 0, v = 0; bool many = false;
+        if (valid) {
+            v = g.order(r); const int e0 = g.in_first(v);
+            if (e0 != NONE16) {
+                t0 = g.rank(g.e_tail(e0)); w0 = g.e_w(e0);
+                const int e1 = g.e_next_in(e0);
+                if (e1 != NONE16) { t1 = g.rank(g.e_tail(e1)); w1 = g.e_w(e1); many = g.e_next_in(e1) != NONE16; }
+            }
+            if (g.out_first(v) == NONE16) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
+        }
+        const bool hard = valid && (many || (t1 != NONE16 && w0 == w1));
+        // candidates of a hard rank inside the chunk?  (with more than two in-edges: be conservative, look at the first two only if both
+        // are early, else treat as inside - such ranks are rare)
+        const bool inside = hard && (many ? true : (t0 >= r0 || t1 >= r0));
+        unsigned long long cm = __ballot(inside && lane > 0);
+        // a rank with many in-edges at lane 0 has all candidates before the chunk by definition
+        const int n = min(min(64, V - r0), cm ? __ffsll((long long)cm) - 1 : 64);
+        const bool act = lane < n;
+        int pv = NONE16; long long val = -1, extv = 0; int ptr = -1;
+        if (act) {
+            long long wv = -1;
+            if (many) {                                   // lane 0 only: walk the list, all tails are final
+                long long spv = 0;
+                for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) {
+                    const int t = g.rank(g.e_tail(e)); const long long st_ = w.sc()[t]; const long long ww = g.e_w(e);
+                    if (wv < ww || (wv == ww && pv != NONE16 && spv <= st_)) { wv = ww; pv = t; spv = st_; }
+                }
+            } else if (t0 != NONE16) {
+                wv = w0; pv = t0;
+                if (t1 != NONE16) {
+                    bool take = w0 < w1;
+                    if (w0 == w1) take = w.sc()[t0] <= w.sc()[t1];       // hard rank whose candidates are final (both before the chunk)
+                    if (take) { wv = w1; pv = t1; }
+                }
+            }
+            val = wv;
+            if (pv != NONE16) { if (pv >= r0) ptr = pv - r0; else extv = w.sc()[pv]; }
+        }
+        // path sums by pointer jumping (ptr < 0: the chain has left the chunk, extv holds the score it ends on)
+#pragma unroll
+        for (int round = 0; round < 6; ++round) {
+            const int src = ptr >= 0 ? ptr : lane;
+            const long long v2 = __shfl(val, src), e2 = __shfl(extv, src); const int p2 = __shfl(ptr, src);
+            if (ptr >= 0) { val += v2; extv = e2; ptr = p2; }
+        }
+        const long long sv = val + extv;
+        if (act) { w.sc()[r] = sv; w.epred[r] = (uint16_t)pv; }
+        // best of the chunk: largest score, first rank on ties
+        long long bv = act ? sv : (long long)0x8000000000000000ll; int bl_ = act ? lane : 64;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const long long ov = __shfl_xor(bv, d); const int ol = __shfl_xor(bl_, d); if (ov > bv || (ov == bv && ol < bl_)) { bv = ov; bl_ = ol; } }
+        if (best < 0 || best_sv < bv) { best = r0 + bl_; best_sv = bv; }
+        lds_sync();                                       // sc[] of this chunk before the next chunk's lookups
+        r0 += n;
+    }
+    return __builtin_amdgcn_readfirstlane(best);
+}
+
 // heaviest bundle + branch completion (oracle g_consensus)
 template <int BW>
 __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uint32_t job, TS& st, int lane)
@@ -208,7 +278,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     mem_sync();
     for (int x = lane; x < (V + 31) / 32; x += 64) w.sinkbits[x] = 0;
     lds_sync();
-    int mx = bundle_pass(g, w, V, 0, 0, lane);
+    int mx = bundle_pass_parallel(g, w, V, lane);
     unsigned long long tph2 = tph; PH(J, 13, tph2);
     for (int guard = 0; !((w.sinkbits[mx >> 5] >> (mx & 31)) & 1u); ++guard) {
         if (guard > V) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow + 1, 2u); break; }   // cannot happen: each completion pass starts further down
@@ -226,12 +296,14 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     PH(J, 14, tph2);
     // backtrack: lane 0 lists the ranks of the path (HBM scratch), then all lanes translate rank -> letter / coverage
     int n = 0;
-    if (lane == 0) { for (int r = mx; r != NONE16; r = w.epred[r]) ++n; int i = n; for (int r = mx; r != NONE16; r = w.epred[r]) g.tmpo(--i) = (uint16_t)r; }
+    // one walk over the predecessor chain: ranks are written from the END of the scratch array, the path then starts at tmpo[V - n]
+    if (lane == 0) { int i = V; for (int r = mx; r != NONE16; r = w.epred[r]) g.tmpo(--i) = (uint16_t)r; n = V - i; }
     n = __builtin_amdgcn_readfirstlane(n);
+    const int poff = V - n;
     mem_sync();
     PH(J, 15, tph2);
     for (int i = lane; i < n; i += 64) {
-        const int v = g.order(g.tmpo(i)); dst[i] = g.code(v);
+        const int v = g.order(g.tmpo(poff + i)); dst[i] = g.code(v);
         if (dcov) { uint32_t c = g.cov(v); for (int u = g.ring(v); u != v; u = g.ring(u)) c += g.cov(u); dcov[i] = c; }
     }
     mem_sync();
