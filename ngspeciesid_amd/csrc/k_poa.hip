@@ -279,7 +279,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     for (int x = lane; x < (V + 31) / 32; x += 64) w.sinkbits[x] = 0;
     lds_sync();
     int mx = bundle_pass_parallel(g, w, V, lane);
-    unsigned long long tph2 = tph; PH(J, 13, tph2);
+    unsigned long long tph2 = tph;
     for (int guard = 0; !((w.sinkbits[mx >> 5] >> (mx & 31)) & 1u); ++guard) {
         if (guard > V) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow + 1, 2u); break; }   // cannot happen: each completion pass starts further down
         const int start = mx;
@@ -293,7 +293,6 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
         if (m2 < 0) break;
         mx = m2;
     }
-    PH(J, 14, tph2);
     // backtrack: lane 0 lists the ranks of the path (HBM scratch), then all lanes translate rank -> letter / coverage
     int n = 0;
     // one walk over the predecessor chain: ranks are written from the END of the scratch array, the path then starts at tmpo[V - n]
@@ -658,39 +657,50 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     if (aligned_any) {
         int r = bestr, j = (int)(__builtin_amdgcn_readfirstlane((unsigned)g.ri(bestr)) & 0xffff) + bestc;
         int blk_lo = (V - 1) & ~(TBR - 1);                 // the forward pass left the last (partial) block of direction rows in LDS
+        // lane k keeps the row info of rank blk_lo + k in registers (k < TBR): one LDS read per iteration (the direction byte) instead of two
+        unsigned long long myri = lane < TBR ? w.rblk()[lane] : 0ull;
+        int n_reload = 0, n_iter = 0; unsigned long long c_reload = 0;
         for (int guard = 0;; ++guard) {
+            ++n_iter;
             if (guard > 2 * (V + L) + 64) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow + 1, 1u); break; }   // cannot happen: every iteration consumes a move (reported by the host as an internal error)
             if (r < blk_lo) {
                 lds_sync();
                 blk_lo = r & ~(TBR - 1);                    // aligned blocks of TBR rows, same layout as the forward pass staged them
+                ++n_reload;
+                const unsigned long long trl0 = J.phase_cycles ? __builtin_readcyclecounter() : 0;
                 constexpr int LPR = 64 / TBR;                         // lanes per direction row
                 const int rr = blk_lo + lane / LPR;
                 {
                     const uint8_t* src = Dg + (size_t)rr * BW; l8 dstp = w.dirblk() + (size_t)(lane / LPR) * BW;
                     for (int x = (lane % LPR) * 16; x < BW; x += 16 * LPR) *(LDSP ngsid_v4u*)(dstp + x) = ngsid_load16_l2(src + x);   // L2-served: rows are rewritten per sequence
-                    if (lane < TBR) w.rblk()[lane] = g.ri(blk_lo + lane);
+                    myri = lane < TBR ? g.ri(blk_lo + lane) : 0ull;
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+                if (J.phase_cycles) c_reload += __builtin_readcyclecounter() - trl0;
             }
-            const int rk = r - lane, jk = j - lane;
-            bool loaded = false, good = false; int dk = 0; unsigned long long rik = 0;
-            if (rk >= blk_lo) {
-                rik = w.rblk()[rk - blk_lo];
-                const int ck = jk - (int)(rik & 0xffff);
-                if (ck >= 0 && ck < BW) { dk = w.dirblk()[(size_t)(rk - blk_lo) * BW + ck]; loaded = true; good = dk == 0 && ((rik >> 56) & 16) && jk >= 1; }
+            // lane k looks at row blk_lo + k: the cell the path reaches there if it only takes diagonal moves through chain rows from (r, j)
+            const int top = r - blk_lo;                        // 0 .. TBR-1
+            const int jk = j - (top - lane);
+            bool loaded = false, good = false; int dk = 0;
+            if (lane <= top) {
+                const int ck = jk - (int)(myri & 0xffff);
+                if (ck >= 0 && ck < BW) { dk = w.dirblk()[(size_t)lane * BW + ck]; loaded = true; good = dk == 0 && ((myri >> 56) & 16) && jk >= 1; }
             }
             const unsigned long long gm = __ballot(good), lm = __ballot(loaded);
 #ifdef POA_NO_SPEC
             const int run = 0;
 #else
-            const int run = (~gm) ? __builtin_ctzll(~gm) : 64;
+            const unsigned long long x = gm << (63 - top);     // lane `top` at bit 63: leading ones = the run
+            const int run = (~x) ? __builtin_clzll(~x) : 64;   // <= top + 1 because lanes above `top` never set their bit
 #endif
-            if (lane < run) w.alnode[jk - 1] = (uint16_t)rk;            // `run` diagonal moves, each to the previous rank
+            if (lane <= top && lane > top - run) w.alnode[jk - 1] = (uint16_t)(blk_lo + lane);      // `run` diagonal moves, each to the previous rank
             r -= run; j -= run;
-            if (run == 64 || !((lm >> run) & 1)) { if (run == 0) break; continue; }   // next cell not inspected (block edge): go round again (run == 0 cannot happen: the current cell is always inside its band)
-            const int d = __builtin_amdgcn_readlane(dk, run);
-            const unsigned rlo = __builtin_amdgcn_readlane((unsigned)rik, run), rhi = __builtin_amdgcn_readlane((unsigned)(rik >> 32), run);
+            const int nk = top - run;                          // lane holding the next cell of the path
+            if (nk < 0) continue;                              // it is in the block below: go round (loads it)
+            if (!((lm >> nk) & 1)) break;                      // cannot happen: the current cell is always inside its band
+            const int d = __builtin_amdgcn_readlane(dk, nk);
+            const unsigned rlo = __builtin_amdgcn_readlane((unsigned)myri, nk), rhi = __builtin_amdgcn_readlane((unsigned)(myri >> 32), nk);
             const int type = d & 3, slot = d >> 2;
             if (type == 3) break;
             if (type == 2) { --j; continue; }
@@ -701,6 +711,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             else { int e = g.in_first(g.order(r)); for (int t = 0; t < slot; ++t) e = g.e_next_in(e); pr = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(e))); }
             r = pr;
         }
+        if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[7], (unsigned long long)n_iter); atomicAdd(&J.phase_cycles[13], (unsigned long long)n_reload); atomicAdd(&J.phase_cycles[14], c_reload); }
     }
     lds_sync();
     PH(J, 2, tph);

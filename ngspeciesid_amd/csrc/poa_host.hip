@@ -95,7 +95,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
             HIPCHK(ctx, hipMemcpyAsync(h_out_len.data(), Lv->out_len.p, 4ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(h_out_cw.data(), Lv->out_cw.p, 8ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            if (want_ph) { unsigned long long h[16]; HIPCHK(ctx, hipMemcpy(h, d_ph.p, 128, hipMemcpyDeviceToHost)); fprintf(stderr, "[ngsid poa phases, Mcycles] jobs %u prepass %.1f forward %.1f traceback %.1f update %.1f emit %.1f | rows %llu non-chain %llu | sums: bestv %llu bestpk %llu nnew %llu alnsum %llu outlen %llu | emit: bundle %.1f completion %.1f backtrack %.1f\n", njobs, h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[13] / 1e6, h[14] / 1e6, h[15] / 1e6); }
+            if (want_ph) { unsigned long long h[16]; HIPCHK(ctx, hipMemcpy(h, d_ph.p, 128, hipMemcpyDeviceToHost)); fprintf(stderr, "[ngsid poa phases, Mcycles] jobs %u prepass %.1f forward %.1f traceback %.1f update %.1f emit %.1f | rows %llu non-chain %llu | sums: bestv %llu bestpk %llu nnew %llu alnsum %llu outlen %llu | tb iters %llu reloads %llu reload Mcycles %.1f | emit backtrack %.1f\n", njobs, h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[7], h[13], h[14] / 1e6, h[15] / 1e6); }
             if (h_flags[2]) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA tile kernel loop guard tripped (code %u)", h_flags[2]);
             if (!h_flags[1]) break;
             if (slots >= (int)maxD) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA output slot overflow at full depth");
