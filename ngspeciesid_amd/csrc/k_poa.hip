@@ -36,7 +36,7 @@ typedef LDSP uint16_t* l16; typedef LDSP uint8_t* l8; typedef LDSP int32_t* l32;
 
 struct GG {   // graph arrays in the workgroup's HBM scratch: ONE base pointer + 32-bit byte offsets derived from three strides, so the
               // arrays cost 2+3 SGPRs instead of 34 and every access is a saddr+voffset global instruction
-    uint8_t* base; uint32_t s16, s8, se;      // bytes of one u16[Vc+1] array, one u8[Vc] array, one u16[Ec] array (16-byte multiples)
+    uint8_t* base; uint32_t s16, s8, se, sl;  // bytes of one u16[Vc+1] array, one u8[Vc] array, one u16[Ec] array, one u16[Lmax] array (16-byte multiples)
 #define GG_U16(name, k) __device__ __forceinline__ uint16_t& name(uint32_t i) const { return *(uint16_t*)(base + ((k) * s16 + 2u * i)); }
     GG_U16(anchor, 0) GG_U16(in_first, 1) GG_U16(in_last, 2) GG_U16(out_first, 3) GG_U16(out_last, 4) GG_U16(ring, 5) GG_U16(order, 6) GG_U16(rank, 7) GG_U16(tmpo, 8)
 #undef GG_U16
@@ -48,14 +48,21 @@ struct GG {   // graph arrays in the workgroup's HBM scratch: ONE base pointer +
     __device__ __forceinline__ int32_t& e_w(uint32_t i) const { return *(int32_t*)(base + (9u * s16 + 2u * s8 + 4u * se + 4u * i)); }
     __device__ __forceinline__ uint32_t& cov(uint32_t i) const { return *(uint32_t*)(base + (9u * s16 + 2u * s8 + 6u * se + 4u * i)); }
     __device__ __forceinline__ unsigned long long& ri(uint32_t i) const { return *(unsigned long long*)(base + (9u * s16 + 6u * s8 + 6u * se + 8u * i)); }   // per-rank row info of the current alignment
+    __device__ __forceinline__ long long& sc(uint32_t i) const { return *(long long*)(base + (9u * s16 + 14u * s8 + 6u * se + 8u * i)); }                    // heaviest-bundle scores per rank
+    __device__ __forceinline__ uint32_t& marks(uint32_t i) const { return *(uint32_t*)(base + (9u * s16 + 22u * s8 + 6u * se + 4u * i)); }                    // new nodes inserted before old rank i
+    // per sequence position (the alignment being merged): aligned rank / node, chosen existing node, insertion reference
+#define GG_L16(name, k) __device__ __forceinline__ uint16_t& name(uint32_t i) const { return *(uint16_t*)(base + (9u * s16 + 26u * s8 + 6u * se + 16u + (k) * sl + 2u * i)); }
+    GG_L16(alnode, 0) GG_L16(nodeof, 1) GG_L16(ref, 2)
+#undef GG_L16
 };
-// LDS working set.  ~16 KB per tile for 750-base reads, so ten tiles are resident per CU.  The hot arrays sit at COMPILE-TIME offsets so the
-// row loop spends no SGPRs on them.  Layout (BW = band width), alignment phases | consensus phase:
-//   [0, HR*RS*4)            hring   ring of DP rows, RS = RPADL + BW + RPADR ints each (guard cells hold PNEG)      | sc (8 bytes per rank)
-//   [.., + TBR*BW)          dirblk  direction rows: staged by the forward pass, block by block for the traceback      | .. epred, sinkbits
-//   [.., + TBR*8)           rblk    row info of the rows in dirblk (the full per-rank row info lives in HBM: GG::ri)
-//   [C1, ..)                alnode, nodeof, ref, tmpv (2 bytes per sequence position each)
-//   [C2, ..)                sq      (one pad byte in front, BW behind)
+// LDS working set.  ~10 KB per tile for 750-base reads, so sixteen tiles (four waves per SIMD) are resident per CU.  The hot arrays sit at
+// COMPILE-TIME offsets so the row loop spends no SGPRs on them.  Layout (BW = band width), alignment phases | consensus phase:
+//   [0, HR*RS*4)            hring   ring of DP rows, RS = RPADL + BW + RPADR ints each (guard cells hold PNEG)      | epred (2 bytes per rank)
+//   [.., + TBR*BW)          dirblk  direction rows: staged by the forward pass, block by block for the traceback      | .. sinkbits
+//   [.., + TBR*8)           rblk    row info of the last staged block (hand-over from the forward pass to the traceback)
+//   [C1, ..)                sq      (one pad byte in front, BW behind)
+// Everything else - the graph, the per-rank row info, the per-position merge arrays, the bundle scores - lives in the L2-resident HBM
+// scratch of the workgroup (GG) and is touched by lane-parallel code only.
 extern __shared__ __attribute__((aligned(16))) unsigned char poa_smem[];     // dynamic LDS of k_poa_tile (starts at LDS address 0)
 #define POA_LDS(T, off) ((T)((LDSP unsigned char*)poa_smem + (off)))
 template <int BW>
@@ -65,9 +72,9 @@ struct LLT {
     static __device__ __forceinline__ l32 hring() { return POA_LDS(l32, HRING); }
     static __device__ __forceinline__ l8 dirblk() { return POA_LDS(l8, DIRBLK); }
     static __device__ __forceinline__ lu64 rblk() { return POA_LDS(lu64, RBLK); }
-    static __device__ __forceinline__ l64 sc() { return POA_LDS(l64, 0); }
-    l16 alnode, nodeof, ref, tmpv; l8 sq;
-    l16 epred; LDSP unsigned int* sinkbits;
+    static __device__ __forceinline__ l8 sq() { return POA_LDS(l8, C1 + 16); }           // one pad byte in front (sq[-1]), BW behind
+    static __device__ __forceinline__ l16 epred() { return POA_LDS(l16, 0); }
+    LDSP unsigned int* sinkbits;
 };
 __host__ __device__ inline size_t poa_al16(size_t b) { return (b + 15) & ~(size_t)15; }
 
@@ -89,6 +96,21 @@ __device__ __forceinline__ int wave_incl_max_scan(int v)
         "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
         "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
         "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "+v"(v));
+    return v;
+}
+
+// inclusive add-scan over the 64 lanes (same DPP pattern as the max-scan; lanes without a source keep their value)
+__device__ __forceinline__ int wave_incl_add_scan(int v)
+{
+    asm volatile(
+        "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
         "s_nop 1\n"
         : "+v"(v));
     return v;
@@ -136,7 +158,7 @@ __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int com
 {
     int best = -1; long long best_sv = 0;
     int prev_r = -2; long long prev_sv = 0;                   // score of the rank handled last (register copy of sc[prev_r])
-    auto SC = [&](int t) -> long long { return t == prev_r ? prev_sv : uniform64(w.sc()[t]); };
+    auto SC = [&](int t) -> long long { return t == prev_r ? prev_sv : uniform64(__builtin_nontemporal_load(&g.sc(t))); };     // L2-served: written by this wave a moment ago
     for (int r0 = rb; r0 < V; r0 += 64) {
         const int r = r0 + lane;
         unsigned tt = NONE16 | (NONE16 << 16), fl = 0; int w0 = 0, w1 = 0;
@@ -185,7 +207,8 @@ __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int com
                 }
                 if (pv != NONE16) sv += spv;
             }
-            if (lane == 0) { w.sc()[rr] = sv; w.epred[rr] = (uint16_t)pv; }
+            if (lane == 0) { g.sc(rr) = sv; w.epred()[rr] = (uint16_t)pv; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the score must have reached L2 before a later rank looks it up (this serial pass is rare)
             prev_r = rr; prev_sv = sv;
             if (best < 0 || best_sv < sv) { best = rr; best_sv = sv; }
         }
@@ -230,19 +253,19 @@ __device__ int bundle_pass_parallel(const GG& g, const LLT<BW>& w, int V, int la
             if (many) {                                   // lane 0 only: walk the list, all tails are final
                 long long spv = 0;
                 for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) {
-                    const int t = g.rank(g.e_tail(e)); const long long st_ = w.sc()[t]; const long long ww = g.e_w(e);
+                    const int t = g.rank(g.e_tail(e)); const long long st_ = g.sc(t); const long long ww = g.e_w(e);
                     if (wv < ww || (wv == ww && pv != NONE16 && spv <= st_)) { wv = ww; pv = t; spv = st_; }
                 }
             } else if (t0 != NONE16) {
                 wv = w0; pv = t0;
                 if (t1 != NONE16) {
                     bool take = w0 < w1;
-                    if (w0 == w1) take = w.sc()[t0] <= w.sc()[t1];       // hard rank whose candidates are final (both before the chunk)
+                    if (w0 == w1) take = g.sc(t0) <= g.sc(t1);       // hard rank whose candidates are final (both before the chunk)
                     if (take) { wv = w1; pv = t1; }
                 }
             }
             val = wv;
-            if (pv != NONE16) { if (pv >= r0) ptr = pv - r0; else extv = w.sc()[pv]; }
+            if (pv != NONE16) { if (pv >= r0) ptr = pv - r0; else extv = g.sc(pv); }
         }
         // path sums by pointer jumping (ptr < 0: the chain has left the chunk, extv holds the score it ends on)
 #pragma unroll
@@ -252,13 +275,13 @@ __device__ int bundle_pass_parallel(const GG& g, const LLT<BW>& w, int V, int la
             if (ptr >= 0) { val += v2; extv = e2; ptr = p2; }
         }
         const long long sv = val + extv;
-        if (act) { w.sc()[r] = sv; w.epred[r] = (uint16_t)pv; }
+        if (act) { g.sc(r) = sv; w.epred()[r] = (uint16_t)pv; }
         // best of the chunk: largest score, first rank on ties
         long long bv = act ? sv : (long long)0x8000000000000000ll; int bl_ = act ? lane : 64;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { const long long ov = __shfl_xor(bv, d); const int ol = __shfl_xor(bl_, d); if (ov > bv || (ov == bv && ol < bl_)) { bv = ov; bl_ = ol; } }
         if (best < 0 || best_sv < bv) { best = r0 + bl_; best_sv = bv; }
-        lds_sync();                                       // sc[] of this chunk before the next chunk's lookups
+        mem_sync();                                       // sc[] of this chunk (HBM) before the next chunk's lookups
         r0 += n;
     }
     return __builtin_amdgcn_readfirstlane(best);
@@ -286,9 +309,9 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
         if (lane == 0) {
             const int sv = g.order(start);
             for (int e = g.out_first(sv); e != NONE16; e = g.e_next_out(e))
-                for (int f = g.in_first(g.e_head(e)); f != NONE16; f = g.e_next_in(f)) if (g.e_tail(f) != sv) w.sc()[g.rank(g.e_tail(f))] = -1;
+                for (int f = g.in_first(g.e_head(e)); f != NONE16; f = g.e_next_in(f)) if (g.e_tail(f) != sv) g.sc(g.rank(g.e_tail(f))) = -1;
         }
-        lds_sync();
+        mem_sync();
         const int m2 = bundle_pass(g, w, V, start + 1, 1, lane);
         if (m2 < 0) break;
         mx = m2;
@@ -296,7 +319,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     // backtrack: lane 0 lists the ranks of the path (HBM scratch), then all lanes translate rank -> letter / coverage
     int n = 0;
     // one walk over the predecessor chain: ranks are written from the END of the scratch array, the path then starts at tmpo[V - n]
-    if (lane == 0) { int i = V; for (int r = mx; r != NONE16; r = w.epred[r]) g.tmpo(--i) = (uint16_t)r; n = V - i; }
+    if (lane == 0) { int i = V; for (int r = mx; r != NONE16; r = w.epred()[r]) g.tmpo(--i) = (uint16_t)r; n = V - i; }
     n = __builtin_amdgcn_readfirstlane(n);
     const int poff = V - n;
     mem_sync();
@@ -396,7 +419,7 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
     constexpr int RS = BW + RPADL + RPADR;
     const l32 ring0 = w.hring() + RPADL + lane * CPL;
     const l8 stage0 = w.dirblk() + lane * CPL;
-    const l8 sq0 = w.sq + lane * CPL - 1;
+    const l8 sq0 = w.sq() + lane * CPL - 1;
     // row info of ranks [r & ~63, +64) in lane order (one v_readlane pair per row, no LDS on the row's critical path); the next 64 are
     // prefetched from HBM a whole chunk ahead
     unsigned clo, chi, nlo, nhi;
@@ -590,6 +613,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     //          16 chain row (single predecessor = previous row, band shift 0/1), 32 = that band shift,
     //          64 near row (one or two predecessors, all within the LDS ring, band shifts 0..DLO_MAX)
     for (int r = lane; r < V; r += 64) g.need(r) = 0;
+    for (int r = lane; r <= V; r += 64) g.marks(r) = 0;
     mem_sync();
     for (int r = lane; r < V; r += 64) {
         const int v = g.order(r);
@@ -621,9 +645,9 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         const int row = i / (RPADL + RPADR), k = i % (RPADL + RPADR);
         w.hring()[row * (BW + RPADL + RPADR) + (k < RPADL ? k : BW + k)] = PNEG;
     }
-    for (int i = lane; i < L; i += 64) { w.alnode[i] = NONE16; w.sq[i] = S.s[i]; }
-    for (int i = lane; i < BW; i += 64) w.sq[L + i] = 0xFF;            // pad: columns past the end never match
-    if (lane == 0) w.sq[-1] = 0xFF;
+    for (int i = lane; i < L; i += 64) { g.alnode(i) = NONE16; w.sq()[i] = S.s[i]; }
+    for (int i = lane; i < BW; i += 64) w.sq()[L + i] = 0xFF;            // pad: columns past the end never match
+    if (lane == 0) w.sq()[-1] = 0xFF;
     mem_sync();
     for (int r = lane; r < V; r += 64) if (g.need(r)) g.ri(r) |= 8ull << 56;
     mem_sync();
@@ -694,7 +718,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             const unsigned long long x = gm << (63 - top);     // lane `top` at bit 63: leading ones = the run
             const int run = (~x) ? __builtin_clzll(~x) : 64;   // <= top + 1 because lanes above `top` never set their bit
 #endif
-            if (lane <= top && lane > top - run) w.alnode[jk - 1] = (uint16_t)(blk_lo + lane);      // `run` diagonal moves, each to the previous rank
+            if (lane <= top && lane > top - run) g.alnode(jk - 1) = (uint16_t)(blk_lo + lane);      // `run` diagonal moves, each to the previous rank
             r -= run; j -= run;
             const int nk = top - run;                          // lane holding the next cell of the path
             if (nk < 0) continue;                              // it is in the block below: go round (loads it)
@@ -704,7 +728,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             const int type = d & 3, slot = d >> 2;
             if (type == 3) break;
             if (type == 2) { --j; continue; }
-            if (type == 0) { if (lane == 0) w.alnode[j - 1] = (uint16_t)r; --j; }
+            if (type == 0) { if (lane == 0) g.alnode(j - 1) = (uint16_t)r; --j; }
             if (slot == SRC_SLOT) break;
             int pr;
             if (!((rhi >> 24) & 2) && slot <= 1) pr = r - (int)(slot == 0 ? ((rlo >> 16) & 0xff) : (rlo >> 24));
@@ -713,7 +737,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         }
         if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[7], (unsigned long long)n_iter); atomicAdd(&J.phase_cycles[13], (unsigned long long)n_reload); atomicAdd(&J.phase_cycles[14], c_reload); }
     }
-    lds_sync();
+    mem_sync();                                       // alnode[] (HBM) is read by other lanes next
     PH(J, 2, tph);
     // ---------- A: rank -> node, then the existing node per position: the aligned node if the letter matches, else a sibling (same column)
     //             with that letter whose rank lies strictly between the previous aligned position's node and this one (oracle
@@ -723,48 +747,50 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         int carry = -1;                                   // rank of the aligned node of the nearest aligned position before the chunk
         for (int i0 = 0; i0 < L; i0 += 64) {
             const int i = i0 + lane; bool isnew = false;
-            const int ar = (i < L) ? (int)w.alnode[i] : NONE16;
+            const int ar = (i < L) ? (int)g.alnode(i) : NONE16;
             const unsigned long long ma = __ballot(ar != NONE16);
             const unsigned long long lt = ma & ((1ull << lane) - 1);
             const int psrc = lt ? 63 - __clzll(lt) : 0;
             const int pv = __shfl(ar, psrc);
             const int prev_rank = lt ? pv : carry;
             if (i < L) {
-                const uint8_t ch = w.sq[i]; int found = NONE16, v = NONE16;
+                const uint8_t ch = w.sq()[i]; int found = NONE16, v = NONE16;
                 if (ar != NONE16) {
                     v = g.order(ar);
                     if (g.code(v) == ch) found = v;
                     else for (int u = g.ring(v); u != v; u = g.ring(u)) if (g.code(u) == ch) { const int ru = g.rank(u); if (ru > prev_rank && ru < ar) { found = u; break; } }
                 }
-                w.alnode[i] = (uint16_t)v; w.nodeof[i] = (uint16_t)found; isnew = found == NONE16;
+                g.alnode(i) = (uint16_t)v; g.nodeof(i) = (uint16_t)found; isnew = found == NONE16;
             }
             nnew += __popcll(__ballot(isnew));
             if (ma) { const int hl = 63 - __clzll(ma); carry = __shfl(ar, hl); }
         }
     }
-    if (J.phase_cycles) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(w.alnode[i] + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&J.phase_cycles[10], (unsigned long long)nnew); atomicAdd(&J.phase_cycles[11], sm_); } }
-    if (V + nnew > st.capV || st.E + L > st.capE) { lds_sync(); return 2; }      // oracle g_add_alignment capacity rule
+    if (J.phase_cycles) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(g.alnode(i) + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&J.phase_cycles[10], (unsigned long long)nnew); atomicAdd(&J.phase_cycles[11], sm_); } }
+    mem_sync();
+    if (V + nnew > st.capV || st.E + L > st.capE) return 2;      // oracle g_add_alignment capacity rule
     // ---------- B: ref(i) = node chosen for the first aligned position >= i (reverse carry scan); new nodes go immediately before it
     {
         int carry = NONE16;
         for (int i0 = ((L - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
-            const int i = i0 + lane; int a = (i < L) ? w.alnode[i] : NONE16;
-            if (a != NONE16 && w.nodeof[i] != NONE16) a = w.nodeof[i];          // the node chosen for an aligned position (reused sibling or the aligned node)
+            const int i = i0 + lane; int a = (i < L) ? g.alnode(i) : NONE16;
+            if (a != NONE16 && g.nodeof(i) != NONE16) a = g.nodeof(i);          // the node chosen for an aligned position (reused sibling or the aligned node)
             const unsigned long long m = __ballot(a != NONE16);
             const unsigned long long ge = m & (~0ull << lane);
             const int src = ge ? __ffsll((long long)ge) - 1 : 0;
             const int val = __shfl(a, src);
-            if (i < L) w.ref[i] = (uint16_t)(ge ? val : carry);
+            if (i < L) g.ref(i) = (uint16_t)(ge ? val : carry);
             if (m) { const int first = __ffsll((long long)m) - 1; carry = __shfl(a, first); }
         }
     }
-    lds_sync();
+    mem_sync();
     // ---------- C: create nodes (ids in sequence order).  anchor: nearest aligned position at or before i, else after, else a0.
-    //             tmpv[k] = old rank the k-th new node is inserted before (V = end); non-decreasing in k.
+    //             The k-th new node is inserted before old rank ins (V = end; non-decreasing in k): it lands on rank ins + k, and marks[ins]
+    //             counts it so that phase D can shift the old nodes with one prefix sum.
     {
         int base = V, lastal = NONE16;
         for (int i0 = 0; i0 < L; i0 += 64) {
-            const int i = i0 + lane; const int a = (i < L) ? w.alnode[i] : NONE16; const bool isnew = (i < L) && w.nodeof[i] == NONE16;
+            const int i = i0 + lane; const int a = (i < L) ? g.alnode(i) : NONE16; const bool isnew = (i < L) && g.nodeof(i) == NONE16;
             const unsigned long long ma = __ballot(a != NONE16);
             const unsigned long long le = ma & (~0ull >> (63 - lane));
             const int src = le ? 63 - __clzll(le) : 0;
@@ -773,25 +799,29 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             const unsigned long long mn = __ballot(isnew);
             const int before = __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
             if (isnew) {
-                const int y = base + before; const int rf = w.ref[i];
+                const int y = base + before; const int rf = g.ref(i);
                 const int anc = la != NONE16 ? g.anchor(la) : (rf != NONE16 ? g.anchor(rf) : (S.a1 < S.a0 ? 0 : S.a0));
-                g.code(y) = w.sq[i]; g.anchor(y) = (uint16_t)anc; g.in_first(y) = g.in_last(y) = g.out_first(y) = g.out_last(y) = NONE16; g.cov(y) = 0;
+                g.code(y) = w.sq()[i]; g.anchor(y) = (uint16_t)anc; g.in_first(y) = g.in_last(y) = g.out_first(y) = g.out_last(y) = NONE16; g.cov(y) = 0;
                 if (a != NONE16) { g.ring(y) = g.ring(a); g.ring(a) = (uint16_t)y; } else g.ring(y) = (uint16_t)y;
-                w.nodeof[i] = (uint16_t)y;
-                w.tmpv[y - V] = (uint16_t)(rf != NONE16 ? g.rank(rf) : V);
+                g.nodeof(i) = (uint16_t)y;
+                const int ins = rf != NONE16 ? (int)g.rank(rf) : V;
+                g.tmpo(ins + (y - V)) = (uint16_t)y; atomicAdd(&g.marks(ins), 1u);
             }
             base += __popcll(mn);
             if (ma) { const int hl = 63 - __clzll(ma); lastal = __shfl(a, hl); }
         }
     }
     mem_sync();
-    // ---------- D: ranks.  k-th new node -> tmpv[k] + k ; old node at rank p -> p + #{k : tmpv[k] <= p}
+    // ---------- D: ranks.  old node at rank p -> p + #{new nodes inserted before a rank <= p} (prefix sum of marks); new nodes were placed in C
     {
-        for (int p = lane; p < V; p += 64) {
-            int lo = 0, hi = nnew; while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.tmpv[mid] <= p) lo = mid + 1; else hi = mid; }
-            g.tmpo(p + lo) = g.order(p);
+        int carry = 0;
+        for (int p0 = 0; p0 < V; p0 += 64) {
+            const int p = p0 + lane;
+            const int m = p < V ? (int)g.marks(p) : 0;
+            const int incl = wave_incl_add_scan(m) + carry;
+            if (p < V) g.tmpo(p + incl) = g.order(p);
+            carry = __builtin_amdgcn_readlane(incl, 63);
         }
-        for (int k = lane; k < nnew; k += 64) g.tmpo(w.tmpv[k] + k) = (uint16_t)(V + k);
         mem_sync();
         for (int r = lane; r < V + nnew; r += 64) { const int v = g.tmpo(r); g.order(r) = (uint16_t)v; g.rank(v) = (uint16_t)r; }
     }
@@ -802,9 +832,9 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         for (int i0 = 0; i0 < L; i0 += 64) {
             const int i = i0 + lane; bool newedge = false; int a = 0, b = 0, wgt = 0;
             if (i < L) {
-                b = w.nodeof[i]; g.cov(b) += S.cw;
+                b = g.nodeof(i); g.cov(b) += S.cw;
                 if (i > 0) {
-                    a = w.nodeof[i - 1]; wgt = wtof(S, i - 1) + wtof(S, i);
+                    a = g.nodeof(i - 1); wgt = wtof(S, i - 1) + wtof(S, i);
                     int e = g.out_first(a);
                     for (; e != NONE16; e = g.e_next_out(e)) if (g.e_head(e) == b) break;
                     if (e != NONE16) g.e_w(e) += wgt; else newedge = true;
@@ -831,19 +861,19 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
 size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW)
 {
     (void)Ec;
-    const size_t aln = (size_t)HR * (BW + RPADL + RPADR) * 4 + (size_t)TBR * BW + (size_t)TBR * 8 + 4 * poa_al16(2 * (size_t)Lm) + poa_al16((size_t)Lm + BW + 32);
-    const size_t cons = poa_al16((size_t)8 * Vc) + poa_al16((size_t)2 * Vc) + poa_al16(((size_t)Vc + 31) / 32 * 4);
+    const size_t aln = (size_t)HR * (BW + RPADL + RPADR) * 4 + (size_t)TBR * BW + (size_t)TBR * 8 + poa_al16((size_t)Lm + BW + 32);
+    const size_t cons = poa_al16((size_t)2 * Vc) + poa_al16(((size_t)Vc + 31) / 32 * 4);
     return aln > cons ? aln : cons;
 }
 // HBM scratch bytes of one workgroup for the graph arrays
-static size_t poa_graph_bytes(int Vc, int Ec)
+static size_t poa_graph_bytes(int Vc, int Ec, int Lm)
 {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    return 9 * al(2 * ((size_t)Vc + 1)) + 6 * al(Vc) + 6 * al(2 * (size_t)Ec) + al(8 * (size_t)Vc);
+    return 9 * al(2 * ((size_t)Vc + 1)) + 26 * al(Vc) + 6 * al(2 * (size_t)Ec) + 16 + 3 * al(2 * (size_t)Lm);
 }
 
 template <int CPL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))      // <= 168 VGPRs: three single-wave tiles per SIMD (the LDS budget allows ten per CU)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))      // <= 128 VGPRs: four single-wave tiles per SIMD (~10 KB of LDS each)
 void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restrict__ work_ctr)
 {
     constexpr int BW = 64 * CPL;
@@ -852,12 +882,9 @@ void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restr
     LLT<BW> w; GG g;
     {
         auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-        LDSP unsigned char* base = POA_LDS(LDSP unsigned char*, LLT<BW>::C1);
-        w.alnode = (l16)base; w.nodeof = (l16)(base + al(2 * (size_t)Lm)); w.ref = (l16)(base + 2 * al(2 * (size_t)Lm)); w.tmpv = (l16)(base + 3 * al(2 * (size_t)Lm));
-        w.sq = (l8)(base + 4 * al(2 * (size_t)Lm) + 16);              // one pad byte in front (sq[-1]), BW behind
-        w.epred = POA_LDS(l16, (unsigned)al((size_t)8 * Vc)); w.sinkbits = POA_LDS(LDSP unsigned int*, (unsigned)(al((size_t)8 * Vc) + al((size_t)2 * Vc)));
+        w.sinkbits = POA_LDS(LDSP unsigned int*, (unsigned)al((size_t)2 * Vc));
         g.base = gscratch + (size_t)blockIdx.x * gbytes;
-        g.s16 = (uint32_t)al(2 * ((size_t)Vc + 1)); g.s8 = (uint32_t)al(Vc); g.se = (uint32_t)al(2 * (size_t)Ec);
+        g.s16 = (uint32_t)al(2 * ((size_t)Vc + 1)); g.s8 = (uint32_t)al(Vc); g.se = (uint32_t)al(2 * (size_t)Ec); g.sl = (uint32_t)al(2 * (size_t)Lm);
     }
     int32_t* Hg = J.Hglob + (size_t)blockIdx.x * Vc * BW;
     uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW;
@@ -911,11 +938,11 @@ int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
     if (J.Vcap > 0xFFF0 || J.Ecap > 0xFFF0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA graph capacity exceeds 16-bit indices (sequence too long for the tile engine)");
     const size_t lds = poa_lds_bytes(J.Vcap, J.Ecap, J.Lmax, BW);
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);
-    int per_cu = std::max<int>(1, std::min<int>(12, (int)((160 * 1024) / lds)));      // 12 = three waves per SIMD, the VGPR budget of the kernel
+    int per_cu = std::max<int>(1, std::min<int>(16, (int)((160 * 1024) / lds)));      // 16 = four waves per SIMD, the VGPR budget of the kernel
     if (const char* e = getenv("NGSID_POA_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));      // dev knob
     uint32_t nwg = (uint32_t)std::min<uint64_t>(J.njobs, (uint64_t)ctx->n_cu * per_cu);
     const size_t cells = (size_t)J.Vcap * BW;
-    const size_t gbytes = poa_graph_bytes(J.Vcap, J.Ecap);
+    const size_t gbytes = poa_graph_bytes(J.Vcap, J.Ecap, J.Lmax);
     if (ctx->poa_h.n < nwg * cells) HIPCHK(ctx, ctx->poa_h.alloc(nwg * cells));
     if (ctx->poa_d.n < nwg * cells) HIPCHK(ctx, ctx->poa_d.alloc(nwg * cells));
     if (ctx->poa_g.n < nwg * gbytes) HIPCHK(ctx, ctx->poa_g.alloc(nwg * gbytes));
