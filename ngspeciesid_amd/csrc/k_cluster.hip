@@ -360,8 +360,9 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     if (!g_cl_tables[ctx->device & 15]) { HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_round2_t), NGSID_ROUND2_T, sizeof(double) * 15)); g_cl_tables[ctx->device & 15] = true; }
 
     // ---- per-read preprocessing (a1-a3)
-    DevBuf<uint64_t> mzcode; DevBuf<uint32_t> mzpos, mzcnt, hlen, d_acc; DevBuf<double> herr0, herr, rawerr, d_known; DevBuf<uint8_t> eidx; DevBuf<int> flag;
-    HIPCHK(ctx, mzcode.alloc(RD.total + 1)); HIPCHK(ctx, mzpos.alloc(RD.total + 1)); HIPCHK(ctx, mzcnt.alloc(N)); HIPCHK(ctx, hlen.alloc(N));
+    DevBuf<uint64_t>& mzcode = ctx->pol_mzcode; DevBuf<uint32_t>& mzpos = ctx->pol_mzpos;      // the two big ones (12 bytes per base) are grow-only scratch of the context
+    DevBuf<uint32_t> mzcnt, hlen, d_acc; DevBuf<double> herr0, herr, rawerr, d_known; DevBuf<uint8_t> eidx; DevBuf<int> flag;
+    HIPCHK(ctx, mzcode.reserve(RD.total + 1)); HIPCHK(ctx, mzpos.reserve(RD.total + 1)); HIPCHK(ctx, mzcnt.alloc(N)); HIPCHK(ctx, hlen.alloc(N));
     HIPCHK(ctx, herr0.alloc(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N)); HIPCHK(ctx, eidx.alloc(N)); HIPCHK(ctx, flag.alloc(2)); HIPCHK(ctx, d_acc.alloc(N));
     HIPCHK(ctx, hipMemsetAsync(flag.p, 0, 2 * sizeof(int), ctx->stream));
     rc = ngsid_launch_minimizers(ctx, RD, k, w, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr0.p, rawerr.p, flag.p); if (rc) return rc;

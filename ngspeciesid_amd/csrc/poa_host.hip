@@ -45,6 +45,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
 {
     const PSeq* cur = d_level0; uint32_t cur_maxlen = maxlen0;
     int slots_cap = 0;
+    HostTimer ht(ctx->stream, "hierarchy");
     for (int level = 0;; ++level) {
         // ---- jobs of this level
         std::vector<uint32_t> job_off{0}, seq_idx, job_unit; std::vector<int32_t> job_bb; uint32_t maxD = 0; int maxL0 = 1; bool any_nobb = false;
@@ -63,6 +64,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
         }
         const uint32_t njobs = (uint32_t)job_unit.size();
         if (njobs == 0) break;
+        if (level == 0) ht.mark("L0 host job lists");
         if (any_nobb) maxL0 = std::max<int>(maxL0, (int)cur_maxlen);   // without a backbone the first member sets L0 (<= the longest member)
         // capacity (LDS sizing): the largest per-job capacity the oracle rule can produce
         long long capV = (long long)maxL0 * (hp.node_cap > 0 ? hp.node_cap : 28) / 16; capV = std::max<long long>(capV, maxL0 + 64); capV = std::max<long long>(capV, (long long)cur_maxlen + 1);
@@ -87,7 +89,9 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
             J.dropped = d_flags.p; J.slot_overflow = d_flags.p + 1;
             DevBuf<unsigned long long> d_ph; static const bool want_ph = getenv("NGSID_POA_PHASES") != nullptr;
             if (want_ph) { HIPCHK(ctx, d_ph.alloc(16)); HIPCHK(ctx, hipMemsetAsync(d_ph.p, 0, 128, ctx->stream)); J.phase_cycles = d_ph.p; }
+            if (level == 0) ht.mark("L0 alloc + upload");
             int32_t rc = poa_run_jobs(ctx, J, hp.band); if (rc) return rc;
+            if (level == 0) ht.mark("L0 kernel");
             uint32_t h_flags[4];
             h_out_n.resize(njobs); h_out_len.resize((size_t)njobs * slots); h_out_cw.resize((size_t)njobs * slots);
             HIPCHK(ctx, hipMemcpyAsync(h_flags, d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -101,6 +105,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
             if (slots >= (int)maxD) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA output slot overflow at full depth");
             slots = (int)std::min<uint32_t>(maxD, (uint32_t)slots * 4); slots_cap = slots;
         }
+        if (level == 0) ht.mark("L0 download");
         // ---- distribute outputs to units
         std::vector<std::vector<uint32_t>> outs(units.size());         // flat slot indices (job*slots + s) in job order
         for (uint32_t j = 0; j < njobs; ++j) for (uint32_t s = 0; s < h_out_n[j]; ++s) outs[job_unit[j]].push_back(j * (uint32_t)slots + s);
@@ -129,12 +134,14 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
                 U.seqs.push_back((uint32_t)next.size()); next.push_back(S); next_maxlen = std::max<uint32_t>(next_maxlen, (uint32_t)S.len);
             }
         }
+        if (level == 0) ht.mark("L0 distribute");
         if (next.empty()) break;
         HIPCHK(ctx, Lv->seqs.reserve(sizeof(PSeq) * next.size()));
         HIPCHK(ctx, hipMemcpyAsync(Lv->seqs.p, next.data(), sizeof(PSeq) * next.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         cur = (const PSeq*)Lv->seqs.p; cur_maxlen = next_maxlen;
     }
+    ht.mark("levels >= 1");
     return NGSID_OK;
 }
 
