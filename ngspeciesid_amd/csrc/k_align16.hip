@@ -381,17 +381,25 @@ static int32_t launch_class(ngsid_ctx* ctx, AlignJob job, int cls, uint32_t max_
     return launch16<RP>(ctx, job, max_qlen < k_cls_bound_host(cls) ? max_qlen : k_cls_bound_host(cls), max_tlen, (uint32_t)(1 + cls));
 }
 
+// pairs -> NCLS index lists in ctx->aln_cls (class c at offset c * npairs), counts in ctx->aln_ctr[8 + c]; all 16 counters are zeroed first
+int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job)
+{
+    const uint64_t n = job.npairs;
+    if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
+    if (ctx->aln_cls.n < (size_t)NCLS * n) HIPCHK(ctx, ctx->aln_cls.reserve((size_t)NCLS * n));
+    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p, 0, 16 * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_pair_classes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, job, ctx->aln_cls.p, ctx->aln_ctr.p + 8);
+    HIPCHK(ctx, hipGetLastError());
+    return NGSID_OK;
+}
+
 int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen)
 {
     // Large batches with mixed query lengths: split the pairs by query-length class so that every pair runs in the instance with the
     // fewest idle rows (a lane owns 2*RP rows; 750-base reads with a few 800-base ones would otherwise all run with RP = 7).
     if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !getenv("NGSID_ALIGN_NOCLASS")) {
         const uint64_t n = job.npairs;
-        if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
-        if (ctx->aln_cls.n < (size_t)NCLS * n) HIPCHK(ctx, ctx->aln_cls.alloc((size_t)NCLS * n));
-        HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p, 0, 16 * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(k_pair_classes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, job, ctx->aln_cls.p, ctx->aln_ctr.p + 8);
-        HIPCHK(ctx, hipGetLastError());
+        { int32_t rcp = ngsid_partition_pairs(ctx, job); if (rcp) return rcp; }
         {   // size the scratch once for the most demanding class launch
             Launch16 L; uint64_t tbw = 0, bw = 0;
             plan16<2>(ctx, n, 256, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);

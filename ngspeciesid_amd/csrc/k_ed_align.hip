@@ -27,13 +27,15 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
     LDSP u64* planes = (LDSP u64*)smem;                     // [block][3][lane]
     ngsid_v4u* mytb = tb + (u64)blockIdx.x * tb_per_wave;
     int8_t* myh = hcar + (u64)blockIdx.x * mstride * 64;
-    const u64 nbundles = (J.npairs + 63) / 64;
+    const u64 npairs = J.npairs_dev ? (u64)*J.npairs_dev : J.npairs;       // optional indirection: a query-length class of a larger batch
+    const u64 nbundles = (npairs + 63) / 64;
     for (;;) {
         uint32_t kq = 0; if (lane == 0) kq = atomicAdd(work_ctr, 1u);
         kq = (uint32_t)__builtin_amdgcn_readfirstlane((int)kq);
         if (kq >= nbundles) break;
-        const u64 p = (u64)kq * 64 + lane;
-        const bool have = p < J.npairs;
+        const u64 pk = (u64)kq * 64 + lane;
+        const bool have = pk < npairs;
+        const u64 p = have ? (J.pair_list ? (u64)J.pair_list[pk] : pk) : 0;
         const uint8_t* q = nullptr; const uint8_t* t = nullptr; int n = 0, m = 0;
         if (have) { const uint32_t qi = J.qidx[p], ti = J.tidx[p]; q = J.qseq + J.qoff[qi]; n = (int)(J.qoff[qi + 1] - J.qoff[qi]); t = J.tseq + J.toff[ti]; m = (int)(J.toff[ti + 1] - J.toff[ti]); }
         int nmax = n, mmax = m;
@@ -139,7 +141,7 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
 }
 
 template <int BMAX>
-static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out)
+static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out, uint32_t ctr_slot = 14)
 {
     const u64 nbundles = (job.npairs + 63) / 64;
     const uint32_t mstride = (max_tlen + 63u) & ~63u;                     // rounded so that backbones growing by a few bases between iterations reuse the scratch
@@ -155,8 +157,8 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen,
     if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.reserve(want * per_wave));
     if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
-    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + 14, 0, sizeof(uint32_t), ctx->stream));
-    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + 14, dist_out, ctx->ed_h.p); }
+    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), ctx->stream));
+    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + ctr_slot, dist_out, ctx->ed_h.p); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }
@@ -165,6 +167,25 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
 {
     if (job.npairs == 0) return NGSID_OK;
     if (max_qlen > NGSID_MAX_READ_LEN || max_tlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in the edit-distance aligner", NGSID_MAX_READ_LEN);
+    if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !getenv("NGSID_ALIGN_NOCLASS")) {
+        // mixed lengths: every pair runs in the instance with the fewest register-resident blocks that holds its query
+        // (the scratch is sized by the longest query; launches of one call share it, the stream serialises them)
+        int32_t rc = ngsid_partition_pairs(ctx, job); if (rc) return rc;
+        const u64 n = job.npairs;
+        auto cls = [&](int c, uint32_t bound) { AlignJob j = job; j.pair_list = ctx->aln_cls.p + (size_t)c * n; j.npairs_dev = ctx->aln_ctr.p + 8 + c; (void)bound; return j; };
+        {   // reserve the scratch once, for the class with the largest footprint (16-block instance, longest query)
+            const uint32_t mstride = (max_tlen + 63u) & ~63u; const u64 nblocks = std::max<u64>(1, ((u64)max_qlen + 63) / 64); const u64 per_wave = nblocks * mstride * 64;
+            const u64 want = std::max<u64>(1, std::min<u64>((u64)8 * ctx->n_cu, std::max<u64>(1, ((size_t)24 << 30) / (per_wave * 16))));
+            if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.reserve(want * per_wave));
+            if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
+        }
+        if ((rc = launch_ed<4>(ctx, cls(0, 256), std::min<uint32_t>(max_qlen, 256), max_tlen, dist_out, 1))) return rc;
+        if (max_qlen > 256 && (rc = launch_ed<8>(ctx, cls(1, 512), std::min<uint32_t>(max_qlen, 512), max_tlen, dist_out, 2))) return rc;
+        if (max_qlen > 512 && (rc = launch_ed<12>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3))) return rc;
+        if (max_qlen > 768 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4))) return rc;
+        if (max_qlen > 896 && (rc = launch_ed<16>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5))) return rc;
+        return NGSID_OK;
+    }
     if (max_qlen <= 256) return launch_ed<4>(ctx, job, max_qlen, max_tlen, dist_out);
     if (max_qlen <= 512) return launch_ed<8>(ctx, job, max_qlen, max_tlen, dist_out);
     if (max_qlen <= 768) return launch_ed<12>(ctx, job, max_qlen, max_tlen, dist_out);

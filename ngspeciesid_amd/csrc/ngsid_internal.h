@@ -100,6 +100,7 @@ struct AlignJob {            // device pointers
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20);
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
 int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen);
+int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job);      // query-length classes {<=256, <=512, <=768, <=896, rest}: lists in ctx->aln_cls, counts in ctx->aln_ctr[8..12]
 int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out);   // k_ed_align.hip (uses qseq..npairs, bp, bp_windows, window, span)
 
 typedef unsigned int ngsid_v4u __attribute__((ext_vector_type(4)));
