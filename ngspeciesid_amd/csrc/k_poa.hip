@@ -122,12 +122,27 @@ struct TS { int V, E, L0, members, nout, capV, capE; unsigned long long cw_sum; 
 
 __device__ __forceinline__ int wtof(const PSeq& S, int i) { return S.q ? (int)S.q[i] - 33 : S.uw; }
 
-__device__ __forceinline__ int band_lo(int anchor, const PSeq& S, int L0, int BW) {
-    int a0 = S.a0, a1 = S.a1; if (a1 < a0) { a0 = 0; a1 = L0 - 1; }
+// band start of a node: centre = trunc((anchor - a0) * len / span) (C division, towards zero), start = centre - BW/2 clamped to [0, len+1-BW].
+// The quotient is taken with a precomputed double reciprocal and one exact correction step (operands are < 2^31, so the estimate is
+// off by at most one) - a 64-bit integer division costs ~100 instructions per lane and there is one per graph node and alignment.
+struct BandMap { int a0; int len; int span; double rcp; int mx; };
+__device__ __forceinline__ BandMap band_map(const PSeq& S, int L0, int BW) {
+    BandMap m; int a0 = S.a0, a1 = S.a1; if (a1 < a0) { a0 = 0; a1 = L0 - 1; }
     long long span = (long long)a1 - a0 + 1; if (span < 1) span = 1;
-    long long c = ((long long)(anchor - a0) * (long long)S.len) / span;
-    long long lo = c - BW / 2; long long mx = (long long)S.len + 1 - BW; if (mx < 0) mx = 0;
-    if (lo < 0) lo = 0; if (lo > mx) lo = mx;
+    m.a0 = a0; m.len = S.len; m.span = (int)span; m.rcp = 1.0 / (double)span;
+    long long mx = (long long)S.len + 1 - BW; if (mx < 0) mx = 0; m.mx = (int)mx;
+    return m;
+}
+__device__ __forceinline__ int band_lo(int anchor, const BandMap& m, int BW) {
+    const long long num = (long long)(anchor - m.a0) * (long long)m.len;
+    const unsigned long long an = (unsigned long long)(num < 0 ? -num : num);
+    long long q = (long long)((double)an * m.rcp);
+    long long rem = (long long)an - q * (long long)m.span;
+    if (rem < 0) { --q; rem += m.span; }
+    if (rem >= (long long)m.span) ++q;
+    const long long c = num < 0 ? -q : q;
+    long long lo = c - BW / 2;
+    if (lo < 0) lo = 0; if (lo > m.mx) lo = m.mx;
     return (int)lo;
 }
 
@@ -612,20 +627,22 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     //          edge list in HBM, 4 sink, 8 keep an HBM copy (a successor is > HR rows away),
     //          16 chain row (single predecessor = previous row, band shift 0/1), 32 = that band shift,
     //          64 near row (one or two predecessors, all within the LDS ring, band shifts 0..DLO_MAX)
-    for (int r = lane; r < V; r += 64) g.need(r) = 0;
+    const BandMap bm = band_map(S, st.L0, BW);
+    for (int r = lane; r < V; r += 64) { g.need(r) = 0; g.ri(r) = (unsigned long long)(unsigned)band_lo(g.anchor(g.order(r)), bm, BW); }      // pass 1: band starts
     for (int r = lane; r <= V; r += 64) g.marks(r) = 0;
     mem_sync();
     for (int r = lane; r < V; r += 64) {
         const int v = g.order(r);
         for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) g.need(pr) = 1; }
-        const int l0 = band_lo(g.anchor(v), S, st.L0, BW);
+        const int l0 = (int)(g.ri(r) & 0xffff);
         const int e0 = g.in_first(v); int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
         if (e0 == NONE16) fl |= 1;
         else {
-            const int t0 = g.e_tail(e0); d0 = r - (int)g.rank(t0); dl0 = l0 - band_lo(g.anchor(t0), S, st.L0, BW);
+            // band start of a predecessor = low 16 bits of its row info (written by pass 1; a concurrent full rewrite keeps those bits)
+            const int p0 = g.rank(g.e_tail(e0)); d0 = r - p0; dl0 = l0 - (int)(g.ri(p0) & 0xffff);
             const int e1 = g.e_next_in(e0);
             if (e1 != NONE16) {
-                const int t1 = g.e_tail(e1); d1 = r - (int)g.rank(t1); dl1 = l0 - band_lo(g.anchor(t1), S, st.L0, BW);
+                const int p1 = g.rank(g.e_tail(e1)); d1 = r - p1; dl1 = l0 - (int)(g.ri(p1) & 0xffff);
                 if (g.e_next_in(e1) != NONE16) fl |= 2;
             }
             if (d0 > 255 || d1 > 255 || dl0 < 0 || dl0 > 255 || dl1 < 0 || dl1 > 255) { fl |= 2; d0 = d1 = dl0 = dl1 = 0; }
