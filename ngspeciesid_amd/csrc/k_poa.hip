@@ -24,10 +24,8 @@
 #define SRC_SLOT 63
 #define NONE16 0xFFFFu
 #define HR 8           // DP rows kept in the LDS ring
-#ifndef RPADL
 #define RPADL 4        // ring row: RPADL guard cells (PNEG) | BW cells | RPADR guard cells, so neighbour reads need no bounds checks
 #define RPADR 12
-#endif
 #define DLO_MAX 11     // largest band-start difference to a predecessor a 'near' row may have (<= RPADR - 1)
 #define TBR 32         // direction rows per traceback block
 
@@ -650,9 +648,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         if (g.out_first(v) == NONE16) fl |= 4;
         if (!(fl & 3)) {
             if (d0 == 1 && d1 == 0 && dl0 <= 1) fl |= 16 | (dl0 << 5);
-#ifndef POA_NO_NEAR
             else if (d0 <= HR && d1 <= HR && dl0 <= DLO_MAX && dl1 <= DLO_MAX) fl |= 64;
-#endif
         }
         g.ri(r) = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)d0 << 16) | ((unsigned long long)(unsigned)d1 << 24)
                    | ((unsigned long long)(unsigned)dl0 << 32) | ((unsigned long long)(unsigned)dl1 << 40)
@@ -729,12 +725,8 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 if (ck >= 0 && ck < BW) { dk = w.dirblk()[(size_t)lane * BW + ck]; loaded = true; good = dk == 0 && ((myri >> 56) & 16) && jk >= 1; }
             }
             const unsigned long long gm = __ballot(good), lm = __ballot(loaded);
-#ifdef POA_NO_SPEC
-            const int run = 0;
-#else
             const unsigned long long x = gm << (63 - top);     // lane `top` at bit 63: leading ones = the run
             const int run = (~x) ? __builtin_clzll(~x) : 64;   // <= top + 1 because lanes above `top` never set their bit
-#endif
             if (lane <= top && lane > top - run) g.alnode(jk - 1) = (uint16_t)(blk_lo + lane);      // `run` diagonal moves, each to the previous rank
             r -= run; j -= run;
             const int nk = top - run;                          // lane holding the next cell of the path
