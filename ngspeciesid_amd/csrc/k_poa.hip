@@ -629,30 +629,45 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     for (int r = lane; r < V; r += 64) { g.need(r) = 0; g.ri(r) = (unsigned long long)(unsigned)band_lo(g.anchor(g.order(r)), bm, BW); }      // pass 1: band starts
     for (int r = lane; r <= V; r += 64) g.marks(r) = 0;
     mem_sync();
-    for (int r = lane; r < V; r += 64) {
-        const int v = g.order(r);
-        for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) g.need(pr) = 1; }
-        const int l0 = (int)(g.ri(r) & 0xffff);
-        const int e0 = g.in_first(v); int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
-        if (e0 == NONE16) fl |= 1;
-        else {
-            // band start of a predecessor = low 16 bits of its row info (written by pass 1; a concurrent full rewrite keeps those bits)
-            const int p0 = g.rank(g.e_tail(e0)); d0 = r - p0; dl0 = l0 - (int)(g.ri(p0) & 0xffff);
-            const int e1 = g.e_next_in(e0);
-            if (e1 != NONE16) {
-                const int p1 = g.rank(g.e_tail(e1)); d1 = r - p1; dl1 = l0 - (int)(g.ri(p1) & 0xffff);
-                if (g.e_next_in(e1) != NONE16) fl |= 2;
+    // pass 2, two 64-rank chunks per iteration: the loads of both chunks are issued before either is consumed, so the dependent chain
+    // order -> in-edge -> tail -> rank -> band start (L2 / HBM latency each) is paid once for 128 ranks
+    for (int rb = 0; rb < V; rb += 128) {
+        int vv[2], e0v[2], e1v[2], p0v[2], p1v[2], l0v[2], lp0[2], lp1[2], e2v[2], ofv[2], cdv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; vv[u] = r < V ? (int)g.order(r) : 0; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; const bool ok = r < V; e0v[u] = ok ? (int)g.in_first(vv[u]) : NONE16; l0v[u] = ok ? (int)(g.ri(r) & 0xffff) : 0; ofv[u] = ok ? (int)g.out_first(vv[u]) : 0; cdv[u] = ok ? (int)g.code(vv[u]) : 0; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const bool h = e0v[u] != NONE16; p0v[u] = h ? (int)g.e_tail(e0v[u]) : 0; e1v[u] = h ? (int)g.e_next_in(e0v[u]) : NONE16; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const bool h0 = e0v[u] != NONE16, h1 = e1v[u] != NONE16; p0v[u] = h0 ? (int)g.rank(p0v[u]) : 0; p1v[u] = h1 ? (int)g.e_tail(e1v[u]) : 0; e2v[u] = h1 ? (int)g.e_next_in(e1v[u]) : NONE16; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const bool h0 = e0v[u] != NONE16, h1 = e1v[u] != NONE16; lp0[u] = h0 ? (int)(g.ri(p0v[u]) & 0xffff) : 0; p1v[u] = h1 ? (int)g.rank(p1v[u]) : 0; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const bool h1 = e1v[u] != NONE16; lp1[u] = h1 ? (int)(g.ri(p1v[u]) & 0xffff) : 0; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = rb + u * 64 + lane; if (r >= V) continue;
+            const int l0 = l0v[u]; int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
+            if (e0v[u] == NONE16) fl |= 1;
+            else {
+                // band start of a predecessor = low 16 bits of its row info (written by pass 1; a concurrent full rewrite keeps those bits)
+                d0 = r - p0v[u]; dl0 = l0 - lp0[u]; if (d0 > HR) g.need(p0v[u]) = 1;
+                if (e1v[u] != NONE16) {
+                    d1 = r - p1v[u]; dl1 = l0 - lp1[u]; if (d1 > HR) g.need(p1v[u]) = 1;
+                    if (e2v[u] != NONE16) { fl |= 2; for (int e = e2v[u]; e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) g.need(pr) = 1; } }
+                }
+                if (d0 > 255 || d1 > 255 || dl0 < 0 || dl0 > 255 || dl1 < 0 || dl1 > 255) { fl |= 2; d0 = d1 = dl0 = dl1 = 0; }
             }
-            if (d0 > 255 || d1 > 255 || dl0 < 0 || dl0 > 255 || dl1 < 0 || dl1 > 255) { fl |= 2; d0 = d1 = dl0 = dl1 = 0; }
+            if (ofv[u] == NONE16) fl |= 4;
+            if (!(fl & 3)) {
+                if (d0 == 1 && d1 == 0 && dl0 <= 1) fl |= 16 | (dl0 << 5);
+                else if (d0 <= HR && d1 <= HR && dl0 <= DLO_MAX && dl1 <= DLO_MAX) fl |= 64;
+            }
+            g.ri(r) = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)d0 << 16) | ((unsigned long long)(unsigned)d1 << 24)
+                       | ((unsigned long long)(unsigned)dl0 << 32) | ((unsigned long long)(unsigned)dl1 << 40)
+                       | ((unsigned long long)(unsigned)cdv[u] << 48) | ((unsigned long long)(unsigned)fl << 56);
         }
-        if (g.out_first(v) == NONE16) fl |= 4;
-        if (!(fl & 3)) {
-            if (d0 == 1 && d1 == 0 && dl0 <= 1) fl |= 16 | (dl0 << 5);
-            else if (d0 <= HR && d1 <= HR && dl0 <= DLO_MAX && dl1 <= DLO_MAX) fl |= 64;
-        }
-        g.ri(r) = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)d0 << 16) | ((unsigned long long)(unsigned)d1 << 24)
-                   | ((unsigned long long)(unsigned)dl0 << 32) | ((unsigned long long)(unsigned)dl1 << 40)
-                   | ((unsigned long long)g.code(v) << 48) | ((unsigned long long)(unsigned)fl << 56);
     }
     for (int i = lane; i < HR * (RPADL + RPADR); i += 64) {       // guard cells of the ring rows
         const int row = i / (RPADL + RPADR), k = i % (RPADL + RPADR);
