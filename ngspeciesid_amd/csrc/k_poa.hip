@@ -769,25 +769,34 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     int nnew = 0;
     {
         int carry = -1;                                   // rank of the aligned node of the nearest aligned position before the chunk
-        for (int i0 = 0; i0 < L; i0 += 64) {
-            const int i = i0 + lane; bool isnew = false;
-            const int ar = (i < L) ? (int)g.alnode(i) : NONE16;
-            const unsigned long long ma = __ballot(ar != NONE16);
-            const unsigned long long lt = ma & ((1ull << lane) - 1);
-            const int psrc = lt ? 63 - __clzll(lt) : 0;
-            const int pv = __shfl(ar, psrc);
-            const int prev_rank = lt ? pv : carry;
-            if (i < L) {
-                const uint8_t ch = w.sq()[i]; int found = NONE16, v = NONE16;
-                if (ar != NONE16) {
-                    v = g.order(ar);
-                    if (g.code(v) == ch) found = v;
-                    else for (int u = g.ring(v); u != v; u = g.ring(u)) if (g.code(u) == ch) { const int ru = g.rank(u); if (ru > prev_rank && ru < ar) { found = u; break; } }
+        for (int ib = 0; ib < L; ib += 128) {             // two chunks per iteration: both chunks' loads are in flight together
+            int arv[2], vv[2], cdv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int i = ib + u * 64 + lane; arv[u] = (i < L) ? (int)g.alnode(i) : NONE16; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) vv[u] = arv[u] != NONE16 ? (int)g.order(arv[u]) : NONE16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) cdv[u] = vv[u] != NONE16 ? (int)g.code(vv[u]) : -1;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = ib + u * 64 + lane; bool isnew = false;
+                const int ar = arv[u];
+                const unsigned long long ma = __ballot(ar != NONE16);
+                const unsigned long long lt = ma & ((1ull << lane) - 1);
+                const int psrc = lt ? 63 - __clzll(lt) : 0;
+                const int pv = __shfl(ar, psrc);
+                const int prev_rank = lt ? pv : carry;
+                if (i < L) {
+                    const uint8_t ch = w.sq()[i]; int found = NONE16; const int v = vv[u];
+                    if (ar != NONE16) {
+                        if (cdv[u] == ch) found = v;
+                        else for (int x = g.ring(v); x != v; x = g.ring(x)) if (g.code(x) == ch) { const int ru = g.rank(x); if (ru > prev_rank && ru < ar) { found = x; break; } }
+                    }
+                    g.alnode(i) = (uint16_t)v; g.nodeof(i) = (uint16_t)found; isnew = found == NONE16;
                 }
-                g.alnode(i) = (uint16_t)v; g.nodeof(i) = (uint16_t)found; isnew = found == NONE16;
+                nnew += __popcll(__ballot(isnew));
+                if (ma) { const int hl = 63 - __clzll(ma); carry = __shfl(ar, hl); }
             }
-            nnew += __popcll(__ballot(isnew));
-            if (ma) { const int hl = 63 - __clzll(ma); carry = __shfl(ar, hl); }
         }
     }
     if (J.phase_cycles) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(g.alnode(i) + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&J.phase_cycles[10], (unsigned long long)nnew); atomicAdd(&J.phase_cycles[11], sm_); } }
@@ -839,39 +848,60 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     // ---------- D: ranks.  old node at rank p -> p + #{new nodes inserted before a rank <= p} (prefix sum of marks); new nodes were placed in C
     {
         int carry = 0;
-        for (int p0 = 0; p0 < V; p0 += 64) {
-            const int p = p0 + lane;
-            const int m = p < V ? (int)g.marks(p) : 0;
-            const int incl = wave_incl_add_scan(m) + carry;
-            if (p < V) g.tmpo(p + incl) = g.order(p);
-            carry = __builtin_amdgcn_readlane(incl, 63);
+        for (int pb = 0; pb < V; pb += 128) {
+            int mv[2], ov[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int p = pb + u * 64 + lane; mv[u] = p < V ? (int)g.marks(p) : 0; ov[u] = p < V ? (int)g.order(p) : 0; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int p = pb + u * 64 + lane;
+                const int incl = wave_incl_add_scan(mv[u]) + carry;
+                if (p < V) g.tmpo(p + incl) = (uint16_t)ov[u];
+                carry = __builtin_amdgcn_readlane(incl, 63);
+            }
         }
         mem_sync();
-        for (int r = lane; r < V + nnew; r += 64) { const int v = g.tmpo(r); g.order(r) = (uint16_t)v; g.rank(v) = (uint16_t)r; }
+        for (int rb = 0; rb < V + nnew; rb += 128) {
+            int tv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; tv[u] = r < V + nnew ? (int)g.tmpo(r) : 0; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; if (r < V + nnew) { g.order(r) = (uint16_t)tv[u]; g.rank(tv[u]) = (uint16_t)r; } }
+        }
     }
     mem_sync();
     // ---------- E: coverage and edges (edge ids in sequence order)
     {
         int ebase = st.E;
-        for (int i0 = 0; i0 < L; i0 += 64) {
-            const int i = i0 + lane; bool newedge = false; int a = 0, b = 0, wgt = 0;
-            if (i < L) {
-                b = g.nodeof(i); g.cov(b) += S.cw;
-                if (i > 0) {
-                    a = g.nodeof(i - 1); wgt = wtof(S, i - 1) + wtof(S, i);
-                    int e = g.out_first(a);
-                    for (; e != NONE16; e = g.e_next_out(e)) if (g.e_head(e) == b) break;
-                    if (e != NONE16) g.e_w(e) += wgt; else newedge = true;
+        for (int ib = 0; ib < L; ib += 128) {             // two chunks per iteration (independent: every node of the path is touched by one position only)
+            int av[2], bv[2], e0v[2], h0v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int i = ib + u * 64 + lane; bv[u] = i < L ? (int)g.nodeof(i) : NONE16; av[u] = (i < L && i > 0) ? (int)g.nodeof(i - 1) : NONE16; }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) e0v[u] = av[u] != NONE16 ? (int)g.out_first(av[u]) : NONE16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) h0v[u] = e0v[u] != NONE16 ? (int)g.e_head(e0v[u]) : NONE16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = ib + u * 64 + lane; bool newedge = false; const int a = av[u], b = bv[u]; int wgt = 0;
+                if (i < L) {
+                    g.cov(b) += S.cw;
+                    if (i > 0) {
+                        wgt = wtof(S, i - 1) + wtof(S, i);
+                        int e = e0v[u];
+                        if (e != NONE16 && h0v[u] != b) for (e = g.e_next_out(e); e != NONE16; e = g.e_next_out(e)) if (g.e_head(e) == b) break;
+                        if (e != NONE16) g.e_w(e) += wgt; else newedge = true;
+                    }
                 }
+                const unsigned long long mn = __ballot(newedge);
+                if (newedge) {
+                    const int e = ebase + __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                    g.e_tail(e) = (uint16_t)a; g.e_head(e) = (uint16_t)b; g.e_w(e) = wgt; g.e_next_in(e) = NONE16; g.e_next_out(e) = NONE16;
+                    if (g.out_last(a) == NONE16) g.out_first(a) = (uint16_t)e; else g.e_next_out(g.out_last(a)) = (uint16_t)e; g.out_last(a) = (uint16_t)e;
+                    if (g.in_last(b) == NONE16) g.in_first(b) = (uint16_t)e; else g.e_next_in(g.in_last(b)) = (uint16_t)e; g.in_last(b) = (uint16_t)e;
+                }
+                ebase += __popcll(mn);
             }
-            const unsigned long long mn = __ballot(newedge);
-            if (newedge) {
-                const int e = ebase + __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-                g.e_tail(e) = (uint16_t)a; g.e_head(e) = (uint16_t)b; g.e_w(e) = wgt; g.e_next_in(e) = NONE16; g.e_next_out(e) = NONE16;
-                if (g.out_last(a) == NONE16) g.out_first(a) = (uint16_t)e; else g.e_next_out(g.out_last(a)) = (uint16_t)e; g.out_last(a) = (uint16_t)e;
-                if (g.in_last(b) == NONE16) g.in_first(b) = (uint16_t)e; else g.e_next_in(g.in_last(b)) = (uint16_t)e; g.in_last(b) = (uint16_t)e;
-            }
-            ebase += __popcll(mn);
         }
         st.E = ebase;
     }
