@@ -426,16 +426,20 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     D.dec = dec.p; D.kind = kind.p; D.alnflag = alnflag.p; D.top = top.p; D.cur_hi = cur_hi.p; D.cur_lo = cur_lo.p;
     D.cache_slot = cache_slot.p; D.cache_region = cache_region.p; D.cache_ptr = cache_ptr.p; D.errflag = flag.p + 1;
 
-    const uint32_t BLK = 32768;
+    // speculative block size: adaptive - blocks grow while new representatives are rare (bigger aligner launches, fewer round trips) and
+    // shrink when they are frequent (every new representative re-decides the rest of its block)
+    const uint32_t BLK = 262144;              // capacity of the per-block buffers
+    uint32_t blk = 32768;
     DevBuf<uint64_t> cnt; uint32_t stride = 0;
     DevBuf<uint32_t> req_q, req_t, req_slot, d_scal; DevBuf<int32_t> req_open, req_mid, req_region;
     HIPCHK(ctx, req_q.alloc(BLK)); HIPCHK(ctx, req_t.alloc(BLK)); HIPCHK(ctx, req_slot.alloc(BLK)); HIPCHK(ctx, req_open.alloc(BLK)); HIPCHK(ctx, req_mid.alloc(BLK)); HIPCHK(ctx, req_region.alloc(BLK));
     HIPCHK(ctx, d_scal.alloc(4));
     auto refresh = [&]() { D.rep_read = S.rep_read.p; D.pool = S.pool.p; D.pool_off = S.pool_off.p; };
 
-    for (uint32_t b0 = 0; b0 < NI; b0 += BLK) {
-        const uint32_t b1 = std::min<uint32_t>(NI, b0 + BLK);
+    for (uint32_t b0 = 0; b0 < NI; ) {
+        const uint32_t b1 = std::min<uint32_t>(NI, b0 + blk);
         uint32_t lo = b0;                         // first uncommitted item
+        uint32_t newreps = 0;
         bool need_full = true;
         while (lo < b1) {
             refresh();
@@ -481,6 +485,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             // commit [lo, first]; `first` founds a cluster: merge it into the index
             const uint32_t fread = h_items[first];
             rc = add_rep(ctx, S, fread, mzcode.p, RD.h_off[fread], h_mzcnt[fread]); if (rc) return rc;
+            ++newreps;
             lo = first + 1;
             if (lo >= b1) break;
             refresh();
@@ -494,6 +499,8 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             hipLaunchKernelGGL(k_reset_items, dim3((b1 - lo + 255) / 256), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1);
             HIPCHK(ctx, hipGetLastError());
         }
+        b0 = b1;
+        if (newreps <= 2) blk = std::min<uint32_t>(blk * 2, BLK); else if (newreps > 32) blk = std::max<uint32_t>(blk / 2, 8192);
     }
     // ---- results
     DevBuf<int32_t> d_rep; DevBuf<uint8_t> d_status; DevBuf<double> d_herr_out; DevBuf<unsigned long long> d_counters;
