@@ -72,3 +72,36 @@ def test_edit_distance_aligner_matches_oracle(pairs, maxq, seed):
     """bit-parallel polisher aligner (k_ed_align): distance, span and window break points vs the oracle's plain DP; every block-count
     instance (queries up to 256 / 512 / 768 / 1024 and block groups beyond), partial last blocks, wildcards, lower case, empty and unrelated sequences"""
     _run(pairs, maxq, seed, tool=TOOL_ED)
+
+
+@pytest.mark.gpu
+def test_cluster_result_independent_of_block_size():
+    """the speculative-block driver is exact: 120 k reads (several blocks, representatives founded in many of them, noisy singletons)
+    must cluster identically with the adaptive block size and with a fixed small one"""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from ngspeciesid_amd import runtime, synth
+from ngspeciesid_amd._capi import ReadSet, cluster_params
+from ngspeciesid_amd.ptable import select_p_table
+from ngspeciesid_amd.hostutil import subset_reads
+api = runtime.get_api(0)
+sp = synth.make_species(40, 600, 0.12, seed=21)
+ab = np.array([0.5 ** (i / 4.0) for i in range(40)]); ab /= ab.sum()
+rd = synth.make_reads(sp, 120000, mu=15.0, seed=22, abundance=ab, rc_fraction=0.2)
+rs0 = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+score, err, keep = api.score_reads(rs0, 13, 7.0)
+idx = np.nonzero(keep)[0]; idx = idx[np.argsort(-score[idx], kind="stable")]
+rs = subset_reads(rs0, idx)
+prm = cluster_params(k=13, w=20, p_shared=select_p_table(13, 20))
+ar = np.arange(rs.n, dtype=np.uint32)
+res = []
+for blk in (None, "3000"):
+    if blk: os.environ["NGSID_CLUSTER_BLK"] = blk
+    rep, herr, st, cnt = api.cluster_greedy(rs, prm, acc_rank=ar)
+    res.append((rep.copy(), st.copy(), cnt.copy()))
+assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), "block size changed the result"
+print("ok", rs.n, len(np.unique(res[0][0])), res[0][2])
+''' % ROOT
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, "\n".join(p.stdout.splitlines()[-10:])
