@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--length", type=int, default=750)
     ap.add_argument("--mu", type=float, default=17.0)
     ap.add_argument("--tile-depth", type=int, default=8)
+    ap.add_argument("--node-cap", type=int, default=0, help="POA graph capacity in 1/16 of the first sequence length (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -81,6 +82,7 @@ def main():
     n = rs.n
     acc_rank = np.asarray(rd["orig"], dtype=np.uint32)            # stand-in for the accession order (unique, deterministic)
     kw = dict(k=13, w=20, abundance_ratio=0.02, racon_iter=3, tile_depth=args.tile_depth, band=128, p_shared=ptab)
+    if args.node_cap and world == 1: kw["node_cap"] = args.node_cap
 
     def step(T=None):
         if dist is None:

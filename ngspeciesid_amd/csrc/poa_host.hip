@@ -134,7 +134,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
                 U.seqs.push_back((uint32_t)next.size()); next.push_back(S); next_maxlen = std::max<uint32_t>(next_maxlen, (uint32_t)S.len);
             }
         }
-        if (level == 0) ht.mark("L0 distribute");
+        if (level == 0) ht.mark("L0 distribute"); else { char lb[48]; snprintf(lb, sizeof lb, "level %d (%u tiles)", level, njobs); ht.mark(lb); }
         if (next.empty()) break;
         HIPCHK(ctx, Lv->seqs.reserve(sizeof(PSeq) * next.size()));
         HIPCHK(ctx, hipMemcpyAsync(Lv->seqs.p, next.data(), sizeof(PSeq) * next.size(), hipMemcpyHostToDevice, ctx->stream));
