@@ -185,7 +185,7 @@ def main():
                "sample": "%d reads strided from the same batch (same params, tile_depth %d), oracle/libngsid_oracle.so, %.1f s" % (ns, args.tile_depth, dtc)}
     out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), 750 bp ONT", "value": round(reads_per_s, 1), "unit": "reads/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "int32/u8 (f64 thresholds)", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic",
            "config": {"workload": "%d synthetic %d bp ONT-profile reads per GPU (mu=%.0f), %d species @15%% divergence, k=13 w=20, cluster + spoa-style POA + racon-style polish x3, abundance_ratio 0.02, POA tile depth %d band 128"
                       % (args.reads, args.length, args.mu, args.species, args.tile_depth),
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
