@@ -30,6 +30,13 @@ def test_polish_groups_match_oracle(groups, depth, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("what,groups,depth,band", [("spoa", 300, 8, 64), ("spoa", 150, 8, 256), ("polish", 40, 24, 64), ("polish", 30, 24, 256)])
+def test_other_band_widths_match_oracle(what, groups, depth, band):
+    """the 64- and 256-column instances of the tile kernel (one and four band cells per lane)"""
+    _run(groups, depth, what, 13, band)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pairs,maxlen,seed", [(2500, 1100, 1), (300, 4400, 2)])
 def test_aligner_pairs_match_oracle(pairs, maxlen, seed):
     """16-bit packed kernel (<= 4000 bases) and the 32-bit kernel, incl. wildcards, lower case, empty and unrelated sequences"""

@@ -1,6 +1,6 @@
 """dev tool / stress parity: many independent POA groups (HIP vs the CPU oracle), to catch rare-case divergences the small tests miss.
 
-    python tools/stress_poa.py [n_groups] [depth] [mode: spoa|polish] [seed]
+    python tools/stress_poa.py [n_groups] [depth] [mode: spoa|polish] [seed] [band: 64|128|256]
 
 spoa  : n_groups groups of `depth` reads -> poa_consensus (local mode, one tile per group when depth <= 8)
 polish: n_groups backbones (noisy drafts) each with `depth` reads -> polish (global + semi-global window layers, aligner included)
@@ -20,6 +20,7 @@ ng = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 what = sys.argv[3] if len(sys.argv) > 3 else "spoa"
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 11
+band = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 api = runtime.get_api(0); orc = load_oracle()
 L = 750
 sp = synth.make_species(4, L, 0.15, seed=seed)
@@ -32,7 +33,7 @@ if os.environ.get("STRESS_ONLY"):            # restrict to one group (same reads
     g0 = int(os.environ["STRESS_ONLY"]); grp = grp[g0:g0 + 2]; ng = 1
 bad = 0
 if what == "spoa":
-    prm = poa_params(tile_depth=8, band=128)
+    prm = poa_params(tile_depth=8, band=band)
     t = time.time(); a = api.poa_consensus(rs, grp, prm, read_order=order); ta = time.time() - t
     t = time.time(); b = orc.poa_consensus(rs, grp, prm, read_order=order); tb = time.time() - t
     for g in range(ng):
@@ -49,7 +50,7 @@ else:
         keep = rng.random(len(s)) >= 0.01
         bbs.append(s[keep].tobytes().decode())
     bb = ReadSet.from_strings(bbs)
-    prm = polish_params(iters=2, tile_depth=8, band=128, trim=2)
+    prm = polish_params(iters=2, tile_depth=8, band=band, trim=2)
     t = time.time(); a, ua = api.polish(bb, rs, grp, prm, read_order=order); ta = time.time() - t
     t = time.time(); b, ub = orc.polish(bb, rs, grp, prm, read_order=order); tb = time.time() - t
     for g in range(ng):
