@@ -24,7 +24,7 @@ band = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 api = runtime.get_api(0); orc = load_oracle()
 L = 750
 sp = synth.make_species(4, L, 0.15, seed=seed)
-rd = synth.make_reads(sp, ng * depth, mu=17.0, seed=seed + 1)
+rd = synth.make_reads(sp, ng * depth, mu=17.0, seed=seed + 1, rc_fraction=0.3 if what == "polish" else 0.0)      # the polisher orients reads itself
 spc = rd["species"].numpy()
 order = np.argsort(spc, kind="stable").astype(np.uint32)          # groups are (mostly) single-species runs of `depth` reads
 rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
