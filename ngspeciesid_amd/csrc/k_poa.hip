@@ -734,19 +734,18 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             // lane k looks at row blk_lo + k: the cell the path reaches there if it only takes diagonal moves through chain rows from (r, j)
             const int top = r - blk_lo;                        // 0 .. TBR-1
             const int jk = j - (top - lane);
-            bool loaded = false, good = false; int dk = 0;
-            if (lane <= top) {
-                const int ck = jk - (int)(myri & 0xffff);
-                if (ck >= 0 && ck < BW) { dk = w.dirblk()[(size_t)lane * BW + ck]; loaded = true; good = dk == 0 && ((myri >> 56) & 16) && jk >= 1; }
-            }
-            const unsigned long long gm = __ballot(good), lm = __ballot(loaded);
+            // branch-free per-lane part: out-of-block / out-of-band lanes read cell 0 and are masked afterwards
+            const int ck = jk - (int)(myri & 0xffff);
+            const bool loaded = (lane <= top) & ((unsigned)ck < (unsigned)BW);
+            const int dk = w.dirblk()[loaded ? lane * BW + ck : 0];
+            const bool good = loaded & (dk == 0) & (((unsigned)(myri >> 56) & 16u) != 0) & (jk >= 1);
+            const unsigned long long gm = __ballot(good);
             const unsigned long long x = gm << (63 - top);     // lane `top` at bit 63: leading ones = the run
             const int run = (~x) ? __builtin_clzll(~x) : 64;   // <= top + 1 because lanes above `top` never set their bit
-            if (lane <= top && lane > top - run) g.alnode(jk - 1) = (uint16_t)(blk_lo + lane);      // `run` diagonal moves, each to the previous rank
+            if ((lane <= top) & (lane > top - run)) g.alnode(jk - 1) = (uint16_t)(blk_lo + lane);      // `run` diagonal moves, each to the previous rank
             r -= run; j -= run;
             const int nk = top - run;                          // lane holding the next cell of the path
             if (nk < 0) continue;                              // it is in the block below: go round (loads it)
-            if (!((lm >> nk) & 1)) break;                      // cannot happen: the current cell is always inside its band
             const int d = __builtin_amdgcn_readlane(dk, nk);
             const unsigned rlo = __builtin_amdgcn_readlane((unsigned)myri, nk), rhi = __builtin_amdgcn_readlane((unsigned)(myri >> 32), nk);
             const int type = d & 3, slot = d >> 2;
