@@ -712,6 +712,20 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         // lane k keeps the row info of rank blk_lo + k in registers (k < TBR): one LDS read per iteration (the direction byte) instead of two
         unsigned long long myri = lane < TBR ? w.rblk()[lane] : 0ull;
         int n_reload = 0, n_iter = 0; unsigned long long c_reload = 0;
+        // the block below the current one is prefetched into registers while the current one is walked (a reload is an L2 / HBM round trip
+        // of several thousand cycles, the walk of a block takes longer than that)
+        constexpr int LPR = 64 / TBR;                         // lanes per direction row
+        constexpr int NPF = BW / (16 * LPR);                   // 16-byte pieces per lane and block
+        ngsid_v4u pf[NPF]; unsigned long long pri = 0ull; int pf_blk = -1;
+        auto prefetch = [&](int b) {
+            if (b < 0) { pf_blk = -1; return; }
+            const uint8_t* src = Dg + (size_t)(b + lane / LPR) * BW + (lane % LPR) * 16;
+#pragma unroll
+            for (int x = 0; x < NPF; ++x) pf[x] = ngsid_load16_l2(src + x * 16 * LPR);       // L2-served: rows are rewritten per sequence
+            pri = lane < TBR ? g.ri(b + lane) : 0ull;
+            pf_blk = b;
+        };
+        prefetch(blk_lo - TBR);
         for (int guard = 0;; ++guard) {
             ++n_iter;
             if (guard > 2 * (V + L) + 64) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow + 1, 1u); break; }   // cannot happen: every iteration consumes a move (reported by the host as an internal error)
@@ -720,14 +734,13 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 blk_lo = r & ~(TBR - 1);                    // aligned blocks of TBR rows, same layout as the forward pass staged them
                 ++n_reload;
                 const unsigned long long trl0 = J.phase_cycles ? __builtin_readcyclecounter() : 0;
-                constexpr int LPR = 64 / TBR;                         // lanes per direction row
-                const int rr = blk_lo + lane / LPR;
-                {
-                    const uint8_t* src = Dg + (size_t)rr * BW; l8 dstp = w.dirblk() + (size_t)(lane / LPR) * BW;
-                    for (int x = (lane % LPR) * 16; x < BW; x += 16 * LPR) *(LDSP ngsid_v4u*)(dstp + x) = ngsid_load16_l2(src + x);   // L2-served: rows are rewritten per sequence
-                    myri = lane < TBR ? g.ri(blk_lo + lane) : 0ull;
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                l8 dstp = w.dirblk() + (size_t)(lane / LPR) * BW + (lane % LPR) * 16;
+                if (blk_lo != pf_blk) prefetch(blk_lo);       // the path jumped further than one block (far predecessor): fetch it now
+#pragma unroll
+                for (int x = 0; x < NPF; ++x) *(LDSP ngsid_v4u*)(dstp + x * 16 * LPR) = pf[x];
+                myri = pri;
+                prefetch(blk_lo - TBR);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 if (J.phase_cycles) c_reload += __builtin_readcyclecounter() - trl0;
             }
