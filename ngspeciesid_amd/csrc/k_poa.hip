@@ -331,8 +331,20 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     }
     // backtrack: lane 0 lists the ranks of the path (HBM scratch), then all lanes translate rank -> letter / coverage
     int n = 0;
-    // one walk over the predecessor chain: ranks are written from the END of the scratch array, the path then starts at tmpo[V - n]
-    if (lane == 0) { int i = V; for (int r = mx; r != NONE16; r = w.epred()[r]) g.tmpo(--i) = (uint16_t)r; n = V - i; }
+    {   // most of the path is "predecessor = previous rank": lane k inspects rank r-k and the wave takes the whole leading run at once.
+        // One walk; ranks are written from the END of the scratch array, the path then starts at tmpo[V - n].
+        int i = V, r = mx;
+        while (r != NONE16) {
+            const int rk = r - lane;
+            const int pk = rk >= 0 ? (int)w.epred()[rk] : NONE16;
+            const unsigned long long gm = __ballot(rk >= 1 && pk == rk - 1) & 0x7fffffffffffffffull;     // at most 63 chained steps per round
+            const int run = __builtin_ctzll(~gm);          // ranks r .. r-run+1 step to their previous rank; rank r-run is reached and decides what follows
+            if (lane <= run) g.tmpo(i - 1 - lane) = (uint16_t)rk;
+            i -= run + 1;
+            r = __builtin_amdgcn_readlane(pk, run);        // predecessor of rank r-run (NONE16 ends the path)
+        }
+        n = V - i;
+    }
     n = __builtin_amdgcn_readfirstlane(n);
     const int poff = V - n;
     mem_sync();
