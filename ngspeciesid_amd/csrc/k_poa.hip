@@ -905,16 +905,22 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             for (int u = 0; u < 2; ++u) e0v[u] = av[u] != NONE16 ? (int)g.out_first(av[u]) : NONE16;
 #pragma unroll
             for (int u = 0; u < 2; ++u) h0v[u] = e0v[u] != NONE16 ? (int)g.e_head(e0v[u]) : NONE16;
+            uint32_t covv[2]; int ewv[2];       // read-modify-write operands fetched with the rest (no two positions of an alignment share a node or an edge)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { covv[u] = bv[u] != NONE16 ? g.cov(bv[u]) : 0u; ewv[u] = (e0v[u] != NONE16 && h0v[u] == bv[u]) ? g.e_w(e0v[u]) : 0; }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int i = ib + u * 64 + lane; bool newedge = false; const int a = av[u], b = bv[u]; int wgt = 0;
                 if (i < L) {
-                    g.cov(b) += S.cw;
+                    g.cov(b) = covv[u] + S.cw;
                     if (i > 0) {
                         wgt = wtof(S, i - 1) + wtof(S, i);
                         int e = e0v[u];
-                        if (e != NONE16 && h0v[u] != b) for (e = g.e_next_out(e); e != NONE16; e = g.e_next_out(e)) if (g.e_head(e) == b) break;
-                        if (e != NONE16) g.e_w(e) += wgt; else newedge = true;
+                        if (e != NONE16 && h0v[u] == b) g.e_w(e) = ewv[u] + wgt;
+                        else {
+                            if (e != NONE16) for (e = g.e_next_out(e); e != NONE16; e = g.e_next_out(e)) if (g.e_head(e) == b) break;
+                            if (e != NONE16) g.e_w(e) += wgt; else newedge = true;
+                        }
                     }
                 }
                 const unsigned long long mn = __ballot(newedge);
