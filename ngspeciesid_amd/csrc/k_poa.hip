@@ -473,7 +473,8 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                     for (int c = 0; c < CPL; ++c) { up[c] = hprev[c]; dg[c] = c ? hprev[c - 1] : lf; }
                 }
                 int X[CPL], Dd[CPL];
-                const int jg0 = l0 * gp_ + lane_jg;
+                int l0g = l0 * gp_; asm volatile("" : "+s"(l0g));      // scalar product (stops the compiler from re-associating it into a per-lane v_mul_lo_u32)
+                const int jg0 = l0g + lane_jg;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const int sc = q[c] == cv ? sm : sn;
@@ -514,7 +515,8 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                 for (int c = 0; c <= CPL; ++c) h1[c] = PNEG;
             }
             int X[CPL], Dd[CPL];
-            const int jg0 = l0 * gp_ + lane_jg;
+            int l0g = l0 * gp_; asm volatile("" : "+s"(l0g));      // scalar product (stops the compiler from re-associating it into a per-lane v_mul_lo_u32)
+                const int jg0 = l0g + lane_jg;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int sc = ((int)sq0[l0 + c] == cv) ? sm : sn;
@@ -580,7 +582,8 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                 if (nopred && !semi) { const int sv = LOCAL ? 0 : j * gp; if (sv + gp > Xu[c]) { Xu[c] = sv + gp; Uslot[c] = SRC_SLOT; } }
                 if (Xd[c] >= Xu[c]) { X[c] = Xd[c]; Dd[c] = 0 | (Dslot[c] << 2); } else { X[c] = Xu[c]; Dd[c] = 1 | (Uslot[c] << 2); }
             }
-            const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, l0 * gp_ + lane_jg, gp, hprev);
+            int l0g = l0 * gp_; asm volatile("" : "+s"(l0g));
+            const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, l0g + lane_jg, gp, hprev);
             poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * RS, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
             if (LOCAL) {
                 const unsigned rk = 0xFFFFu - (unsigned)r;
