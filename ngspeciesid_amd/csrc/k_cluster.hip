@@ -235,11 +235,56 @@ __global__ void k_cache_insert(ClDev D, const uint32_t* __restrict__ req_q, cons
     D.cache_ptr[read] = (uint8_t)((ptr + 1) % NCACHE);
 }
 
-__global__ void k_first_newrep(const int32_t* __restrict__ dec, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t* __restrict__ first)
+// one bit per block item: the item decided "new representative" (word w covers the items row0 + 64 w ... of the block)
+__global__ void k_newrep_mask(const int32_t* __restrict__ dec, const uint32_t* __restrict__ items, uint32_t it_first /* row0 + multiple of 64 */, uint32_t it_lo, uint32_t it_hi,
+                              uint32_t row0, unsigned long long* __restrict__ mask)
 {
-    const uint32_t it = it_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t it = it_first + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool v = it >= it_lo && it < it_hi && dec[items[it]] == DEC_NEWREP;
+    const unsigned long long bits = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && it < it_hi) mask[(it - row0) >> 6] = bits;
+}
+
+// hits of the block items [it_lo,it_hi) against ONE freshly built representative (its sorted unique codes in the pool; the offsets are read on the
+// device, so tentative representatives need no host round trip)
+__global__ __launch_bounds__(256)
+void k_count_hits_rep(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t row0, uint32_t slot, uint64_t* __restrict__ cnt, uint32_t stride)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (it >= it_hi) return;
-    if (dec[items[it]] == DEC_NEWREP) atomicMin(first, it);
+    const uint32_t read = items[it];
+    if (D.hlen[read] < (uint32_t)D.k) return;
+    const uint64_t* __restrict__ rc = D.pool + D.pool_off[slot];
+    const uint32_t n = (uint32_t)(D.pool_off[slot + 1] - D.pool_off[slot]);
+    const uint32_t M = D.mzcnt[read];
+    const uint64_t base = D.off[read];
+    unsigned long long* cell = (unsigned long long*)(cnt + (uint64_t)(it - row0) * stride + slot);
+    unsigned long long acc = 0;
+    for (uint32_t a = lane; a < M; a += 64) {
+        const uint64_t code = D.mzcode[base + a];
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rc[mid] < code) lo = mid + 1; else hi = mid; }
+        if (lo < n && rc[lo] == code) acc += (1ull << 48) + (unsigned long long)D.mzpos[base + a];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0 && acc) *cell += acc;
+}
+
+// first block item in [it_lo,it_hi) that shares at least min_shared minimizers with one of the T tentative representatives in the columns
+// R0 .. R0+T-1 (only such an item can decide differently once they exist: get_best_cluster breaks below min_shared, cluster.py:82,88, and the
+// alignment stage only looks at the top count, :181, which is >= min_shared, :310)
+__global__ __launch_bounds__(256)
+void k_first_affected(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t row0, const uint64_t* __restrict__ cnt, uint32_t stride,
+                      uint32_t R0, uint32_t T, uint32_t* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (it >= it_hi) return;
+    const uint64_t* row = cnt + (uint64_t)(it - row0) * stride;
+    const bool hit = (uint32_t)lane < T && (int)(row[R0 + lane] >> 48) >= D.min_shared;
+    if (__ballot(hit) != 0ull && lane == 0) atomicMin(out, it);
 }
 
 // sort + unique the minimizer codes of one read into the representative pool (single workgroup, bitonic in LDS);
@@ -293,17 +338,26 @@ __global__ void k_finalize(ClDev D, uint64_t n, const uint8_t* __restrict__ seed
                            double* __restrict__ herr_out, unsigned long long* __restrict__ counters)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const double nan = __longlong_as_double(0x7ff8000000000000ULL);
-    if (seeded && seeded[i]) { rep_of[i] = (int32_t)i; status[i] = NGSID_ST_SEEDED; herr_out[i] = D.herr[i]; return; }
-    const int32_t d = D.dec[i];
-    if (d == DEC_SHORT) { rep_of[i] = (int32_t)i; status[i] = NGSID_ST_SHORT; herr_out[i] = nan; return; }
-    herr_out[i] = D.herr[i];
-    if (D.alnflag[i]) atomicAdd(&counters[2], 1ull);
-    if (d >= 0) {
-        rep_of[i] = (int32_t)D.rep_read[d]; status[i] = D.kind[i];
-        atomicAdd(&counters[D.kind[i] == NGSID_ST_MAPPED ? 0 : 1], 1ull);
-    } else { rep_of[i] = (int32_t)i; status[i] = NGSID_ST_NEWREP; atomicAdd(&counters[3], 1ull); }
+    int which = -1; bool aln = false;               // counter this read adds to (0 mapped, 1 aligned, 3 new representative); counted once per wave
+    if (i < n) {
+        const int32_t d = D.dec[i];
+        if (seeded && seeded[i]) { rep_of[i] = (int32_t)i; status[i] = NGSID_ST_SEEDED; herr_out[i] = D.herr[i]; }
+        else if (d == DEC_SHORT) { rep_of[i] = (int32_t)i; status[i] = NGSID_ST_SHORT; herr_out[i] = nan; }
+        else {
+            herr_out[i] = D.herr[i];
+            aln = D.alnflag[i] != 0;
+            if (d >= 0) { const uint8_t kd = D.kind[i]; rep_of[i] = (int32_t)D.rep_read[d]; status[i] = kd; which = kd == NGSID_ST_MAPPED ? 0 : 1; }
+            else { rep_of[i] = (int32_t)i; status[i] = NGSID_ST_NEWREP; which = 3; }
+        }
+    }
+    const unsigned long long c0 = __popcll(__ballot(which == 0)), c1 = __popcll(__ballot(which == 1)), c2 = __popcll(__ballot(aln)), c3 = __popcll(__ballot(which == 3));
+    if ((threadIdx.x & 63) == 0) {
+        if (c0) atomicAdd(&counters[0], c0);
+        if (c1) atomicAdd(&counters[1], c1);
+        if (c2) atomicAdd(&counters[2], c2);
+        if (c3) atomicAdd(&counters[3], c3);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host driver
@@ -316,31 +370,43 @@ struct RepStore {
 };
 }
 
-static int32_t add_rep(ngsid_ctx* ctx, RepStore& S, uint32_t read, const uint64_t* d_mzcode, uint64_t base, uint32_t M)
+// Builds the representatives of `reads` in the slots S.R, S.R+1, ... (pool offsets chained on the device) without registering them on the host:
+// the caller copies pool_off[S.R .. S.R+n] back and commits a prefix.  A slot that is not committed is simply overwritten by the next build.
+static int32_t build_reps(ngsid_ctx* ctx, RepStore& S, const uint32_t* reads, uint32_t n, const uint64_t* d_mzcode, const uint64_t* h_off, const uint32_t* h_mzcnt)
 {
-    if (S.R + 1 > S.Rcap) {
-        const uint32_t nc = S.Rcap ? S.Rcap * 2 : 1024;
+    if (S.R + n + 1 > S.Rcap) {
+        uint32_t nc = S.Rcap ? S.Rcap : 1024; while (nc < S.R + n + 1) nc *= 2;
         HIPCHK(ctx, S.rep_read.grow(nc, ctx->stream)); HIPCHK(ctx, S.pool_off.grow((size_t)nc + 1, ctx->stream));
         S.Rcap = nc;
     }
-    const uint64_t po = S.h_pool_off[S.R];
-    if (po + M + 1 > S.pool.n) HIPCHK(ctx, S.pool.grow(std::max<size_t>((po + M + 1) * 2, 1 << 16), ctx->stream));
-    uint32_t P2 = 1; while (P2 < M) P2 <<= 1; if (P2 < 2) P2 = 2;
-    const size_t lds = (size_t)P2 * 8;
-    if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_rep_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_rep_build, dim3(1), dim3(256), lds, ctx->stream, d_mzcode, base, M, P2, S.pool.p, S.pool_off.p, S.rep_read.p, S.R, read, S.d_count.p);
-    HIPCHK(ctx, hipGetLastError());
-    uint32_t u = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&u, S.d_count.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    S.h_pool_off.push_back(po + u);
-    const int nx = S.cur ^ 1;
-    if (S.n_db + u + 1 > S.dbc[nx].n) { const size_t cap = std::max<size_t>((S.n_db + u + 1) * 2, 1 << 16); HIPCHK(ctx, S.dbc[nx].alloc(cap)); HIPCHK(ctx, S.dbs[nx].alloc(cap)); }
-    const uint64_t tot = S.n_db + u;
-    if (tot) hipLaunchKernelGGL(k_db_merge, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
-                                S.dbc[S.cur].p, S.dbs[S.cur].p, S.n_db, S.pool.p + po, u, S.R, S.dbc[nx].p, S.dbs[nx].p);
-    HIPCHK(ctx, hipGetLastError());
-    S.cur = nx; S.n_db = tot; S.R += 1;
+    uint64_t need = S.h_pool_off[S.R];
+    for (uint32_t t = 0; t < n; ++t) need += h_mzcnt[reads[t]];
+    if (need + 1 > S.pool.n) HIPCHK(ctx, S.pool.grow(std::max<size_t>((need + 1) * 2, 1 << 16), ctx->stream));
+    for (uint32_t t = 0; t < n; ++t) {
+        const uint32_t M = h_mzcnt[reads[t]];
+        uint32_t P2 = 1; while (P2 < M) P2 <<= 1; if (P2 < 2) P2 = 2;
+        const size_t lds = (size_t)P2 * 8;
+        if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_rep_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_rep_build, dim3(1), dim3(256), lds, ctx->stream, d_mzcode, h_off[reads[t]], M, P2, S.pool.p, S.pool_off.p, S.rep_read.p, S.R + t, reads[t], S.d_count.p);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return NGSID_OK;
+}
+
+// Registers the first c built representatives: host mirror of the pool offsets (h_po = pool_off[S.R .. S.R+c] as read back) and the merged index.
+static int32_t commit_reps(ngsid_ctx* ctx, RepStore& S, uint32_t c, const uint64_t* h_po)
+{
+    for (uint32_t t = 0; t < c; ++t) {
+        const uint64_t po = h_po[t]; const uint32_t u = (uint32_t)(h_po[t + 1] - h_po[t]);
+        S.h_pool_off.push_back(h_po[t + 1]);
+        const int nx = S.cur ^ 1;
+        if (S.n_db + u + 1 > S.dbc[nx].n) { const size_t cap = std::max<size_t>((S.n_db + u + 1) * 2, 1 << 16); HIPCHK(ctx, S.dbc[nx].alloc(cap)); HIPCHK(ctx, S.dbs[nx].alloc(cap)); }
+        const uint64_t tot = S.n_db + u;
+        if (tot) hipLaunchKernelGGL(k_db_merge, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                                    S.dbc[S.cur].p, S.dbs[S.cur].p, S.n_db, S.pool.p + po, u, S.R, S.dbc[nx].p, S.dbs[nx].p);
+        HIPCHK(ctx, hipGetLastError());
+        S.cur = nx; S.n_db = tot; S.R += 1;
+    }
     return NGSID_OK;
 }
 
@@ -352,7 +418,9 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     if (!reads || !prm || !rep_of_read) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
     const int k = prm->k, w = prm->w;
     if (k < 1 || k > NGSID_MAX_K || w < k) NGSID_FAIL(ctx, NGSID_ERR_ARG, "bad k/w (k=%d, w=%d; k <= %d)", k, w, NGSID_MAX_K);
+    HostTimer ht(ctx->stream, "cluster");
     DevReads RD; int32_t rc = ngsid_upload_reads(ctx, reads, &RD, true); if (rc) return rc;
+    ht.mark("upload");
     const uint64_t N = RD.n;
     if (counters) counters[0] = counters[1] = counters[2] = counters[3] = 0;
     if (N == 0) return NGSID_OK;
@@ -417,7 +485,19 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     HIPCHK(ctx, S.d_count.alloc(4)); HIPCHK(ctx, S.rep_read.alloc(1024)); HIPCHK(ctx, S.pool_off.alloc(1025)); S.Rcap = 1024;
     HIPCHK(ctx, hipMemsetAsync(S.pool_off.p, 0, 8, ctx->stream));
     HIPCHK(ctx, S.pool.alloc(1 << 16)); HIPCHK(ctx, S.dbc[0].alloc(1 << 16)); HIPCHK(ctx, S.dbs[0].alloc(1 << 16)); HIPCHK(ctx, S.dbc[1].alloc(1 << 16)); HIPCHK(ctx, S.dbs[1].alloc(1 << 16));
-    if (prev_batch) for (uint64_t i = 0; i < N; ++i) if (h_seeded[i] && h_hlen[i] >= (uint32_t)k) { rc = add_rep(ctx, S, (uint32_t)i, mzcode.p, RD.h_off[i], h_mzcnt[i]); if (rc) return rc; }
+    std::vector<uint64_t> h_po;
+    if (prev_batch) {       // the seeded representatives, built in chunks (one host round trip per chunk)
+        std::vector<uint32_t> seeds;
+        for (uint64_t i = 0; i < N; ++i) if (h_seeded[i] && h_hlen[i] >= (uint32_t)k) seeds.push_back((uint32_t)i);
+        for (size_t s0 = 0; s0 < seeds.size(); s0 += 512) {
+            const uint32_t nch = (uint32_t)std::min<size_t>(512, seeds.size() - s0);
+            rc = build_reps(ctx, S, seeds.data() + s0, nch, mzcode.p, RD.h_off.data(), h_mzcnt.data()); if (rc) return rc;
+            h_po.resize(nch + 1);
+            HIPCHK(ctx, hipMemcpyAsync(h_po.data(), S.pool_off.p + S.R, 8ull * (nch + 1), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            rc = commit_reps(ctx, S, nch, h_po.data()); if (rc) return rc;
+        }
+    }
 
     ClDev D{};
     D.seq = RD.seq; D.qual = RD.qual; D.off = RD.off; D.n = N; D.hlen = hlen.p; D.mzcnt = mzcnt.p; D.herr = herr.p; D.rawerr = rawerr.p; D.eidx = eidx.p; D.accrank = d_acc.p;
@@ -436,8 +516,12 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     DevBuf<uint32_t> req_q, req_t, req_slot, d_scal; DevBuf<int32_t> req_open, req_mid, req_region;
     HIPCHK(ctx, req_q.alloc(BLK)); HIPCHK(ctx, req_t.alloc(BLK)); HIPCHK(ctx, req_slot.alloc(BLK)); HIPCHK(ctx, req_open.alloc(BLK)); HIPCHK(ctx, req_mid.alloc(BLK)); HIPCHK(ctx, req_region.alloc(BLK));
     HIPCHK(ctx, d_scal.alloc(4));
+    uint32_t tcur = 1;
+    constexpr uint32_t TMAX = 64;             // new representatives committed per pass (one lane per tentative column in k_first_affected)
+    DevBuf<unsigned long long> d_mask; HIPCHK(ctx, d_mask.alloc(BLK / 64 + 1)); std::vector<unsigned long long> h_mask(BLK / 64 + 1);
     auto refresh = [&]() { D.rep_read = S.rep_read.p; D.pool = S.pool.p; D.pool_off = S.pool_off.p; };
 
+    ht.mark("setup");
     for (uint32_t b0 = 0; b0 < NI; ) {
         const uint32_t b1 = std::min<uint32_t>(NI, b0 + blk);
         uint32_t lo = b0;                         // first uncommitted item
@@ -474,36 +558,62 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
                 hipLaunchKernelGGL(k_cache_insert, dim3((nreq + 255) / 256), dim3(256), 0, ctx->stream, D, req_q.p, req_slot.p, req_region.p, nreq);
                 HIPCHK(ctx, hipGetLastError());
             }
-            uint32_t first = 0xffffffffu;
-            HIPCHK(ctx, hipMemsetAsync(d_scal.p + 1, 0xff, 4, ctx->stream));
-            hipLaunchKernelGGL(k_first_newrep, dim3((b1 - lo + 255) / 256), dim3(256), 0, ctx->stream, dec.p, d_items.p, lo, b1, d_scal.p + 1);
+            // ---- the items that decided "new representative", in block order (bit mask of the block, scanned on the host)
+            const uint32_t w0 = (lo - b0) >> 6, w1 = (b1 - b0 + 63) >> 6;
+            hipLaunchKernelGGL(k_newrep_mask, dim3(((w1 - w0) * 64 + 255) / 256), dim3(256), 0, ctx->stream, dec.p, d_items.p, b0 + w0 * 64, lo, b1, b0, d_mask.p);
             HIPCHK(ctx, hipGetLastError());
             int eflag = 0;
-            HIPCHK(ctx, hipMemcpyAsync(&first, d_scal.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_mask.data() + w0, d_mask.p + w0, 8ull * (w1 - w0), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(&eflag, flag.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             if (eflag) NGSID_FAIL(ctx, NGSID_ERR_NO_PTABLE, "no p_shared entry for an (e1,e2) pair met during mapping (KeyError in cluster.py:367)");
-            if (first == 0xffffffffu) { lo = b1; break; }
-            // commit [lo, first]; `first` founds a cluster: merge it into the index
-            const uint32_t fread = h_items[first];
-            rc = add_rep(ctx, S, fread, mzcode.p, RD.h_off[fread], h_mzcnt[fread]); if (rc) return rc;
-            ++newreps;
-            lo = first + 1;
-            if (lo >= b1) break;
-            refresh();
-            if (S.R > stride) { need_full = true; }
-            else {
-                // delta: hits of the later items against the new representative only
-                { ProfScope ps_(ctx, "k_count_hits"); hipLaunchKernelGGL(k_count_hits, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0,
-                                   S.pool.p + S.h_pool_off[S.R - 1], (const uint32_t*)nullptr, S.R - 1, S.h_pool_off[S.R] - S.h_pool_off[S.R - 1], cnt.p, stride); }
-                HIPCHK(ctx, hipGetLastError());
+            uint32_t C[TMAX + 1]; uint32_t nC = 0;
+            for (uint32_t wd = w0; wd < w1 && nC <= TMAX; ++wd) {
+                unsigned long long m = h_mask[wd];
+                while (m && nC <= TMAX) { C[nC++] = b0 + wd * 64 + (uint32_t)__builtin_ctzll(m); m &= m - 1; }
             }
+            if (nC == 0) { lo = b1; break; }
+            // ---- up to TMAX of them become representatives at once.  All are built (slots R, R+1, ...) and the later items are counted against
+            // each; everything before the first item that shares >= min_shared minimizers with an EARLIER tentative representative is final
+            // (such an item is the only kind whose decision can change), the tentative representatives before that item are committed, the
+            // rest of the block is decided again.  With one new representative per pass this is the plain greedy restart.
+            const uint32_t T = std::min<uint32_t>(std::min<uint32_t>(tcur, nC), stride - S.R);
+            const uint32_t next_c = nC > T ? C[T] : 0xffffffffu;
+            uint32_t creads[TMAX];
+            for (uint32_t t = 0; t < T; ++t) creads[t] = h_items[C[t]];
+            rc = build_reps(ctx, S, creads, T, mzcode.p, RD.h_off.data(), h_mzcnt.data()); if (rc) return rc;
+            refresh();
+            for (uint32_t t = 0; t < T; ++t) if (C[t] + 1 < b1) {
+                ProfScope ps_(ctx, "k_count_hits");
+                hipLaunchKernelGGL(k_count_hits_rep, dim3((b1 - C[t] - 1 + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, C[t] + 1, b1, b0, S.R + t, cnt.p, stride);
+            }
+            HIPCHK(ctx, hipGetLastError());
+            uint32_t cut = 0xffffffffu;
+            HIPCHK(ctx, hipMemsetAsync(d_scal.p + 1, 0xff, 4, ctx->stream));
+            if (C[0] + 1 < b1) hipLaunchKernelGGL(k_first_affected, dim3((b1 - C[0] - 1 + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, C[0] + 1, b1, b0, cnt.p, stride, S.R, T, d_scal.p + 1);
+            HIPCHK(ctx, hipGetLastError());
+            h_po.resize(T + 1);
+            HIPCHK(ctx, hipMemcpyAsync(&cut, d_scal.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_po.data(), S.pool_off.p + S.R, 8ull * (T + 1), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            cut = std::min(cut, next_c);
+            uint32_t c = 0; while (c < T && C[c] < cut) ++c;                 // >= 1: the affected item lies behind C[0]
+            rc = commit_reps(ctx, S, c, h_po.data()); if (rc) return rc;
+            newreps += c;
+            tcur = c == T ? std::min<uint32_t>(TMAX, tcur * 2) : std::max<uint32_t>(1, c);      // speculate wider only while it pays
+            if (cut >= b1) { lo = b1; break; }
+            lo = cut;
+            // the columns of the tentative representatives that were not committed go back to zero (their entries sit in rows >= cut)
+            if (c < T) HIPCHK(ctx, hipMemset2DAsync(cnt.p + (uint64_t)(lo - b0) * stride + S.R, (size_t)stride * 8, 0, (size_t)(T - c) * 8, b1 - lo, ctx->stream));
+            refresh();
+            if (S.R + 1 > stride) need_full = true;
             hipLaunchKernelGGL(k_reset_items, dim3((b1 - lo + 255) / 256), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1);
             HIPCHK(ctx, hipGetLastError());
         }
         b0 = b1;
         if (!blk_fixed) { if (newreps <= 2) blk = std::min<uint32_t>(blk * 2, BLK); else if (newreps > 32) blk = std::max<uint32_t>(blk / 2, 8192); }
     }
+    ht.mark("blocks");
     // ---- results
     DevBuf<int32_t> d_rep; DevBuf<uint8_t> d_status; DevBuf<double> d_herr_out; DevBuf<unsigned long long> d_counters;
     HIPCHK(ctx, d_rep.alloc(N)); HIPCHK(ctx, d_status.alloc(N)); HIPCHK(ctx, d_herr_out.alloc(N)); HIPCHK(ctx, d_counters.alloc(4));
@@ -517,6 +627,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     HIPCHK(ctx, hipMemcpyAsync(h_herr.data(), d_herr_out.p, 8 * N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_cnt, d_counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ht.mark("finalize + download");
     if (status_out) memcpy(status_out, h_status.data(), N);
     if (hpc_err_out) memcpy(hpc_err_out, h_herr.data(), 8 * N);
     if (counters) for (int i = 0; i < 4; ++i) counters[i] = h_cnt[i];

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <chrono>
 #include "../../include/ngsid.h"
 
 // RAII device buffer (freed at scope exit; all work is synchronised before return)
@@ -110,3 +111,10 @@ __device__ __forceinline__ ngsid_v4u ngsid_load16_l2(const void* p) { return __b
 __device__ __forceinline__ int ngsid_bcode(uint8_t c) {
     switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
 }
+
+// dev aid: NGSID_HOST_TIMERS=1 prints host-side wall time per section (stream synchronised at each mark)
+struct HostTimer {
+    bool on; hipStream_t st; std::chrono::steady_clock::time_point t0; const char* what;
+    HostTimer(hipStream_t s, const char* w) : on(getenv("NGSID_HOST_TIMERS") != nullptr), st(s), what(w) { if (on) { (void)hipStreamSynchronize(st); t0 = std::chrono::steady_clock::now(); } }
+    void mark(const char* label) { if (!on) return; (void)hipStreamSynchronize(st); auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[ngsid host] %s: %s %.2f ms\n", what, label, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
+};

@@ -9,12 +9,6 @@
 #include <memory>
 
 namespace {
-// dev aid: NGSID_HOST_TIMERS=1 prints host-side wall time per section (stream synchronised at each mark)
-struct HostTimer {
-    bool on; hipStream_t st; std::chrono::steady_clock::time_point t0; const char* what;
-    HostTimer(hipStream_t s, const char* w) : on(getenv("NGSID_HOST_TIMERS") != nullptr), st(s), what(w) { if (on) { (void)hipStreamSynchronize(st); t0 = std::chrono::steady_clock::now(); } }
-    void mark(const char* label) { if (!on) return; (void)hipStreamSynchronize(st); auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[ngsid host] %s: %s %.2f ms\n", what, label, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
-};
 #define HT_INIT
 
 struct Unit {                       // one consensus problem: a cluster (spoa stage) or a backbone window (polish)

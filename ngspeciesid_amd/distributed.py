@@ -53,22 +53,9 @@ def _weighted_merge(api, partials, counts, tile_depth, band):
     return api.poa_consensus(rs, [0, len(seqs)], poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=band))[0]
 
 
-def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k=13, w=20, abundance_ratio=0.1, rc_identity_threshold=0.9,
-                     racon_iter=3, tile_depth=8, band=128, p_shared=None, cluster_kwargs=None, do_consensus=True, polish_trim=2, device=None, timings=None):
-    """Runs on every rank; returns dict(final_rep=(rank, local idx) per local read as two arrays, centers=[(n, key, draft, polished)])."""
-    import time
-    T = timings if timings is not None else {}
-    world, rank = dist.get_world_size(), dist.get_rank()
-    device = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
-    prm = cluster_params(k=k, w=w, p_shared=p_shared, **(cluster_kwargs or {}))
+def representative_payload(rs_local, rep_local, herr, score_local, acc_rank_local=None):
+    """What a shard contributes to the all-gather: its surviving representatives (a few KB each).  -> (mine, payload)"""
     n_local = rs_local.n
-    score_local = np.asarray(score_local, dtype=np.float64)
-    # ---- 1. round 1 on the shard (no communication)
-    t0 = time.perf_counter()
-    rep_local, herr, st, cnt = api.cluster_greedy(rs_local, prm, acc_rank=acc_rank_local)
-    T["cluster_local"] = T.get("cluster_local", 0.0) + time.perf_counter() - t0
-    # ---- 2. all-gather the representatives, replay the tree merge everywhere
-    t0 = time.perf_counter()
     mine = np.nonzero(rep_local == np.arange(n_local))[0]
     if rs_local.mem == 0:
         sub = subset_reads(rs_local, mine)
@@ -82,7 +69,13 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
         gi = torch.from_numpy(np.repeat(offs[mine] - noff[:-1].astype(np.int64), lens) + np.arange(int(noff[-1]), dtype=np.int64)).to(seq_t.device)
         payload = dict(idx=mine.astype(np.int64), seq=seq_t[gi].cpu().numpy(), qual=qual_t[gi].cpu().numpy(), off=noff, score=score_local[mine], herr=herr[mine],
                        rank_key=None if acc_rank_local is None else np.asarray(acc_rank_local)[mine], n=n_local)
-    gathered = all_gather_obj(payload, device)
+    return mine, payload
+
+
+def merge_representatives(api, gathered, prm, world):
+    """Replay of the reference's pairwise tree merge (parallelize.py:169-215) on the all-gathered representatives of `world` shards;
+    identical on every rank.  gathered[b] = dict(idx, seq, qual, off, score, herr, rank_key, n) of shard b.
+    -> (rep_of_rep, r_owner, r_lidx, r_score, n_total): for every gathered representative the global id of its final representative."""
     n_total = sum(g["n"] for g in gathered)
     seqs = np.concatenate([g["seq"] for g in gathered]); quals = np.concatenate([g["qual"] for g in gathered])
     lens_all = np.concatenate([np.diff(g["off"].astype(np.int64)) for g in gathered])
@@ -103,6 +96,28 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
         s = subset_reads(reps_rs, read_idx)
         return api.cluster_greedy(s, prm, acc_rank=r_accrank[np.asarray(read_idx, dtype=np.int64)], prev_batch=prev_batch, known_err=known_err)
     rep_of_rep, _, joins = parallelize.tree_cluster(cfn, lens_all, r_score, world, state=(r_batch, r_herr))
+    return rep_of_rep, r_owner, r_lidx, r_score, n_total
+
+
+def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k=13, w=20, abundance_ratio=0.1, rc_identity_threshold=0.9,
+                     racon_iter=3, tile_depth=8, band=128, p_shared=None, cluster_kwargs=None, do_consensus=True, polish_trim=2, device=None, timings=None):
+    """Runs on every rank; returns dict(final_rep=(rank, local idx) per local read as two arrays, centers=[(n, key, draft, polished)])."""
+    import time
+    T = timings if timings is not None else {}
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    prm = cluster_params(k=k, w=w, p_shared=p_shared, **(cluster_kwargs or {}))
+    n_local = rs_local.n
+    score_local = np.asarray(score_local, dtype=np.float64)
+    # ---- 1. round 1 on the shard (no communication)
+    t0 = time.perf_counter()
+    rep_local, herr, st, cnt = api.cluster_greedy(rs_local, prm, acc_rank=acc_rank_local)
+    T["cluster_local"] = T.get("cluster_local", 0.0) + time.perf_counter() - t0
+    # ---- 2. all-gather the representatives, replay the tree merge everywhere
+    t0 = time.perf_counter()
+    mine, payload = representative_payload(rs_local, rep_local, herr, score_local, acc_rank_local)
+    gathered = all_gather_obj(payload, device)
+    rep_of_rep, r_owner, r_lidx, r_score, n_total = merge_representatives(api, gathered, prm, world)
     base = np.concatenate(([0], np.cumsum([len(g["idx"]) for g in gathered])))
     my_gid = np.full(n_local, -1, dtype=np.int64); my_gid[mine] = base[rank] + np.arange(len(mine))
     final_gid = rep_of_rep[my_gid[rep_local]]                                 # global representative id of every local read
