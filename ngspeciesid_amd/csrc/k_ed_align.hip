@@ -20,7 +20,8 @@ typedef unsigned long long u64;
 template <int BMAX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
 void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-byte units */, uint32_t mstride, uint32_t* __restrict__ work_ctr, int32_t* __restrict__ dist_out,
-                int8_t* __restrict__ hcar /* per wave mstride x 64: horizontal delta below the last block of a block group */)
+                int8_t* __restrict__ hcar /* per wave mstride x 64: horizontal delta below the last block of a block group */,
+                int bandK /* > 0: Ukkonen band for distances <= bandK (single block group only) */, uint32_t* __restrict__ fail_list, uint32_t* __restrict__ fail_count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -45,6 +46,18 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
         const int B = (nmax + 63) >> 6;                     // 64-row blocks the wave walks, in groups of BMAX (register-resident states)
         const int bl = n > 0 ? (n - 1) >> 6 : 0, lastbit = n > 0 ? (n - 1) & 63 : 0;
         int score = n, best = n, bestj = 0;                 // D[n][0] = n
+        // Band (exact for pairs whose distance turns out <= bandK, the others are handed to an unbanded launch): a cell (i,c) of an alignment
+        // with at most K edits has i - c <= K (its prefix costs at least i - c) and (n - i) - (m - c) <= K (the rest of the query still needs
+        // that many columns), so column c only needs the rows c + min(n - m) - K ... c + K.  Blocks below the band keep their initial state
+        // (vertical deltas +1, an upper bound, as in edlib); the row above the first block of the band is taken as +1 per column.
+        const bool band = bandK > 0 && B <= BMAX;
+        int dmin = 0, lbprev = -1, sb = 0;                  // sb: value at the bottom row of the last block of the band (per lane)
+        if (band) {
+            dmin = have ? n - m : 0x3fffffff;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) dmin = min(dmin, __shfl_xor(dmin, d));
+            dmin = __builtin_amdgcn_readfirstlane(dmin);
+        }
         for (int g0 = 0; g0 < B; g0 += BMAX) {
             const int Bg = min(BMAX, B - g0);
             // ---- query bit planes of the group -> LDS
@@ -66,11 +79,20 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
             for (int j = 0; j < mmax; ++j) {
                 const int tc = j < m ? ngsid_bcode(t[j]) : 4;
                 const u64 Tlo = (tc & 1) ? ~0ull : 0ull, Thi = (tc & 2) ? ~0ull : 0ull, Tok = tc < 4 ? ~0ull : 0ull;
-                int hin = g0 ? (int)myh[(u64)j * 64 + lane] : 0;      // top row of the matrix is all zeros (target prefix free)
+                int fb = 0, lb = Bg - 1;
+                if (band) {
+                    const int lo_row = j + dmin - bandK - 1;
+                    fb = lo_row > 0 ? (lo_row >> 6) : 0; lb = min(B - 1, (j + 1 + bandK) >> 6);
+                    if (lb > lbprev) {          // blocks entering the band: the last row of a lane may be among them
+                        if (n > 0 && bl > lbprev && bl <= lb) score = sb + 64 * (bl - 1 - lbprev) + lastbit + 1;
+                        sb += 64 * (lb - lbprev);
+                    }
+                }
+                int hin = g0 ? (int)myh[(u64)j * 64 + lane] : (fb > 0 ? 1 : 0);      // top row of the matrix is all zeros (target prefix free)
                 ngsid_v4u* col = mytb + ((u64)j * 64 + lane);
 #pragma unroll
                 for (int b = 0; b < BMAX; ++b) {
-                    if (b < Bg) {
+                    if (b >= fb && b <= lb) {
                         const u64 lo = planes[(b * 3 + 0) * 64 + lane], hi = planes[(b * 3 + 1) * 64 + lane], ok = planes[(b * 3 + 2) * 64 + lane];
                         const u64 Eq = ~(lo ^ Tlo) & ~(hi ^ Thi) & ok & Tok;
                         const u64 pv = Pv[b], mv = Mv[b];
@@ -96,13 +118,16 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
                     }
                 }
                 if (more) myh[(u64)j * 64 + lane] = (int8_t)hin;
+                if (band) { sb += hin; lbprev = lb; }
             }
             if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // ---- traceback, every lane on its own path
-        int i = n, j = bestj;
+        bool ok = true;
+        if (band && have && best > bandK) { ok = false; fail_list[atomicAdd(fail_count, 1u)] = (uint32_t)p; }
+        int i = ok ? n : 0, j = bestj;
         int q_end = -1, t_end = -1, q_beg = -1, t_beg = -1;
         int32_t* bpp = (J.bp && have) ? J.bp + p * (u64)J.bp_windows * 4 : nullptr;
         if (bpp) for (int x = 0; x < J.bp_windows * 4; ++x) bpp[x] = -1;
@@ -131,8 +156,8 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
             } else if (up) --i;
             else --j;
         }
-        if (bpp && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
-        if (have) {
+        if (bpp && ok && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
+        if (have && ok) {
             if (dist_out) dist_out[p] = best;
             if (J.span) { J.span[p * 4 + 0] = q_beg; J.span[p * 4 + 1] = q_end; J.span[p * 4 + 2] = t_beg; J.span[p * 4 + 3] = t_end; }
         }
@@ -141,7 +166,7 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
 }
 
 template <int BMAX>
-static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out, uint32_t ctr_slot = 14)
+static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out, uint32_t ctr_slot = 14, int bandK = 0)
 {
     const u64 nbundles = (job.npairs + 63) / 64;
     const uint32_t mstride = (max_tlen + 63u) & ~63u;                     // rounded so that backbones growing by a few bases between iterations reuse the scratch
@@ -158,15 +183,29 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen,
     if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
     HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), ctx->stream));
-    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + ctr_slot, dist_out, ctx->ed_h.p); }
+    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + ctr_slot, dist_out, ctx->ed_h.p,
+                                                            bandK, ctx->ed_fail.p, ctx->aln_ctr.p + 15); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
+}
+
+// pairs whose distance exceeded the band of the first launch (list ctx->ed_fail, count aln_ctr[15]): unbanded
+static int32_t launch_ed_fallback(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out)
+{
+    AlignJob j = job; j.pair_list = ctx->ed_fail.p; j.npairs_dev = ctx->aln_ctr.p + 15;
+    return launch_ed<16>(ctx, j, max_qlen, max_tlen, dist_out, 13, 0);
 }
 
 int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out)
 {
     if (job.npairs == 0) return NGSID_OK;
     if (max_qlen > NGSID_MAX_READ_LEN || max_tlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in the edit-distance aligner", NGSID_MAX_READ_LEN);
+    // band: wide enough for the usual read-to-draft distance, pairs beyond it take the unbanded launch (the result does not depend on it)
+    int bandK = 64 + (int)(max_qlen / 32);
+    if (const char* e = getenv("NGSID_ED_BAND")) bandK = atoi(e);
+    if (max_qlen > 1024) bandK = 0;                 // several block groups: unbanded
+    if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
+    if (bandK > 0) HIPCHK(ctx, ctx->ed_fail.reserve(job.npairs));
     if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !getenv("NGSID_ALIGN_NOCLASS")) {
         // mixed lengths: every pair runs in the instance with the fewest register-resident blocks that holds its query
         // (the scratch is sized by the longest query; launches of one call share it, the stream serialises them)
@@ -179,15 +218,19 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
             if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.reserve(want * per_wave));
             if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
         }
-        if ((rc = launch_ed<4>(ctx, cls(0, 256), std::min<uint32_t>(max_qlen, 256), max_tlen, dist_out, 1))) return rc;
-        if (max_qlen > 256 && (rc = launch_ed<8>(ctx, cls(1, 512), std::min<uint32_t>(max_qlen, 512), max_tlen, dist_out, 2))) return rc;
-        if (max_qlen > 512 && (rc = launch_ed<12>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3))) return rc;
-        if (max_qlen > 768 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4))) return rc;
-        if (max_qlen > 896 && (rc = launch_ed<16>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5))) return rc;
-        return NGSID_OK;
+        if ((rc = launch_ed<4>(ctx, cls(0, 256), std::min<uint32_t>(max_qlen, 256), max_tlen, dist_out, 1, bandK))) return rc;
+        if (max_qlen > 256 && (rc = launch_ed<8>(ctx, cls(1, 512), std::min<uint32_t>(max_qlen, 512), max_tlen, dist_out, 2, bandK))) return rc;
+        if (max_qlen > 512 && (rc = launch_ed<12>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK))) return rc;
+        if (max_qlen > 768 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4, bandK))) return rc;
+        if (max_qlen > 896 && (rc = launch_ed<16>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK))) return rc;
+        return bandK > 0 ? launch_ed_fallback(ctx, job, max_qlen, max_tlen, dist_out) : NGSID_OK;
     }
-    if (max_qlen <= 256) return launch_ed<4>(ctx, job, max_qlen, max_tlen, dist_out);
-    if (max_qlen <= 512) return launch_ed<8>(ctx, job, max_qlen, max_tlen, dist_out);
-    if (max_qlen <= 768) return launch_ed<12>(ctx, job, max_qlen, max_tlen, dist_out);
-    return launch_ed<16>(ctx, job, max_qlen, max_tlen, dist_out);          // longer queries: groups of 16 blocks, horizontal deltas carried through HBM
+    if (bandK > 0) HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + 15, 0, sizeof(uint32_t), ctx->stream));
+    int32_t rc;
+    if (max_qlen <= 256) rc = launch_ed<4>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
+    else if (max_qlen <= 512) rc = launch_ed<8>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
+    else if (max_qlen <= 768) rc = launch_ed<12>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
+    else rc = launch_ed<16>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);          // longer queries: groups of 16 blocks, horizontal deltas carried through HBM
+    if (rc || bandK <= 0) return rc;
+    return launch_ed_fallback(ctx, job, max_qlen, max_tlen, dist_out);
 }

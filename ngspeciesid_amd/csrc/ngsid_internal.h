@@ -44,6 +44,7 @@ struct ngsid_ctx {
     DevBuf<uint32_t> aln_cls; // pair lists of the length classes
     DevBuf<ngsid_v4u_t> ed_tb; // traceback vectors of the edit-distance aligner
     DevBuf<int8_t> ed_h;       // its horizontal deltas between block groups
+    DevBuf<uint32_t> ed_fail;  // pairs beyond the band of the first launch
     DevBuf<uint32_t> poa_ctr; // POA tile work-queue counter
     struct PoaLevelBufs { DevBuf<uint8_t> out, seqs /* PSeq[] */; DevBuf<int32_t> out_len, job_bb; DevBuf<uint64_t> out_cw; DevBuf<uint32_t> out_n, out_cov, job_off, seq_idx, flags; };
     PoaLevelBufs poa_lv[2];   // hierarchy levels ping-pong between two buffer sets (level L+1 reads what level L wrote)

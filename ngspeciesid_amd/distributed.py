@@ -39,18 +39,26 @@ def all_gather_obj(obj, device):
     return [pickle.loads(b) for b in all_gather_bytes(pickle.dumps(obj, protocol=4), device)]
 
 
-def _weighted_merge(api, partials, counts, tile_depth, band):
-    """POA of per-shard partial consensuses; the quality string carries the weight (reads represented, scaled to 1..93)."""
-    items = [(s, c) for s, c in zip(partials, counts) if s and c > 0]
-    if not items:
-        return ""
-    if len(items) == 1:
-        return items[0][0]
-    mx = max(c for _, c in items)
-    seqs = [s for s, _ in items]
-    quals = [chr(33 + max(1, min(93, int(round(93.0 * c / mx))))) * len(s) for s, c in items]
-    rs = ReadSet.from_strings(seqs, quals)
-    return api.poa_consensus(rs, [0, len(seqs)], poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=band))[0]
+def _weighted_merge_all(api, partials, counts, band):
+    """For every selected cluster: POA of its per-shard partial consensuses; the quality string carries the weight (reads represented,
+    scaled to 1..93).  partials[c] / counts[c] = one entry per shard.  All clusters go through ONE library call (one group each)."""
+    out = [""] * len(partials)
+    seqs, quals, grp, which = [], [], [0], []
+    for c, (ps, cs) in enumerate(zip(partials, counts)):
+        items = [(s, n) for s, n in zip(ps, cs) if s and n > 0]
+        if not items:
+            continue
+        if len(items) == 1:
+            out[c] = items[0][0]; continue
+        mx = max(n for _, n in items)
+        for s, n in items:
+            seqs.append(s); quals.append(chr(33 + max(1, min(93, int(round(93.0 * n / mx))))) * len(s))
+        grp.append(len(seqs)); which.append(c)
+    if which:
+        res = api.poa_consensus(ReadSet.from_strings(seqs, quals), grp, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=band))
+        for c, r in zip(which, res):
+            out[c] = r
+    return out
 
 
 def representative_payload(rs_local, rep_local, herr, score_local, acc_rank_local=None):
@@ -141,7 +149,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
     sub_off = np.concatenate(([0], np.cumsum(hi - lo))).astype(np.uint64)
     partial = api.poa_consensus(rs_local, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band), read_order=sub_order) if len(cand) else []
     allp = all_gather_obj(dict(cons=partial, cnt=(hi - lo).tolist()), device)
-    drafts = [_weighted_merge(api, [p["cons"][c] for p in allp], [p["cnt"][c] for p in allp], tile_depth, band) for c in range(len(cand))]
+    drafts = _weighted_merge_all(api, [[p["cons"][c] for p in allp] for c in range(len(cand))], [[p["cnt"][c] for p in allp] for c in range(len(cand))], band)
     T["consensus"] = T.get("consensus", 0.0) + time.perf_counter() - t0
     # ---- 5. reverse-complement merge (identical on every rank), then polish: per iteration local window consensus + weighted merge
     t0 = time.perf_counter()
@@ -158,7 +166,8 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
         bb = ReadSet.from_strings(polished)
         loc, used = api.polish(bb, rs_local, p_off, polish_params(iters=1, k=k, w=w, tile_depth=tile_depth, band=band, trim=polish_trim), read_order=p_order) if len(merged) else ([], [])
         allq = all_gather_obj(dict(cons=loc, cnt=[int(u) for u in used]), device)
-        polished = [_weighted_merge(api, [q["cons"][c] for q in allq], [q["cnt"][c] for q in allq], tile_depth, band) or polished[c] for c in range(len(merged))]
+        mg = _weighted_merge_all(api, [[q["cons"][c] for q in allq] for c in range(len(merged))], [[q["cnt"][c] for q in allq] for c in range(len(merged))], band)
+        polished = [mg[c] or polished[c] for c in range(len(merged))]
     T["polish"] = T.get("polish", 0.0) + time.perf_counter() - t0
     res["centers"] = [(m[0], m[1], m[2], polished[i]) for i, m in enumerate(merged)]
     return res
