@@ -65,7 +65,8 @@ def main():
     dist = None
     backend = os.environ.get("NGSID_DIST_BACKEND", "nccl")
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    force_dist = os.environ.get("NGSID_FORCE_DIST") == "1"          # dev aid: run the sharded code path (and its RCCL collectives) with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

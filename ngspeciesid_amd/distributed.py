@@ -6,8 +6,8 @@ shard, tile consensuses and window consensuses of the shard's own reads.  Collec
      reference's only exchange (parallelize.py:169-184) - then every rank replays the pairwise tree merge on them;
   2. all-reduce of cluster sizes (which clusters reach the abundance cutoff);
   3. all-gather of the per-shard partial consensuses (one string per selected cluster and rank), merged by a POA whose
-     per-base weights are proportional to the reads each partial stands for - once for the draft and once per polishing
-     iteration.
+     per-base weights are proportional to the reads each partial stands for - once for the draft and once after the
+     polishing iterations (which every shard runs locally against the common merged draft).
 Reads never move between GPUs.
 """
 from __future__ import annotations
@@ -142,7 +142,8 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
     cand = np.nonzero((sizes >= cutoff) & (sizes > 0))[0]
     cand = cand[np.lexsort((-r_score[cand], -sizes[cand]))]
     # ---- 4. per-shard partial consensus of every selected cluster, all-gather, weighted merge
-    order = np.argsort(final_gid, kind="stable").astype(np.uint32)
+    # (few distinct keys: a 16-bit key makes numpy's stable sort a radix sort)
+    order = np.argsort(final_gid.astype(np.uint16 if len(r_lidx) < 65536 else np.int64), kind="stable").astype(np.uint32)
     sorted_gid = final_gid[order]
     lo = np.searchsorted(sorted_gid, cand, side="left"); hi = np.searchsorted(sorted_gid, cand, side="right")
     sub_order = np.concatenate([order[a:b] for a, b in zip(lo, hi)]) if len(cand) else np.zeros(0, np.uint32)
@@ -156,7 +157,9 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
     centers = [[int(sizes[g]), int(g), drafts[c], [c]] for c, g in enumerate(cand)]
     merged = pipeline.detect_reverse_complements(api, centers, rc_identity_threshold)
     polished = [m[2] for m in merged]
-    for it in range(racon_iter):
+    if racon_iter > 0 and len(merged):
+        # every shard polishes the (identical) merged drafts with its own reads, all iterations locally - the orientation, the alignments and
+        # the window graphs never leave the GPU - then ONE all-gather of the polished strings and a weighted merge
         p_order, p_off = [], [0]
         for m in merged:
             for c in m[3]:
@@ -164,7 +167,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
             p_off.append(sum(len(x) for x in p_order))
         p_order = np.concatenate(p_order) if p_order else np.zeros(0, np.uint32)
         bb = ReadSet.from_strings(polished)
-        loc, used = api.polish(bb, rs_local, p_off, polish_params(iters=1, k=k, w=w, tile_depth=tile_depth, band=band, trim=polish_trim), read_order=p_order) if len(merged) else ([], [])
+        loc, used = api.polish(bb, rs_local, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, trim=polish_trim), read_order=p_order)
         allq = all_gather_obj(dict(cons=loc, cnt=[int(u) for u in used]), device)
         mg = _weighted_merge_all(api, [[q["cons"][c] for q in allq] for c in range(len(merged))], [[q["cnt"][c] for q in allq] for c in range(len(merged))], band)
         polished = [mg[c] or polished[c] for c in range(len(merged))]

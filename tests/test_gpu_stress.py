@@ -11,8 +11,9 @@ TOOL = os.path.join(ROOT, "tools", "stress_poa.py")
 TOOL_ALN = os.path.join(ROOT, "tools", "stress_align.py")
 
 
-def _run(*args, tool=TOOL):
-    p = subprocess.run([sys.executable, tool] + [str(a) for a in args], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+def _run(*args, tool=TOOL, env=None):
+    p = subprocess.run([sys.executable, tool] + [str(a) for a in args], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       env=dict(os.environ, **env) if env else None)
     tail = "\n".join(p.stdout.splitlines()[-8:])
     assert p.returncode == 0, tail
 
@@ -80,6 +81,14 @@ def test_edit_distance_aligner_matches_oracle(pairs, maxq, seed):
     """bit-parallel polisher aligner (k_ed_align): distance, span and window break points vs the oracle's plain DP; every block-count
     instance (queries up to 256 / 512 / 768 / 1024 and block groups beyond), partial last blocks, wildcards, lower case, empty and unrelated sequences"""
     _run(pairs, maxq, seed, tool=TOOL_ED)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("band", ["12", "40", "300", "0"])
+def test_edit_distance_band_does_not_change_results(band):
+    """the Ukkonen band of the first launch is exact: with a narrow band most pairs take the unbanded second launch, with a wide one none,
+    with 0 the band is off - the oracle comparison must hold for all of them"""
+    _run(3000, 900, 8, tool=TOOL_ED, env={"NGSID_ED_BAND": band})
 
 
 @pytest.mark.gpu
