@@ -45,7 +45,7 @@ def test_aligner_pairs_match_oracle(pairs, maxlen, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_reads,n_species,div,mu,seed", [(5000, 6, 0.15, 17.0, 3), (3000, 12, 0.06, 14.0, 4), (2000, 150, 0.10, 13.0, 5), (2500, 300, 0.03, 15.0, 6)])
+@pytest.mark.parametrize("n_reads,n_species,div,mu,seed", [(5000, 6, 0.15, 17.0, 3), (3000, 12, 0.06, 14.0, 4), (2000, 150, 0.10, 13.0, 5), (2500, 300, 0.03, 15.0, 6), (3200, 1600, 0.30, 15.0, 7)])
 def test_cluster_volume_matches_oracle(gpu_api, oracle, n_reads, n_species, div, mu, seed):
     """greedy clustering at a size where speculative blocks, cache hits and database merges all occur; closely related species
     (6 % divergence) force many aligner decisions; the cases with hundreds of species found many representatives per block (several are
