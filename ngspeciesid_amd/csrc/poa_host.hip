@@ -42,7 +42,11 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
     HostTimer ht(ctx->stream, "hierarchy");
     for (int level = 0;; ++level) {
         // ---- jobs of this level
-        std::vector<uint32_t> job_off{0}, seq_idx, job_unit; std::vector<int32_t> job_bb; uint32_t maxD = 0; int maxL0 = 1; bool any_nobb = false;
+        // host lists of a level: kept across levels and calls (a million entries per level; fresh allocations would page-fault every time)
+        static thread_local std::vector<uint32_t> job_off, seq_idx, job_unit; static thread_local std::vector<int32_t> job_bb;
+        job_off.clear(); job_off.push_back(0); seq_idx.clear(); job_unit.clear(); job_bb.clear();
+        { size_t tot = 0; for (const Unit& U : units) if (!U.done) tot += U.seqs.size(); seq_idx.reserve(tot); }
+        uint32_t maxD = 0; int maxL0 = 1; bool any_nobb = false;
         for (size_t u = 0; u < units.size(); ++u) {
             Unit& U = units[u]; if (U.done) continue;
             const uint32_t ncur = (uint32_t)U.seqs.size();
@@ -71,7 +75,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
         HIPCHK(ctx, hipMemcpyAsync(d_seq_idx.p, seq_idx.data(), 4 * seq_idx.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_job_bb.p, job_bb.data(), 4 * job_bb.size(), hipMemcpyHostToDevice, ctx->stream));
         int slots = slots_cap ? slots_cap : (int)std::min<uint32_t>(maxD, 4);
-        std::vector<uint32_t> h_out_n; std::vector<int32_t> h_out_len; std::vector<uint64_t> h_out_cw;
+        static thread_local std::vector<uint32_t> h_out_n; static thread_local std::vector<int32_t> h_out_len; static thread_local std::vector<uint64_t> h_out_cw;
         for (;;) {      // retry with more output slots if a tile had to split more often than `slots`
             HIPCHK(ctx, Lv->out.reserve((size_t)njobs * slots * capV)); HIPCHK(ctx, Lv->out_len.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_cw.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_n.reserve(njobs));
             if (hp.want_cov) HIPCHK(ctx, Lv->out_cov.reserve((size_t)njobs * slots * capV));
@@ -103,7 +107,8 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
         // ---- distribute outputs to units
         std::vector<std::vector<uint32_t>> outs(units.size());         // flat slot indices (job*slots + s) in job order
         for (uint32_t j = 0; j < njobs; ++j) for (uint32_t s = 0; s < h_out_n[j]; ++s) outs[job_unit[j]].push_back(j * (uint32_t)slots + s);
-        std::vector<PSeq> next; uint32_t next_maxlen = 0;
+        static thread_local std::vector<PSeq> next; uint32_t next_maxlen = 0;
+        { size_t tot = 0; for (uint32_t j = 0; j < njobs; ++j) tot += h_out_n[j]; next.clear(); next.reserve(tot); }
         for (size_t u = 0; u < units.size(); ++u) {
             Unit& U = units[u]; if (U.done) continue;
             const std::vector<uint32_t>& O = outs[u];
@@ -372,10 +377,16 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         std::vector<std::vector<int>> unit_of(G);
         for (uint32_t g = 0; g < G; ++g) { const int nw = (int)((B[g].size() + W - 1) / W); unit_of[g].assign(nw, -1);
             for (int wdx = 0; wdx < nw; ++wdx) { unit_of[g][wdx] = (int)units.size(); units.emplace_back(); unit_gw.push_back({g, wdx}); } }
-        for (uint64_t p = 0; p < NP; ++p) {
-            bool any = false; const uint32_t g = pair_group[p];
-            for (int wdx = 0; wdx < (int)unit_of[g].size(); ++wdx) if (h_valid[p * (uint64_t)nwinmax + wdx]) { units[unit_of[g][wdx]].seqs.push_back((uint32_t)(p * (uint64_t)nwinmax + wdx)); any = true; }
-            if (any) used[g]++;
+        {   // layers of every window in pair (= read) order; the units of a group are consecutive, a window holds at most one layer per pair of its group
+            std::vector<uint32_t> ubase(G), unw(G), npg(G, 0);
+            for (uint32_t g = 0; g < G; ++g) { unw[g] = (uint32_t)unit_of[g].size(); ubase[g] = unw[g] ? (uint32_t)unit_of[g][0] : 0; }
+            for (uint64_t p = 0; p < NP; ++p) npg[pair_group[p]]++;
+            for (uint32_t g = 0; g < G; ++g) for (uint32_t wdx = 0; wdx < unw[g]; ++wdx) units[ubase[g] + wdx].seqs.reserve(npg[g]);
+            for (uint64_t p = 0; p < NP; ++p) {
+                const uint32_t g = pair_group[p]; const uint8_t* hv = h_valid.data() + p * (uint64_t)nwinmax; bool any = false;
+                for (uint32_t wdx = 0; wdx < unw[g]; ++wdx) if (hv[wdx]) { units[ubase[g] + wdx].seqs.push_back((uint32_t)(p * (uint64_t)nwinmax + wdx)); any = true; }
+                if (any) used[g]++;
+            }
         }
         std::vector<size_t> nlayers(units.size());
         for (size_t u = 0; u < units.size(); ++u) {
