@@ -351,7 +351,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         HIPCHK(ctx, hipMemcpyAsync(d_blen.p, blen.data(), 4 * G, hipMemcpyHostToDevice, ctx->stream));
         std::fill(used.begin(), used.end(), 0);
         std::vector<Unit> units; std::vector<PSeq> bbs; std::vector<int> bb_len; std::vector<std::pair<uint32_t, int>> unit_gw;
-        std::vector<uint8_t> h_valid; int max_layer = 1;
+        static thread_local std::vector<uint8_t> h_valid; int max_layer = 1;
         HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
         if (NP) {
             HIPCHK(ctx, d_bp.reserve(NP * (uint64_t)nwinmax * 4)); HIPCHK(ctx, d_lay_raw.reserve(sizeof(PSeq) * NP * (uint64_t)nwinmax)); HIPCHK(ctx, d_valid.reserve(NP * (uint64_t)nwinmax));
