@@ -46,7 +46,8 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
     int* hist_h = (int*)smem; int* hist_r = hist_h + 128;
     int* scr = hist_r + 128;                 // 16 ints
     int* am = scr + 16;                      // 257 ints (window argmin exchange), padded to 272
-    uint64_t* codes = (uint64_t*)(smem + 1024 + 64 + 272 * 4);
+    double* term_h = (double*)(smem + 1024 + 64 + 272 * 4); double* term_r = term_h + 128;      // per quality character: count x error probability
+    uint64_t* codes = (uint64_t*)(smem + 1024 + 64 + 272 * 4 + 2048);
     const int W = w - k + 1;
     const int ncodes_cap = (n > W ? n : W) + 1;
     uint8_t* hs = (uint8_t*)(codes + ncodes_cap);
@@ -66,7 +67,7 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
         if (q) atomicAdd(&hist_r[q[i] & 127], 1);
         if (i == 0 || s[i] != s[i - 1]) {
             const uint8_t c = s[i];
-            hs[hidx] = c;
+            hs[hidx] = (uint8_t)enc3(c);          // 3-bit letter code, 0xff = outside ACGTN (reported in phase 2)
             if (q) {
                 uint8_t best = q[i];
                 for (int j = i + 1; j < n && s[j] == c; ++j) if (c_phred_p[q[j] & 127] < c_phred_p[best & 127]) best = q[j];
@@ -77,14 +78,20 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
     }
     __syncthreads();
     const int hl = total_heads;
+    // error rates = sum over the quality characters in ascending order of count x p (the order fixes the rounding: ngsid_oracle.c does the same);
+    // the products are formed by 128 threads, the two ordered sums run on two different waves
+    if (tid < 128) { term_h[tid] = (double)hist_h[tid] * c_phred_p[tid]; term_r[tid] = (double)hist_r[tid] * c_phred_p[tid]; }
+    __syncthreads();
+    const double qnan = __longlong_as_double(0x7ff8000000000000ULL);
     if (tid == 0) {
         out_hlen[r] = (uint32_t)hl;
-        double sh = 0.0, sr = 0.0;
-        if (q) {
-            for (int c = 0; c < 128; ++c) { if (hist_h[c]) sh = sh + (double)hist_h[c] * c_phred_p[c]; if (hist_r[c]) sr = sr + (double)hist_r[c] * c_phred_p[c]; }
-            out_herr[r] = hl > 0 ? sh / (double)hl : __longlong_as_double(0x7ff8000000000000ULL);
-            out_rawerr[r] = n > 0 ? sr / (double)n : __longlong_as_double(0x7ff8000000000000ULL);
-        } else { out_herr[r] = __longlong_as_double(0x7ff8000000000000ULL); out_rawerr[r] = __longlong_as_double(0x7ff8000000000000ULL); }
+        double sh = 0.0;
+        if (q) { for (int c = 0; c < 128; ++c) sh = sh + term_h[c]; }
+        out_herr[r] = (q && hl > 0) ? sh / (double)hl : qnan;
+    } else if (tid == 64) {
+        double sr = 0.0;
+        if (q) { for (int c = 0; c < 128; ++c) sr = sr + term_r[c]; }
+        out_rawerr[r] = (q && n > 0) ? sr / (double)n : qnan;
     }
     if (hl < k) { if (tid == 0) out_cnt[r] = 0; return; }
 
@@ -96,7 +103,7 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
         uint64_t c = 0;
         for (int t = 0; t < k; ++t) {
             int e = 0;
-            if (i + t < hl) { e = enc3(hs[i + t]); if (e < 0) { bad = 1; e = 0; } }
+            if (i + t < hl) { e = hs[i + t]; if (e == 0xff) { bad = 1; e = 0; } }
             c = (c << 3) | (uint64_t)e;
         }
         codes[i] = c;
@@ -143,7 +150,7 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     if (R.n == 0) return NGSID_OK;
     const int W = w - k + 1;
     const size_t ncap = (size_t)((int)R.maxlen > W ? (int)R.maxlen : W) + 1;
-    size_t lds = 1024 + 64 + 272 * 4 + ncap * 8 + (size_t)R.maxlen + 16;
+    size_t lds = 1024 + 64 + 272 * 4 + 2048 + ncap * 8 + (size_t)R.maxlen + 16;
     lds = (lds + 15) & ~(size_t)15;
     if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_hpc_minimizers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     { ProfScope ps_(ctx, "k_hpc_minimizers"); hipLaunchKernelGGL(k_hpc_minimizers, dim3((unsigned)R.n), dim3(256), lds, ctx->stream,
