@@ -182,45 +182,60 @@ void k_decide_map(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, u
 }
 
 // ---- alignment criterion cursor (get_best_cluster_block_align, cluster.py:172-205): resolve from cache or request a pair
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void k_aln_next(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t row0,
                 const uint64_t* __restrict__ cnt, uint32_t stride, uint32_t R,
                 uint32_t* __restrict__ req_q, uint32_t* __restrict__ req_t, uint32_t* __restrict__ req_slot, int32_t* __restrict__ req_open, int32_t* __restrict__ req_mid,
                 uint32_t* __restrict__ req_count)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (it >= it_hi) return;
-    const uint32_t read = items[it];
-    if (D.dec[read] != DEC_PENDING) return;
-    const uint64_t* row = cnt + (uint64_t)(it - row0) * stride;
-    const int top = D.top[read];
-    uint64_t bh = D.cur_hi[read], bl = D.cur_lo[read];
-    const double qlen = (double)(D.off[read + 1] - D.off[read]);
-    for (;;) {
-        uint64_t kh, kl;
-        if (!next_candidate(D, row, R, lane, bh, bl, top, kh, kl)) { if (lane == 0) D.dec[read] = DEC_NEWREP; return; }   // :181 / :205
-        const uint32_t slot = 0xffffffffu - (uint32_t)(kl & 0xffffffffu);
-        const uint32_t rr = D.rep_read[slot];
-        int region = -1;
-        for (int c = 0; c < NCACHE; ++c) if (D.cache_slot[(uint64_t)read * NCACHE + c] == (int32_t)slot) region = D.cache_region[(uint64_t)read * NCACHE + c];
-        if (region < 0) {
-            if (lane == 0) {
-                const double ers = D.rawerr[read] + D.rawerr[rr];                                         // :188
-                const int gopen = ers <= 0.01 ? 5 : (ers <= 0.04 ? 4 : (ers <= 0.1 ? 3 : 2));             // :189-196
-                const int mid = (int)floor((1.0 - ers) * (double)D.k);                                    // :198
-                const uint32_t idx = atomicAdd(req_count, 1u);
-                req_q[idx] = read; req_t[idx] = rr; req_slot[idx] = slot; req_open[idx] = gopen; req_mid[idx] = mid;
-                D.cur_hi[read] = bh; D.cur_lo[read] = bl;
+    // one wave per read, 16 reads per workgroup; the requests of a workgroup take their list slots with ONE atomic (a million single
+    // atomics on the same counter would serialise)
+    __shared__ uint32_t s_want[16]; __shared__ uint32_t s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + wv;
+    bool want = false; uint32_t q_read = 0, q_rr = 0, q_slot = 0; int q_open = 0, q_mid = 0;
+    if (it < it_hi) {
+        const uint32_t read = items[it];
+        if (D.dec[read] == DEC_PENDING) {
+            const uint64_t* row = cnt + (uint64_t)(it - row0) * stride;
+            const int top = D.top[read];
+            uint64_t bh = D.cur_hi[read], bl = D.cur_lo[read];
+            const double qlen = (double)(D.off[read + 1] - D.off[read]);
+            for (;;) {
+                uint64_t kh, kl;
+                if (!next_candidate(D, row, R, lane, bh, bl, top, kh, kl)) { if (lane == 0) D.dec[read] = DEC_NEWREP; break; }   // :181 / :205
+                const uint32_t slot = 0xffffffffu - (uint32_t)(kl & 0xffffffffu);
+                const uint32_t rr = D.rep_read[slot];
+                int region = -1;
+                for (int c = 0; c < NCACHE; ++c) if (D.cache_slot[(uint64_t)read * NCACHE + c] == (int32_t)slot) region = D.cache_region[(uint64_t)read * NCACHE + c];
+                if (region < 0) {
+                    const double ers = D.rawerr[read] + D.rawerr[rr];                                         // :188
+                    q_open = ers <= 0.01 ? 5 : (ers <= 0.04 ? 4 : (ers <= 0.1 ? 3 : 2));                      // :189-196
+                    q_mid = (int)floor((1.0 - ers) * (double)D.k);                                            // :198
+                    q_read = read; q_rr = rr; q_slot = slot; want = true;
+                    if (lane == 0) { D.cur_hi[read] = bh; D.cur_lo[read] = bl; }
+                    break;
+                }
+                const double ar = (double)region / qlen;                                                          // :167
+                bool pass;
+                if (D.symmetric) { const double tr = (double)region / (double)(D.off[rr + 1] - D.off[rr]); pass = fmin(ar, tr) >= D.aligned_threshold; }
+                else pass = ar >= D.aligned_threshold;
+                if (pass) { if (lane == 0) { D.dec[read] = (int32_t)slot; D.kind[read] = NGSID_ST_ALIGNED; } break; }
+                bh = kh; bl = kl;
             }
-            return;
         }
-        const double ar = (double)region / qlen;                                                          // :167
-        bool pass;
-        if (D.symmetric) { const double tr = (double)region / (double)(D.off[rr + 1] - D.off[rr]); pass = fmin(ar, tr) >= D.aligned_threshold; }
-        else pass = ar >= D.aligned_threshold;
-        if (pass) { if (lane == 0) { D.dec[read] = (int32_t)slot; D.kind[read] = NGSID_ST_ALIGNED; } return; }
-        bh = kh; bl = kl;
+    }
+    if (lane == 0) s_want[wv] = want ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { const uint32_t w = s_want[i]; s_want[i] = n; n += w; }
+        s_base = n ? atomicAdd(req_count, n) : 0u;
+    }
+    __syncthreads();
+    if (want && lane == 0) {
+        const uint32_t idx = s_base + s_want[wv];
+        req_q[idx] = q_read; req_t[idx] = q_rr; req_slot[idx] = q_slot; req_open[idx] = q_open; req_mid[idx] = q_mid;
     }
 }
 
@@ -544,7 +559,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             HIPCHK(ctx, hipGetLastError());
             for (;;) {      // alignment rounds: resolve from cache or request pairs, align, cache, repeat
                 HIPCHK(ctx, hipMemsetAsync(d_scal.p, 0, 4, ctx->stream));
-                { ProfScope ps_(ctx, "k_aln_next"); hipLaunchKernelGGL(k_aln_next, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R,
+                { ProfScope ps_(ctx, "k_aln_next"); hipLaunchKernelGGL(k_aln_next, dim3((b1 - lo + 15) / 16), dim3(1024), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R,
                                    req_q.p, req_t.p, req_slot.p, req_open.p, req_mid.p, d_scal.p); }
                 HIPCHK(ctx, hipGetLastError());
                 uint32_t nreq = 0;

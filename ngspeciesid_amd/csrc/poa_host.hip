@@ -217,16 +217,18 @@ __global__ void k_orient(const uint8_t* __restrict__ seq, const uint8_t* __restr
     }
 }
 
-// one thread per (pair, window): validity filters of racon's window assignment + the PSeq of the layer (oracle ongsid_polish)
-__global__ void k_layers(const uint8_t* __restrict__ oseq, const uint8_t* __restrict__ oqual, const uint64_t* __restrict__ off,
+// one wave per (pair, window): validity filters of racon's window assignment + the PSeq of the layer (oracle ongsid_polish);
+// the lanes share the mean-quality sum over the layer's bases (coalesced), everything else is wave-uniform
+__global__ __launch_bounds__(256) void k_layers(const uint8_t* __restrict__ oseq, const uint8_t* __restrict__ oqual, const uint64_t* __restrict__ off,
                          const uint32_t* __restrict__ pair_read, const uint32_t* __restrict__ pair_group, uint64_t npairs, int nwinmax,
                          const int32_t* __restrict__ bp, const int32_t* __restrict__ span, const int32_t* __restrict__ blen /* per group */,
                          int W, double qthr, double ethr, PSeq* __restrict__ lay, uint8_t* __restrict__ valid, int* __restrict__ maxlen_out)
 {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint64_t t = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (t >= npairs * (uint64_t)nwinmax) return;
     const uint64_t p = t / nwinmax; const int wdx = (int)(t % nwinmax);
-    valid[t] = 0;
+    if (lane == 0) valid[t] = 0;
     const int qb = span[p * 4 + 0], qe = span[p * 4 + 1], tb = span[p * 4 + 2], te = span[p * 4 + 3];
     if (qb < 0) return;
     const int qs = qe - qb + 1, ts = te - tb + 1; const int mn = qs < ts ? qs : ts, mx = qs < ts ? ts : qs;
@@ -236,12 +238,18 @@ __global__ void k_layers(const uint8_t* __restrict__ oseq, const uint8_t* __rest
     if (qf < 0) return;
     const int len = ql - qf + 1; if ((double)len < 0.02 * (double)W) return;
     const uint32_t read = pair_read[p]; const uint64_t rb = off[read];
-    if (oqual) { long long sq = 0; for (int x = qf; x <= ql; ++x) sq += (long long)oqual[rb + x] - 33; if ((double)sq / (double)len < qthr) return; }
+    if (oqual) {
+        long long sq = 0;
+        for (int x = qf + lane; x <= ql; x += 64) sq += (long long)oqual[rb + x] - 33;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sq += __shfl_xor(sq, d);
+        if ((double)sq / (double)len < qthr) return;
+    }
     const int Bl = blen[pair_group[p]]; const int ws = wdx * W; const int wlen = (Bl - ws) < W ? (Bl - ws) : W;
     const int begin = tf - ws, end = tl - ws; const int offset = (int)(0.01 * (double)wlen);
     PSeq S; S.s = oseq + rb + qf; S.q = oqual ? oqual + rb + qf : nullptr; S.len = len; S.uw = 1; S.cw = 1; S.a0 = begin; S.a1 = end;
     S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI;
-    lay[t] = S; valid[t] = 1; atomicMax(maxlen_out, len);
+    if (lane == 0) { lay[t] = S; valid[t] = 1; if (len > __atomic_load_n(maxlen_out, __ATOMIC_RELAXED)) atomicMax(maxlen_out, len); }      // (millions of atomics on one word would serialise)
 }
 
 std::string revcomp(const std::string& s) { std::string r(s.size(), 'N'); for (size_t i = 0; i < s.size(); ++i) { char c = s[s.size() - 1 - i]; r[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; } return r; }
@@ -364,7 +372,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             else rc = ngsid_launch_align(ctx, J, RD.maxlen, maxb, prm->aln_open);
             if (rc) return rc;
             const uint64_t T = NP * (uint64_t)nwinmax;
-            { ProfScope ps_(ctx, "k_layers"); hipLaunchKernelGGL(k_layers, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, oseq.p, RD.qual ? oqual.p : nullptr, RD.off, d_pair_read.p, d_pair_group.p, NP, nwinmax,
+            { ProfScope ps_(ctx, "k_layers"); hipLaunchKernelGGL(k_layers, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, ctx->stream, oseq.p, RD.qual ? oqual.p : nullptr, RD.off, d_pair_read.p, d_pair_group.p, NP, nwinmax,
                                d_bp.p, d_span.p, d_blen.p, W, prm->quality_threshold, prm->error_threshold, (PSeq*)d_lay_raw.p, d_valid.p, flag.p); }
             HIPCHK(ctx, hipGetLastError());
             h_valid.resize(T);
