@@ -342,6 +342,101 @@ __global__ void k_db_merge(const uint64_t* __restrict__ oc, const uint32_t* __re
     }
 }
 
+// ---- batched variants (up to 64 representatives per launch): one launch builds them, one counts the block against them, one merges them
+struct RepBatch { uint32_t read[64]; uint32_t M[64]; uint64_t base[64]; };
+struct PosBatch { uint32_t pos[64]; };
+
+// workgroup t sorts + uniques the codes of read t (bitonic in LDS) and appends them to the pool behind workgroup t-1: the offsets are chained
+// through `chain` (zero before the launch; all <= 64 workgroups are resident, so waiting on the predecessor cannot deadlock)
+__global__ __launch_bounds__(256)
+void k_rep_build_batch(const uint64_t* __restrict__ mzcode, RepBatch B, uint64_t* __restrict__ pool, uint64_t* __restrict__ pool_off,
+                       uint32_t* __restrict__ rep_read, uint32_t slot0, uint32_t* __restrict__ chain)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* a = (uint64_t*)smem;
+    __shared__ uint32_t s_u; __shared__ uint64_t s_off;
+    const uint32_t t = blockIdx.x, M = B.M[t]; const uint64_t base = B.base[t];
+    uint32_t P2 = 2; while (P2 < M) P2 <<= 1;
+    for (uint32_t i = threadIdx.x; i < P2; i += 256) a[i] = i < M ? mzcode[base + i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1)
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P2; i += 256) {
+                const uint32_t l = i ^ j;
+                if (l > i) { const uint64_t x = a[i], y = a[l]; const bool up = (i & k2) == 0; if ((x > y) == up) { a[i] = y; a[l] = x; } }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0) {
+        uint32_t c = 0; for (uint32_t i = 0; i < M; ++i) if (i == 0 || a[i] != a[i - 1]) a[c++] = a[i];      // in place: c <= i
+        while (__atomic_load_n(chain, __ATOMIC_ACQUIRE) != t) __builtin_amdgcn_s_sleep(1);
+        const uint64_t off = pool_off[slot0 + t];
+        pool_off[slot0 + t + 1] = off + c; rep_read[slot0 + t] = B.read[t];
+        __threadfence();
+        __atomic_store_n(chain, t + 1, __ATOMIC_RELEASE);
+        s_u = c; s_off = off;
+    }
+    __syncthreads();
+    const uint32_t u = s_u; uint64_t* dst = pool + s_off;
+    for (uint32_t i = threadIdx.x; i < u; i += 256) dst[i] = a[i];
+}
+
+// hits of the block items behind position P.pos[t] against the tentative representative in slot slot0 + t (blockIdx.y = t)
+__global__ __launch_bounds__(256)
+void k_count_hits_reps(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t row0, uint32_t slot0, PosBatch P,
+                       uint64_t* __restrict__ cnt, uint32_t stride)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t t = blockIdx.y, slot = slot0 + t;
+    if (it >= it_hi || it <= P.pos[t]) return;
+    const uint32_t read = items[it];
+    if (D.hlen[read] < (uint32_t)D.k) return;
+    const uint64_t* __restrict__ rc = D.pool + D.pool_off[slot];
+    const uint32_t n = (uint32_t)(D.pool_off[slot + 1] - D.pool_off[slot]);
+    const uint32_t M = D.mzcnt[read];
+    const uint64_t base = D.off[read];
+    unsigned long long acc = 0;
+    for (uint32_t a = lane; a < M; a += 64) {
+        const uint64_t code = D.mzcode[base + a];
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rc[mid] < code) lo = mid + 1; else hi = mid; }
+        if (lo < n && rc[lo] == code) acc += (1ull << 48) + (unsigned long long)D.mzpos[base + a];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0 && acc) cnt[(uint64_t)(it - row0) * stride + slot] += acc;
+}
+
+// merges the sorted code lists of the c consecutive slots slot0 .. slot0+c-1 (contiguous in the pool) into the sorted index in one pass; the
+// result equals c successive k_db_merge calls: equal codes keep the order old entries, then ascending slot
+__global__ void k_db_merge_batch(const uint64_t* __restrict__ oc, const uint32_t* __restrict__ os, uint64_t n_old,
+                                 const uint64_t* __restrict__ pool, const uint64_t* __restrict__ pool_off, uint32_t slot0, uint32_t c,
+                                 uint64_t* __restrict__ nc, uint32_t* __restrict__ ns)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p0 = pool_off[slot0], n_new = pool_off[slot0 + c] - p0;
+    if (i >= n_old + n_new) return;
+    uint64_t code, idx; uint32_t slot, mine = 0xffffffffu;
+    if (i < n_old) { code = oc[i]; slot = os[i]; idx = i; }
+    else {
+        const uint64_t j = p0 + (i - n_old);                         // position in the pool: which list?
+        uint32_t lo = 0, hi = c; while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pool_off[slot0 + mid] <= j) lo = mid; else hi = mid; }
+        mine = lo; code = pool[j]; slot = slot0 + lo; idx = j - pool_off[slot0 + lo];
+        uint64_t l2 = 0, h2 = n_old; while (l2 < h2) { const uint64_t mid = (l2 + h2) >> 1; if (oc[mid] <= code) l2 = mid + 1; else h2 = mid; }   // old codes <= code
+        idx += l2;
+    }
+    for (uint32_t t = 0; t < c; ++t) {
+        if (t == mine) continue;
+        const uint64_t* l = pool + pool_off[slot0 + t]; const uint32_t n = (uint32_t)(pool_off[slot0 + t + 1] - pool_off[slot0 + t]);
+        const bool incl = mine != 0xffffffffu && t < mine;           // lists before mine: their codes <= code come first; old entries and later lists: only codes < code
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (incl ? l[mid] <= code : l[mid] < code) lo = mid + 1; else hi = mid; }
+        idx += lo;
+    }
+    nc[idx] = code; ns[idx] = slot;
+}
+
 __global__ void k_reset_items(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi)
 {
     const uint32_t it = it_lo + blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,6 +482,8 @@ struct RepStore {
 
 // Builds the representatives of `reads` in the slots S.R, S.R+1, ... (pool offsets chained on the device) without registering them on the host:
 // the caller copies pool_off[S.R .. S.R+n] back and commits a prefix.  A slot that is not committed is simply overwritten by the next build.
+// Builds the representatives of `reads` in the slots S.R, S.R+1, ... (pool offsets chained on the device) without registering them on the host:
+// the caller copies pool_off[S.R .. S.R+n] back and commits a prefix.  A slot that is not committed is simply overwritten by the next build.
 static int32_t build_reps(ngsid_ctx* ctx, RepStore& S, const uint32_t* reads, uint32_t n, const uint64_t* d_mzcode, const uint64_t* h_off, const uint32_t* h_mzcnt)
 {
     if (S.R + n + 1 > S.Rcap) {
@@ -397,12 +494,15 @@ static int32_t build_reps(ngsid_ctx* ctx, RepStore& S, const uint32_t* reads, ui
     uint64_t need = S.h_pool_off[S.R];
     for (uint32_t t = 0; t < n; ++t) need += h_mzcnt[reads[t]];
     if (need + 1 > S.pool.n) HIPCHK(ctx, S.pool.grow(std::max<size_t>((need + 1) * 2, 1 << 16), ctx->stream));
-    for (uint32_t t = 0; t < n; ++t) {
-        const uint32_t M = h_mzcnt[reads[t]];
-        uint32_t P2 = 1; while (P2 < M) P2 <<= 1; if (P2 < 2) P2 = 2;
+    for (uint32_t t0 = 0; t0 < n; t0 += 64) {
+        const uint32_t nb = std::min<uint32_t>(64, n - t0);
+        RepBatch B; uint32_t maxM = 2;
+        for (uint32_t t = 0; t < nb; ++t) { B.read[t] = reads[t0 + t]; B.M[t] = h_mzcnt[reads[t0 + t]]; B.base[t] = h_off[reads[t0 + t]]; maxM = std::max(maxM, B.M[t]); }
+        uint32_t P2 = 2; while (P2 < maxM) P2 <<= 1;
         const size_t lds = (size_t)P2 * 8;
-        if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_rep_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_rep_build, dim3(1), dim3(256), lds, ctx->stream, d_mzcode, h_off[reads[t]], M, P2, S.pool.p, S.pool_off.p, S.rep_read.p, S.R + t, reads[t], S.d_count.p);
+        if (lds > 48 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_rep_build_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(ctx, hipMemsetAsync(S.d_count.p, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_rep_build_batch, dim3(nb), dim3(256), lds, ctx->stream, d_mzcode, B, S.pool.p, S.pool_off.p, S.rep_read.p, S.R + t0, S.d_count.p);
         HIPCHK(ctx, hipGetLastError());
     }
     return NGSID_OK;
@@ -411,16 +511,17 @@ static int32_t build_reps(ngsid_ctx* ctx, RepStore& S, const uint32_t* reads, ui
 // Registers the first c built representatives: host mirror of the pool offsets (h_po = pool_off[S.R .. S.R+c] as read back) and the merged index.
 static int32_t commit_reps(ngsid_ctx* ctx, RepStore& S, uint32_t c, const uint64_t* h_po)
 {
-    for (uint32_t t = 0; t < c; ++t) {
-        const uint64_t po = h_po[t]; const uint32_t u = (uint32_t)(h_po[t + 1] - h_po[t]);
-        S.h_pool_off.push_back(h_po[t + 1]);
+    for (uint32_t t0 = 0; t0 < c; t0 += 64) {
+        const uint32_t nb = std::min<uint32_t>(64, c - t0);
+        const uint64_t n_new = h_po[t0 + nb] - h_po[t0];
+        for (uint32_t t = 0; t < nb; ++t) S.h_pool_off.push_back(h_po[t0 + t + 1]);
         const int nx = S.cur ^ 1;
-        if (S.n_db + u + 1 > S.dbc[nx].n) { const size_t cap = std::max<size_t>((S.n_db + u + 1) * 2, 1 << 16); HIPCHK(ctx, S.dbc[nx].alloc(cap)); HIPCHK(ctx, S.dbs[nx].alloc(cap)); }
-        const uint64_t tot = S.n_db + u;
-        if (tot) hipLaunchKernelGGL(k_db_merge, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
-                                    S.dbc[S.cur].p, S.dbs[S.cur].p, S.n_db, S.pool.p + po, u, S.R, S.dbc[nx].p, S.dbs[nx].p);
+        if (S.n_db + n_new + 1 > S.dbc[nx].n) { const size_t cap = std::max<size_t>((S.n_db + n_new + 1) * 2, 1 << 16); HIPCHK(ctx, S.dbc[nx].alloc(cap)); HIPCHK(ctx, S.dbs[nx].alloc(cap)); }
+        const uint64_t tot = S.n_db + n_new;
+        if (tot) hipLaunchKernelGGL(k_db_merge_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream,
+                                    S.dbc[S.cur].p, S.dbs[S.cur].p, S.n_db, S.pool.p, S.pool_off.p, S.R, nb, S.dbc[nx].p, S.dbs[nx].p);
         HIPCHK(ctx, hipGetLastError());
-        S.cur = nx; S.n_db = tot; S.R += 1;
+        S.cur = nx; S.n_db = tot; S.R += nb;
     }
     return NGSID_OK;
 }
@@ -599,9 +700,10 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             for (uint32_t t = 0; t < T; ++t) creads[t] = h_items[C[t]];
             rc = build_reps(ctx, S, creads, T, mzcode.p, RD.h_off.data(), h_mzcnt.data()); if (rc) return rc;
             refresh();
-            for (uint32_t t = 0; t < T; ++t) if (C[t] + 1 < b1) {
+            if (C[0] + 1 < b1) {
+                PosBatch PB; for (uint32_t t = 0; t < 64; ++t) PB.pos[t] = t < T ? C[t] : 0xffffffffu;
                 ProfScope ps_(ctx, "k_count_hits");
-                hipLaunchKernelGGL(k_count_hits_rep, dim3((b1 - C[t] - 1 + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, C[t] + 1, b1, b0, S.R + t, cnt.p, stride);
+                hipLaunchKernelGGL(k_count_hits_reps, dim3((b1 - C[0] - 1 + 3) / 4, T), dim3(256), 0, ctx->stream, D, d_items.p, C[0] + 1, b1, b0, S.R, PB, cnt.p, stride);
             }
             HIPCHK(ctx, hipGetLastError());
             uint32_t cut = 0xffffffffu;
