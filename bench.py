@@ -141,8 +141,8 @@ def main():
     roof = None
     if dom[0]:
         cnt, ms = dom[1]
-        if dom[0] == "k_sg_align":      # cluster aligner (f_aln*N pairs) + 3 polish alignments per read
-            units = (f_aln + 3.0) * n * args.steps
+        if dom[0] == "k_sg_align":      # cluster aligner: f_aln*N pairs (the polisher aligns with k_ed_align)
+            units = f_aln * n * args.steps
         elif dom[0] == "k_poa_tile":    # 1 spoa pass + 3 polish passes per read
             units = 4.0 * n * args.steps
         else:

@@ -350,17 +350,23 @@ static int32_t plan16(ngsid_ctx* ctx, uint64_t npairs, uint32_t max_qlen, uint32
 }
 
 template <int RP>
-static int32_t launch16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t ctr_slot = 0)
+static int32_t launch16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t ctr_slot = 0,
+                        hipStream_t st = nullptr, uint64_t tb_off = ~0ull, uint64_t bnd_off = 0)
 {
     Launch16 L; int32_t rc = plan16<RP>(ctx, job.npairs, max_qlen, max_tlen, &L); if (rc) return rc;
+    if (!st) st = ctx->stream;
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
-    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), st));
     // scratch is grow-only and sized by the caller for all launches of a call BEFORE the first one (a reallocation frees memory
-    // that an earlier, still running launch uses)
-    if (ctx->tb.n < L.nwaves * L.words) HIPCHK(ctx, ctx->tb.alloc(L.nwaves * L.words));
-    if (ctx->bnd.n < L.nwaves * 2ull * L.bnd_stride) HIPCHK(ctx, ctx->bnd.alloc(L.nwaves * 2ull * L.bnd_stride));
-    { ProfScope ps_(ctx, "k_sg_align"); hipLaunchKernelGGL((k_sg_align16<RP>), dim3((unsigned)L.blocks), dim3(64 * L.wpb), (size_t)L.wpb * L.lds_per_wave, ctx->stream,
-                       job, ctx->tb.p, L.words, ctx->bnd.p, L.bnd_stride, L.lds_per_wave, ctx->aln_ctr.p + ctr_slot); }
+    // that an earlier, still running launch uses); concurrent class launches get their own slices (tb_off / bnd_off)
+    if (tb_off == ~0ull) {
+        tb_off = 0; bnd_off = 0;
+        if (ctx->tb.n < L.nwaves * L.words) HIPCHK(ctx, ctx->tb.alloc(L.nwaves * L.words));
+        if (ctx->bnd.n < L.nwaves * 2ull * L.bnd_stride) HIPCHK(ctx, ctx->bnd.alloc(L.nwaves * 2ull * L.bnd_stride));
+    }
+    { ProfScope ps_(ctx, st == ctx->stream ? "k_sg_align" : "k_sg_align_side", st);      // side-stream launches overlap the main one: timed under their own name
+      hipLaunchKernelGGL((k_sg_align16<RP>), dim3((unsigned)L.blocks), dim3(64 * L.wpb), (size_t)L.wpb * L.lds_per_wave, st,
+                       job, ctx->tb.p + tb_off, L.words, ctx->bnd.p + bnd_off, L.bnd_stride, L.lds_per_wave, ctx->aln_ctr.p + ctr_slot); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }
@@ -373,12 +379,11 @@ bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t m
 }
 
 template <int RP>
-static int32_t launch_class(ngsid_ctx* ctx, AlignJob job, int cls, uint32_t max_qlen, uint32_t max_tlen)
+static int32_t launch_class(ngsid_ctx* ctx, AlignJob job, int cls, uint32_t max_qlen, uint32_t max_tlen, hipStream_t st, uint64_t tb_off, uint64_t bnd_off)
 {
     const uint64_t n = job.npairs;
     job.pair_list = ctx->aln_cls.p + (size_t)cls * n; job.npairs_dev = ctx->aln_ctr.p + 8 + cls;
-    // waves serialise on the scratch of the launches before them only through the stream: every class launch uses its own slice
-    return launch16<RP>(ctx, job, max_qlen < k_cls_bound_host(cls) ? max_qlen : k_cls_bound_host(cls), max_tlen, (uint32_t)(1 + cls));
+    return launch16<RP>(ctx, job, max_qlen < k_cls_bound_host(cls) ? max_qlen : k_cls_bound_host(cls), max_tlen, (uint32_t)(1 + cls), st, tb_off, bnd_off);
 }
 
 // pairs -> NCLS index lists in ctx->aln_cls (class c at offset c * npairs), counts in ctx->aln_ctr[8 + c]; all 16 counters are zeroed first
@@ -400,22 +405,32 @@ int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_q
     if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !getenv("NGSID_ALIGN_NOCLASS")) {
         const uint64_t n = job.npairs;
         { int32_t rcp = ngsid_partition_pairs(ctx, job); if (rcp) return rcp; }
-        {   // size the scratch once for the most demanding class launch
-            Launch16 L; uint64_t tbw = 0, bw = 0;
-            plan16<2>(ctx, n, 256, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
-            plan16<4>(ctx, n, 512, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
-            plan16<6>(ctx, n, 768, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
-            plan16<7>(ctx, n, 896, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
-            plan16<8>(ctx, n, max_qlen, max_tlen, &L); tbw = std::max<uint64_t>(tbw, L.nwaves * L.words); bw = std::max<uint64_t>(bw, L.nwaves * 2ull * L.bnd_stride);
-            if (ctx->tb.n < tbw) HIPCHK(ctx, ctx->tb.alloc(tbw));
-            if (ctx->bnd.n < bw) HIPCHK(ctx, ctx->bnd.alloc(bw));
+        // The class launches run CONCURRENTLY (the big class on the context's stream, the others on side streams): a class with a few hundred
+        // pairs costs the latency of one pair, which would otherwise be paid once per class and call.  Every launch has its own scratch slice.
+        { int32_t rs = ngsid_side_streams(ctx); if (rs) return rs; }
+        uint64_t tbo[NCLS + 1] = {0}, bo[NCLS + 1] = {0};
+        {
+            Launch16 L; const uint32_t qb[NCLS] = {256, 512, 768, 896, max_qlen};
+            for (int c = 0; c < NCLS; ++c) {
+                const uint32_t q = std::min<uint32_t>(max_qlen, qb[c]);
+                if (c == 0) plan16<2>(ctx, n, q, max_tlen, &L); else if (c == 1) plan16<4>(ctx, n, q, max_tlen, &L); else if (c == 2) plan16<6>(ctx, n, q, max_tlen, &L);
+                else if (c == 3) plan16<7>(ctx, n, q, max_tlen, &L); else plan16<8>(ctx, n, q, max_tlen, &L);
+                const bool used = c == 0 || max_qlen > qb[c - 1];
+                tbo[c + 1] = tbo[c] + (used ? L.nwaves * L.words : 0); bo[c + 1] = bo[c] + (used ? L.nwaves * 2ull * L.bnd_stride : 0);
+            }
+            if (ctx->tb.n < tbo[NCLS]) HIPCHK(ctx, ctx->tb.reserve(tbo[NCLS]));
+            if (ctx->bnd.n < bo[NCLS]) HIPCHK(ctx, ctx->bnd.reserve(bo[NCLS]));
         }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0));
         int32_t rc;
-        if ((rc = launch_class<2>(ctx, job, 0, max_qlen, max_tlen))) return rc;
-        if (max_qlen > 256 && (rc = launch_class<4>(ctx, job, 1, max_qlen, max_tlen))) return rc;
-        if (max_qlen > 512 && (rc = launch_class<6>(ctx, job, 2, max_qlen, max_tlen))) return rc;
-        if (max_qlen > 768 && (rc = launch_class<7>(ctx, job, 3, max_qlen, max_tlen))) return rc;
-        if (max_qlen > 896 && (rc = launch_class<8>(ctx, job, 4, max_qlen, max_tlen))) return rc;
+        // class 2 (<= 768 bases, the ONT amplicon lengths) stays on the main stream
+        if ((rc = launch_class<2>(ctx, job, 0, max_qlen, max_tlen, ctx->side[0], tbo[0], bo[0]))) return rc;
+        if (max_qlen > 256 && (rc = launch_class<4>(ctx, job, 1, max_qlen, max_tlen, ctx->side[1], tbo[1], bo[1]))) return rc;
+        if (max_qlen > 768 && (rc = launch_class<7>(ctx, job, 3, max_qlen, max_tlen, ctx->side[2], tbo[3], bo[3]))) return rc;
+        if (max_qlen > 896 && (rc = launch_class<8>(ctx, job, 4, max_qlen, max_tlen, ctx->side[3], tbo[4], bo[4]))) return rc;
+        if (max_qlen > 512 && (rc = launch_class<6>(ctx, job, 2, max_qlen, max_tlen, ctx->stream, tbo[2], bo[2]))) return rc;
+        for (int i = 0; i < 4; ++i) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[i], ctx->side[i])); HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0)); }
         return NGSID_OK;
     }
     if (max_qlen <= 256) return launch16<2>(ctx, job, max_qlen, max_tlen);

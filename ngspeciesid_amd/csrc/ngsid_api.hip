@@ -39,8 +39,18 @@ extern "C" void ngsid_destroy(ngsid_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < 4; ++i) { if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); } if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
+}
+
+int32_t ngsid_side_streams(ngsid_ctx* ctx)
+{
+    if (ctx->ev_fork) return NGSID_OK;
+    for (int i = 0; i < 4; ++i) { HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)); HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming)); }
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    return NGSID_OK;
 }
 
 int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* out, bool need_qual)

@@ -49,6 +49,8 @@ struct ngsid_ctx {
     struct PoaLevelBufs { DevBuf<uint8_t> out, seqs /* PSeq[] */; DevBuf<int32_t> out_len, job_bb; DevBuf<uint64_t> out_cw; DevBuf<uint32_t> out_n, out_cov, job_off, seq_idx, flags; };
     PoaLevelBufs poa_lv[2];   // hierarchy levels ping-pong between two buffer sets (level L+1 reads what level L wrote)
     DevBuf<uint64_t> pol_mzcode; DevBuf<uint32_t> pol_mzpos; DevBuf<uint8_t> pol_oseq, pol_oqual, pol_valid; DevBuf<int32_t> pol_bp; DevBuf<uint8_t> pol_lay;   // polisher scratch (grow-only)
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams: the launches of the small length classes overlap the big one
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool debug_sync = false;
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
@@ -61,16 +63,16 @@ struct ngsid_ctx {
 // brackets one kernel launch with HIP events on the ctx stream when profiling is enabled
 struct ProfScope {
     ngsid_ctx* c; ProfEntry e; bool on;
-    const char* dbg_name;
-    ProfScope(ngsid_ctx* ctx, const char* name) : c(ctx), on(ctx->prof), dbg_name(name) {
+    const char* dbg_name; hipStream_t st;
+    ProfScope(ngsid_ctx* ctx, const char* name, hipStream_t s = nullptr) : c(ctx), on(ctx->prof), dbg_name(name), st(s ? s : ctx->stream) {
         if (c->debug_sync) { fprintf(stderr, "[ngsid] launch %s\n", name); fflush(stderr); }
         if (!on) return; e.name = name;
         if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
-        (void)hipEventRecord(e.a, c->stream);
+        (void)hipEventRecord(e.a, st);
     }
     ~ProfScope() {
-        if (c->debug_sync) { hipError_t er = hipStreamSynchronize(c->stream); fprintf(stderr, "[ngsid] %s -> %s\n", dbg_name, hipGetErrorString(er)); fflush(stderr); }
-        if (!on) return; (void)hipEventRecord(e.b, c->stream); c->prof_events.push_back(e);
+        if (c->debug_sync) { hipError_t er = hipStreamSynchronize(st); fprintf(stderr, "[ngsid] %s -> %s\n", dbg_name, hipGetErrorString(er)); fflush(stderr); }
+        if (!on) return; (void)hipEventRecord(e.b, st); c->prof_events.push_back(e);
     }
 };
 
@@ -102,6 +104,7 @@ struct AlignJob {            // device pointers
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20);
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
 int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen);
+int32_t ngsid_side_streams(ngsid_ctx* ctx);          // creates ctx->side / events on first use
 int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job);      // query-length classes {<=256, <=512, <=768, <=896, rest}: lists in ctx->aln_cls, counts in ctx->aln_ctr[8..12]
 int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out);   // k_ed_align.hip (uses qseq..npairs, bp, bp_windows, window, span)
 
