@@ -356,7 +356,7 @@ static int32_t launch16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, 
     Launch16 L; int32_t rc = plan16<RP>(ctx, job.npairs, max_qlen, max_tlen, &L); if (rc) return rc;
     if (!st) st = ctx->stream;
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
-    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), st));
+    if (tb_off == ~0ull) HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), st));      // (class launches: ngsid_partition_pairs has zeroed all counters)
     // scratch is grow-only and sized by the caller for all launches of a call BEFORE the first one (a reallocation frees memory
     // that an earlier, still running launch uses); concurrent class launches get their own slices (tb_off / bnd_off)
     if (tb_off == ~0ull) {
