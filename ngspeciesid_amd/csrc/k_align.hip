@@ -244,13 +244,13 @@ static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen
     return NGSID_OK;
 }
 
-int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open)
+int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open, uint32_t min_qlen)
 {
     if (job.npairs == 0) return NGSID_OK;
     if (job.npairs > 0xf0000000ull) NGSID_FAIL(ctx, NGSID_ERR_ARG, "more than 2^32 pairs in one aligner call");
     if (max_tlen > NGSID_MAX_READ_LEN || max_qlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in aligner", NGSID_MAX_READ_LEN);
     if (job.k > 64) NGSID_FAIL(ctx, NGSID_ERR_ARG, "window k > 64 unsupported");
-    if (!getenv("NGSID_ALIGN32") && ngsid_align16_applicable(job, max_qlen, max_tlen, max_open)) return ngsid_launch_align16(ctx, job, max_qlen, max_tlen);   // packed int16 path (bit-identical)
+    if (!getenv("NGSID_ALIGN32") && ngsid_align16_applicable(job, max_qlen, max_tlen, max_open)) return ngsid_launch_align16(ctx, job, max_qlen, max_tlen, min_qlen);   // packed int16 path (bit-identical)
     if (max_qlen <= 256) return launch_rpl<4>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 512) return launch_rpl<8>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 768) return launch_rpl<12>(ctx, job, max_qlen, max_tlen);

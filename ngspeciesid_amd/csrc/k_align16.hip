@@ -398,7 +398,7 @@ int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job)
     return NGSID_OK;
 }
 
-int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen)
+int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t min_qlen)
 {
     // Large batches with mixed query lengths: split the pairs by query-length class so that every pair runs in the instance with the
     // fewest idle rows (a lane owns 2*RP rows; 750-base reads with a few 800-base ones would otherwise all run with RP = 7).
@@ -415,7 +415,7 @@ int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_q
                 const uint32_t q = std::min<uint32_t>(max_qlen, qb[c]);
                 if (c == 0) plan16<2>(ctx, n, q, max_tlen, &L); else if (c == 1) plan16<4>(ctx, n, q, max_tlen, &L); else if (c == 2) plan16<6>(ctx, n, q, max_tlen, &L);
                 else if (c == 3) plan16<7>(ctx, n, q, max_tlen, &L); else plan16<8>(ctx, n, q, max_tlen, &L);
-                const bool used = c == 0 || max_qlen > qb[c - 1];
+                const bool used = (c == 0 || max_qlen > qb[c - 1]) && min_qlen <= qb[c];
                 tbo[c + 1] = tbo[c] + (used ? L.nwaves * L.words : 0); bo[c + 1] = bo[c] + (used ? L.nwaves * 2ull * L.bnd_stride : 0);
             }
             if (ctx->tb.n < tbo[NCLS]) HIPCHK(ctx, ctx->tb.reserve(tbo[NCLS]));
@@ -425,11 +425,11 @@ int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_q
         for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0));
         int32_t rc;
         // class 2 (<= 768 bases, the ONT amplicon lengths) stays on the main stream
-        if ((rc = launch_class<2>(ctx, job, 0, max_qlen, max_tlen, ctx->side[0], tbo[0], bo[0]))) return rc;
-        if (max_qlen > 256 && (rc = launch_class<4>(ctx, job, 1, max_qlen, max_tlen, ctx->side[1], tbo[1], bo[1]))) return rc;
-        if (max_qlen > 768 && (rc = launch_class<7>(ctx, job, 3, max_qlen, max_tlen, ctx->side[2], tbo[3], bo[3]))) return rc;
+        if (min_qlen <= 256 && (rc = launch_class<2>(ctx, job, 0, max_qlen, max_tlen, ctx->side[0], tbo[0], bo[0]))) return rc;
+        if (max_qlen > 256 && min_qlen <= 512 && (rc = launch_class<4>(ctx, job, 1, max_qlen, max_tlen, ctx->side[1], tbo[1], bo[1]))) return rc;
+        if (max_qlen > 768 && min_qlen <= 896 && (rc = launch_class<7>(ctx, job, 3, max_qlen, max_tlen, ctx->side[2], tbo[3], bo[3]))) return rc;
         if (max_qlen > 896 && (rc = launch_class<8>(ctx, job, 4, max_qlen, max_tlen, ctx->side[3], tbo[4], bo[4]))) return rc;
-        if (max_qlen > 512 && (rc = launch_class<6>(ctx, job, 2, max_qlen, max_tlen, ctx->stream, tbo[2], bo[2]))) return rc;
+        if (max_qlen > 512 && min_qlen <= 768 && (rc = launch_class<6>(ctx, job, 2, max_qlen, max_tlen, ctx->stream, tbo[2], bo[2]))) return rc;
         for (int i = 0; i < 4; ++i) { HIPCHK(ctx, hipEventRecord(ctx->ev_join[i], ctx->side[i])); HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0)); }
         return NGSID_OK;
     }

@@ -671,7 +671,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
                 J.qseq = RD.seq; J.qoff = RD.off; J.tseq = RD.seq; J.toff = RD.off; J.qidx = req_q.p; J.tidx = req_t.p; J.npairs = nreq;
                 J.match = 2; J.mismatch = -2; J.ext = 1; J.k = k; J.open = req_open.p; J.match_id = req_mid.p;     // cluster.py:130
                 J.score = nullptr; J.ncols = nullptr; J.nmatch = nullptr; J.region = req_region.p; J.bp = nullptr; J.bp_windows = 0; J.window = 1; J.span = nullptr;
-                rc = ngsid_launch_align(ctx, J, RD.maxlen, RD.maxlen, 5); if (rc) return rc;     // gap open is 2..5 (cluster.py:189-196)
+                rc = ngsid_launch_align(ctx, J, RD.maxlen, RD.maxlen, 5, RD.minlen); if (rc) return rc;     // gap open is 2..5 (cluster.py:189-196)
                 hipLaunchKernelGGL(k_cache_insert, dim3((nreq + 255) / 256), dim3(256), 0, ctx->stream, D, req_q.p, req_slot.p, req_region.p, nreq);
                 HIPCHK(ctx, hipGetLastError());
             }

@@ -74,14 +74,14 @@ int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* ou
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     out->total = out->h_off[in->n];
-    uint32_t mx = 0;
+    uint32_t mx = 0, mn = 0xffffffffu;
     for (uint64_t i = 0; i < in->n; ++i) {
         if (out->h_off[i + 1] < out->h_off[i]) NGSID_FAIL(ctx, NGSID_ERR_ARG, "offsets not monotone at read %llu", (unsigned long long)i);
         const uint64_t l = out->h_off[i + 1] - out->h_off[i];
         if (l > 0xffffffffull) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "read %llu too long", (unsigned long long)i);
-        mx = std::max<uint32_t>(mx, (uint32_t)l);
+        mx = std::max<uint32_t>(mx, (uint32_t)l); mn = std::min<uint32_t>(mn, (uint32_t)l);
     }
-    out->maxlen = mx;
+    out->maxlen = mx; out->minlen = in->n ? mn : 0;
     return NGSID_OK;
 }
 

@@ -79,7 +79,7 @@ struct ProfScope {
 // A read set resident in HBM (+ host copy of the offsets, which every host-side planner needs)
 struct DevReads {
     const uint8_t* seq = nullptr; const uint8_t* qual = nullptr; const uint64_t* off = nullptr;
-    uint64_t n = 0, total = 0; uint32_t maxlen = 0;
+    uint64_t n = 0, total = 0; uint32_t maxlen = 0, minlen = 0;
     std::vector<uint64_t> h_off;
     DevBuf<uint8_t> own_seq, own_qual; DevBuf<uint64_t> own_off;
 };
@@ -101,9 +101,9 @@ struct AlignJob {            // device pointers
     // optional indirection (length classes): the k-th work item is pair pair_list[k], and the item count is read from device memory
     const uint32_t* pair_list; const uint32_t* npairs_dev;
 };
-int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20);
+int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20, uint32_t min_qlen = 0);   // min_qlen: lower bound of the query lengths (lets empty length classes be skipped)
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
-int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen);
+int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t min_qlen = 0);
 int32_t ngsid_side_streams(ngsid_ctx* ctx);          // creates ctx->side / events on first use
 int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job);      // query-length classes {<=256, <=512, <=768, <=896, rest}: lists in ctx->aln_cls, counts in ctx->aln_ctr[8..12]
 int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out);   // k_ed_align.hip (uses qseq..npairs, bp, bp_windows, window, span)
