@@ -555,7 +555,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     HIPCHK(ctx, hipGetLastError());
     if (acc_rank) HIPCHK(ctx, hipMemcpyAsync(d_acc.p, acc_rank, 4 * N, hipMemcpyHostToDevice, ctx->stream));
     else { std::vector<uint32_t> id(N); for (uint64_t i = 0; i < N; ++i) id[i] = (uint32_t)i; HIPCHK(ctx, hipMemcpyAsync(d_acc.p, id.data(), 4 * N, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
-    static thread_local std::vector<uint32_t> h_hlen, h_mzcnt;      // host mirrors are kept across calls (fresh multi-megabyte vectors page-fault on every call)
+    static thread_local PinVec<uint32_t> h_hlen, h_mzcnt;      // host mirrors are kept across calls (fresh multi-megabyte vectors page-fault on every call)
     h_hlen.resize(N); h_mzcnt.resize(N); int h_flag[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(h_hlen.data(), hlen.p, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_mzcnt.data(), mzcnt.p, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
@@ -579,7 +579,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     // ---- items (reads to process) and seeded representatives
     int lowest = 1;
     if (prev_batch) { int mn = prev_batch[0]; for (uint64_t i = 1; i < N; ++i) mn = std::min(mn, prev_batch[i]); lowest = std::max(1, mn); }
-    static thread_local std::vector<uint32_t> h_items; h_items.clear(); h_items.reserve(N);
+    static thread_local PinVec<uint32_t> h_items; h_items.clear(); h_items.reserve(N);
     std::vector<uint8_t> h_seeded;
     if (prev_batch) { h_seeded.assign(N, 0); for (uint64_t i = 0; i < N; ++i) { if (prev_batch[i] == lowest) h_seeded[i] = 1; else h_items.push_back((uint32_t)i); } }
     else for (uint64_t i = 0; i < N; ++i) h_items.push_back((uint32_t)i);
@@ -635,7 +635,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     HIPCHK(ctx, d_scal.alloc(4));
     uint32_t tcur = 1;
     constexpr uint32_t TMAX = 64;             // new representatives committed per pass (one lane per tentative column in k_first_affected)
-    DevBuf<unsigned long long> d_mask; HIPCHK(ctx, d_mask.alloc(BLK / 64 + 1)); std::vector<unsigned long long> h_mask(BLK / 64 + 1);
+    DevBuf<unsigned long long> d_mask; HIPCHK(ctx, d_mask.alloc(BLK / 64 + 1)); PinVec<unsigned long long> h_mask(BLK / 64 + 1);
     auto refresh = [&]() { D.rep_read = S.rep_read.p; D.pool = S.pool.p; D.pool_off = S.pool_off.p; };
 
     ht.mark("setup");
@@ -739,13 +739,14 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     refresh();
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, D, N, prev_batch ? d_seeded.p : nullptr, d_rep.p, d_status.p, d_herr_out.p, d_counters.p);
     HIPCHK(ctx, hipGetLastError());
-    static thread_local std::vector<uint8_t> h_status; static thread_local std::vector<double> h_herr; h_status.resize(N); h_herr.resize(N); unsigned long long h_cnt[4];
-    HIPCHK(ctx, hipMemcpyAsync(rep_of_read, d_rep.p, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
+    static thread_local PinVec<uint8_t> h_status; static thread_local PinVec<double> h_herr; static thread_local PinVec<int32_t> h_rep; h_status.resize(N); h_herr.resize(N); h_rep.resize(N); unsigned long long h_cnt[4];
+    HIPCHK(ctx, hipMemcpyAsync(h_rep.data(), d_rep.p, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_status.data(), d_status.p, N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_herr.data(), d_herr_out.p, 8 * N, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_cnt, d_counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ht.mark("finalize + download");
+    memcpy(rep_of_read, h_rep.data(), 4 * N);
     if (status_out) memcpy(status_out, h_status.data(), N);
     if (hpc_err_out) memcpy(hpc_err_out, h_herr.data(), 8 * N);
     if (counters) for (int i = 0; i < 4; ++i) counters[i] = h_cnt[i];

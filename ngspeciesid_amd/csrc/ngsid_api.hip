@@ -9,6 +9,46 @@ extern "C" uint32_t ngsid_abi_version(void) { return 1u; }
 static char g_static_err[256] = "";
 extern "C" const char* ngsid_last_error(ngsid_ctx* ctx) { return ctx ? ctx->err : g_static_err; }
 
+// ---------------------------------------------------------------------------------------------- device memory cache
+namespace {
+struct DevPool { std::mutex mu; std::multimap<unsigned long long, void*> free_; size_t cached = 0; int contexts = 0; };
+DevPool g_pool;
+const size_t POOL_LIMIT = (size_t)48 << 30;          // bytes kept for reuse; beyond it blocks go back to the driver
+inline size_t pool_class(size_t b) { if (b < 4096) return 4096; int sh = 63 - __builtin_clzll((unsigned long long)b) - 3; size_t m = ((size_t)1 << sh) - 1; return (b + m) & ~m; }
+inline unsigned long long pool_key(int dev, size_t cls) { return ((unsigned long long)dev << 56) | (unsigned long long)cls; }
+}
+hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got)
+{
+    const size_t cls = pool_class(bytes ? bytes : 1); int dev = 0; (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto it = g_pool.free_.find(pool_key(dev, cls));
+        if (it != g_pool.free_.end()) { *p = it->second; g_pool.free_.erase(it); g_pool.cached -= cls; *got = cls; return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess) {          // out of memory: give the cached blocks back and retry once
+        (void)hipGetLastError(); ngsid_pool_release_all(); e = hipMalloc(p, cls);
+    }
+    *got = e == hipSuccess ? cls : 0;
+    return e;
+}
+void ngsid_pool_free(void* p, size_t bytes)
+{
+    if (!p) return;
+    int dev = 0; (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        if (bytes && g_pool.cached + bytes <= POOL_LIMIT) { g_pool.free_.emplace(pool_key(dev, bytes), p); g_pool.cached += bytes; return; }
+    }
+    (void)hipFree(p);
+}
+void ngsid_pool_release_all()
+{
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (auto& kv : g_pool.free_) (void)hipFree(kv.second);
+    g_pool.free_.clear(); g_pool.cached = 0;
+}
+
 extern "C" int32_t ngsid_create(int32_t device_ordinal, uint32_t flags, ngsid_ctx** out)
 {
     (void)flags;
@@ -31,6 +71,7 @@ extern "C" int32_t ngsid_create(int32_t device_ordinal, uint32_t flags, ngsid_ct
     }
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { snprintf(g_static_err, sizeof g_static_err, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return NGSID_ERR_HIP; }
+    { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.contexts++; }
     *out = c;
     return NGSID_OK;
 }
@@ -41,8 +82,11 @@ extern "C" void ngsid_destroy(ngsid_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i < 4; ++i) { if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); } if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
+    bool last; { std::lock_guard<std::mutex> lk(g_pool.mu); last = --g_pool.contexts <= 0; }
+    if (last) ngsid_pool_release_all();
 }
 
 int32_t ngsid_side_streams(ngsid_ctx* ctx)
@@ -58,10 +102,19 @@ int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* ou
     if (!in || (!in->off) || (in->n && !in->seq)) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null read set");
     if (need_qual && in->n && !in->qual) NGSID_FAIL(ctx, NGSID_ERR_ARG, "this entry point needs qualities");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    HostTimer hu(ctx->stream, "upload_reads");
     out->n = in->n;
     out->h_off.resize(in->n + 1);
+    hu.mark("resize");
     if (in->mem == NGSID_MEM_DEVICE) {
-        HIPCHK(ctx, hipMemcpy(out->h_off.data(), in->off, sizeof(uint64_t) * (in->n + 1), hipMemcpyDeviceToHost));
+        // through pinned staging on the context's stream: a blocking copy into fresh pageable memory cost 26 ms for 8 MB here
+        const size_t nb = sizeof(uint64_t) * (in->n + 1);
+        if (ctx->pin_bytes < nb) { if (ctx->pin) (void)hipHostFree(ctx->pin); ctx->pin = nullptr; ctx->pin_bytes = 0; HIPCHK(ctx, hipHostMalloc(&ctx->pin, nb + nb / 8, hipHostMallocDefault)); ctx->pin_bytes = nb + nb / 8; }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin, in->off, nb, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        hu.mark("d2h");
+        memcpy(out->h_off.data(), ctx->pin, nb);
+        hu.mark("memcpy");
         out->seq = in->seq; out->qual = in->qual; out->off = in->off;
     } else {
         memcpy(out->h_off.data(), in->off, sizeof(uint64_t) * (in->n + 1));
@@ -82,6 +135,7 @@ int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* ou
         mx = std::max<uint32_t>(mx, (uint32_t)l); mn = std::min<uint32_t>(mn, (uint32_t)l);
     }
     out->maxlen = mx; out->minlen = in->n ? mn : 0;
+    hu.mark("scan");
     return NGSID_OK;
 }
 

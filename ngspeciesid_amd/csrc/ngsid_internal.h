@@ -8,26 +8,56 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <new>
+#include <mutex>
 #include <chrono>
 #include "../../include/ngsid.h"
 
-// RAII device buffer (freed at scope exit; all work is synchronised before return)
+// Device memory goes through a small per-process cache of freed blocks (size classes with 4 significant bits): the drivers allocate
+// some forty temporaries per call, and hipFree synchronises the device and costs up to a millisecond each (a 35 ms idle gap per
+// clustering call in the rocprofv3 trace).  Blocks are only handed out again after the call that freed them has synchronised its
+// streams (every entry point does before it returns), so reuse is stream-safe.  The cache is released with the last context.
+hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got);
+void ngsid_pool_free(void* p, size_t bytes);
+void ngsid_pool_release_all();
+
+// RAII device buffer (returned to the cache at scope exit; all work is synchronised before return)
 template <typename T> struct DevBuf {
     T* p = nullptr; size_t n = 0;
     DevBuf() {}
     DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    size_t cap = 0;
-    hipError_t alloc(size_t count) { if (p) { (void)hipFree(p); p = nullptr; } n = count; if (!count) count = 1; cap = count; return hipMalloc((void**)&p, count * sizeof(T)); }
-    // grow-only, contents not kept: for scratch that is reused call after call (hipMalloc/hipFree of GB-sized buffers cost milliseconds and synchronise)
+    ~DevBuf() { if (p) ngsid_pool_free(p, abytes); }
+    size_t cap = 0, abytes = 0;
+    hipError_t alloc(size_t count) {
+        if (p) { ngsid_pool_free(p, abytes); p = nullptr; }
+        n = count; if (!count) count = 1;
+        void* q = nullptr; hipError_t e = ngsid_pool_alloc(&q, count * sizeof(T), &abytes);
+        p = (T*)q; cap = e == hipSuccess ? abytes / sizeof(T) : 0; return e;
+    }
+    // grow-only, contents not kept: for scratch that is reused call after call
     hipError_t reserve(size_t count) { if (p && count <= cap) { n = count; return hipSuccess; } return alloc(count + count / 8); }
     hipError_t grow(size_t count, hipStream_t s) {   // keeps contents
         if (count <= n) return hipSuccess;
-        T* q = nullptr; hipError_t e = hipMalloc((void**)&q, count * sizeof(T)); if (e != hipSuccess) return e;
+        void* q = nullptr; size_t qb = 0; hipError_t e = ngsid_pool_alloc(&q, count * sizeof(T), &qb); if (e != hipSuccess) return e;
         if (p && n) { e = hipMemcpyAsync(q, p, n * sizeof(T), hipMemcpyDeviceToDevice, s); if (e != hipSuccess) return e; e = hipStreamSynchronize(s); if (e != hipSuccess) return e; }
-        if (p) (void)hipFree(p); p = q; n = count; return hipSuccess;
+        if (p) ngsid_pool_free(p, abytes);
+        p = (T*)q; abytes = qb; cap = qb / sizeof(T); n = count; return hipSuccess;
     }
 };
+
+// Host vectors in pinned memory for the big, recurring host <-> device copies.  A copy from / to pageable memory makes the runtime pin the
+// pages for the transfer and release them afterwards; with 8-40 MB per hierarchy level that showed up as milliseconds on the NEXT
+// submission (8 ms after the clustering results, rocprofv3 trace + host timers).  These vectors live in thread-local statics and only grow.
+template <typename T> struct PinnedAlloc {
+    using value_type = T;
+    PinnedAlloc() = default;
+    template <class U> PinnedAlloc(const PinnedAlloc<U>&) {}
+    T* allocate(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, (n ? n : 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc(); return (T*)p; }
+    void deallocate(T* p, size_t) { (void)hipHostFree(p); }
+    template <class U> bool operator==(const PinnedAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
+};
+template <typename T> using PinVec = std::vector<T, PinnedAlloc<T>>;
 
 struct ProfEntry { const char* name; hipEvent_t a, b; };
 
@@ -51,6 +81,7 @@ struct ngsid_ctx {
     DevBuf<uint64_t> pol_mzcode; DevBuf<uint32_t> pol_mzpos; DevBuf<uint8_t> pol_oseq, pol_oqual, pol_valid; DevBuf<int32_t> pol_bp; DevBuf<uint8_t> pol_lay;   // polisher scratch (grow-only)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams: the launches of the small length classes overlap the big one
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* pin = nullptr; size_t pin_bytes = 0;     // pinned host staging (device -> host copies of offsets)
     bool debug_sync = false;
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
@@ -120,5 +151,5 @@ __device__ __forceinline__ int ngsid_bcode(uint8_t c) {
 struct HostTimer {
     bool on; hipStream_t st; std::chrono::steady_clock::time_point t0; const char* what;
     HostTimer(hipStream_t s, const char* w) : on(getenv("NGSID_HOST_TIMERS") != nullptr), st(s), what(w) { if (on) { (void)hipStreamSynchronize(st); t0 = std::chrono::steady_clock::now(); } }
-    void mark(const char* label) { if (!on) return; (void)hipStreamSynchronize(st); auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[ngsid host] %s: %s %.2f ms\n", what, label, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
+    void mark(const char* label) { if (!on) return; (void)hipStreamSynchronize(st); auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[ngsid host] %s: %s %.2f ms   (t=%.2f)\n", what, label, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t1.time_since_epoch()).count() - 1e3 * (double)((long long)(std::chrono::duration<double>(t1.time_since_epoch()).count()) / 1000 * 1000)); t0 = t1; }
 };

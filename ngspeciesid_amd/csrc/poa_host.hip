@@ -43,7 +43,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
     for (int level = 0;; ++level) {
         // ---- jobs of this level
         // host lists of a level: kept across levels and calls (a million entries per level; fresh allocations would page-fault every time)
-        static thread_local std::vector<uint32_t> job_off, seq_idx, job_unit; static thread_local std::vector<int32_t> job_bb;
+        static thread_local PinVec<uint32_t> job_off, seq_idx; static thread_local std::vector<uint32_t> job_unit; static thread_local PinVec<int32_t> job_bb;
         job_off.clear(); job_off.push_back(0); seq_idx.clear(); job_unit.clear(); job_bb.clear();
         { size_t tot = 0; for (const Unit& U : units) if (!U.done) tot += U.seqs.size(); seq_idx.reserve(tot); }
         uint32_t maxD = 0; int maxL0 = 1; bool any_nobb = false;
@@ -75,7 +75,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
         HIPCHK(ctx, hipMemcpyAsync(d_seq_idx.p, seq_idx.data(), 4 * seq_idx.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_job_bb.p, job_bb.data(), 4 * job_bb.size(), hipMemcpyHostToDevice, ctx->stream));
         int slots = slots_cap ? slots_cap : (int)std::min<uint32_t>(maxD, 4);
-        static thread_local std::vector<uint32_t> h_out_n; static thread_local std::vector<int32_t> h_out_len; static thread_local std::vector<uint64_t> h_out_cw;
+        static thread_local PinVec<uint32_t> h_out_n; static thread_local PinVec<int32_t> h_out_len; static thread_local PinVec<uint64_t> h_out_cw;
         for (;;) {      // retry with more output slots if a tile had to split more often than `slots`
             HIPCHK(ctx, Lv->out.reserve((size_t)njobs * slots * capV)); HIPCHK(ctx, Lv->out_len.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_cw.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_n.reserve(njobs));
             if (hp.want_cov) HIPCHK(ctx, Lv->out_cov.reserve((size_t)njobs * slots * capV));
@@ -107,7 +107,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
         // ---- distribute outputs to units
         std::vector<std::vector<uint32_t>> outs(units.size());         // flat slot indices (job*slots + s) in job order
         for (uint32_t j = 0; j < njobs; ++j) for (uint32_t s = 0; s < h_out_n[j]; ++s) outs[job_unit[j]].push_back(j * (uint32_t)slots + s);
-        static thread_local std::vector<PSeq> next; uint32_t next_maxlen = 0;
+        static thread_local PinVec<PSeq> next; uint32_t next_maxlen = 0;
         { size_t tot = 0; for (uint32_t j = 0; j < njobs; ++j) tot += h_out_n[j]; next.clear(); next.reserve(tot); }
         for (size_t u = 0; u < units.size(); ++u) {
             Unit& U = units[u]; if (U.done) continue;
@@ -152,9 +152,12 @@ extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* read
 {
     if (!ctx) return NGSID_ERR_ARG;
     if (!reads || !grp_off || !prm || !cons_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    HostTimer htc(ctx->stream, "consensus");
     DevReads RD; int32_t rc = ngsid_upload_reads(ctx, reads, &RD, false); if (rc) return rc;
+    htc.mark("upload");
     if (!read_order && grp_off[n_groups] > RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "group offsets exceed the read set");
     if (read_order) for (uint64_t x = 0; x < grp_off[n_groups]; ++x) if (read_order[x] >= RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "read_order[%llu] out of range", (unsigned long long)x);
+    htc.mark("checks");
     DevBuf<PSeq> d_seqs; HIPCHK(ctx, d_seqs.alloc(RD.n));
     if (RD.n) hipLaunchKernelGGL(k_make_pseq_reads, dim3((unsigned)((RD.n + 255) / 256)), dim3(256), 0, ctx->stream, RD.seq, RD.qual, RD.off, RD.n, prm->mode, d_seqs.p);
     HIPCHK(ctx, hipGetLastError());
@@ -162,7 +165,9 @@ extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* read
     for (uint64_t g = 0; g < n_groups; ++g) { units[g].seqs.reserve(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs.push_back(read_order ? read_order[r] : (uint32_t)r); }
     HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, prm->mode, false, 0};
     std::vector<int> nobb;
+    htc.mark("units");
     rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;
+    htc.mark("hierarchy");
     uint64_t total = 0; bool overflow = false; cons_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         const std::string& s = units[g].result;
@@ -331,7 +336,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    std::vector<uint8_t> h_orient(N);
+    static thread_local PinVec<uint8_t> h_orient; h_orient.resize(N);
     HIPCHK(ctx, hipMemcpy(h_orient.data(), d_orient.p, N, hipMemcpyDeviceToHost));
     ht.mark("minimizers + strand");
     // ---- oriented copies of the reads
@@ -339,7 +344,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     { ProfScope ps_(ctx, "k_orient"); hipLaunchKernelGGL(k_orient, dim3((unsigned)N), dim3(128), 0, ctx->stream, RD.seq, RD.qual, RD.off, N, d_orient.p, oseq.p, RD.qual ? oqual.p : nullptr); }
     HIPCHK(ctx, hipGetLastError());
     // ---- pairs (usable reads of reads that belong to a group), fixed over the iterations
-    std::vector<uint32_t> pair_read, pair_group;
+    static thread_local PinVec<uint32_t> pair_read, pair_group; pair_read.clear(); pair_group.clear();
     for (uint64_t x = 0; x < grp_off[n_groups]; ++x) { const uint64_t r = read_order ? read_order[x] : x; if (h_orient[r] != 255) { pair_read.push_back((uint32_t)r); pair_group.push_back(h_rgroup[r]); } }
     const uint64_t NP = pair_read.size();
     DevBuf<uint32_t> d_pair_read, d_pair_group; DevBuf<int32_t> d_open, d_span, d_blen; DevBuf<int32_t>& d_bp = ctx->pol_bp; DevBuf<uint8_t>& d_lay_raw = ctx->pol_lay; DevBuf<uint8_t>& d_valid = ctx->pol_valid;
@@ -359,7 +364,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         HIPCHK(ctx, hipMemcpyAsync(d_blen.p, blen.data(), 4 * G, hipMemcpyHostToDevice, ctx->stream));
         std::fill(used.begin(), used.end(), 0);
         std::vector<Unit> units; std::vector<PSeq> bbs; std::vector<int> bb_len; std::vector<std::pair<uint32_t, int>> unit_gw;
-        static thread_local std::vector<uint8_t> h_valid; int max_layer = 1;
+        static thread_local PinVec<uint8_t> h_valid; int max_layer = 1;
         HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
         if (NP) {
             HIPCHK(ctx, d_bp.reserve(NP * (uint64_t)nwinmax * 4)); HIPCHK(ctx, d_lay_raw.reserve(sizeof(PSeq) * NP * (uint64_t)nwinmax)); HIPCHK(ctx, d_valid.reserve(NP * (uint64_t)nwinmax));
