@@ -169,6 +169,9 @@ typedef struct {
                                  minimap2 span); traceback prefers match/mismatch, then a read-only column, then a backbone-only column;
                                  end column = leftmost minimum of the last row; non-ACGT letters match nothing;
                                  2 = the library's default (currently mode 1) */
+    int32_t stop_when_stable; /* 1 = a group whose backbone comes back unchanged from an iteration is not polished again: the polisher is a
+                                 deterministic function of (backbone, reads), so every further iteration would return the same string and
+                                 the same n_used - the result is identical, only the time differs.  0 = always run `iters` iterations */
 } ngsid_polish_params_t;
 
 /* (a16,a17) replaces run_racon's (minimap2 -> racon) x racon_iter chain (consensus.py:107-126).

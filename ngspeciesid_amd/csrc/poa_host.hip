@@ -346,7 +346,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     // ---- pairs (usable reads of reads that belong to a group), fixed over the iterations
     static thread_local PinVec<uint32_t> pair_read, pair_group; pair_read.clear(); pair_group.clear();
     for (uint64_t x = 0; x < grp_off[n_groups]; ++x) { const uint64_t r = read_order ? read_order[x] : x; if (h_orient[r] != 255) { pair_read.push_back((uint32_t)r); pair_group.push_back(h_rgroup[r]); } }
-    const uint64_t NP = pair_read.size();
+    uint64_t NP = pair_read.size();
     DevBuf<uint32_t> d_pair_read, d_pair_group; DevBuf<int32_t> d_open, d_span, d_blen; DevBuf<int32_t>& d_bp = ctx->pol_bp; DevBuf<uint8_t>& d_lay_raw = ctx->pol_lay; DevBuf<uint8_t>& d_valid = ctx->pol_valid;
     HIPCHK(ctx, d_pair_read.alloc(NP)); HIPCHK(ctx, d_pair_group.alloc(NP)); HIPCHK(ctx, d_open.alloc(NP)); HIPCHK(ctx, d_span.alloc(NP * 4)); HIPCHK(ctx, d_blen.alloc(G));
     if (NP) { HIPCHK(ctx, hipMemcpyAsync(d_pair_read.p, pair_read.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d_pair_group.p, pair_group.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream));
@@ -355,14 +355,26 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     std::vector<uint64_t> used(G, 0);
     ht.mark("orient + pairs");
 
+    std::vector<uint8_t> stable(G, 0);              // stop_when_stable: groups whose last iteration returned the backbone unchanged
     for (int it = 0; it < prm->iters; ++it) {
+        if (prm->stop_when_stable && it > 0) {
+            bool any_active = false; for (uint32_t g = 0; g < G; ++g) any_active = any_active || !stable[g];
+            if (!any_active) break;
+            // drop the pairs of the stable groups (their reads would be aligned and stacked into exactly the same windows again)
+            size_t keep = 0;
+            for (size_t p = 0; p < pair_read.size(); ++p) if (!stable[pair_group[p]]) { pair_read[keep] = pair_read[p]; pair_group[keep] = pair_group[p]; ++keep; }
+            if (keep != pair_read.size()) {
+                pair_read.resize(keep); pair_group.resize(keep); NP = keep;
+                if (NP) { HIPCHK(ctx, hipMemcpyAsync(d_pair_read.p, pair_read.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d_pair_group.p, pair_group.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
+            }
+        }
         // upload the current backbones
         std::vector<uint64_t> boff(G + 1, 0); std::string cat; std::vector<int32_t> blen(G); int nwinmax = 1; uint32_t maxb = 0;
         for (uint32_t g = 0; g < G; ++g) { cat += B[g]; boff[g + 1] = cat.size(); blen[g] = (int32_t)B[g].size(); nwinmax = std::max(nwinmax, (int)((B[g].size() + W - 1) / W)); maxb = std::max<uint32_t>(maxb, (uint32_t)B[g].size()); }
         ngsid_reads_t br{(const uint8_t*)cat.data(), nullptr, boff.data(), G, NGSID_MEM_HOST, 0};
         DevReads BB; rc = ngsid_upload_reads(ctx, &br, &BB, false); if (rc) return rc;
         HIPCHK(ctx, hipMemcpyAsync(d_blen.p, blen.data(), 4 * G, hipMemcpyHostToDevice, ctx->stream));
-        std::fill(used.begin(), used.end(), 0);
+        for (uint32_t g = 0; g < G; ++g) if (!stable[g]) used[g] = 0;
         std::vector<Unit> units; std::vector<PSeq> bbs; std::vector<int> bb_len; std::vector<std::pair<uint32_t, int>> unit_gw;
         static thread_local PinVec<uint8_t> h_valid; int max_layer = 1;
         HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
@@ -388,7 +400,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         ht.mark("align + layers + valid copy");
         // ---- units = (group, window) with their layers in read order
         std::vector<std::vector<int>> unit_of(G);
-        for (uint32_t g = 0; g < G; ++g) { const int nw = (int)((B[g].size() + W - 1) / W); unit_of[g].assign(nw, -1);
+        for (uint32_t g = 0; g < G; ++g) { if (stable[g]) continue; const int nw = (int)((B[g].size() + W - 1) / W); unit_of[g].assign(nw, -1);
             for (int wdx = 0; wdx < nw; ++wdx) { unit_of[g][wdx] = (int)units.size(); units.emplace_back(); unit_gw.push_back({g, wdx}); } }
         {   // layers of every window in pair (= read) order; the units of a group are consecutive, a window holds at most one layer per pair of its group
             std::vector<uint32_t> ubase(G), unw(G), npg(G, 0);
@@ -430,6 +442,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             if (c.empty()) c = B[g].substr(ws, wlen);
             NB[g] += c;
         }
+        for (uint32_t g = 0; g < G; ++g) { if (stable[g]) NB[g] = B[g]; else if (prm->stop_when_stable && NB[g] == B[g]) stable[g] = 1; }
         B.swap(NB);
     }
     uint64_t total = 0; bool ovf = false; out_off[0] = 0;

@@ -108,7 +108,7 @@ def merge_representatives(api, gathered, prm, world):
 
 
 def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k=13, w=20, abundance_ratio=0.1, rc_identity_threshold=0.9,
-                     racon_iter=3, tile_depth=8, band=128, p_shared=None, cluster_kwargs=None, do_consensus=True, polish_trim=2, device=None, timings=None):
+                     racon_iter=3, tile_depth=8, band=128, p_shared=None, cluster_kwargs=None, do_consensus=True, polish_trim=2, device=None, timings=None, polish_stop_when_stable=True):
     """Runs on every rank; returns dict(final_rep=(rank, local idx) per local read as two arrays, centers=[(n, key, draft, polished)])."""
     import time
     T = timings if timings is not None else {}
@@ -167,7 +167,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
             p_off.append(sum(len(x) for x in p_order))
         p_order = np.concatenate(p_order) if p_order else np.zeros(0, np.uint32)
         bb = ReadSet.from_strings(polished)
-        loc, used = api.polish(bb, rs_local, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, trim=polish_trim), read_order=p_order)
+        loc, used = api.polish(bb, rs_local, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, trim=polish_trim, stop_when_stable=polish_stop_when_stable), read_order=p_order)
         allq = all_gather_obj(dict(cons=loc, cnt=[int(u) for u in used]), device)
         mg = _weighted_merge_all(api, [[q["cons"][c] for q in allq] for c in range(len(merged))], [[q["cnt"][c] for q in allq] for c in range(len(merged))], band)
         polished = [mg[c] or polished[c] for c in range(len(merged))]

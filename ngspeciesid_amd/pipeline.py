@@ -77,7 +77,7 @@ def detect_reverse_complements(api: Api, centers, rc_identity_threshold):
 
 def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, w=20, abundance_ratio=0.1,
                  rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=8, band=128, node_cap=0,
-                 p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2, polish_aln_mode=2):
+                 p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2, polish_aln_mode=2, polish_stop_when_stable=True):
     """Returns dict(rep_of, status, counters, hpc_err, centers=[(n_reads, c_id, draft, polished, groups)])."""
     T = timings if timings is not None else {}
     t0 = time.perf_counter()
@@ -123,7 +123,7 @@ def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, 
             p_off.append(sum(len(x) for x in p_order))
         p_order = np.concatenate(p_order)
         bb = ReadSet.from_strings([m[2] for m in merged])
-        polished, used = api.polish(bb, rs, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=polish_trim, aln_mode=polish_aln_mode), read_order=p_order)
+        polished, used = api.polish(bb, rs, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=polish_trim, aln_mode=polish_aln_mode, stop_when_stable=polish_stop_when_stable), read_order=p_order)
         T["polish"] = T.get("polish", 0.0) + time.perf_counter() - t0
     res["centers"] = [(m[0], m[1], m[2], polished[i], [int(reps[ci]) for ci in m[3]]) for i, m in enumerate(merged)]
     return res

@@ -73,3 +73,24 @@ def test_polish_two_groups(gpu_api, oracle):
     got, gused = gpu_api.polish(bb, rs2, goff, prm)
     exp, eused = oracle.polish(bb, rs2, goff, prm)
     assert got == exp and np.array_equal(gused, eused)
+
+
+def test_polish_stop_when_stable_is_exact(gpu_api, oracle):
+    """stop_when_stable (library default) skips the iterations of a group whose backbone came back unchanged; the polisher is a
+    deterministic function of (backbone, reads), so the result - sequences and n_used - must equal the run with all iterations, and
+    the oracle (which always runs them all).  Three groups: one starts from the exact amplicon (stable at once), one from a noisy
+    read (needs several iterations), one from a truncated amplicon."""
+    sp, rd, rs = make_set(240, L=600, nsp=3, seed=17, rc_fraction=0.3)
+    spc = rd["species"].numpy()
+    order = np.argsort(spc, kind="stable")
+    rs2 = ReadSet.from_strings([rs.get(i)[0] for i in order], [rs.get(i)[1] for i in order])
+    cnt = np.bincount(spc, minlength=3); goff = np.concatenate(([0], np.cumsum(cnt))).tolist()
+    noisy = rs.get(int(np.nonzero((spc == 1) & (rd["strand"].numpy() == 0))[0][0]))[0]
+    bb = ReadSet.from_strings([sp[0].tobytes().decode(), noisy, sp[2].tobytes().decode()[9:-11]])
+    res = {}
+    for stop in (0, 1):
+        prm = polish_params(iters=4, tile_depth=8, band=128, trim=2, stop_when_stable=stop)
+        res[stop] = gpu_api.polish(bb, rs2, goff, prm)
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    exp, eused = oracle.polish(bb, rs2, goff, polish_params(iters=4, tile_depth=8, band=128, trim=2, stop_when_stable=1))
+    assert res[1][0] == exp and np.array_equal(res[1][1], eused)
