@@ -17,7 +17,7 @@
 typedef unsigned long long u64;
 #define LDSP __attribute__((address_space(3)))
 
-template <int BMAX>
+template <int BMAX, bool WIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
 void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-byte units */, uint32_t mstride, uint32_t* __restrict__ work_ctr, int32_t* __restrict__ dist_out,
                 int8_t* __restrict__ hcar /* per wave mstride x 64: horizontal delta below the last block of a block group */,
@@ -50,7 +50,11 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
         // with at most K edits has i - c <= K (its prefix costs at least i - c) and (n - i) - (m - c) <= K (the rest of the query still needs
         // that many columns), so column c only needs the rows c + min(n - m) - K ... c + K.  Blocks below the band keep their initial state
         // (vertical deltas +1, an upper bound, as in edlib); the row above the first block of the band is taken as +1 per column.
-        const bool band = bandK > 0 && B <= BMAX;
+        // WIN instances (queries of any length): the register-resident blocks are a WINDOW of BMAX blocks that slides down with the band, the
+        // query bit planes of a block are built when it enters the window (LDS ring), and the traceback vectors are stored band-relative
+        // ([block - first block of the band in that column][column]).  A wave whose band needs more than BMAX blocks hands its pairs to the
+        // unbanded launch.
+        const bool band = bandK > 0 && (WIN || B <= BMAX);
         int dmin = 0, lbprev = -1, sb = 0;                  // sb: value at the bottom row of the last block of the band (per lane)
         if (band) {
             dmin = have ? n - m : 0x3fffffff;
@@ -58,23 +62,32 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
             for (int d = 32; d >= 1; d >>= 1) dmin = min(dmin, __shfl_xor(dmin, d));
             dmin = __builtin_amdgcn_readfirstlane(dmin);
         }
-        for (int g0 = 0; g0 < B; g0 += BMAX) {
+        if (WIN) {
+            const int span = ((2 * bandK + 2 - (dmin < 0 ? dmin : 0)) >> 6) + 2;       // blocks a column's band can touch
+            if (span > BMAX) {                                                             // (wave-uniform)
+                if (have) fail_list[atomicAdd(fail_count, 1u)] = (uint32_t)p;
+                continue;
+            }
+        }
+        int fbw = 0;                                        // WIN: block held by register slot 0
+        for (int g0 = 0; g0 < B; g0 += (WIN ? B : BMAX)) {
             const int Bg = min(BMAX, B - g0);
-            // ---- query bit planes of the group -> LDS
-            for (int b = 0; b < Bg; ++b) {
+            // ---- query bit planes of the group (WIN: of the first BMAX blocks) -> LDS
+            auto build_planes = [&](int blk, int slot) {
                 u64 lo = 0, hi = 0, ok = 0;
-                const int base = (g0 + b) * 64;
+                const int base = blk * 64;
                 for (int r = 0; r < 64; ++r) {
                     const int i = base + r;
                     const int c = i < n ? ngsid_bcode(q[i]) : 4;
                     lo |= (u64)(c & 1) << r; hi |= (u64)((c >> 1) & 1) << r; ok |= (u64)(c < 4) << r;
                 }
-                planes[(b * 3 + 0) * 64 + lane] = lo; planes[(b * 3 + 1) * 64 + lane] = hi; planes[(b * 3 + 2) * 64 + lane] = ok;
-            }
+                planes[(slot * 3 + 0) * 64 + lane] = lo; planes[(slot * 3 + 1) * 64 + lane] = hi; planes[(slot * 3 + 2) * 64 + lane] = ok;
+            };
+            for (int b = 0; b < Bg; ++b) build_planes(g0 + b, b);
             u64 Pv[BMAX], Mv[BMAX];
 #pragma unroll
             for (int b = 0; b < BMAX; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
-            const bool more = g0 + BMAX < B;                // a further group follows: keep the horizontal deltas of this group's last row
+            const bool more = !WIN && g0 + BMAX < B;        // a further group follows: keep the horizontal deltas of this group's last row
             // ---- forward: column by column, blocks top to bottom
             for (int j = 0; j < mmax; ++j) {
                 const int tc = j < m ? ngsid_bcode(t[j]) : 4;
@@ -88,12 +101,25 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
                         sb += 64 * (lb - lbprev);
                     }
                 }
+                if (WIN) {
+                    while (fb > fbw) {          // the band has left block fbw: slide the register window, build the planes of the block that enters
+#pragma unroll
+                        for (int b = 0; b + 1 < BMAX; ++b) { Pv[b] = Pv[b + 1]; Mv[b] = Mv[b + 1]; }
+                        Pv[BMAX - 1] = ~0ull; Mv[BMAX - 1] = 0ull;
+                        ++fbw;
+                        const int nb = fbw + BMAX - 1;
+                        if (nb < B) build_planes(nb, nb % BMAX);
+                    }
+                }
                 int hin = g0 ? (int)myh[(u64)j * 64 + lane] : (fb > 0 ? 1 : 0);      // top row of the matrix is all zeros (target prefix free)
                 ngsid_v4u* col = mytb + ((u64)j * 64 + lane);
+                const int slot0 = WIN ? fbw % BMAX : 0;
 #pragma unroll
                 for (int b = 0; b < BMAX; ++b) {
-                    if (b >= fb && b <= lb) {
-                        const u64 lo = planes[(b * 3 + 0) * 64 + lane], hi = planes[(b * 3 + 1) * 64 + lane], ok = planes[(b * 3 + 2) * 64 + lane];
+                    const int blk = WIN ? fbw + b : g0 + b;                          // block held by register slot b
+                    if ((WIN ? blk : b) >= fb && (WIN ? blk : b) <= lb) {
+                        const int ps = WIN ? (slot0 + b >= BMAX ? slot0 + b - BMAX : slot0 + b) : b;
+                        const u64 lo = planes[(ps * 3 + 0) * 64 + lane], hi = planes[(ps * 3 + 1) * 64 + lane], ok = planes[(ps * 3 + 2) * 64 + lane];
                         const u64 Eq = ~(lo ^ Tlo) & ~(hi ^ Thi) & ok & Tok;
                         const u64 pv = Pv[b], mv = Mv[b];
                         const u64 Xv = Eq | mv;
@@ -104,7 +130,7 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
                         // h(i,j) + v(i,j-1) is +1, i.e. (h,v) = (+1,0) or (0,+1)
                         const u64 diag = Eq | (Ph & ~(pv | mv)) | (~(Ph | Mh) & pv);
                         const int hout63 = (int)((Ph >> 63) & 1) - (int)((Mh >> 63) & 1);
-                        if (g0 + b == bl && j < m) {
+                        if (blk == bl && j < m) {
                             score += (int)((Ph >> lastbit) & 1) - (int)((Mh >> lastbit) & 1);
                             if (score < best) { best = score; bestj = j + 1; }
                         }
@@ -113,7 +139,7 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
                         const u64 npv = Mh | ~(Xv | Ph);
                         Pv[b] = npv; Mv[b] = Ph & Xv;
                         ngsid_v4u w; w.x = (unsigned)diag; w.y = (unsigned)(diag >> 32); w.z = (unsigned)npv; w.w = (unsigned)(npv >> 32);
-                        col[(u64)(g0 + b) * mstride * 64] = w;
+                        col[(u64)(WIN ? blk - fb : blk) * mstride * 64] = w;
                         hin = hout63;
                     }
                 }
@@ -137,7 +163,9 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
         while (i > 0) {
             bool diag = false, up = true;
             if (j > 0) {
-                const ngsid_v4u w = __builtin_nontemporal_load(mytb + (((u64)((i - 1) >> 6) * mstride + (u64)(j - 1)) * 64 + lane));
+                int tblk = (i - 1) >> 6;
+                if (WIN) { const int lo_row = (j - 1) + dmin - bandK - 1; tblk -= lo_row > 0 ? (lo_row >> 6) : 0; }      // band-relative storage
+                const ngsid_v4u w = __builtin_nontemporal_load(mytb + (((u64)tblk * mstride + (u64)(j - 1)) * 64 + lane));
                 const int bit = (i - 1) & 63;
                 const u64 dv = ((u64)w.y << 32) | w.x, uv = ((u64)w.w << 32) | w.z;
                 diag = (dv >> bit) & 1; up = (uv >> bit) & 1;
@@ -165,16 +193,16 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
     }
 }
 
-template <int BMAX>
+template <int BMAX, bool WIN = false>
 static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out, uint32_t ctr_slot = 14, int bandK = 0)
 {
     const u64 nbundles = (job.npairs + 63) / 64;
     const uint32_t mstride = (max_tlen + 63u) & ~63u;                     // rounded so that backbones growing by a few bases between iterations reuse the scratch
-    const u64 nblocks = std::max<u64>(1, ((u64)max_qlen + 63) / 64);
+    const u64 nblocks = WIN ? (u64)BMAX : std::max<u64>(1, ((u64)max_qlen + 63) / 64);     // WIN: band-relative storage, BMAX blocks per column
     const u64 per_wave = nblocks * mstride * 64;                           // 16-byte units
     const size_t lds = (size_t)BMAX * 3 * 64 * 8;
     int occ = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ed_align<BMAX>, 64, lds));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ed_align<BMAX, WIN>, 64, lds));
     if (occ < 1) occ = 1;
     u64 want = std::min<u64>(nbundles, (u64)occ * ctx->n_cu);
     const u64 by_mem = std::max<u64>(1, ((size_t)24 << 30) / (per_wave * 16));
@@ -183,7 +211,7 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen,
     if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
     HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), ctx->stream));
-    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + ctr_slot, dist_out, ctx->ed_h.p,
+    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX, WIN>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + ctr_slot, dist_out, ctx->ed_h.p,
                                                             bandK, ctx->ed_fail.p, ctx->aln_ctr.p + 15); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
@@ -203,7 +231,8 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
     // band: wide enough for the usual read-to-draft distance, pairs beyond it take the unbanded launch (the result does not depend on it)
     int bandK = 64 + (int)(max_qlen / 32);
     if (const char* e = getenv("NGSID_ED_BAND")) bandK = atoi(e);
-    if (max_qlen > 1024) bandK = 0;                 // several block groups: unbanded
+    const bool win = max_qlen > 1024 && bandK > 0;  // long queries: sliding window of 8 register-resident blocks (band of at most ~380 rows)
+    if (win) bandK = std::min(bandK, 150);
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
     if (bandK > 0) HIPCHK(ctx, ctx->ed_fail.reserve(job.npairs));
     if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !getenv("NGSID_ALIGN_NOCLASS")) {
@@ -222,7 +251,7 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
         if (max_qlen > 256 && (rc = launch_ed<8>(ctx, cls(1, 512), std::min<uint32_t>(max_qlen, 512), max_tlen, dist_out, 2, bandK))) return rc;
         if (max_qlen > 512 && (rc = launch_ed<12>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK))) return rc;
         if (max_qlen > 768 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4, bandK))) return rc;
-        if (max_qlen > 896 && (rc = launch_ed<16>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK))) return rc;
+        if (max_qlen > 896 && (rc = win ? launch_ed<8, true>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK) : launch_ed<16>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK))) return rc;
         return bandK > 0 ? launch_ed_fallback(ctx, job, max_qlen, max_tlen, dist_out) : NGSID_OK;
     }
     if (bandK > 0) HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + 15, 0, sizeof(uint32_t), ctx->stream));
@@ -230,6 +259,7 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
     if (max_qlen <= 256) rc = launch_ed<4>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
     else if (max_qlen <= 512) rc = launch_ed<8>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
     else if (max_qlen <= 768) rc = launch_ed<12>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
+    else if (win) rc = launch_ed<8, true>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
     else rc = launch_ed<16>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);          // longer queries: groups of 16 blocks, horizontal deltas carried through HBM
     if (rc || bandK <= 0) return rc;
     return launch_ed_fallback(ctx, job, max_qlen, max_tlen, dist_out);

@@ -35,6 +35,9 @@ hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got)
 void ngsid_pool_free(void* p, size_t bytes)
 {
     if (!p) return;
+    // like hipFree, giving a block back waits for the device: a buffer may be replaced (alloc / reserve / grow, error paths) while kernels that
+    // use the old block are still in flight, and the block can be handed out again at once.  On an idle device this costs microseconds.
+    (void)hipDeviceSynchronize();
     int dev = 0; (void)hipGetDevice(&dev);
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);

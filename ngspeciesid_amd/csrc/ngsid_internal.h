@@ -16,7 +16,7 @@
 // Device memory goes through a small per-process cache of freed blocks (size classes with 4 significant bits): the drivers allocate
 // some forty temporaries per call, and hipFree synchronises the device and costs up to a millisecond each (a 35 ms idle gap per
 // clustering call in the rocprofv3 trace).  Blocks are only handed out again after the call that freed them has synchronised its
-// streams (every entry point does before it returns), so reuse is stream-safe.  The cache is released with the last context.
+// streams, and returning a block waits for the device like hipFree does, so reuse is safe.  The cache is released with the last context.
 hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got);
 void ngsid_pool_free(void* p, size_t bytes);
 void ngsid_pool_release_all();

@@ -84,6 +84,22 @@ def test_edit_distance_aligner_matches_oracle(pairs, maxq, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pairs,maxq,seed,escale", [(3000, 2600, 9, 0.1), (1200, 5000, 10, 0.05), (3000, 1300, 12, 0.3), (4000, 760, 14, 0.4)])
+def test_edit_distance_full_length_reads_match_oracle(pairs, maxq, seed, escale):
+    """the polisher's situation: full-length queries against targets of similar length with a small distance - whole waves stay inside the
+    band; queries over 1 024 bases run in the sliding-window instance (register window of 8 blocks, band-relative traceback storage)"""
+    _run(pairs, maxq, seed, escale, "full", tool=TOOL_ED)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pairs,length,err", [(20000, 2000, 0.02), (6000, 5000, 0.05)])
+def test_edit_distance_banded_equals_unbanded_at_scale(pairs, length, err):
+    """batches large enough for the length-class launches, at sizes the oracle cannot do: the banded / windowed launches (+ the unbanded
+    second launch for pairs beyond the band) must return exactly what the unbanded kernel returns"""
+    _run(pairs, length, err, tool=os.path.join(ROOT, "tools", "micro", "check_ed_band.py"))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("band", ["12", "40", "300", "0"])
 def test_edit_distance_band_does_not_change_results(band):
     """the Ukkonen band of the first launch is exact: with a narrow band most pairs take the unbanded second launch, with a wide one none,

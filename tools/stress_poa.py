@@ -22,7 +22,7 @@ what = sys.argv[3] if len(sys.argv) > 3 else "spoa"
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 11
 band = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 api = runtime.get_api(0); orc = load_oracle()
-L = 750
+L = int(os.environ.get("STRESS_L", 750))          # amplicon length
 sp = synth.make_species(4, L, 0.15, seed=seed)
 rd = synth.make_reads(sp, ng * depth, mu=17.0, seed=seed + 1, rc_fraction=0.3 if what == "polish" else 0.0)      # the polisher orients reads itself
 spc = rd["species"].numpy()
