@@ -84,7 +84,7 @@ def test_edit_distance_aligner_matches_oracle(pairs, maxq, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pairs,maxq,seed,escale", [(3000, 2600, 9, 0.1), (1200, 5000, 10, 0.05), (3000, 1300, 12, 0.3), (4000, 760, 14, 0.4)])
+@pytest.mark.parametrize("pairs,maxq,seed,escale", [(3000, 2600, 9, 0.1), (400, 5000, 10, 0.05), (3000, 1300, 12, 0.3), (4000, 760, 14, 0.4)])
 def test_edit_distance_full_length_reads_match_oracle(pairs, maxq, seed, escale):
     """the polisher's situation: full-length queries against targets of similar length with a small distance - whole waves stay inside the
     band; queries over 1 024 bases run in the sliding-window instance (register window of 8 blocks, band-relative traceback storage)"""
