@@ -231,8 +231,12 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
     // band: wide enough for the usual read-to-draft distance, pairs beyond it take the unbanded launch (the result does not depend on it)
     int bandK = 64 + (int)(max_qlen / 32);
     if (const char* e = getenv("NGSID_ED_BAND")) bandK = atoi(e);
-    const bool win = max_qlen > 1024 && bandK > 0;  // long queries: sliding window of 8 register-resident blocks (band of at most ~380 rows)
-    if (win) bandK = std::min(bandK, 150);
+    const bool win = max_qlen > 1024 && bandK > 0;  // long queries: sliding window of 8 register-resident blocks (band of at most ~380 rows) ...
+    bool win16 = false;                             // ... or of 16 (~900 rows) when the reads are so long that a 5 % error rate needs it
+    if (win) {
+        if (bandK > 150 && !getenv("NGSID_ED_BAND")) { win16 = true; bandK = std::min(64 + (int)(max_qlen / 16), 400); }
+        else if (bandK > 150) { win16 = true; bandK = std::min(bandK, 400); }
+    }
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
     if (bandK > 0) HIPCHK(ctx, ctx->ed_fail.reserve(job.npairs));
     if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !getenv("NGSID_ALIGN_NOCLASS")) {
@@ -251,7 +255,7 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
         if (max_qlen > 256 && (rc = launch_ed<8>(ctx, cls(1, 512), std::min<uint32_t>(max_qlen, 512), max_tlen, dist_out, 2, bandK))) return rc;
         if (max_qlen > 512 && (rc = launch_ed<12>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK))) return rc;
         if (max_qlen > 768 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4, bandK))) return rc;
-        if (max_qlen > 896 && (rc = win ? launch_ed<8, true>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK) : launch_ed<16>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK))) return rc;
+        if (max_qlen > 896 && (rc = win16 ? launch_ed<16, true>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK) : win ? launch_ed<8, true>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK) : launch_ed<16>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK))) return rc;
         return bandK > 0 ? launch_ed_fallback(ctx, job, max_qlen, max_tlen, dist_out) : NGSID_OK;
     }
     if (bandK > 0) HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + 15, 0, sizeof(uint32_t), ctx->stream));
@@ -259,6 +263,7 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
     if (max_qlen <= 256) rc = launch_ed<4>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
     else if (max_qlen <= 512) rc = launch_ed<8>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
     else if (max_qlen <= 768) rc = launch_ed<12>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
+    else if (win16) rc = launch_ed<16, true>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
     else if (win) rc = launch_ed<8, true>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);
     else rc = launch_ed<16>(ctx, job, max_qlen, max_tlen, dist_out, 14, bandK);          // longer queries: groups of 16 blocks, horizontal deltas carried through HBM
     if (rc || bandK <= 0) return rc;
