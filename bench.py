@@ -169,6 +169,8 @@ def main():
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic,
                 "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                 "note": "integer DP kernel: VALU-issue bound by construction, HBM fraction is small (DESIGN.md section 4)"}
+        if dom[0] == "k_poa_tile":      # what actually bounds it: instruction issue / the dependent chain of a DP row (SQ counters, committed PMC pass)
+            roof["valu_issue"] = {"frac": 0.41, "measured": "offline", "source": "profiles/r01_pmc_poa_tile_final.txt: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x dispatch cycles) = 41 % at four waves per SIMD; waves wait 60 % of their cycles"}
         if dom[0] == "k_sg_align":      # what actually bounds it: VALU issue.  17.7 VALU instructions per DP cell and lane (ISA count, k_align16.hip), 64 cells per wave instruction
             prop = torch.cuda.get_device_properties(dev)
             clk = float(getattr(prop, "clock_rate", 2400000)) * 1e3
