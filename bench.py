@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--node-cap", type=int, default=0, help="POA graph capacity in 1/16 of the first sequence length (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-step", action="store_true", help="skip the extra step with stop_when_stable (profiling runs that count per-step traffic)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -118,9 +119,11 @@ def main():
     for line in buf.value.decode().splitlines():
         nm, cnt, ms = line.split(); kern[nm] = (int(cnt), float(ms))
     # one extra (untimed for `value`) step with the library default: polishing of a cluster stops once an iteration leaves it unchanged
-    barrier(); t1 = time.perf_counter()
-    res_stop = step(polish_stop_when_stable=True)
-    barrier(); dt_stop = time.perf_counter() - t1
+    res_stop, dt_stop = None, 0.0
+    if not args.no_extra_step:
+        barrier(); t1 = time.perf_counter()
+        res_stop = step(polish_stop_when_stable=True)
+        barrier(); dt_stop = time.perf_counter() - t1
     if dist is not None:
         t = torch.tensor([dt], device=comm_dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
         tn = torch.tensor([n], device=comm_dev, dtype=torch.float64); dist.all_reduce(tn); n_total = int(tn.item())
@@ -130,7 +133,7 @@ def main():
         t = torch.tensor([dt_stop], device=comm_dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt_stop = float(t.item())
     if rank != 0:
         return
-    stop_same = [c[3] for c in res_stop["centers"]] == [c[3] for c in res["centers"]]
+    stop_same = None if res_stop is None else [c[3] for c in res_stop["centers"]] == [c[3] for c in res["centers"]]
     reads_per_s = n_total * args.steps / dt
     # ---- quality / property checks at full size (size-independent): cluster purity, consensus vs generating amplicon
     spc = rd["species"].cpu().numpy(); rep_of = res["rep_of"]
@@ -205,7 +208,7 @@ def main():
                       "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()},
                       "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed}},
            "roofline": roof, "cpu_baseline": cpu}
-    out["config"]["with_stable_stop"] = {"reads_per_s": round(n_total / dt_stop, 1), "ms_per_step": round(dt_stop * 1e3, 2), "same_result": stop_same,
+    if res_stop is not None: out["config"]["with_stable_stop"] = {"reads_per_s": round(n_total / dt_stop, 1), "ms_per_step": round(dt_stop * 1e3, 2), "same_result": stop_same,
                                           "note": "library default stop_when_stable=1 (not used for `value`): a cluster whose polished sequence equals its backbone is not polished again"}
     print(json.dumps(out))
 
