@@ -280,36 +280,74 @@ extern "C" int32_t ngsid_hpc_minimizers(ngsid_ctx* ctx, const ngsid_reads_t* rea
 }
 
 // ---------------------------------------------------------------------------------------------- (f1)
-// get_sorted_fastq_for_cluster.py:23-33,124-155.  One thread per read: the sliding product
-// cur *= (1-p_new)/(1-p_old) is a sequential recurrence that must be replayed op for op to give the
-// reference's exact double; reads are independent, so the batch is the parallel axis.
+// get_sorted_fastq_for_cluster.py:23-33,124-155.  One LANE per read (64 reads per wave): the sliding product
+// cur *= (1-p_new)/(1-p_old) is a sequential recurrence that must be replayed op for op to give the reference's exact double; reads are
+// independent, so the batch is the parallel axis.  The bases and qualities of the 64 reads pass through LDS in 64-byte slices (dword loads,
+// 16 lanes per read and instruction, instead of 64 scattered byte loads), the per-read quality histogram lives in LDS ([bin][lane]) and the
+// two probability tables are read from LDS as well.
 __constant__ double c_p_clamped[128];
 __constant__ double c_p_nomin[128];
 static bool g_score_tables[16] = {false};
 
-__global__ void k_score_reads(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t n,
-                              int k, double qthr, double* __restrict__ score, double* __restrict__ err, uint8_t* __restrict__ keep)
+#define SC_QS 132      /* quality ring row: two 64-byte slices + pad (33 dwords: lanes hit different banks) */
+#define SC_SS 68       /* sequence slice row */
+__global__ __launch_bounds__(64)
+void k_score_reads(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t n,
+                   int k, double qthr, double* __restrict__ score, double* __restrict__ err, uint8_t* __restrict__ keep)
 {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const uint64_t b = off[r]; const int len = (int)(off[r + 1] - b);
-    const uint8_t* s = seq + b; const uint8_t* q = qual + b;
+    __shared__ __attribute__((aligned(16))) uint8_t qt[64 * SC_QS];
+    __shared__ __attribute__((aligned(16))) uint8_t st[64 * SC_SS];
+    __shared__ unsigned short hist[128 * 64];
+    __shared__ double tp[128], tn[128];
+    const int lane = threadIdx.x;
+    const uint64_t r = (uint64_t)blockIdx.x * 64 + lane;
+    const bool have = r < n;
+    const uint64_t b = have ? off[r] : 0; const int len = have ? (int)(off[r + 1] - b) : 0;
+    tp[lane] = c_p_clamped[lane]; tp[lane + 64] = c_p_clamped[lane + 64]; tn[lane] = c_p_nomin[lane]; tn[lane + 64] = c_p_nomin[lane + 64];
+    for (int c = 0; c < 128; ++c) hist[c * 64 + lane] = 0;
+    int maxlen = len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, d));
+    maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+    const bool active = have && len >= 2 * k;               // :142 (reads shorter than 2k are dropped before anything is computed)
+    int hl = 0; uint8_t prevc = 0;
+    double cur = 1.0, sum = 0.0;
+    const int sub = lane >> 4, dj = lane & 15;               // slice loads: 4 reads per instruction, 16 dwords each
+    for (int c0 = 0; c0 < maxlen; c0 += 64) {
+        const int half = c0 & 64;
+        for (int it = 0; it < 16; ++it) {
+            const int rr = it * 4 + sub;
+            const uint64_t rb = __shfl((unsigned long long)b, rr); const int rl = __shfl(len, rr);
+            const int x = c0 + dj * 4;
+            unsigned qw = 0, sw = 0;
+            if (x + 3 < rl) { qw = *(const unsigned*)(qual + rb + x); sw = *(const unsigned*)(seq + rb + x); }
+            else for (int y = 0; y < 4; ++y) if (x + y < rl) { qw |= (unsigned)qual[rb + x + y] << (8 * y); sw |= (unsigned)seq[rb + x + y] << (8 * y); }
+            *(unsigned*)(qt + rr * SC_QS + half + dj * 4) = qw;
+            *(unsigned*)(st + rr * SC_SS + dj * 4) = sw;
+        }
+        __syncthreads();
+        if (active) {
+            const int e = min(64, len - c0);
+            for (int i = 0; i < e; ++i) {
+                const int gi = c0 + i;
+                const uint8_t sc = st[lane * SC_SS + i], qc = qt[lane * SC_QS + half + i] & 127;
+                hl += (gi == 0 || sc != prevc); prevc = sc;
+                hist[qc * 64 + lane] += 1;
+                const double pn = 1.0 - tp[qc];
+                if (gi < k) { cur = cur * pn; if (gi == k - 1) sum = cur; }
+                else { const double leave = 1.0 - tp[qt[lane * SC_QS + ((gi - k) & 127)] & 127]; cur *= (pn / leave); sum += cur; }
+            }
+        }
+        __syncthreads();
+    }
+    if (!have) return;
     score[r] = 0.0; err[r] = 0.0; keep[r] = 0;
-    if (len < 2 * k) return;
-    int hl = 0; for (int i = 0; i < len; ++i) hl += (i == 0 || s[i] != s[i - 1]);
-    if (hl < k) return;
-    double cur = 1.0;
-    for (int i = 0; i < k; ++i) cur = cur * (1.0 - c_p_clamped[q[i] & 127]);
-    double sum = cur;
-    for (int i = k; i < len; ++i) { const double leave = 1.0 - c_p_clamped[q[i - k] & 127]; cur *= ((1.0 - c_p_clamped[q[i] & 127]) / leave); sum += cur; }
+    if (!active || hl < k) return;
     const double ee = (double)(len - k + 1) - sum;
     const double pno = 1.0 - ee / (double)(len - k + 1);
     score[r] = pno * (double)(len - k + 1);
-    int hist[128];
-    for (int c = 0; c < 128; ++c) hist[c] = 0;
-    for (int i = 0; i < len; ++i) hist[q[i] & 127]++;
     double se = 0.0;
-    for (int c = 0; c < 128; ++c) if (hist[c]) se = se + (double)hist[c] * c_p_nomin[c];
+    for (int c = 0; c < 128; ++c) { const int h = hist[c * 64 + lane]; if (h) se = se + (double)h * tn[c]; }
     const double er = se / (double)len;
     err[r] = er;
     if (10.0 * -(log(er) / log(10.0)) <= qthr) return;      // device log(): last-ulp differences only matter exactly on the threshold
@@ -330,7 +368,7 @@ extern "C" int32_t ngsid_score_reads(ngsid_ctx* ctx, const ngsid_reads_t* reads,
     const uint64_t n = R.n; if (!n) return NGSID_OK;
     DevBuf<double> ds, de; DevBuf<uint8_t> dk;
     HIPCHK(ctx, ds.alloc(n)); HIPCHK(ctx, de.alloc(n)); HIPCHK(ctx, dk.alloc(n));
-    hipLaunchKernelGGL(k_score_reads, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, R.seq, R.qual, R.off, n, k, q_threshold, ds.p, de.p, dk.p);
+    { ProfScope ps_(ctx, "k_score_reads"); hipLaunchKernelGGL(k_score_reads, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, R.seq, R.qual, R.off, n, k, q_threshold, ds.p, de.p, dk.p); }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(score, ds.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(err_rate, de.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
