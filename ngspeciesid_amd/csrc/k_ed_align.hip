@@ -253,7 +253,9 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
         }
         if ((rc = launch_ed<4>(ctx, cls(0, 256), std::min<uint32_t>(max_qlen, 256), max_tlen, dist_out, 1, bandK))) return rc;
         if (max_qlen > 256 && (rc = launch_ed<8>(ctx, cls(1, 512), std::min<uint32_t>(max_qlen, 512), max_tlen, dist_out, 2, bandK))) return rc;
-        static const bool win_all = getenv("NGSID_ED_WIN_ALL") != nullptr;
+        // 513-768 bases: the 8-block window instance as well (12 KB of LDS per wave instead of 18 KB: three waves per SIMD instead of two, -8 %);
+        // NGSID_ED_WIN_ALL=0 selects the 12-block instance with all blocks resident
+        static const bool win_all = !(getenv("NGSID_ED_WIN_ALL") && atoi(getenv("NGSID_ED_WIN_ALL")) == 0);
         if (max_qlen > 512 && (rc = (win_all && bandK > 0 && bandK <= 150) ? launch_ed<8, true>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK)
                                                           : launch_ed<12>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK))) return rc;
         if (max_qlen > 768 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4, bandK))) return rc;
