@@ -45,3 +45,26 @@ def test_dict_api_matches_reference(oracle, tag, t):
         if len(tup) == 8:
             ref = g["t%d_rep_err" % t][int(kk)]
             assert abs(tup[6] - ref) <= 16 * np.spacing(ref)
+
+
+def test_clusters_from_rep_matches_the_plain_definition():
+    """pipeline.clusters_from_rep (radix-friendly grouping) == stable argsort + np.unique on the representative map, incl. > 65 535 clusters"""
+    import numpy as np
+    from ngspeciesid_amd.pipeline import clusters_from_rep, select_centers
+    rng = np.random.default_rng(5)
+    for n, nrep in ((1, 1), (50, 7), (20000, 300), (150000, 70000)):
+        reps = np.sort(rng.choice(n, nrep, replace=False)); reps[0] = 0
+        rep_of = reps[rng.integers(0, nrep, n)].astype(np.int32)
+        rep_of = np.minimum(rep_of, np.arange(n, dtype=np.int32))          # a read never joins a later read ...
+        rep_of[reps] = reps                                                # ... and representatives are their own
+        rep_of = rep_of[rep_of]; rep_of = rep_of[rep_of]                   # make the map idempotent
+        keep = rep_of[rep_of] == rep_of
+        assert keep.all()
+        r, order, goff, counts = clusters_from_rep(rep_of)
+        o2 = np.argsort(rep_of, kind="stable").astype(np.uint32)
+        r2, st, c2 = np.unique(rep_of[o2], return_index=True, return_counts=True)
+        assert np.array_equal(order, o2) and np.array_equal(r, r2) and np.array_equal(counts, c2) and np.array_equal(goff[:-1], st) and goff[-1] == n
+        score = rng.random(n)
+        sel = select_centers(r, counts, score, 3)
+        assert all(counts[i] >= 3 for i in sel)
+        assert sel == sorted(sel, key=lambda i: (-counts[i], -score[r[i]]))
