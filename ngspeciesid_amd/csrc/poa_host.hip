@@ -406,12 +406,16 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             std::vector<uint32_t> ubase(G), unw(G), npg(G, 0);
             for (uint32_t g = 0; g < G; ++g) { unw[g] = (uint32_t)unit_of[g].size(); ubase[g] = unw[g] ? (uint32_t)unit_of[g][0] : 0; }
             for (uint64_t p = 0; p < NP; ++p) npg[pair_group[p]]++;
-            for (uint32_t g = 0; g < G; ++g) for (uint32_t wdx = 0; wdx < unw[g]; ++wdx) units[ubase[g] + wdx].seqs.reserve(npg[g]);
+            // lists sized for the worst case, filled through raw cursors (two million appends per iteration), trimmed afterwards
+            std::vector<uint32_t*> cur(units.size(), nullptr);
+            for (uint32_t g = 0; g < G; ++g) for (uint32_t wdx = 0; wdx < unw[g]; ++wdx) { auto& v = units[ubase[g] + wdx].seqs; v.resize(npg[g]); cur[ubase[g] + wdx] = v.data(); }
+            const uint32_t* pg = pair_group.data(); const uint8_t* hv0 = h_valid.data();
             for (uint64_t p = 0; p < NP; ++p) {
-                const uint32_t g = pair_group[p]; const uint8_t* hv = h_valid.data() + p * (uint64_t)nwinmax; bool any = false;
-                for (uint32_t wdx = 0; wdx < unw[g]; ++wdx) if (hv[wdx]) { units[ubase[g] + wdx].seqs.push_back((uint32_t)(p * (uint64_t)nwinmax + wdx)); any = true; }
-                if (any) used[g]++;
+                const uint32_t g = pg[p]; const uint8_t* hv = hv0 + p * (uint64_t)nwinmax; const uint32_t nwg = unw[g], ub = ubase[g]; uint32_t any = 0;
+                for (uint32_t wdx = 0; wdx < nwg; ++wdx) { const uint32_t v = hv[wdx] != 0; *cur[ub + wdx] = (uint32_t)(p * (uint64_t)nwinmax + wdx); cur[ub + wdx] += v; any |= v; }
+                used[g] += any;
             }
+            for (size_t u = 0; u < units.size(); ++u) if (cur[u]) units[u].seqs.resize((size_t)(cur[u] - units[u].seqs.data()));
         }
         std::vector<size_t> nlayers(units.size());
         for (size_t u = 0; u < units.size(); ++u) {
