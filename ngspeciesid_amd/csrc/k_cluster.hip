@@ -649,7 +649,10 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             if (need_full) {
                 // hit matrix for items [lo,b1) against the whole index; stride leaves room for new representatives
                 const uint32_t want = ((S.R + 256 + 63) / 64) * 64;
-                if (want > stride || cnt.n < (uint64_t)BLK * stride) { stride = std::max(stride, want); HIPCHK(ctx, cnt.alloc((uint64_t)BLK * stride)); }
+                // rows = the items of THIS block (blocks shrink when representatives are frequent, so rows x columns stays moderate: a noisy read
+                // set with 50 k representatives would otherwise ask for BLK x 50 k x 8 B = 100 GB)
+                stride = std::max(stride, want);
+                { const uint64_t need = (uint64_t)(b1 - b0) * stride; if (cnt.n < need) HIPCHK(ctx, cnt.alloc(need + need / 4)); }
                 HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, 8ull * (uint64_t)(b1 - b0) * stride, ctx->stream));
                 { ProfScope ps_(ctx, "k_count_hits"); hipLaunchKernelGGL(k_count_hits, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0,
                                    S.dbc[S.cur].p, S.dbs[S.cur].p, 0u, S.n_db, cnt.p, stride); }
