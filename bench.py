@@ -20,6 +20,7 @@ def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device):
     sp = synth.make_species(n_species, L, 0.15, seed=1)
     rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed, device=device)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
+    torch.cuda.synchronize(device)       # the library runs on its own HIP stream: torch's generator kernels must have finished writing the reads
     score, err, keep = api.score_reads(rs, 13, 7.0)
     keep_idx = np.nonzero(keep)[0]
     perm = keep_idx[np.argsort(-score[keep_idx], kind="stable")]
@@ -38,6 +39,7 @@ def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device):
         d0 = int(dst0[0].item())
         nseq[d0:d0 + len(src)] = rd["seq"][src]; nqual[d0:d0 + len(src)] = rd["qual"][src]
     out = dict(seq=nseq, qual=nqual, off=noff, species=rd["species"][perm_t], score=score[perm], orig=perm)
+    torch.cuda.synchronize(device)       # same for the gather into score order
     return sp, out
 
 

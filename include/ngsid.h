@@ -143,7 +143,8 @@ typedef struct {
     int32_t tile_depth;    /* reads per exact-order POA tile; <=0 = one tile per group (exact spoa order) */
     int32_t band;          /* DP band width in columns (64/128/256); <=0 = library default */
     int32_t node_cap;      /* graph node capacity per tile as a multiple of 1/16 of the first read length (<=0 default) */
-    int32_t _pad;
+    int32_t trim;          /* 0 = none (spoa: the heaviest bundle is completed to a sink, so the consensus can carry the unsupported tail of a single
+                              read); 1 = coverage-trim the ends of every tile consensus (bases covered by less than half of the sequences merged) */
 } ngsid_poa_params_t;
 
 /* (a13,a14) replaces form_draft_consensus' per-cluster `spoa reads.fq -l 0 -r 0 -g -2` (consensus.py:83-92,249-278).

@@ -33,7 +33,7 @@ class ClusterParams(C.Structure):
 
 class PoaParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32), ("gap", C.c_int32),
-                ("tile_depth", C.c_int32), ("band", C.c_int32), ("node_cap", C.c_int32), ("_pad", C.c_int32)]
+                ("tile_depth", C.c_int32), ("band", C.c_int32), ("node_cap", C.c_int32), ("trim", C.c_int32)]
 
 
 class PolishParams(C.Structure):
@@ -54,9 +54,9 @@ def cluster_params(k=13, w=20, min_shared=5, min_fraction=0.8, mapped_threshold=
     return p
 
 
-def poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=0, node_cap=0):
+def poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=0, node_cap=0, trim=0):
     """Defaults = `spoa -l 0 -r 0 -g -2` (consensus.py:87; spoa 4.0.x m=5 n=-4, linear because g>=e)."""
-    return PoaParams(int(mode), int(match), int(mismatch), int(gap), int(tile_depth), int(band), int(node_cap), 0)
+    return PoaParams(int(mode), int(match), int(mismatch), int(gap), int(tile_depth), int(band), int(node_cap), int(trim))
 
 
 def polish_params(iters=2, window=500, quality_threshold=10.0, error_threshold=0.3, match=3, mismatch=-5, gap=-4,
@@ -95,7 +95,10 @@ class ReadSet:
 
     @staticmethod
     def from_torch(seq_t, qual_t, off_t):
-        """torch tensors on a cuda/hip device: uint8, uint8, int64 (n+1)."""
+        """torch tensors on a cuda/hip device: uint8, uint8, int64 (n+1).  The library works on its own HIP stream, so torch's stream
+        is drained first: whatever produced the tensors must have finished writing them before the hand-over."""
+        import torch
+        torch.cuda.current_stream(seq_t.device).synchronize()
         keep = dict(seq=seq_t, qual=qual_t, off=off_t, n=off_t.numel() - 1)
         return ReadSet(seq_t.data_ptr(), None if qual_t is None else qual_t.data_ptr(), off_t.data_ptr(), MEM_DEVICE, keep)
 

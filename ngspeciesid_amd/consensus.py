@@ -38,7 +38,7 @@ def run_spoa(reads, spoa_out_file, spoa_path, api=None, tile_depth=DEFAULT_TILE_
     accs, seqs, quals = _read_fastx(reads)
     rs = ReadSet.from_strings(seqs, quals if all(q is not None for q in quals) and quals else None)
     node_cap = 0 if max((len(s) for s in seqs), default=0) <= 1000 else 22
-    consensus = api.poa_consensus(rs, [0, len(seqs)], poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap))[0]
+    consensus = api.poa_consensus(rs, [0, len(seqs)], poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=pipeline.DRAFT_TRIM))[0]
     with open(spoa_out_file, "w") as f:
         f.write(">Consensus LN:i:{0}\n{1}\n".format(len(consensus), consensus))
     return consensus

@@ -354,6 +354,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
         if (dcov) { uint32_t c = g.cov(v); for (int u = g.ring(v); u != v; u = g.ring(u)) c += g.cov(u); dcov[i] = c; }
     }
     mem_sync();
+    int span_b = 0, span_e = n - 1;              // consensus positions whose nodes give the span (a0, a1) of the output in the first sequence's coordinates
     if (J.trim_tiles && dcov && n > 0) {     // oracle EMIT: coverage-trim the tile consensus ends
         const uint32_t thr = (uint32_t)(st.cw_sum / 2);
         int b = 0x7fffffff, e = -1;
@@ -361,6 +362,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { b = min(b, __shfl_xor(b, d)); e = max(e, __shfl_xor(e, d)); }
         if (b < e && b != 0x7fffffff) {
+            span_b = b; span_e = e;
             const int m2 = e - b + 1;
             if (b > 0) for (int c0 = 0; c0 < m2; c0 += 64) {
                 const int x = c0 + lane; uint8_t ch = 0; uint32_t cv = 0;
@@ -372,7 +374,10 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
             n = m2;
         }
     }
-    if (lane == 0) { J.out_len[slot] = n; J.out_cw[slot] = st.cw_sum; }
+    if (lane == 0) {
+        J.out_len[slot] = n; J.out_cw[slot] = st.cw_sum;
+        if (J.out_span) { J.out_span[2 * slot] = n > 0 ? (int32_t)g.anchor(g.order(g.tmpo(poff + span_b))) : 0; J.out_span[2 * slot + 1] = n > 0 ? (int32_t)g.anchor(g.order(g.tmpo(poff + span_e))) : -1; }
+    }
     if (J.phase_cycles && lane == 0) atomicAdd(&J.phase_cycles[12], (unsigned long long)n);
     mem_sync();
     PH(J, 4, tph);

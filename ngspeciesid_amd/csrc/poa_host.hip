@@ -75,15 +75,16 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
         HIPCHK(ctx, hipMemcpyAsync(d_seq_idx.p, seq_idx.data(), 4 * seq_idx.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_job_bb.p, job_bb.data(), 4 * job_bb.size(), hipMemcpyHostToDevice, ctx->stream));
         int slots = slots_cap ? slots_cap : (int)std::min<uint32_t>(maxD, 4);
-        static thread_local PinVec<uint32_t> h_out_n; static thread_local PinVec<int32_t> h_out_len; static thread_local PinVec<uint64_t> h_out_cw;
+        static thread_local PinVec<uint32_t> h_out_n; static thread_local PinVec<int32_t> h_out_len, h_out_span; static thread_local PinVec<uint64_t> h_out_cw;
+        const bool need_cov = hp.want_cov || hp.trim_tiles;
         for (;;) {      // retry with more output slots if a tile had to split more often than `slots`
-            HIPCHK(ctx, Lv->out.reserve((size_t)njobs * slots * capV)); HIPCHK(ctx, Lv->out_len.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_cw.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_n.reserve(njobs));
-            if (hp.want_cov) HIPCHK(ctx, Lv->out_cov.reserve((size_t)njobs * slots * capV));
+            HIPCHK(ctx, Lv->out.reserve((size_t)njobs * slots * capV)); HIPCHK(ctx, Lv->out_len.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_cw.reserve((size_t)njobs * slots)); HIPCHK(ctx, Lv->out_n.reserve(njobs)); HIPCHK(ctx, Lv->out_span.reserve((size_t)njobs * slots * 2));
+            if (need_cov) HIPCHK(ctx, Lv->out_cov.reserve((size_t)njobs * slots * capV));
             HIPCHK(ctx, hipMemsetAsync(d_flags.p, 0, 16, ctx->stream));
             PoaJobSet J{};
             J.seqs = cur; J.bbs = d_bbs; J.seq_idx = d_seq_idx.p; J.job_off = d_job_off.p; J.job_bb = d_job_bb.p; J.njobs = njobs;
             J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles;
-            J.out = Lv->out.p; J.out_len = Lv->out_len.p; J.out_cw = Lv->out_cw.p; J.out_n = Lv->out_n.p; J.out_cov = hp.want_cov ? Lv->out_cov.p : nullptr;
+            J.out = Lv->out.p; J.out_len = Lv->out_len.p; J.out_cw = Lv->out_cw.p; J.out_n = Lv->out_n.p; J.out_cov = need_cov ? Lv->out_cov.p : nullptr; J.out_span = Lv->out_span.p;
             J.dropped = d_flags.p; J.slot_overflow = d_flags.p + 1;
             DevBuf<unsigned long long> d_ph; static const bool want_ph = getenv("NGSID_POA_PHASES") != nullptr;
             if (want_ph) { HIPCHK(ctx, d_ph.alloc(16)); HIPCHK(ctx, hipMemsetAsync(d_ph.p, 0, 128, ctx->stream)); J.phase_cycles = d_ph.p; }
@@ -91,11 +92,12 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
             int32_t rc = poa_run_jobs(ctx, J, hp.band); if (rc) return rc;
             if (level == 0) ht.mark("L0 kernel");
             uint32_t h_flags[4];
-            h_out_n.resize(njobs); h_out_len.resize((size_t)njobs * slots); h_out_cw.resize((size_t)njobs * slots);
+            h_out_n.resize(njobs); h_out_len.resize((size_t)njobs * slots); h_out_cw.resize((size_t)njobs * slots); h_out_span.resize((size_t)njobs * slots * 2);
             HIPCHK(ctx, hipMemcpyAsync(h_flags, d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(h_out_n.data(), Lv->out_n.p, 4ull * njobs, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(h_out_len.data(), Lv->out_len.p, 4ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(h_out_cw.data(), Lv->out_cw.p, 8ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_out_span.data(), Lv->out_span.p, 8ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             if (want_ph) { unsigned long long h[16]; HIPCHK(ctx, hipMemcpy(h, d_ph.p, 128, hipMemcpyDeviceToHost)); fprintf(stderr, "[ngsid poa phases, Mcycles] jobs %u prepass %.1f forward %.1f traceback %.1f update %.1f emit %.1f | rows %llu non-chain %llu | sums: bestv %llu bestpk %llu nnew %llu alnsum %llu outlen %llu | tb iters %llu reloads %llu reload Mcycles %.1f | emit backtrack %.1f\n", njobs, h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[7], h[13], h[14] / 1e6, h[15] / 1e6); }
             if (h_flags[2]) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA tile kernel loop guard tripped (code %u)", h_flags[2]);
@@ -130,6 +132,10 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
                 PSeq S; S.s = Lv->out.p + (size_t)sl * capV; S.q = nullptr; S.len = h_out_len[sl];
                 S.uw = cw > (1u << 20) ? (1 << 20) : (int)cw; if (S.uw < 1) S.uw = 1;
                 S.cw = (uint32_t)(cw > 0xffffffffull ? 0xffffffffull : cw); S.mode = hp.upper_mode; S.a0 = 0; S.a1 = -1;
+                if (U.bb >= 0) {     // a tile consensus is a layer of the window like the reads it stands for (oracle run_hierarchy): global only if it spans the window
+                    const int wlen = bb_len[U.bb], offset = (int)(0.01 * (double)wlen), begin = h_out_span[2 * (size_t)sl], end = h_out_span[2 * (size_t)sl + 1];
+                    if (end >= begin) { S.a0 = begin; S.a1 = end; S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI; }
+                }
                 U.seqs.push_back((uint32_t)next.size()); next.push_back(S); next_maxlen = std::max<uint32_t>(next_maxlen, (uint32_t)S.len);
             }
         }
@@ -163,7 +169,7 @@ extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* read
     HIPCHK(ctx, hipGetLastError());
     std::vector<Unit> units(n_groups);
     for (uint64_t g = 0; g < n_groups; ++g) { units[g].seqs.reserve(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs.push_back(read_order ? read_order[r] : (uint32_t)r); }
-    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, prm->mode, false, 0};
+    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, prm->mode, false, prm->trim > 0 ? 1 : 0};
     std::vector<int> nobb;
     htc.mark("units");
     rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;

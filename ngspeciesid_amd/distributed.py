@@ -148,7 +148,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
     lo = np.searchsorted(sorted_gid, cand, side="left"); hi = np.searchsorted(sorted_gid, cand, side="right")
     sub_order = np.concatenate([order[a:b] for a, b in zip(lo, hi)]) if len(cand) else np.zeros(0, np.uint32)
     sub_off = np.concatenate(([0], np.cumsum(hi - lo))).astype(np.uint64)
-    partial = api.poa_consensus(rs_local, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band), read_order=sub_order) if len(cand) else []
+    partial = api.poa_consensus(rs_local, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, trim=pipeline.DRAFT_TRIM), read_order=sub_order) if len(cand) else []
     allp = all_gather_obj(dict(cons=partial, cnt=(hi - lo).tolist()), device)
     drafts = _weighted_merge_all(api, [[p["cons"][c] for p in allp] for c in range(len(cand))], [[p["cnt"][c] for p in allp] for c in range(len(cand))], band)
     T["consensus"] = T.get("consensus", 0.0) + time.perf_counter() - t0

@@ -9,6 +9,11 @@ import time
 import numpy as np
 from ._capi import Api, ReadSet, cluster_params, poa_params, polish_params, POA_LOCAL
 
+# Draft consensus: coverage-trim the ends of every tile consensus (ngsid_poa_params_t.trim).  spoa itself completes the heaviest bundle to
+# a sink, so its consensus can end in the unsupported tail of a single read, and racon cannot shorten or extend a backbone end; with the
+# trim the drafts of the noisy synthetic sets equal their amplicons before polishing.
+DRAFT_TRIM = 1
+
 _COMP = np.zeros(256, dtype=np.uint8)
 for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
     _COMP[_a] = _b
@@ -103,7 +108,7 @@ def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, 
             b = min(b, a + max_seqs_for_consensus)                              # consensus.py:260
         sub_order.append(order[a:b]); sub_off.append(sub_off[-1] + (b - a))
     sub_order = np.concatenate(sub_order) if sub_order else np.zeros(0, np.uint32)
-    drafts = api.poa_consensus(rs, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap),
+    drafts = api.poa_consensus(rs, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=DRAFT_TRIM),
                                read_order=sub_order)
     T["consensus"] = T.get("consensus", 0.0) + time.perf_counter() - t0
     t0 = time.perf_counter()

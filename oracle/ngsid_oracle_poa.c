@@ -222,7 +222,7 @@ static int g_add_alignment(graph* G, const pseq* S, const ppair* path, int np) {
 }
 
 /* ---------------------------------------------------------------- heaviest bundle (spoa Graph::TraverseHeaviestBundle + BranchCompletion) */
-static int g_consensus(const graph* G, uint8_t* out, uint32_t* cov_out) {
+static int g_consensus(const graph* G, uint8_t* out, uint32_t* cov_out, int* anc_out) {
     const int V = G->V; if (V == 0) return 0;
     int* pred = malloc(sizeof(int) * (size_t)V); int64_t* sc = malloc(sizeof(int64_t) * (size_t)V);
     for (int v = 0; v < V; ++v) { pred[v] = -1; sc[v] = -1; }
@@ -254,13 +254,13 @@ static int g_consensus(const graph* G, uint8_t* out, uint32_t* cov_out) {
         mx = m2;
     }
     int n = 0; for (int v = mx; v != -1; v = pred[v]) ++n;
-    int i = n; for (int v = mx; v != -1; v = pred[v]) { --i; out[i] = G->code[v]; if (cov_out) { uint32_t c = G->cov[v]; for (int u = G->ring[v]; u != v; u = G->ring[u]) c += G->cov[u]; cov_out[i] = c; } }
+    int i = n; for (int v = mx; v != -1; v = pred[v]) { --i; out[i] = G->code[v]; if (anc_out) anc_out[i] = G->anchor[v]; if (cov_out) { uint32_t c = G->cov[v]; for (int u = G->ring[v]; u != v; u = G->ring[u]) c += G->cov[u]; cov_out[i] = c; } }
     free(pred); free(sc);
     return n;
 }
 
 /* ---------------------------------------------------------------- tile engine: sequences in order -> one or more (consensus, cw) */
-typedef struct { uint8_t* s; uint32_t* cov; int len; uint64_t cw; } pout;
+typedef struct { uint8_t* s; uint32_t* cov; int len; uint64_t cw; int a0, a1; /* anchors (coordinates in the first sequence of the graph) of the first / last consensus node */ } pout;
 typedef struct { int m, n, g, band, node_cap, trim_tiles; } pprm;
 
 static int cap_for(int L0, int node_cap) { long c = (long)L0 * (node_cap > 0 ? node_cap : 28) / 16; if (c < L0 + 64) c = L0 + 64; return (int)c; }
@@ -274,10 +274,12 @@ static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* 
     graph G; g_init(&G, capV > maxlen + 1 ? capV : maxlen + 1);
     ppair* path = malloc(sizeof(ppair) * (size_t)(maxlen + G.capV + 4));
     int members = 0;
-#define EMIT() do { if (G.V > 0 && members > 0) { pout* o = &outs[nout++]; o->s = malloc((size_t)G.V + 1); o->cov = (want_cov || P->trim_tiles) ? malloc(sizeof(uint32_t) * ((size_t)G.V + 1)) : NULL; o->len = g_consensus(&G, o->s, o->cov); o->cw = G.cw_sum; \
+#define EMIT() do { if (G.V > 0 && members > 0) { pout* o = &outs[nout++]; o->s = malloc((size_t)G.V + 1); o->cov = (want_cov || P->trim_tiles) ? malloc(sizeof(uint32_t) * ((size_t)G.V + 1)) : NULL; int* anc_ = malloc(sizeof(int) * ((size_t)G.V + 1)); \
+        o->len = g_consensus(&G, o->s, o->cov, anc_); o->cw = G.cw_sum; int b_ = 0, e_ = o->len - 1; \
         if (P->trim_tiles && o->len > 0) { /* coverage-trim the tile consensus ends: keeps unsupported backbone ends from propagating up the hierarchy */ \
-            uint32_t thr = (uint32_t)(G.cw_sum / 2); int b_ = 0, e_ = o->len - 1; for (; b_ < o->len; ++b_) if (o->cov[b_] >= thr) break; for (; e_ >= 0; --e_) if (o->cov[e_] >= thr) break; \
-            if (b_ < e_) { memmove(o->s, o->s + b_, (size_t)(e_ - b_ + 1)); memmove(o->cov, o->cov + b_, sizeof(uint32_t) * (size_t)(e_ - b_ + 1)); o->len = e_ - b_ + 1; } } \
+            uint32_t thr = (uint32_t)(G.cw_sum / 2); for (; b_ < o->len; ++b_) if (o->cov[b_] >= thr) break; for (; e_ >= 0; --e_) if (o->cov[e_] >= thr) break; \
+            if (b_ < e_) { memmove(o->s, o->s + b_, (size_t)(e_ - b_ + 1)); memmove(o->cov, o->cov + b_, sizeof(uint32_t) * (size_t)(e_ - b_ + 1)); o->len = e_ - b_ + 1; } else { b_ = 0; e_ = o->len - 1; } } \
+        o->a0 = o->len > 0 ? anc_[b_] : 0; o->a1 = o->len > 0 ? anc_[e_] : -1; free(anc_); \
         if (!want_cov) { free(o->cov); o->cov = NULL; } } } while (0)
     for (int i = 0; i < ns; ++i) {
         const pseq* S = &seqs[i];
@@ -327,6 +329,10 @@ static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P
         for (int i = 0; i < nout; ++i) {
             uint64_t cw = outs[i].cw; int uw = cw > (1u << 20) ? (1 << 20) : (int)cw; if (uw < 1) uw = 1;
             nx[i].s = outs[i].s; nx[i].q = NULL; nx[i].len = outs[i].len; nx[i].uw = uw; nx[i].cw = (uint32_t)(cw > 0xffffffffull ? 0xffffffffull : cw); nx[i].mode = upper_mode; nx[i].a0 = 0; nx[i].a1 = -1;
+            if (backbone) {   /* a tile consensus is a layer of the window like the reads it stands for: it spans [a0, a1] of the backbone and is aligned globally only if that is the whole window (racon's rule for layers, 1 % slack) */
+                const int wlen = backbone->len, offset = (int)(0.01 * (double)wlen), begin = outs[i].a0, end = outs[i].a1;
+                if (end >= begin) { nx[i].a0 = begin; nx[i].a1 = end; nx[i].mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI; }
+            }
             owned[i] = outs[i].s; free(outs[i].cov);
         }
         free(outs); cur = nx; ncur = nout; ++level;
@@ -335,7 +341,7 @@ static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P
 
 int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                              const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed) {
-    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, 0 };
+    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->trim > 0 };
     uint64_t total = 0; int overflow = 0; cons_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         int ns = (int)(grp_off[g + 1] - grp_off[g]);

@@ -61,3 +61,35 @@ def test_multiple_groups_and_empty(oracle):
     cons = oracle.poa_consensus(rs2, [0, n0, n0, rs2.n], poa_params(tile_depth=8, band=128))
     assert cons[1] == ""                                          # empty group -> empty consensus
     assert interior_ed(cons[0], sp[0].tobytes().decode()) <= 1 and interior_ed(cons[2], sp[1].tobytes().decode()) <= 1
+
+
+@pytest.mark.parametrize("mu", [14.0, 17.0])
+def test_trimmed_drafts_and_polish_equal_the_amplicon_on_noisy_reads(oracle, mu):
+    """coverage-trimmed tile consensuses (poa trim = 1): the draft of 1 500 noisy 750-base reads is within 2 edits of the amplicon with NO
+    end slack, and one polishing iteration returns the amplicon exactly; a backbone with junk overhangs is polished back to it as well."""
+    sp, rd, rs = make_set(1500, L=750, mu=mu, seed=11)
+    truth = sp[0].tobytes().decode()
+    draft = oracle.poa_consensus(rs, [0, rs.n], poa_params(tile_depth=8, band=128, trim=1))[0]
+    assert edit_distance(draft, truth) <= 2
+    raw = oracle.poa_consensus(rs, [0, rs.n], poa_params(tile_depth=8, band=128, trim=0))[0]
+    assert edit_distance(draft, truth) <= edit_distance(raw, truth)
+    for bb in (draft, "CC" + truth + "GCCATAAATG"):
+        pol, used = oracle.polish(ReadSet.from_strings([bb]), rs, [0, rs.n], polish_params(iters=1, k=13, w=20, tile_depth=8, band=128, trim=2))
+        assert pol[0] == truth
+
+
+def test_rc_identity_equals_the_reference(oracle):
+    """(a15) consensus.highest_aln_identity (consensus.py:129-145): golden produced by the reference function itself (oracle/make_golden.py,
+    aligner behind the parasail shim = this oracle's scalar aligner, so the alignment stage is self-referential; the identity arithmetic is not)."""
+    import os
+    from oracle_lib import GOLD
+    g = np.load(os.path.join(GOLD, "align_sample_h1.npz"))
+    comp = {65: 84, 67: 71, 71: 67, 84: 65, 78: 78}
+    n = len(g["identity"])
+    qs = [g["q"][int(g["q_off"][i]):int(g["q_off"][i + 1])].tobytes().decode() for i in range(n)]
+    ts = [g["t"][int(g["t_off"][i]):int(g["t_off"][i + 1])].tobytes().decode() for i in range(n)]
+    rcs = ["".join(chr(comp.get(ord(c), 78)) for c in reversed(t)) for t in ts]
+    q = ReadSet.from_strings(qs); t = ReadSet.from_strings(ts + rcs)
+    score, ncols, nmatch, _ = oracle.sg_align_batch(q, t, list(range(n)) * 2, list(range(2 * n)), 3, 1, 2, -2, 13, None)
+    ident = np.maximum(nmatch[:n] / ncols[:n].astype(np.float64), nmatch[n:] / ncols[n:].astype(np.float64))
+    assert np.array_equal(ident, g["identity"])

@@ -94,3 +94,14 @@ def test_polish_stop_when_stable_is_exact(gpu_api, oracle):
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
     exp, eused = oracle.polish(bb, rs2, goff, polish_params(iters=4, tile_depth=8, band=128, trim=2, stop_when_stable=1))
     assert res[1][0] == exp and np.array_equal(res[1][1], eused)
+
+
+def test_rc_identity_equals_the_reference_golden(gpu_api):
+    """(a15) the product's consensus.highest_aln_identity on the HIP aligner == the reference's own function (tests/golden/align_sample_h1.npz)."""
+    import os
+    from oracle_lib import GOLD
+    from ngspeciesid_amd import consensus
+    g = np.load(os.path.join(GOLD, "align_sample_h1.npz"))
+    for i in range(len(g["identity"])):
+        a = g["q"][int(g["q_off"][i]):int(g["q_off"][i + 1])].tobytes().decode(); b = g["t"][int(g["t_off"][i]):int(g["t_off"][i + 1])].tobytes().decode()
+        assert consensus.highest_aln_identity(a, b, api=gpu_api) == g["identity"][i]
