@@ -13,12 +13,12 @@ import numpy as np
 import torch
 
 
-def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device):
+def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device, abundance=None):
     """synthetic reads, scored (f1) and physically ordered by score descending (stable) = the greedy order."""
     from ngspeciesid_amd import synth
     from ngspeciesid_amd._capi import ReadSet
     sp = synth.make_species(n_species, L, 0.15, seed=1)
-    rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed, device=device)
+    rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed, device=device, abundance=abundance)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     torch.cuda.synchronize(device)       # the library runs on its own HIP stream: torch's generator kernels must have finished writing the reads
     score, err, keep = api.score_reads(rs, 13, 7.0)
@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-step", action="store_true", help="skip the extra step with stop_when_stable (profiling runs that count per-step traffic)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --reads per GPU, an independent set per rank.  strong: ONE global score-sorted set of --reads reads, rank g gets batch g+1 of the "
+                         "reference's `--t N` partition (parallelize.batch_list total_nt), so the N-GPU membership is the reference's --t N membership of that set")
+    ap.add_argument("--check-membership", action="store_true", help="strong scaling: after the timed region rank 0 replays the `--t N` schedule on one GPU and compares the membership")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -80,7 +84,21 @@ def main():
     from ngspeciesid_amd.ptable import select_p_table
     api = runtime.get_api(local)
     ptab = select_p_table(13, 20)
-    sp, rd = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7 + rank, device=dev)
+    rd_global = None
+    if args.scaling == "strong" and (world > 1 or force_dist):
+        # every rank builds the same global set (same seed, same device type) and keeps its own `--t N` batch of it
+        from ngspeciesid_amd import parallelize
+        sp, rd_global = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7, device=dev)
+        goff = rd_global["off"]; glens = (goff[1:] - goff[:-1]).cpu().numpy()
+        batches = parallelize.batch_list_total_nt(glens, world)
+        a, b = batches[rank] if rank < len(batches) else (len(glens), len(glens))
+        o0, o1 = int(goff[a].item()), int(goff[b].item())
+        rd = dict(seq=rd_global["seq"][o0:o1].clone(), qual=rd_global["qual"][o0:o1].clone(), off=(goff[a:b + 1] - goff[a]).clone(), species=rd_global["species"][a:b],
+                  score=rd_global["score"][a:b], orig=rd_global["orig"][a:b])
+        shard_start = a
+        if not (args.check_membership and rank == 0): rd_global = None
+    else:
+        sp, rd = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7 + rank, device=dev)
     torch.cuda.synchronize()
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     n = rs.n
@@ -133,6 +151,22 @@ def main():
         n_total = n
     if dist is not None:
         t = torch.tensor([dt_stop], device=comm_dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt_stop = float(t.item())
+    membership_ok = None
+    if args.scaling == "strong" and dist is not None and args.check_membership:
+        # N-GPU membership against the reference's `--t N` schedule replayed on ONE GPU (rank 0), outside the timed region
+        from ngspeciesid_amd import distributed, parallelize
+        from ngspeciesid_amd._capi import cluster_params
+        from ngspeciesid_amd.hostutil import make_cluster_fn
+        starts = [x for x, _ in batches]
+        mine = np.asarray([starts[o] + l for o, l in zip(res["final_owner"], res["final_lidx"])], dtype=np.int64)
+        allm = distributed.all_gather_obj(dict(a=int(shard_start), final=mine), comm_dev)
+        if rank == 0:
+            final = np.full(len(glens), -1, dtype=np.int64)
+            for m_ in allm: final[m_["a"]:m_["a"] + len(m_["final"])] = m_["final"]
+            hrs = ReadSet(rd_global["seq"].cpu().numpy(), rd_global["qual"].cpu().numpy(), rd_global["off"].cpu().numpy().astype(np.uint64))
+            fn = make_cluster_fn(api, hrs, np.asarray(rd_global["orig"], dtype=np.uint32), cluster_params(k=13, w=20, p_shared=ptab))
+            rep_ref, _, _ = parallelize.tree_cluster(fn, glens, np.asarray(rd_global["score"]), world)
+            membership_ok = bool(np.array_equal(final, rep_ref))
     if rank != 0:
         return
     stop_same = None if res_stop is None else [c[3] for c in res_stop["centers"]] == [c[3] for c in res["centers"]]
@@ -202,13 +236,13 @@ def main():
                "sample": "%d reads strided from the same batch (same params, tile_depth %d), oracle/libngsid_oracle.so, %.1f s" % (ns, args.tile_depth, dtc)}
     out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), 750 bp ONT", "value": round(reads_per_s, 1), "unit": "reads/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic",
-           "config": {"workload": "%d synthetic %d bp ONT-profile reads per GPU (mu=%.0f), %d species @15%% divergence, k=13 w=20, cluster + spoa-style POA + racon-style polish x3, abundance_ratio 0.02, POA tile depth %d band 128"
+           "scaling": args.scaling if world > 1 or force_dist else "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic",
+           "config": {"workload": ("%d synthetic %d bp ONT-profile reads " + ("in total, one `--t N` batch per GPU" if (args.scaling == "strong" and (world > 1 or force_dist)) else "per GPU") + " (mu=%.0f), %d species @15%% divergence, k=13 w=20, cluster + spoa-style POA + racon-style polish x3, abundance_ratio 0.02, POA tile depth %d band 128")
                       % (args.reads, args.length, args.mu, args.species, args.tile_depth),
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
                       "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()},
                       "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()},
-                      "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed}},
+                      "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok}},
            "roofline": roof, "cpu_baseline": cpu}
     if res_stop is not None: out["config"]["with_stable_stop"] = {"reads_per_s": round(n_total / dt_stop, 1), "ms_per_step": round(dt_stop * 1e3, 2), "same_result": stop_same,
                                           "note": "library default stop_when_stable=1 (not used for `value`): a cluster whose polished sequence equals its backbone is not polished again"}

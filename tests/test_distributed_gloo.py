@@ -54,5 +54,16 @@ def test_two_rank_consensus_agrees_between_ranks():
     assert outs[0]["centers"] == outs[1]["centers"] and len(outs[0]["centers"]) == 5
     sizes = sorted(c[0] for c in outs[0]["centers"])
     assert sizes == [372, 393, 403, 411, 414]                 # the reference's cluster sizes for this fixture
+    # against the truth and against the single-process path on the same reads (oracle backend both times)
+    from util_seq import edit_distance
+    from oracle_lib import load_oracle
+    from ngspeciesid_amd import synth, pipeline
+    from ngspeciesid_amd._capi import ReadSet
+    from ngspeciesid_amd.hostutil import acc_rank
+    truths = [t.tobytes().decode() for t in synth.make_species(5, 750, 0.15, seed=11)]          # oracle/make_golden.py builds the fixture from these
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cluster_synth2k_d15.npz"))
     for n, seq in outs[0]["centers"]:
-        assert 730 < len(seq) < 770
+        assert min(edit_distance(seq, t) for t in truths) == 0, "sharded consensus of the %d-read cluster differs from its amplicon" % n
+    one = pipeline.run_hot_path(load_oracle(), ReadSet(g["seq"], g["qual"], g["off"]), g["score"], acc_rank=acc_rank([str(x) for x in g["acc"]]), k=int(g["k"]), w=int(g["w"]),
+                                p_shared=g["p_table"], abundance_ratio=0.1, racon_iter=1, tile_depth=8)
+    assert sorted(c[3] for c in one["centers"]) == sorted(seq for n, seq in outs[0]["centers"]), "sharded and single-process consensus differ"
