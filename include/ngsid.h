@@ -141,7 +141,8 @@ typedef struct {
     int32_t mode;          /* NGSID_POA_* */
     int32_t match, mismatch, gap;   /* spoa -m/-n/-g ; linear gaps (g >= e in consensus.py:87) */
     int32_t tile_depth;    /* reads per exact-order POA tile; <=0 = one tile per group (exact spoa order) */
-    int32_t band;          /* DP band width in columns (64/128/256); <=0 = library default */
+    int32_t band;          /* DP band width in columns (64/128/256) of the first attempt; <=0 = library default (64 when every read of the call has
+                              <= 1 024 bases, else 128).  A tile in which a traceback touches a clipped band edge is redone with twice the band (up to 256) */
     int32_t node_cap;      /* graph node capacity per tile as a multiple of 1/16 of the first read length (<=0 default) */
     int32_t trim;          /* 0 = none (spoa: the heaviest bundle is completed to a sink, so the consensus can carry the unsupported tail of a single
                               read); 1 = coverage-trim the ends of every tile consensus (bases covered by less than half of the sequences merged) */

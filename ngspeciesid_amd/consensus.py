@@ -15,7 +15,7 @@ from ._capi import ReadSet, poa_params, polish_params, POA_LOCAL
 from .help_functions import readfq, mkdir_p
 
 DEFAULT_TILE_DEPTH = 8
-DEFAULT_BAND = 128
+DEFAULT_BAND = 0          # library default: 64 columns for reads up to 1 024 bases, 128 beyond; widened per tile by the band-edge check
 
 
 def reverse_complement(string):

@@ -114,6 +114,29 @@ __device__ __forceinline__ int wave_incl_add_scan(int v)
     return v;
 }
 
+// Direction bytes (type | slot << 2; slot 0 / 1 = first / second in-edge, SRC_SLOT = virtual source) go to HBM as 4 bits per cell:
+// type | code << 2 with code 0, 1, 2 = slot 0, 1, SRC_SLOT.  Rows with more than two in-edges (row flag 2, a fraction of a percent) can hold
+// other slots: their byte rows are kept in full next to the packed block and patched in when the traceback reloads the block.
+__device__ __forceinline__ unsigned dir_nib4(unsigned w) { const unsigned t = w & 0x03030303u, sl = (w >> 2) & 0x01010101u, gq = (w >> 7) & 0x01010101u; return t | ((sl & ~gq) << 2) | (gq << 3); }
+__device__ __forceinline__ unsigned dir_pack8(unsigned w0, unsigned w1)
+{
+    const unsigned n0 = dir_nib4(w0), n1 = dir_nib4(w1);
+    const unsigned c0 = (n0 | (n0 >> 4)) & 0x00FF00FFu, c1 = (n1 | (n1 >> 4)) & 0x00FF00FFu;
+    return ((c0 | (c0 >> 8)) & 0xFFFFu) | (((c1 | (c1 >> 8)) & 0xFFFFu) << 16);
+}
+__device__ __forceinline__ unsigned dir_unpack4(unsigned h16)
+{
+    const unsigned c = (h16 | (h16 << 8)) & 0x00FF00FFu, n = (c | (c << 4)) & 0x0F0F0F0Fu;
+    const unsigned t = n & 0x03030303u, s1 = (n >> 2) & 0x01010101u, gq = (n >> 3) & 0x01010101u;
+    return t | (s1 << 2) | (((gq << 6) - gq) << 2);
+}
+__device__ __forceinline__ ngsid_v4u dir_pack32(const ngsid_v4u a, const ngsid_v4u b) { ngsid_v4u o; o.x = dir_pack8(a.x, a.y); o.y = dir_pack8(a.z, a.w); o.z = dir_pack8(b.x, b.y); o.w = dir_pack8(b.z, b.w); return o; }
+__device__ __forceinline__ void dir_unpack32(const ngsid_v4u p, ngsid_v4u& a, ngsid_v4u& b)
+{
+    a.x = dir_unpack4(p.x & 0xFFFFu); a.y = dir_unpack4(p.x >> 16); a.z = dir_unpack4(p.y & 0xFFFFu); a.w = dir_unpack4(p.y >> 16);
+    b.x = dir_unpack4(p.z & 0xFFFFu); b.y = dir_unpack4(p.z >> 16); b.z = dir_unpack4(p.w & 0xFFFFu); b.w = dir_unpack4(p.w >> 16);
+}
+
 #define PH(J, idx, t0) do { if ((J).phase_cycles && lane == 0) { const unsigned long long t1_ = __builtin_readcyclecounter(); atomicAdd(&(J).phase_cycles[idx], t1_ - (t0)); (t0) = t1_; } } while (0)
 
 struct TS { int V, E, L0, members, nout, capV, capE; unsigned long long cw_sum; };
@@ -431,7 +454,7 @@ __device__ __forceinline__ unsigned poa_row_finish(const int (&X)[CPL], const in
 }
 
 template <int CPL, int MODE>
-__device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, const PSeq& S, int V, int gp_, int sm_, int sn_, int lane, int& bestv_out, int& bestpk_out, int& nslow_out)
+__device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, uint8_t* Dfull, const PSeq& S, int V, int gp_, int sm_, int sn_, int lane, int& bestv_out, int& bestpk_out, int& nslow_out)
 {
     constexpr int BW = 64 * CPL;
     int nslow = 0;
@@ -607,9 +630,20 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
         }
         if ((r & (TBR - 1)) == 0) {
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
-            uint8_t* dstb = Dg + (size_t)(r - TBR) * BW;
+            uint8_t* dstb = Dg + (size_t)(r - TBR) * (BW / 2);            // packed: 4 bits per cell
 #pragma unroll
-            for (int x = 0; x < TBR * BW / 16 / 64; ++x) { const int piece = lane + 64 * x; *(ngsid_v4u*)(dstb + piece * 16) = *(LDSP ngsid_v4u*)(w.dirblk() + piece * 16); }
+            for (int x = 0; x < TBR * BW / 32 / 64; ++x) {
+                const int q = lane + 64 * x;
+                const ngsid_v4u a = *(LDSP ngsid_v4u*)(w.dirblk() + q * 32), b = *(LDSP ngsid_v4u*)(w.dirblk() + q * 32 + 16);
+                *(ngsid_v4u*)(dstb + q * 16) = dir_pack32(a, b);
+            }
+            // rows with more than two in-edges keep their byte rows (row info of the block's ranks is still in this chunk's registers)
+            unsigned long long irr = __ballot(((chi >> 24) & 2u) != 0) & (0xFFFFFFFFull << ((r - TBR) & 63));
+            while (irr) {
+                const int bq = __builtin_ctzll(irr); irr &= irr - 1;
+                const int row = ((r - 1) & ~63) + bq;
+                if (lane < BW / 16) *(ngsid_v4u*)(Dfull + (size_t)row * BW + lane * 16) = *(LDSP ngsid_v4u*)(w.dirblk() + (row & (TBR - 1)) * BW + lane * 16);
+            }
             asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
         }
         if ((r & 63) == 0 && r < V) {          // next chunk of row info; prefetch the one after
@@ -632,7 +666,7 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
 
 // align S to the graph and merge it.  returns 0 = dropped (no valid end cell), 1 = added, 2 = does not fit
 template <int CPL>
-__device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, const PoaJobSet& J, const PSeq& S, TS& st, int lane)
+__device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, uint8_t* Dfull, const PoaJobSet& J, const PSeq& S, TS& st, int lane, int& edge_out)
 {
     constexpr int BW = 64 * CPL;
     // wave-uniform by construction; tell the compiler so the row loops get scalar control flow
@@ -703,9 +737,9 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     // ---------- forward DP, one row per graph node in topological order
     const bool local = mode == NGSID_POA_LOCAL;
     int bestv, bestpk, nslow;
-    if (local) poa_forward<CPL, NGSID_POA_LOCAL>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
-    else if (mode == NGSID_POA_SEMI) poa_forward<CPL, NGSID_POA_SEMI>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
-    else poa_forward<CPL, NGSID_POA_GLOBAL>(g, w, Hg, Dg, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    if (local) poa_forward<CPL, NGSID_POA_LOCAL>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    else if (mode == NGSID_POA_SEMI) poa_forward<CPL, NGSID_POA_SEMI>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    else poa_forward<CPL, NGSID_POA_GLOBAL>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[5], (unsigned long long)V); atomicAdd(&J.phase_cycles[6], (unsigned long long)nslow); }
     mem_sync();                                       // direction rows must have landed before the traceback pulls them back
     PH(J, 1, tph);
@@ -734,17 +768,17 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         int n_reload = 0, n_iter = 0; unsigned long long c_reload = 0;
         // the block below the current one is prefetched into registers while the current one is walked (a reload is an L2 / HBM round trip
         // of several thousand cycles, the walk of a block takes longer than that)
-        constexpr int LPR = 64 / TBR;                         // lanes per direction row
-        constexpr int NPF = BW / (16 * LPR);                   // 16-byte pieces per lane and block
+        constexpr int NPF = TBR * BW / 32 / 64;                // packed 16-byte pieces per lane and block (piece q = 32 direction bytes)
         ngsid_v4u pf[NPF]; unsigned long long pri = 0ull; int pf_blk = -1;
         auto prefetch = [&](int b) {
             if (b < 0) { pf_blk = -1; return; }
-            const uint8_t* src = Dg + (size_t)(b + lane / LPR) * BW + (lane % LPR) * 16;
+            const uint8_t* src = Dg + (size_t)b * (BW / 2);
 #pragma unroll
-            for (int x = 0; x < NPF; ++x) pf[x] = ngsid_load16_l2(src + x * 16 * LPR);       // L2-served: rows are rewritten per sequence
+            for (int x = 0; x < NPF; ++x) pf[x] = ngsid_load16_l2(src + (lane + 64 * x) * 16);       // L2-served: rows are rewritten per sequence
             pri = lane < TBR ? g.ri(b + lane) : 0ull;
             pf_blk = b;
         };
+        int edge = 0;
         prefetch(blk_lo - TBR);
         for (int guard = 0;; ++guard) {
             ++n_iter;
@@ -754,11 +788,21 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 blk_lo = r & ~(TBR - 1);                    // aligned blocks of TBR rows, same layout as the forward pass staged them
                 ++n_reload;
                 const unsigned long long trl0 = J.phase_cycles ? __builtin_readcyclecounter() : 0;
-                l8 dstp = w.dirblk() + (size_t)(lane / LPR) * BW + (lane % LPR) * 16;
                 if (blk_lo != pf_blk) prefetch(blk_lo);       // the path jumped further than one block (far predecessor): fetch it now
 #pragma unroll
-                for (int x = 0; x < NPF; ++x) *(LDSP ngsid_v4u*)(dstp + x * 16 * LPR) = pf[x];
+                for (int x = 0; x < NPF; ++x) {
+                    ngsid_v4u a, b; dir_unpack32(pf[x], a, b);
+                    l8 dstp = w.dirblk() + (size_t)(lane + 64 * x) * 32;
+                    *(LDSP ngsid_v4u*)dstp = a; *(LDSP ngsid_v4u*)(dstp + 16) = b;
+                }
                 myri = pri;
+                {   // rows with more than two in-edges: their full byte rows replace the unpacked ones
+                    unsigned long long irr = __ballot(lane < TBR && (((unsigned)(myri >> 56)) & 2u) != 0);
+                    while (irr) {
+                        const int bq = __builtin_ctzll(irr); irr &= irr - 1;
+                        if (lane < BW / 16) *(LDSP ngsid_v4u*)(w.dirblk() + bq * BW + lane * 16) = ngsid_load16_l2(Dfull + (size_t)(blk_lo + bq) * BW + lane * 16);
+                    }
+                }
                 prefetch(blk_lo - TBR);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -775,6 +819,11 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             const unsigned long long gm = __ballot(good);
             const unsigned long long x = gm << (63 - top);     // lane `top` at bit 63: leading ones = the run
             const int run = (~x) ? __builtin_clzll(~x) : 64;   // <= top + 1 because lanes above `top` never set their bit
+            {   // band-edge check (oracle poa_align): a visited cell (the run and the cell it ends on) on a clipped edge of its row's band
+                const int lok = (int)(myri & 0xffff);
+                const bool clipped = ((ck == 0) & (lok > 0)) | ((ck == BW - 1) & (lok + BW - 1 < L));
+                if (__ballot(loaded & (lane >= top - run) & clipped)) edge = 1;
+            }
             if ((lane <= top) & (lane > top - run)) g.alnode(jk - 1) = (uint16_t)(blk_lo + lane);      // `run` diagonal moves, each to the previous rank
             r -= run; j -= run;
             const int nk = top - run;                          // lane holding the next cell of the path
@@ -792,6 +841,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             r = pr;
         }
         if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[7], (unsigned long long)n_iter); atomicAdd(&J.phase_cycles[13], (unsigned long long)n_reload); atomicAdd(&J.phase_cycles[14], c_reload); }
+        edge_out |= edge;
     }
     mem_sync();                                       // alnode[] (HBM) is read by other lanes next
     PH(J, 2, tph);
@@ -965,8 +1015,7 @@ static size_t poa_graph_bytes(int Vc, int Ec, int Lm)
 }
 
 template <int CPL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))      // <= 128 VGPRs: four single-wave tiles per SIMD (~10 KB of LDS each)
-void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restrict__ work_ctr)
+__device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscratch, size_t gbytes, uint32_t* __restrict__ work_ctr)
 {
     constexpr int BW = 64 * CPL;
     const int lane = threadIdx.x;
@@ -979,13 +1028,16 @@ void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restr
         g.s16 = (uint32_t)al(2 * ((size_t)Vc + 1)); g.s8 = (uint32_t)al(Vc); g.se = (uint32_t)al(2 * (size_t)Ec); g.sl = (uint32_t)al(2 * (size_t)Lm);
     }
     int32_t* Hg = J.Hglob + (size_t)blockIdx.x * Vc * BW;
-    uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW;
+    uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW * 3 / 2;      // packed direction blocks (4 bits per cell) ...
+    uint8_t* Dfull = Dg + (size_t)Vc * BW / 2;                            // ... and the byte rows of the ranks with more than two in-edges (sparse)
 
     for (;;) {
         // persistent workgroups pull tiles from a queue (tiles differ a lot in cost: depth, graph growth, splits)
         uint32_t jq = 0; if (lane == 0) jq = atomicAdd(work_ctr, 1u);
-        const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)jq);
-        if (job >= J.njobs) break;
+        const uint32_t jqi = (uint32_t)__builtin_amdgcn_readfirstlane((int)jq);
+        if (jqi >= J.nrun) break;
+        const uint32_t job = J.job_list ? J.job_list[jqi] : jqi;          // a redo launch (wider band) runs a list of tiles
+        int edge = 0;
         const uint32_t s0 = J.job_off[job], s1 = J.job_off[job + 1];
         const int bbi = J.job_bb ? J.job_bb[job] : -1;
         TS st; st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.nout = 0; st.cw_sum = 0;
@@ -1007,7 +1059,7 @@ void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restr
                     if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, B, st, lane); }
                     else { if (S.len > st.capV) ++ndrop; else { tile_add_first(g, S, st, lane); st.members = 1; } break; }
                 }
-                const int rcode = tile_align_add<CPL>(g, w, Hg, Dg, J, S, st, lane);
+                const int rcode = tile_align_add<CPL>(g, w, Hg, Dg, Dfull, J, S, st, lane, edge);
                 if (rcode == 1) { st.members += 1; break; }
                 if (rcode == 0 || attempt == 1) { ++ndrop; break; }
                 tile_emit(g, w, J, job, st, lane);
@@ -1015,36 +1067,51 @@ void k_poa_tile(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restr
             }
         }
         tile_emit(g, w, J, job, st, lane);
-        if (lane == 0) { J.out_n[job] = (uint32_t)st.nout; if (ndrop && J.dropped) atomicAdd(J.dropped, ndrop); }
+        if (lane == 0) { J.out_n[job] = (uint32_t)st.nout | (edge ? 0x80000000u : 0u); if (ndrop && J.dropped) atomicAdd(J.dropped, ndrop); }      // bit 31: a traceback touched a clipped band edge
         mem_sync();
     }
 }
+
+// One kernel per band width, so that each gets its own register budget: the 64-column instance keeps one DP cell per lane and fits
+// POA_W1 waves per SIMD (its LDS working set is ~5.7 KB per tile); the wider ones need the 128 VGPRs of four waves per SIMD.
+#ifndef POA_W1
+#define POA_W1 6
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(POA_W1, POA_W1)))
+void k_poa_tile1(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restrict__ work_ctr) { poa_tile_body<1>(J, gscratch, gbytes, work_ctr); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_poa_tile2(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restrict__ work_ctr) { poa_tile_body<2>(J, gscratch, gbytes, work_ctr); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_poa_tile4(PoaJobSet J, uint8_t* gscratch, size_t gbytes, uint32_t* __restrict__ work_ctr) { poa_tile_body<4>(J, gscratch, gbytes, work_ctr); }
 
 // ------------------------------------------------------------------------------------------------ host side
 int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
 {
     if (J.njobs == 0) return NGSID_OK;
+    if (!J.job_list) J.nrun = J.njobs;
+    if (J.nrun == 0) return NGSID_OK;
     const int BW = band <= 64 ? 64 : (band <= 128 ? 128 : 256);
     if (J.g >= 0) NGSID_FAIL(ctx, NGSID_ERR_ARG, "POA gap score must be negative");
     if ((long long)J.m * J.Lmax >= 65536 || J.m < 0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA local score range exceeds 16 bits (match %d x length %d)", J.m, J.Lmax);
     if (J.Vcap > 0xFFF0 || J.Ecap > 0xFFF0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA graph capacity exceeds 16-bit indices (sequence too long for the tile engine)");
     const size_t lds = poa_lds_bytes(J.Vcap, J.Ecap, J.Lmax, BW);
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);
-    int per_cu = std::max<int>(1, std::min<int>(16, (int)((160 * 1024) / lds)));      // 16 = four waves per SIMD, the VGPR budget of the kernel
+    const int wave_cap = BW == 64 ? 4 * POA_W1 : 16;                                  // waves per CU the register budget of the instance allows
+    int per_cu = std::max<int>(1, std::min<int>(wave_cap, (int)((160 * 1024) / lds)));
     if (const char* e = getenv("NGSID_POA_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));      // dev knob
-    uint32_t nwg = (uint32_t)std::min<uint64_t>(J.njobs, (uint64_t)ctx->n_cu * per_cu);
+    uint32_t nwg = (uint32_t)std::min<uint64_t>(J.nrun, (uint64_t)ctx->n_cu * per_cu);
     const size_t cells = (size_t)J.Vcap * BW;
     const size_t gbytes = poa_graph_bytes(J.Vcap, J.Ecap, J.Lmax);
     if (ctx->poa_h.n < nwg * cells) HIPCHK(ctx, ctx->poa_h.alloc(nwg * cells));
-    if (ctx->poa_d.n < nwg * cells) HIPCHK(ctx, ctx->poa_d.alloc(nwg * cells));
+    if (ctx->poa_d.n < nwg * cells * 3 / 2) HIPCHK(ctx, ctx->poa_d.alloc(nwg * cells * 3 / 2));
     if (ctx->poa_g.n < nwg * gbytes) HIPCHK(ctx, ctx->poa_g.alloc(nwg * gbytes));
     J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = nullptr;
     if (ctx->poa_ctr.n < 1) HIPCHK(ctx, ctx->poa_ctr.alloc(16));
     HIPCHK(ctx, hipMemsetAsync(ctx->poa_ctr.p, 0, sizeof(uint32_t), ctx->stream));
     ProfScope ps_(ctx, "k_poa_tile");
-    if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<1>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
-    else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<2>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
-    else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile<4>, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
+    if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile1, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
+    else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile2, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
+    else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile4, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }

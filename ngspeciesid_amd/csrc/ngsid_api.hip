@@ -401,6 +401,7 @@ extern "C" int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap)
     std::string out;
     for (auto& kv : ctx->prof_acc) { char line[256]; snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.second, kv.second.first); out += line; }
     ctx->prof_acc.clear();
+    { char line[128]; snprintf(line, sizeof line, "poa_band_redo_tiles %llu 0.0\n", (unsigned long long)ctx->poa_redo_tiles); out += line; ctx->poa_redo_tiles = 0; }   // not a kernel: tiles redone with a wider band (band-edge check)
     if (out.size() + 1 > cap) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "profile buffer too small");
     memcpy(buf, out.c_str(), out.size() + 1);
     return NGSID_OK;

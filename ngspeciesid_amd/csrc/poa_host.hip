@@ -93,12 +93,30 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
             if (level == 0) ht.mark("L0 kernel");
             uint32_t h_flags[4];
             h_out_n.resize(njobs); h_out_len.resize((size_t)njobs * slots); h_out_cw.resize((size_t)njobs * slots); h_out_span.resize((size_t)njobs * slots * 2);
-            HIPCHK(ctx, hipMemcpyAsync(h_flags, d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_out_n.data(), Lv->out_n.p, 4ull * njobs, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_out_len.data(), Lv->out_len.p, 4ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_out_cw.data(), Lv->out_cw.p, 8ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_out_span.data(), Lv->out_span.p, 8ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            auto download = [&]() -> int32_t {
+                HIPCHK(ctx, hipMemcpyAsync(h_flags, d_flags.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(h_out_n.data(), Lv->out_n.p, 4ull * njobs, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(h_out_len.data(), Lv->out_len.p, 4ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(h_out_cw.data(), Lv->out_cw.p, 8ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(h_out_span.data(), Lv->out_span.p, 8ull * njobs * slots, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                return NGSID_OK;
+            };
+            rc = download(); if (rc) return rc;
+            // band-edge check (oracle run_tile): tiles in which a traceback touched a clipped edge of its band run again, whole, with twice the band
+            for (int bw = hp.band <= 64 ? 64 : (hp.band <= 128 ? 128 : 256); bw < 256 && !h_flags[1] && !h_flags[2];) {
+                static thread_local PinVec<uint32_t> redo; redo.clear();
+                for (uint32_t j = 0; j < njobs; ++j) if (h_out_n[j] & 0x80000000u) redo.push_back(j);
+                if (redo.empty()) break;
+                bw *= 2;
+                HIPCHK(ctx, Lv->job_list.reserve(redo.size()));
+                HIPCHK(ctx, hipMemcpyAsync(Lv->job_list.p, redo.data(), 4 * redo.size(), hipMemcpyHostToDevice, ctx->stream));
+                J.job_list = Lv->job_list.p; J.nrun = (uint32_t)redo.size();
+                rc = poa_run_jobs(ctx, J, bw); if (rc) return rc;
+                rc = download(); if (rc) return rc;
+                ctx->poa_redo_tiles += redo.size();
+            }
+            for (uint32_t j = 0; j < njobs; ++j) h_out_n[j] &= 0x7fffffffu;
             if (want_ph) { unsigned long long h[16]; HIPCHK(ctx, hipMemcpy(h, d_ph.p, 128, hipMemcpyDeviceToHost)); fprintf(stderr, "[ngsid poa phases, Mcycles] jobs %u prepass %.1f forward %.1f traceback %.1f update %.1f emit %.1f | rows %llu non-chain %llu | sums: bestv %llu bestpk %llu nnew %llu alnsum %llu outlen %llu | tb iters %llu reloads %llu reload Mcycles %.1f | emit backtrack %.1f\n", njobs, h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[7], h[13], h[14] / 1e6, h[15] / 1e6); }
             if (h_flags[2]) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA tile kernel loop guard tripped (code %u)", h_flags[2]);
             if (!h_flags[1]) break;
@@ -169,7 +187,7 @@ extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* read
     HIPCHK(ctx, hipGetLastError());
     std::vector<Unit> units(n_groups);
     for (uint64_t g = 0; g < n_groups; ++g) { units[g].seqs.reserve(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs.push_back(read_order ? read_order[r] : (uint32_t)r); }
-    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, prm->mode, false, prm->trim > 0 ? 1 : 0};
+    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= 1024 ? 64 : 128), prm->node_cap, prm->tile_depth, prm->mode, false, prm->trim > 0 ? 1 : 0};
     std::vector<int> nobb;
     htc.mark("units");
     rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;
@@ -434,7 +452,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         DevBuf<PSeq> d_bbs; HIPCHK(ctx, d_bbs.alloc(bbs.size()));
         if (!bbs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_bbs.p, bbs.data(), sizeof(PSeq) * bbs.size(), hipMemcpyHostToDevice, ctx->stream));
         bool any_tgs = prm->trim >= 2; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
-        HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, prm->trim >= 2 ? 1 : 0};
+        HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= 1024 ? 64 : 128), prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, prm->trim >= 2 ? 1 : 0};
         ht.mark("unit lists");
         rc = run_hierarchy(ctx, (const PSeq*)d_lay_raw.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
         ht.mark("hierarchy");

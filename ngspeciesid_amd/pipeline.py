@@ -81,7 +81,7 @@ def detect_reverse_complements(api: Api, centers, rc_identity_threshold):
 
 
 def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, w=20, abundance_ratio=0.1,
-                 rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=8, band=128, node_cap=0,
+                 rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=8, band=0, node_cap=0,
                  p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2, polish_aln_mode=2, polish_stop_when_stable=True):
     """Returns dict(rep_of, status, counters, hpc_err, centers=[(n_reads, c_id, draft, polished, groups)])."""
     T = timings if timings is not None else {}

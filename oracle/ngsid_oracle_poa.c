@@ -96,7 +96,7 @@ static inline int band_lo(const graph* G, const pseq* S, int v, int BW) {
     return (int)lo;
 }
 
-static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW, ppair* path /* cap len+V */, int* npath) {
+static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW, ppair* path /* cap len+V */, int* npath, int* edge /* |= 1 when the traceback visits a clipped band-edge cell */) {
     const int V = G->V, L = S->len, mode = S->mode;
     int* H = malloc(sizeof(int) * (size_t)V * (size_t)BW); uint8_t* dir = malloc((size_t)V * (size_t)BW); int* lo = malloc(sizeof(int) * (size_t)V);
     for (int r = 0; r < V; ++r) lo[r] = band_lo(G, S, G->order[r], BW);
@@ -152,6 +152,7 @@ static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW,
         int j = jend;
         for (;;) {
             const int v = G->order[r]; const int d = dir[(size_t)r * BW + c]; const int type = d & 3, slot = d >> 2;
+            if ((c == 0 && lo[r] > 0) || (c == BW - 1 && lo[r] + BW - 1 < L)) *edge |= 1;      /* the optimal path may continue outside the band */
             if (type == 3) break;
             if (type == 2) { rev[nr].node = -1; rev[nr].pos = j - 1; ++nr; --j; --c; continue; }
             if (type == 0) { rev[nr].node = v; rev[nr].pos = j - 1; ++nr; --j; } else { rev[nr].node = v; rev[nr].pos = -1; ++nr; }
@@ -266,7 +267,7 @@ typedef struct { int m, n, g, band, node_cap, trim_tiles; } pprm;
 static int cap_for(int L0, int node_cap) { long c = (long)L0 * (node_cap > 0 ? node_cap : 28) / 16; if (c < L0 + 64) c = L0 + 64; return (int)c; }
 
 /* returns number of outputs appended to outs (caller frees .s/.cov) */
-static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* P, pout* outs, int want_cov) {
+static int run_tile_band(const pseq* seqs, int ns, const pseq* backbone, const pprm* P, int band, int* edge, pout* outs, int want_cov) {
     int nout = 0, maxlen = backbone ? backbone->len : 0;
     for (int i = 0; i < ns; ++i) if (seqs[i].len > maxlen) maxlen = seqs[i].len;
     int L0 = backbone ? backbone->len : (ns ? seqs[0].len : 0);
@@ -289,12 +290,12 @@ static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* 
             else { if (S->len > G.capV) continue; g_add_first(&G, S); members = 1; continue; }
         }
         int np = 0;
-        int ok = poa_align(&G, S, P->m, P->n, P->g, P->band, path, &np);
+        int ok = poa_align(&G, S, P->m, P->n, P->g, band, path, &np, edge);
         if (!ok) continue;                                   /* no valid end cell inside the band: sequence dropped */
         if (!g_add_alignment(&G, S, path, np)) {
             /* does not fit: close this graph, start a new one with this sequence */
             EMIT(); g_reset(&G); members = 0;
-            if (backbone) { g_add_first(&G, backbone); ok = poa_align(&G, S, P->m, P->n, P->g, P->band, path, &np); if (ok && g_add_alignment(&G, S, path, np)) members = 1; }
+            if (backbone) { g_add_first(&G, backbone); ok = poa_align(&G, S, P->m, P->n, P->g, band, path, &np, edge); if (ok && g_add_alignment(&G, S, path, np)) members = 1; }
             else if (S->len <= G.capV) { g_add_first(&G, S); members = 1; }
             continue;
         }
@@ -303,6 +304,18 @@ static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* 
     EMIT();
     free(path); g_free(&G);
     return nout;
+}
+
+/* Band-edge check: a tile in which any traceback touched a clipped edge of its band is redone as a whole with twice the band (up to 256
+   columns), so a path that wants to leave the band gets the room - the result then does not depend on the narrow default band. */
+static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* P, pout* outs, int want_cov) {
+    for (int band = P->band;; band *= 2) {
+        int edge = 0;
+        const int nout = run_tile_band(seqs, ns, backbone, P, band, &edge, outs, want_cov);
+        if (getenv("ODBG_EDGE")) { static long ntile = 0, nredo = 0; ++ntile; if (edge && band < 256) ++nredo; if ((ntile & 1023) == 0) fprintf(stderr, "tiles %ld redone %ld\n", ntile, nredo); }
+        if (!edge || band >= 256) return nout;
+        for (int i = 0; i < nout; ++i) { free(outs[i].s); free(outs[i].cov); }
+    }
 }
 
 /* hierarchy: level 0 = the given sequences; tiles of D in order; repeat on the tile consensuses until one is left */
@@ -339,9 +352,13 @@ static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P
     }
 }
 
+/* library default band (band <= 0): 64 columns when every read of the call is at most 1 024 bases, else 128; the band-edge check of
+   run_tile widens it per tile where a path asks for more, so the choice only decides how much work the first attempt does */
+static int default_band(const ngsid_reads_t* reads) { uint64_t mx = 0; for (uint64_t i = 0; i < reads->n; ++i) { const uint64_t l = reads->off[i + 1] - reads->off[i]; if (l > mx) mx = l; } return mx <= 1024 ? 64 : 128; }
+
 int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                              const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed) {
-    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->trim > 0 };
+    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : default_band(reads), prm->node_cap, prm->trim > 0 };
     uint64_t total = 0; int overflow = 0; cons_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         int ns = (int)(grp_off[g + 1] - grp_off[g]);
@@ -375,7 +392,7 @@ static void lv_push(layervec* L, pseq s) { if (L->n == L->cap) { L->cap = L->cap
 
 int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                       const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used) {
-    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : 128, prm->node_cap, prm->trim >= 2 };
+    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : default_band(reads), prm->node_cap, prm->trim >= 2 };
     const int W = prm->window > 0 ? prm->window : 500;
     int aln_mode = prm->aln_mode;
     if (aln_mode == 2) aln_mode = 1;

@@ -26,7 +26,7 @@ def _run(gpu_api, n, nsp, L, mu, k, w, ab, seed, abundance=None):
     sp, rd = bench.gen_sorted_reads(gpu_api, n, nsp, L, mu, seed=seed, device=dev, abundance=abundance)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     res = pipeline.run_hot_path(gpu_api, rs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=k, w=w, abundance_ratio=ab, racon_iter=3,
-                                tile_depth=8, band=128, p_shared=select_p_table(k, w), polish_stop_when_stable=False)
+                                tile_depth=8, band=0, p_shared=select_p_table(k, w), polish_stop_when_stable=False)
     return sp, rd, rs, res
 
 

@@ -31,7 +31,7 @@ def test_noisy_whole_path_consensus_equals_amplicon(gpu_api, cfg):
     sp, rd = bench.gen_sorted_reads(gpu_api, n, 5, 750, mu, seed=seed, device=dev)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     res = pipeline.run_hot_path(gpu_api, rs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=13, w=20, abundance_ratio=0.02, racon_iter=3,
-                                tile_depth=8, band=128, p_shared=select_p_table(13, 20), polish_stop_when_stable=False)
+                                tile_depth=8, band=0, p_shared=select_p_table(13, 20), polish_stop_when_stable=False)
     truths = sorted(s.tobytes().decode() for s in sp)
     assert len(res["centers"]) == 5
     got = sorted(c[3] for c in res["centers"])
