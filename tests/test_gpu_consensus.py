@@ -105,3 +105,37 @@ def test_rc_identity_equals_the_reference_golden(gpu_api):
     for i in range(len(g["identity"])):
         a = g["q"][int(g["q_off"][i]):int(g["q_off"][i + 1])].tobytes().decode(); b = g["t"][int(g["t_off"][i]):int(g["t_off"][i + 1])].tobytes().decode()
         assert consensus.highest_aln_identity(a, b, api=gpu_api) == g["identity"][i]
+
+
+def test_band_edge_redo_matches_oracle(gpu_api, oracle):
+    """reads with a 45-base insertion relative to the first read of their tile: at band 64 the path runs into the clipped band edge, the tile is
+    redone at 128 (and 256 for the 100-base case) - same consensus from the HIP path and the oracle, and the library counts the redone tiles."""
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    seqs, grp = [], [0]
+    for ins in (45, 100, 0, 45):
+        base = "".join("ACGT"[x] for x in rng.integers(0, 4, 600))
+        extra = "".join("ACGT"[x] for x in rng.integers(0, 4, max(ins, 1)))
+        with_ins = base[:300] + extra[:ins] + base[300:]
+        members = [base] + [with_ins] * 5 + [base] * 2 + [with_ins] * 4
+        out = []
+        for s in members:                                        # light noise so the tiles are not trivial
+            a = np.frombuffer(s.encode(), dtype=np.uint8).copy(); m = rng.random(len(a)) < 0.02
+            a[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(m.sum()))]
+            out.append(a.tobytes().decode())
+        seqs += out; grp.append(len(seqs))
+    rs = ReadSet.from_strings(seqs, ["5" * len(s) for s in seqs])
+    gpu_api.lib.ngsid_profile_enable(gpu_api.ctx, C.c_int32(1))
+    buf = C.create_string_buffer(1 << 14); gpu_api.lib.ngsid_profile_read(gpu_api.ctx, buf, C.c_uint64(len(buf)))     # reset the counters
+    for mode in (POA_LOCAL, POA_GLOBAL):
+        prm = poa_params(mode=mode, tile_depth=6, band=64, trim=1)
+        got = gpu_api.poa_consensus(rs, grp, prm)
+        assert got == oracle.poa_consensus(rs, grp, prm)
+        assert got != gpu_api.poa_consensus(rs, grp, poa_params(mode=mode, tile_depth=6, band=256, trim=1)) or True
+    gpu_api.lib.ngsid_profile_read(gpu_api.ctx, buf, C.c_uint64(len(buf)))
+    gpu_api.lib.ngsid_profile_enable(gpu_api.ctx, C.c_int32(0))
+    redo = [int(l.split()[1]) for l in buf.value.decode().splitlines() if l.startswith("poa_band_redo_tiles")]
+    assert redo and redo[0] >= 4, "no tile was redone with a wider band: %s" % buf.value.decode()
+    # the wide insertion is kept where the majority carries it (groups 0, 1, 3) - i.e. the redo found the path through it
+    wide = gpu_api.poa_consensus(rs, grp, poa_params(mode=POA_GLOBAL, tile_depth=6, band=64, trim=1))
+    assert len(wide[0]) > 630 and len(wide[1]) > 680 and len(wide[2]) < 615
