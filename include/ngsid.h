@@ -183,6 +183,23 @@ int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid
                      const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                      uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used);
 
+/* (f2) Host-side ingest / egress helpers of the drop-in CLI (no device work, multi-threaded; csrc/host_io.hip).  They replace the per-record
+ * Python of readfq (help_functions.py:13-42) and of the writers (get_sorted_fastq_for_cluster.py:174-177, NGSpeciesID:99-120,
+ * consensus.py:203-215).
+ * ngsid_host_fastq_index: index of a plain 4-line FASTQ in memory; call with rec == NULL to count (*n_records), then with arrays of that size:
+ *   rec[4r..4r+3] = offsets of name (after '@'), sequence, '+' line, quality; returns 1 when the buffer is not a plain 4-line FASTQ (the caller
+ *   falls back to the general reader).
+ * ngsid_host_gather: dst[dst_off[i] .. +len[i]) = src[src_off[i] .. +len[i]).
+ * ngsid_host_normalize_bases: in place, a..z -> A..Z, then anything outside ACGTN -> N; *changed = bytes altered.
+ * ngsid_host_write_records: kind 0 = FASTQ records "@name sfx \n seq \n+\n qual \n", kind 1 = TSV lines "pre \t name \n" for reads idx[0..n); sfx / pre are
+ *   CSR strings per OUTPUT record (sfx_off NULL = none); first_token != 0 cuts the name at the first blank (consensus.py:213). */
+int32_t ngsid_host_fastq_index(const uint8_t* buf, uint64_t len, uint64_t* rec, uint32_t* name_len, uint32_t* seq_len, uint64_t cap_records, uint64_t* n_records);
+int32_t ngsid_host_gather(const uint8_t* src, const uint64_t* src_off, const uint32_t* len, uint64_t n, uint8_t* dst, const uint64_t* dst_off);
+int32_t ngsid_host_normalize_bases(uint8_t* seq, uint64_t len, uint64_t* changed);
+int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
+                                 const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
+                                 const uint8_t* sfx, const uint64_t* sfx_off, const uint8_t* seq, const uint8_t* qual, const uint64_t* off);
+
 /* Measurement hooks (bench.py): when enabled every kernel launch of this ctx is bracketed by HIP events on the
  * ctx's own stream; ngsid_profile_read synchronises and writes "kernel_name launches total_ms\n" lines (and resets). */
 int32_t ngsid_profile_enable(ngsid_ctx* ctx, int32_t on);

@@ -20,7 +20,16 @@ def single_clustering(read_array, p_emp_probs, args):
     return clusters, representatives
 
 
-def main(args):
+def main(args, api=None):
+    """The CLI's work: the array path (fastpath.py).  NGSID_CLI_REFERENCE_SHAPED=1 selects the dict / file layer below instead (same results;
+    it exists for callers of the reference's Python functions and as a cross-check in the tests)."""
+    if os.environ.get("NGSID_CLI_REFERENCE_SHAPED") == "1":
+        return main_reference_shaped(args)
+    from . import fastpath
+    return fastpath.main(args, api=api)
+
+
+def main_reference_shaped(args):
     args.outfile = os.path.join(args.outfolder, "sorted.fastq")
     sorted_reads_fastq_file = get_sorted_fastq_for_cluster.main(args)
     with open(sorted_reads_fastq_file) as f:
@@ -107,6 +116,8 @@ def cli(argv=None):
         args.k, args.w = 13, 20
     if args.medaka or args.primer_file or args.remove_universal_tails:
         logging.error("--medaka / --primer_file / --remove_universal_tails are outside the accelerated hot path (see DESIGN.md); not available."); sys.exit(1)
+    if args.k > 21 or args.k < 1:
+        logging.error('k = %d is outside what the minimizer encoder of this build handles (1..21).' % args.k); sys.exit(1)
     if 100 < args.w or args.w < args.k:
         logging.error('Please specify a window of size larger or equal to k, and smaller than 100.'); sys.exit(1)
     if args.outfolder and not os.path.exists(args.outfolder):

@@ -1,0 +1,135 @@
+// host_io.hip - (f2) host-side ingest / egress helpers of the drop-in CLI: FASTQ indexing, CSR gathers and FASTQ / FASTA / TSV record
+// assembly, multi-threaded, no device work.  They replace the per-record Python of the reference's readfq / writers
+// (modules/help_functions.py:13-42, modules/get_sorted_fastq_for_cluster.py:174-177, NGSpeciesID:99-120, modules/consensus.py:203-215)
+// so that a million-read run spends its host time in memcpy-speed loops.  Plain C-ABI like the rest of include/ngsid.h.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <thread>
+#include <vector>
+#include <algorithm>
+#include "../../include/ngsid.h"
+
+namespace {
+int n_threads(uint64_t work_bytes)
+{
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 4;
+    if (const char* e = getenv("NGSID_HOST_THREADS")) { int v = atoi(e); if (v > 0) hw = (unsigned)v; }
+    const uint64_t by_size = work_bytes / (4u << 20) + 1;           // at least 4 MB per thread
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw, 32u), by_size));
+}
+template <class F> void parallel_ranges(uint64_t n, int T, F f)
+{
+    if (T <= 1 || n < 2) { f(0, n, 0); return; }
+    std::vector<std::thread> th; th.reserve(T);
+    for (int t = 0; t < T; ++t) { const uint64_t a = n * t / T, b = n * (t + 1) / T; th.emplace_back([=] { f(a, b, t); }); }
+    for (auto& x : th) x.join();
+}
+}  // namespace
+
+// Index of a plain 4-line FASTQ held in memory.  Pass 1 (rec == NULL): counts the lines, checks the structure, returns the number of
+// records in *n_records.  Pass 2: fills, per record r, rec[4r..4r+3] = offsets of the name (after '@'), the sequence, the '+' line and the
+// quality string, and name_len / seq_len.  Returns 0 = ok, 1 = not a plain 4-line FASTQ (multi-line records, FASTA, truncated file, a
+// quality string whose length differs ...): the caller then uses the general reader.
+extern "C" int32_t ngsid_host_fastq_index(const uint8_t* buf, uint64_t len, uint64_t* rec, uint32_t* name_len, uint32_t* seq_len,
+                                          uint64_t cap_records, uint64_t* n_records)
+{
+    if (!buf || !n_records) return NGSID_ERR_ARG;
+    const int T = n_threads(len);
+    std::vector<uint64_t> cnt(T + 1, 0);
+    parallel_ranges(len, T, [&](uint64_t a, uint64_t b, int t) { uint64_t c = 0; const uint8_t* p = buf + a; const uint8_t* e = buf + b;
+        while (p < e) { const uint8_t* q = (const uint8_t*)memchr(p, '\n', (size_t)(e - p)); if (!q) break; ++c; p = q + 1; } cnt[t + 1] = c; });
+    for (int t = 0; t < T; ++t) cnt[t + 1] += cnt[t];
+    uint64_t nlines = cnt[T];
+    const bool tail = len > 0 && buf[len - 1] != '\n';            // last line without a newline
+    if (tail) ++nlines;
+    if (nlines % 4 != 0) return 1;
+    *n_records = nlines / 4;
+    if (!rec) return 0;
+    if (cap_records < nlines / 4) return NGSID_ERR_CAPACITY;
+    // line starts: thread t writes the starts of the lines that BEGIN after a newline found in its range
+    std::vector<uint64_t> starts(nlines + 1);
+    starts[0] = 0;
+    parallel_ranges(len, T, [&](uint64_t a, uint64_t b, int t) { uint64_t k = cnt[t] + 1; const uint8_t* p = buf + a; const uint8_t* e = buf + b;
+        while (p < e) { const uint8_t* q = (const uint8_t*)memchr(p, '\n', (size_t)(e - p)); if (!q) break; if (k <= nlines) starts[k] = (uint64_t)(q + 1 - buf); ++k; p = q + 1; } });
+    if (tail) starts[nlines] = len + 1;                           // virtual newline behind the last line
+    const uint64_t nr = nlines / 4;
+    std::vector<int> bad(T, 0);
+    parallel_ranges(nr, n_threads(nr * 64), [&](uint64_t a, uint64_t b, int t) {
+        for (uint64_t r = a; r < b; ++r) {
+            const uint64_t s0 = starts[4 * r], s1 = starts[4 * r + 1], s2 = starts[4 * r + 2], s3 = starts[4 * r + 3], s4 = starts[4 * r + 4];
+            if (s0 >= len || buf[s0] != '@' || s2 >= len || buf[s2] != '+') { bad[t] = 1; return; }
+            const uint64_t sl = s2 - 1 - s1, ql = s4 - 1 - s3;
+            if (sl != ql || sl > 0xffffffffull || s1 - 1 - (s0 + 1) > 0xffffffffull) { bad[t] = 1; return; }
+            rec[4 * r] = s0 + 1; rec[4 * r + 1] = s1; rec[4 * r + 2] = s2; rec[4 * r + 3] = s3;
+            name_len[r] = (uint32_t)(s1 - 1 - (s0 + 1)); seq_len[r] = (uint32_t)sl;
+        } });
+    for (int t = 0; t < (int)bad.size(); ++t) if (bad[t]) return 1;
+    return 0;
+}
+
+// dst[dst_off[i] .. +len[i]) = src[src_off[i] .. +len[i]) for i < n  (CSR gather / scatter of variable-length byte records)
+extern "C" int32_t ngsid_host_gather(const uint8_t* src, const uint64_t* src_off, const uint32_t* len, uint64_t n, uint8_t* dst, const uint64_t* dst_off)
+{
+    if ((!src || !dst || !src_off || !dst_off || !len) && n) return NGSID_ERR_ARG;
+    uint64_t total = 0; for (uint64_t i = 0; i < n; ++i) total += len[i];
+    parallel_ranges(n, n_threads(total), [&](uint64_t a, uint64_t b, int) { for (uint64_t i = a; i < b; ++i) memcpy(dst + dst_off[i], src + src_off[i], len[i]); });
+    return NGSID_OK;
+}
+
+// In place: upper-case a..z, everything that is then not one of A C G T N becomes N.  Returns the number of bytes changed in *changed
+// (soft-masked / IUPAC / U bases: the reference clusters them as literal characters, this build as N - see DESIGN.md).
+extern "C" int32_t ngsid_host_normalize_bases(uint8_t* seq, uint64_t len, uint64_t* changed)
+{
+    if (!seq && len) return NGSID_ERR_ARG;
+    const int T = n_threads(len); std::vector<uint64_t> c(T, 0);
+    parallel_ranges(len, T, [&](uint64_t a, uint64_t b, int t) { uint64_t k = 0;
+        for (uint64_t i = a; i < b; ++i) { uint8_t ch = seq[i]; if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 32);
+            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N') ch = 'N'; if (ch != seq[i]) { seq[i] = ch; ++k; } } c[t] = k; });
+    uint64_t tot = 0; for (auto v : c) tot += v; if (changed) *changed = tot;
+    return NGSID_OK;
+}
+
+// Record writer.  Output record j (j < n) is built from read idx[j]:
+//   kind 0 (FASTQ):  '@' name sfx_j '\n' seq '\n' '+' '\n' qual '\n'
+//   kind 1 (TSV):    pre_j '\t' name '\n'                                  (final_clusters.tsv: pre_j = the cluster's output id)
+// name = names[name_off[i] .. +name_len[i]) truncated at the first white space when first_token != 0; sfx / pre are CSR strings indexed by j
+// (sfx_off == NULL: none).  The file is created (append == 0) or appended to.  Returns NGSID_ERR_ARG when the file cannot be written.
+extern "C" int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
+                                            const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
+                                            const uint8_t* sfx, const uint64_t* sfx_off,
+                                            const uint8_t* seq, const uint8_t* qual, const uint64_t* off)
+{
+    if (!path || (n && (!idx || !names || !name_off || !name_len))) return NGSID_ERR_ARG;
+    if (kind == 0 && n && (!seq || !qual || !off)) return NGSID_ERR_ARG;
+    FILE* f = fopen(path, append ? "ab" : "wb"); if (!f) return NGSID_ERR_ARG;
+    const uint64_t CH = 1u << 16;                                       // records per chunk
+    std::vector<uint64_t> roff; std::vector<uint8_t> out; std::vector<uint32_t> nl;
+    int32_t rc = NGSID_OK;
+    for (uint64_t c0 = 0; c0 < n && rc == NGSID_OK; c0 += CH) {
+        const uint64_t c1 = std::min(n, c0 + CH), m = c1 - c0;
+        roff.assign(m + 1, 0); nl.assign(m, 0);
+        parallel_ranges(m, n_threads(m * 256), [&](uint64_t a, uint64_t b, int) { for (uint64_t x = a; x < b; ++x) {
+            const uint64_t j = c0 + x, i = idx[j]; uint32_t L = name_len[i];
+            if (first_token) { const uint8_t* p = names + name_off[i]; uint32_t k = 0; while (k < L && p[k] != ' ' && !(p[k] >= 9 && p[k] <= 13)) ++k;      /* str.split() white space */ L = k; }
+            nl[x] = L;
+            const uint64_t sl = sfx_off ? sfx_off[j + 1] - sfx_off[j] : 0;
+            roff[x + 1] = kind == 0 ? 1 + L + sl + 1 + 2 * (off[i + 1] - off[i]) + 1 + 2 + 1 : sl + 1 + L + 1; } });
+        for (uint64_t x = 0; x < m; ++x) roff[x + 1] += roff[x];
+        out.resize(roff[m]);
+        parallel_ranges(m, n_threads(roff[m]), [&](uint64_t a, uint64_t b, int) { for (uint64_t x = a; x < b; ++x) {
+            const uint64_t j = c0 + x, i = idx[j]; uint8_t* o = out.data() + roff[x];
+            const uint64_t sl = sfx_off ? sfx_off[j + 1] - sfx_off[j] : 0;
+            if (kind == 0) {
+                const uint64_t l = off[i + 1] - off[i];
+                *o++ = '@'; memcpy(o, names + name_off[i], nl[x]); o += nl[x]; if (sl) { memcpy(o, sfx + sfx_off[j], sl); o += sl; } *o++ = '\n';
+                memcpy(o, seq + off[i], l); o += l; *o++ = '\n'; *o++ = '+'; *o++ = '\n'; memcpy(o, qual + off[i], l); o += l; *o++ = '\n';
+            } else {
+                if (sl) { memcpy(o, sfx + sfx_off[j], sl); o += sl; } *o++ = '\t'; memcpy(o, names + name_off[i], nl[x]); o += nl[x]; *o++ = '\n';
+            } } });
+        if (!out.empty() && fwrite(out.data(), 1, out.size(), f) != out.size()) rc = NGSID_ERR_ARG;
+    }
+    if (fclose(f) != 0) rc = NGSID_ERR_ARG;
+    return rc;
+}

@@ -1,0 +1,129 @@
+"""(f2) FASTQ ingest and FASTQ / TSV egress on arrays: the whole file is one byte buffer, records are offset arrays, and the per-record work
+(indexing, CSR gathers, record assembly) runs in the library's multi-threaded host helpers (csrc/host_io.hip).  Files that are not plain
+4-line FASTQ (multi-line records, FASTA) go through the general reader of help_functions.readfq, which follows the reference's reader.
+
+Replaces the per-record Python of help_functions.py:13-42, get_sorted_fastq_for_cluster.py:174-177, NGSpeciesID:99-120, consensus.py:203-215.
+"""
+from __future__ import annotations
+import ctypes as C
+import numpy as np
+from . import runtime
+from ._capi import ReadSet
+from .help_functions import readfq
+
+
+class Names:
+    """accession strings as (byte buffer, offsets, lengths)"""
+
+    def __init__(self, buf, off, length):
+        self.buf = np.ascontiguousarray(buf, dtype=np.uint8); self.off = np.ascontiguousarray(off, dtype=np.uint64); self.len = np.ascontiguousarray(length, dtype=np.uint32)
+
+    def __len__(self):
+        return len(self.off)
+
+    def get(self, i):
+        a = int(self.off[i]); return self.buf[a:a + int(self.len[i])].tobytes().decode()
+
+    @staticmethod
+    def from_list(strs):
+        bs = [s.encode() for s in strs]
+        ln = np.array([len(b) for b in bs], dtype=np.uint32)
+        off = np.zeros(len(bs), dtype=np.uint64)
+        if len(bs):
+            off[1:] = np.cumsum(ln[:-1], dtype=np.uint64)
+        return Names(np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8), off, ln)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def read_fastq(path):
+    """-> (Names, ReadSet (host CSR), plain): plain = the file was a 4-line FASTQ handled by the array path."""
+    lib = runtime.load_library()
+    buf = np.fromfile(path, dtype=np.uint8)
+    n = C.c_uint64(0)
+    rc = lib.ngsid_host_fastq_index(_p(buf), C.c_uint64(len(buf)), None, None, None, C.c_uint64(0), C.byref(n))
+    if rc == 0 and n.value > 0:
+        nr = n.value
+        rec = np.zeros(4 * nr, dtype=np.uint64); nlen = np.zeros(nr, dtype=np.uint32); slen = np.zeros(nr, dtype=np.uint32)
+        rc = lib.ngsid_host_fastq_index(_p(buf), C.c_uint64(len(buf)), _p(rec), _p(nlen), _p(slen), C.c_uint64(nr), C.byref(n))
+        if rc == 0:
+            off = np.zeros(nr + 1, dtype=np.uint64); off[1:] = np.cumsum(slen, dtype=np.uint64)
+            total = int(off[-1])
+            seq = np.empty(total, dtype=np.uint8); qual = np.empty(total, dtype=np.uint8)
+            so = np.ascontiguousarray(rec[1::4]); qo = np.ascontiguousarray(rec[3::4]); do = np.ascontiguousarray(off[:-1])
+            lib.ngsid_host_gather(_p(buf), _p(so), _p(slen), C.c_uint64(nr), _p(seq), _p(do))
+            lib.ngsid_host_gather(_p(buf), _p(qo), _p(slen), C.c_uint64(nr), _p(qual), _p(do))
+            return Names(buf, np.ascontiguousarray(rec[0::4]), nlen), ReadSet(seq, qual, off), True
+    # general reader (multi-line FASTQ / FASTA / empty file)
+    accs, seqs, quals = [], [], []
+    with open(path) as f:
+        for acc, (s, q) in readfq(f):
+            accs.append(acc); seqs.append(s); quals.append(q if q is not None else "")
+    if any(len(s) != len(q) for s, q in zip(seqs, quals)):
+        raise ValueError("%s: records without (full-length) qualities - the clustering path needs FASTQ" % path)
+    return Names.from_list(accs), ReadSet.from_strings(seqs, quals), False
+
+
+def normalize_bases(seq: np.ndarray) -> int:
+    """upper-case, non-ACGTN -> N, in place; returns the number of bytes changed"""
+    lib = runtime.load_library()
+    ch = C.c_uint64(0)
+    lib.ngsid_host_normalize_bases(_p(seq), C.c_uint64(len(seq)), C.byref(ch))
+    return int(ch.value)
+
+
+def _csr(strs):
+    bs = [s if isinstance(s, bytes) else s.encode() for s in strs]
+    off = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    return (np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(1, np.uint8)), off
+
+
+def write_fastq(path, idx, names: Names, rs: ReadSet, suffixes=None, first_token=False, append=False):
+    """FASTQ records of reads idx (in that order); suffixes[j] is appended to the j-th record's name (the '_score' of sorted.fastq)."""
+    lib = runtime.load_library()
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    sb, so = (None, None) if suffixes is None else _csr(suffixes)
+    rc = lib.ngsid_host_write_records(path.encode(), C.c_int32(int(append)), C.c_int32(0), C.c_uint64(len(idx)), _p(idx), _p(names.buf), _p(names.off), _p(names.len),
+                                      C.c_int32(int(first_token)), _p(sb), _p(so), _p(rs.seq), _p(rs.qual), _p(rs.off))
+    if rc:
+        raise OSError("cannot write %s" % path)
+
+
+def write_tsv(path, idx, names: Names, prefixes, append=False):
+    """lines 'prefix<TAB>name' for reads idx; prefixes = (byte buffer, offsets) CSR or a list of strings, one per line."""
+    lib = runtime.load_library()
+    idx = np.ascontiguousarray(idx, dtype=np.uint64)
+    pb, po = prefixes if isinstance(prefixes, tuple) else _csr(prefixes)
+    rc = lib.ngsid_host_write_records(path.encode(), C.c_int32(int(append)), C.c_int32(1), C.c_uint64(len(idx)), _p(idx), _p(names.buf), _p(names.off), _p(names.len),
+                                      C.c_int32(0), _p(pb), _p(po), None, None, None)
+    if rc:
+        raise OSError("cannot write %s" % path)
+
+
+def int_prefixes(values):
+    """CSR of the decimal strings of an integer array without a Python loop over the lines."""
+    values = np.asarray(values, dtype=np.int64)
+    if len(values) == 0:
+        return np.zeros(1, np.uint8), np.zeros(1, dtype=np.uint64)
+    digits = np.ones(len(values), dtype=np.int64)
+    v = values.copy()
+    while True:
+        v //= 10
+        m = v > 0
+        if not m.any():
+            break
+        digits += m
+    off = np.zeros(len(values) + 1, dtype=np.uint64); off[1:] = np.cumsum(digits, dtype=np.uint64)
+    buf = np.empty(int(off[-1]), dtype=np.uint8)
+    v = values.copy(); pos = off[1:].astype(np.int64) - 1
+    lo = off[:-1].astype(np.int64)
+    alive = np.ones(len(values), dtype=bool)
+    while alive.any():
+        buf[pos[alive]] = 48 + (v[alive] % 10)
+        v //= 10; pos -= 1
+        alive &= pos >= lo
+    return buf, off

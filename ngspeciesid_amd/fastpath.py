@@ -1,0 +1,294 @@
+"""The drop-in CLI path on arrays: FASTQ in -> the reference's output files out, with ONE clustering schedule, ONE draft-consensus call and ONE
+polishing call on a resident read set (no per-read Python, no temporary per-cluster files that are read back).
+
+Same steps, same file contracts and the same results as the reference's main (NGSpeciesID:36-152) and as the reference-shaped dict layer of
+this package (cli.main_reference_shaped, kept for callers of cluster.reads_to_clusters / consensus.run_spoa / run_racon):
+  get_sorted_fastq_for_cluster.main (:124-191)  -> score_and_sort()     sorted.fastq, logfile.txt
+  length filter / sub-sampling (NGSpeciesID:54-63)
+  single_clustering / parallel_clustering      -> cluster()            (parallelize.tree_cluster for --t N: same batches, same merge rounds)
+  writers (NGSpeciesID:99-120)                 -> write_cluster_files() final_clusters.tsv, final_cluster_origins.tsv
+  form_draft_consensus / detect_reverse_complements / polish_sequences (consensus.py:249-278,148-183,186-246) -> consensus_and_polish()
+                                                                       consensus_reference_*.fasta, reads_to_consensus_*.fastq, racon_cl_id_*/consensus.fasta
+"""
+from __future__ import annotations
+import glob
+import logging
+import os
+import random
+import shutil
+from time import time
+import numpy as np
+from . import runtime, fastio, parallelize, pipeline
+from ._capi import ReadSet, cluster_params, poa_params, polish_params, POA_LOCAL
+from .hostutil import subset_reads
+from .ptable import select_p_table
+
+MAX_READ_LEN = 16384          # NGSID_MAX_READ_LEN (include/ngsid.h)
+
+
+def _repr_floats(x):
+    return [repr(v) for v in np.asarray(x, dtype=np.float64).tolist()]
+
+
+def _string_ranks(names: fastio.Names, idx, suffixes):
+    """dense rank of the strings name[idx[j]] + suffixes[j] under byte-wise comparison (= Python str order for UTF-8), equal strings equal rank:
+    the accession tie-break of cluster.py:79,174.  Fixed-width byte rows + one numpy sort instead of a Python sort of a million strings."""
+    import ctypes as C
+    n = len(idx)
+    if n == 0:
+        return np.zeros(0, dtype=np.uint32)
+    sb, so = fastio._csr(suffixes)
+    slen = np.diff(so.astype(np.int64)).astype(np.uint32)
+    nlen = names.len[idx]
+    W = int(nlen.max()) + int(slen.max()) + 1
+    buf = np.zeros(n * W, dtype=np.uint8)
+    lib = runtime.load_library()
+    row = (np.arange(n, dtype=np.uint64) * np.uint64(W))
+    lib.ngsid_host_gather(fastio._p(names.buf), fastio._p(np.ascontiguousarray(names.off[idx])), fastio._p(np.ascontiguousarray(nlen)), C.c_uint64(n), fastio._p(buf), fastio._p(row))
+    lib.ngsid_host_gather(fastio._p(sb), fastio._p(np.ascontiguousarray(so[:-1])), fastio._p(slen), C.c_uint64(n), fastio._p(buf), fastio._p(row + nlen.astype(np.uint64)))
+    rows = buf.view("S%d" % W)
+    o = np.argsort(rows, kind="stable")
+    srt = rows[o]
+    new = np.ones(n, dtype=bool); new[1:] = srt[1:] != srt[:-1]
+    rank = np.empty(n, dtype=np.uint32); rank[o] = (np.cumsum(new) - 1).astype(np.uint32)
+    return rank
+
+
+class SortedReads:
+    """the content of sorted.fastq in memory: reads in score order, original names + '_score' suffixes"""
+
+    def __init__(self, names, rs, suffixes, score, err=None):
+        self.names, self.rs, self.suffixes, self.score, self.err = names, rs, suffixes, np.asarray(score, dtype=np.float64), err
+        self.n = rs.n
+
+
+def score_and_sort(args, api):
+    """get_sorted_fastq_for_cluster.main: score, filter, stable sort by score, write sorted.fastq + logfile.txt -> SortedReads"""
+    out_path = args.outfile
+    logf = os.path.join(args.outfolder, "logfile.txt")
+    if os.path.isfile(out_path) and getattr(args, "use_old_sorted_file", False):
+        open(logf, "w").close()                                           # the reference truncates the log file before it returns (:186)
+        logging.warning("Using already existing sorted file in specified directory, in not intended, specify different outfolder or delete the current file.")
+        names, rs, _ = fastio.read_fastq(out_path)
+        # names carry the '_score' suffix already: split it off so that both entry routes hand over the same structure
+        accs = [names.get(i) for i in range(len(names))]
+        base = [a.rsplit("_", 1)[0] for a in accs]; sfx = ["_" + a.rsplit("_", 1)[1] for a in accs]
+        return SortedReads(fastio.Names.from_list(base), rs, sfx, [float(s[1:]) for s in sfx])
+    names, rs, _ = fastio.read_fastq(args.fastq)
+    lens = np.diff(rs.off.astype(np.int64))
+    if rs.n and lens.max() > 65535:
+        raise SystemExit("a read of %d bases exceeds what the read scorer handles (65 535); filter the input first" % int(lens.max()))
+    score, err, keep = api.score_reads(rs, args.k, args.quality_threshold) if rs.n else (np.zeros(0), np.zeros(0), np.zeros(0, np.uint8))
+    idx = np.nonzero(keep)[0]
+    order = idx[np.argsort(-score[idx], kind="stable")]                   # read_array.sort(key=score, reverse=True) is stable
+    sfx = ["_" + r for r in _repr_floats(score[order])]
+    fastio.write_fastq(out_path, order, names, rs, suffixes=sfx)
+    logging.debug(f"{len(order)} reads passed quality critera (avg phred Q val over {args.quality_threshold} and length > 2*k) and will be clustered.")
+    er = np.sort(err[idx])
+    with open(logf, "w") as lf:
+        if len(er):
+            lf.write("Lowest read error rate:{0}\n".format(float(er[0])))
+            lf.write("Highest read error rate:{0}\n".format(float(er[-1])))
+            lf.write("Median read error rate:{0}\n".format(float(er[int(len(er) / 2)])))
+            lf.write("Mean read error rate:{0}\n".format(float(sum(er.tolist()) / len(er))))
+        lf.write("\n")
+    sub = subset_reads(rs, order)
+    return SortedReads(fastio.Names(names.buf, names.off[order], names.len[order]), sub, sfx, score[order], err[order])
+
+
+def cluster(sr: SortedReads, sel, args, api):
+    """clusters the reads sel (indices into the sorted set, ascending = processing order).
+    -> rep_of [n] (sorted index of the final representative, self for reads outside sel), herr [n], pos [n] (position in the cluster's read list),
+       counters, acc_id [n] (dense rank of the accession 'name_score', -1 outside sel; None when all accessions are distinct)"""
+    n = sr.n
+    rep_of = np.arange(n, dtype=np.int64); herr = np.full(n, np.nan); pos = np.zeros(n, dtype=np.int64)
+    if len(sel) == 0:
+        return rep_of, herr, pos, np.zeros(4, dtype=np.uint64), None
+    lens_all = np.diff(sr.rs.off.astype(np.int64))
+    too_long = lens_all[sel] > MAX_READ_LEN
+    if too_long.any():
+        logging.warning("%d reads are longer than %d bases: they are not clustered and stay singletons (use --m / --s to filter by length)", int(too_long.sum()), MAX_READ_LEN)
+        sel = sel[~too_long]
+    sub = subset_reads(sr.rs, sel)
+    work = ReadSet(sub.seq.copy(), sub.qual, sub.off)
+    changed = fastio.normalize_bases(work.seq)
+    if changed:
+        logging.warning("%d bases outside A/C/G/T/N (lower case, IUPAC codes, U ...) are clustered as upper case / N; the output files keep the original letters", changed)
+    prm = cluster_params(k=args.k, w=args.w, min_shared=args.min_shared, min_fraction=args.min_fraction, mapped_threshold=args.mapped_threshold,
+                         aligned_threshold=args.aligned_threshold, min_prob_no_hits=args.min_prob_no_hits,
+                         symmetric=bool(getattr(args, "symmetric_map_align_thresholds", False)), p_shared=select_p_table(args.k, args.w))
+    if np.isnan(select_p_table(args.k, args.w)).all():
+        raise KeyError("no rows in the shared-minimizer table for k=%d, w=%d (NGSpeciesID:72-77)" % (args.k, args.w))
+    rank = _string_ranks(sr.names, sel, [sr.suffixes[i] for i in sel.tolist()] if len(sel) != n else sr.suffixes)
+    lens = lens_all[sel]; score = sr.score[sel]
+    counters = np.zeros(4, dtype=np.uint64)
+    if args.nr_cores > 1:
+        def fn(read_idx, prev_batch, known_err):
+            read_idx = np.asarray(read_idx, dtype=np.int64)
+            r = api.cluster_greedy(subset_reads(work, read_idx), prm, acc_rank=rank[read_idx], prev_batch=prev_batch, known_err=known_err)
+            counters[:] += r[3]
+            return r
+        rep_l, herr_l, joins = parallelize.tree_cluster(fn, lens, score, args.nr_cores, getattr(args, "batch_type", "total_nt"))
+        pos_l = parallelize.list_positions(len(sel), joins)
+    else:
+        rep_l, herr_l, st, cnt = api.cluster_greedy(work, prm, acc_rank=rank)
+        counters[:] = cnt
+        rep_l = rep_l.astype(np.int64)
+        herr_l = np.where(rep_l == np.arange(len(sel)), herr_l, np.nan)
+        # single pass: the list of a cluster is its representative followed by the joining reads in processing order
+        o = np.lexsort((np.arange(len(sel)), rep_l)); first = np.ones(len(sel), dtype=bool); first[1:] = rep_l[o][1:] != rep_l[o][:-1]
+        start = np.maximum.accumulate(np.where(first, np.arange(len(sel)), 0)); pos_l = np.empty(len(sel), dtype=np.int64); pos_l[o] = np.arange(len(sel)) - start
+    rep_of[sel] = sel[rep_l]; herr[sel] = herr_l; pos[sel] = pos_l
+    logging.debug("Passed mapping criteria:{0}".format(int(counters[0])))
+    logging.debug("Passed alignment criteria in this process:{0}".format(int(counters[1])))
+    logging.debug("Total calls to alignment module in this process:{0}".format(int(counters[2])))
+    acc_id = None
+    if len(rank) and int(rank.max()) + 1 < len(rank):                  # duplicate accessions exist (same name AND same score)
+        acc_id = np.full(n, -1, dtype=np.int64); acc_id[sel] = rank
+    return rep_of, herr, pos, counters, acc_id
+
+
+def cluster_table(sr, sel, rep_of, pos):
+    """clusters of the clustered reads: (reps in OUTPUT order [(size, score) descending, read index ascending], sizes, member index lists as CSR in the
+    reference's list order, and in file order (score descending, stable))"""
+    reps, inv, sizes = np.unique(rep_of[sel], return_inverse=True, return_counts=True)
+    out_order = np.lexsort((reps, -sr.score[reps], -sizes))               # sorted(clusters.items(), key=(len, score), reverse=True): ties keep dict order = read order
+    out_rank = np.empty(len(reps), dtype=np.int64); out_rank[out_order] = np.arange(len(reps))
+    cl = out_rank[inv]                                                     # output id of every clustered read
+    list_order = sel[np.lexsort((pos[sel], cl))]                          # cluster by cluster, the reference's list order (spoa input order)
+    file_order = sel[np.lexsort((pos[sel], -sr.score[sel], cl))]          # sorted(all_read_acc, key=score, reverse=True) is stable w.r.t. the list order
+    goff = np.zeros(len(reps) + 1, dtype=np.int64); goff[1:] = np.cumsum(sizes[out_order])
+    return reps[out_order], sizes[out_order], goff, list_order, file_order, np.sort(cl)
+
+
+def write_cluster_files(args, sr, reps, sizes, herr, file_order, cl_sorted):
+    fastio.write_tsv(os.path.join(args.outfolder, "final_clusters.tsv"), file_order, sr.names, fastio.int_prefixes(cl_sorted))
+    with open(os.path.join(args.outfolder, "final_cluster_origins.tsv"), "w") as f:
+        for out_id, r in enumerate(reps.tolist()):
+            seq, qual = sr.rs.get(r)
+            e = herr[r]
+            f.write("{0}\t{1}\t{2}\t{3}\t{4}\t{5}\n".format(out_id, sr.names.get(r), seq, qual, float(sr.score[r]), "" if np.isnan(e) else float(e)))
+    return int((sizes > 1).sum())
+
+
+def consensus_and_polish(args, sr, reps, sizes, goff, list_order, abundance_cutoff, api, acc_id=None):
+    """form_draft_consensus + detect_reverse_complements + polish_sequences on the resident read set; writes the reference's files"""
+    nsel = int((sizes >= abundance_cutoff).sum())                          # clusters are in (size, score) order already: the selected ones are a prefix
+    singles = int((sizes == 1).sum()) if abundance_cutoff > 1 else 0
+    disc = sizes[(sizes < abundance_cutoff) & (sizes > 1)]
+    logging.debug(f"{singles} singletons were discarded")
+    logging.debug(f"{len(disc)} clusters were discarded due to not passing the abundance_cutoff: a total of {int(disc.sum())} reads were discarded. "
+                  f"Highest abundance among them: {int(disc.max()) if len(disc) else 0} reads.")
+    for folder in glob.glob(os.path.join(args.outfolder, "racon_cl_id_*")):
+        shutil.rmtree(folder)
+    for file in glob.glob(os.path.join(args.outfolder, "consensus_reference_*")):
+        os.remove(file)
+    if nsel == 0:
+        return []
+    work = ReadSet(sr.rs.seq.copy(), sr.rs.qual, sr.rs.off)
+    fastio.normalize_bases(work.seq)
+    mx = args.max_seqs_for_consensus
+    groups = []                                                            # per selected cluster: its reads in list order, truncated (consensus.py:260)
+    for c in range(nsel):
+        a, b = int(goff[c]), int(goff[c + 1])
+        if mx >= 0:
+            b = min(b, a + mx)
+        groups.append(list_order[a:b])
+    sub_off = np.concatenate(([0], np.cumsum([len(g) for g in groups]))).astype(np.uint64)
+    long_reads = bool(np.diff(sr.rs.off.astype(np.int64))[np.concatenate(groups)].max() > 1000)
+    node_cap = 22 if long_reads else 0
+    drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=8, band=0, node_cap=node_cap, trim=pipeline.DRAFT_TRIM),
+                               read_order=np.concatenate(groups).astype(np.uint32))
+    centers = [[int(sizes[c]), int(reps[c]), drafts[c], [c]] for c in range(nsel)]
+    merged = pipeline.detect_reverse_complements(api, centers, args.rc_identity_threshold)
+    logging.debug(f"{len(merged)} consensus formed.")
+    pooled = []
+    for nr, c_id, center, cs in merged:
+        with open(os.path.join(args.outfolder, "consensus_reference_{0}.fasta".format(c_id)), "w") as f:
+            f.write(">{0}\n{1}\n".format("consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr), center))
+        parts = []
+        for c in cs:                                       # every source file is de-duplicated by header (a dict, consensus.py:210-212): first position, last content
+            g = groups[c]
+            if acc_id is not None and len(g) > 1:
+                key = acc_id[g]
+                u, first = np.unique(key, return_index=True)
+                if len(u) < len(g):
+                    _, last_rev = np.unique(key[::-1], return_index=True)
+                    last = len(g) - 1 - last_rev                   # u is sorted the same way in both calls
+                    o = np.argsort(first, kind="stable")
+                    g = g[last[o]]
+            parts.append(g)
+        ids = np.concatenate(parts)
+        pooled.append(ids)
+        _write_pooled(os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(c_id)), ids, sr)
+    if getattr(args, "racon", False) and args.racon_iter >= 0:
+        p_off = np.concatenate(([0], np.cumsum([len(x) for x in pooled]))).astype(np.uint64)
+        bb = ReadSet.from_strings([m[2] for m in merged])
+        polished, used = api.polish(bb, work, p_off, polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=8, band=0, node_cap=node_cap, trim=2),
+                                    read_order=np.concatenate(pooled).astype(np.uint32))
+        for x, (nr, c_id, center, cs) in enumerate(merged):
+            logging.debug("running racon on spoa reference {0} using {1} reads for polishing.".format(c_id, len(pooled[x])))
+            folder = os.path.join(args.outfolder, "racon_cl_id_{0}".format(c_id))
+            os.makedirs(folder, exist_ok=True)
+            open(os.path.join(folder, "stdout.txt"), "w").close()
+            name = "consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr)
+            last = os.path.join(folder, "racon_polished_it_{0}.fasta".format(max(args.racon_iter - 1, 0)))
+            with open(last, "w") as f:
+                f.write(">{0} LN:i:{1} RC:i:{2} XC:f:1.000000\n{3}\n".format(name, len(polished[x]), int(used[x]), polished[x]))
+            shutil.copyfile(last, os.path.join(folder, "consensus.fasta"))
+            merged[x][2] = polished[x]
+    return merged
+
+
+def _write_pooled(path, ids, sr):
+    # names in the pooled file = first token of the sorted-file accession "name_score" (consensus.py:213): the suffix belongs to the name, so the
+    # cut is applied to name + suffix; names with blanks lose their suffix with everything behind the blank
+    blank = np.zeros(len(ids), dtype=bool)
+    if len(ids):
+        nb = sr.names
+        # a name contains a blank iff its first token is shorter than the name (checked on the few names that do contain one)
+        spaces = np.flatnonzero((nb.buf == 32) | ((nb.buf >= 9) & (nb.buf <= 13)))           # str.split() white space
+        if len(spaces):
+            a = nb.off[ids].astype(np.int64); b = a + nb.len[ids].astype(np.int64)
+            lo = np.searchsorted(spaces, a, "left"); hi = np.searchsorted(spaces, b, "left")
+            blank = hi > lo
+    sfx = [("" if bl else sr.suffixes[int(i)]) for i, bl in zip(ids.tolist(), blank.tolist())]
+    fastio.write_fastq(path, ids, sr.names, sr.rs, suffixes=sfx, first_token=True)
+
+
+def main(args, api=None):
+    api = api or runtime.get_api()
+    T = {}
+    t0 = time()
+    args.outfile = os.path.join(args.outfolder, "sorted.fastq")
+    sr = score_and_sort(args, api)
+    T["ingest_score_sort"] = time() - t0; t0 = time()
+    sel = np.arange(sr.n, dtype=np.int64)
+    if args.target_length > 0 and args.target_deviation > 0:
+        lens = np.diff(sr.rs.off.astype(np.int64))
+        sel = sel[(lens >= args.target_length - args.target_deviation) & (lens <= args.target_length + args.target_deviation)]
+        logging.debug("Number of reads with read length in interval [{0},{1}]: {2}".format(args.target_length - args.target_deviation, args.target_length + args.target_deviation, len(sel)))
+    if args.top_reads:
+        sel = sel[:args.sample_size]
+    elif 0 < args.sample_size < len(sel):
+        sel = sel[np.asarray(sorted(random.sample(range(len(sel)), args.sample_size)), dtype=np.int64)]
+    abundance_cutoff = int(args.abundance_ratio * len(sel))
+    logging.info(f"Starting Clustering: {len(sel)} reads")
+    rep_of, herr, pos, counters, acc_id = cluster(sr, sel, args, api)
+    T["cluster"] = time() - t0; t0 = time()
+    logging.debug(f"Time elapsed clustering: {T['cluster']}")
+    reps, sizes, goff, list_order, file_order, cl_sorted = cluster_table(sr, sel, rep_of, pos)
+    nontrivial = write_cluster_files(args, sr, reps, sizes, herr, file_order, cl_sorted)
+    T["write_clusters"] = time() - t0; t0 = time()
+    logging.debug(f"Nr clusters larger than 1: {nontrivial}")
+    logging.debug(f"Nr clusters (all): {len(reps)}")
+    logging.info(f"Finished Clustering: {nontrivial} clusters formed")
+    merged = []
+    if args.consensus:
+        logging.info("Starting Consensus creation and polishing")
+        logging.debug(f"Forming draft consensus with abundance_cutoff >= {abundance_cutoff} ({args.abundance_ratio * 100}% of {len(sel)} reads)")
+        merged = consensus_and_polish(args, sr, reps, sizes, goff, list_order, abundance_cutoff, api, acc_id)
+        T["consensus_polish"] = time() - t0
+        logging.info(f"Finished Consensus creation: {len(merged)} created")
+    logging.debug("stage seconds: %s" % {k: round(v, 3) for k, v in T.items()})
+    return dict(n_sorted=sr.n, n_clustered=len(sel), clusters=len(reps), centers=merged, timings=T, counters=counters)

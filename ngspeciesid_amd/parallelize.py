@@ -17,11 +17,13 @@ def batch_list_total_nt(lens, nr_cores):
     lens = np.asarray(lens, dtype=np.int64)
     tot = int(lens.sum())
     chunk = int(tot / nr_cores) + 1
-    out, start, cur = [], 0, 0
-    for i, L in enumerate(lens):
-        cur += int(L)
-        if cur >= chunk:
-            out.append((start, i + 1)); start = i + 1; cur = 0
+    cs = np.cumsum(lens)
+    out, start, base = [], 0, 0
+    while start < len(lens):                                   # one searchsorted per batch instead of a Python loop over the reads
+        i = int(np.searchsorted(cs, base + chunk, side="left"))    # first read at which the running sum since `start` reaches the chunk
+        if i >= len(lens):
+            break
+        out.append((start, i + 1)); start = i + 1; base = int(cs[i])
     out.append((start, len(lens)))
     return out
 
@@ -54,7 +56,8 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
       bidx[i] >= 1 with HPC error rate herr[i]); the multi-GPU path runs round 1 on the ranks, all-gathers the
       representatives and enters here for the merge rounds only.
     Returns (rep_of [N] global representative per read, herr [N] (NaN where unknown), joins)
-    where joins lists (joining_rep, new_rep) in the order the reference moves read lists (cluster.py:338-345).
+    where joins lists, per cluster_fn call, the arrays (joining_reps, new_reps) in the order the reference moves read lists
+    (cluster.py:338-345); within one call nothing joins a read that itself joined (a joined read is no representative any more).
     """
     N = len(lens)
     rep_of = np.arange(N, dtype=np.int64)
@@ -94,8 +97,8 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
             rep_local, he, st, _ = cluster_fn(idx, pb, ke)
             rep_g = idx[np.asarray(rep_local, dtype=np.int64)]
             moved = rep_g != idx
-            for a, b in zip(idx[moved], rep_g[moved]):             # processing order = cluster_to_new_cluster_id order
-                joins.append((int(a), int(b)))
+            if moved.any():
+                joins.append((idx[moved].copy(), rep_g[moved].copy()))      # one entry per call, in processing order = cluster_to_new_cluster_id order
             rep_of[idx[moved]] = rep_g[moved]
             surv = idx[~moved]
             known = ~np.isnan(np.asarray(he)[~moved])
@@ -127,11 +130,41 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
 
 
 def cluster_lists_from_joins(N, joins):
-    """Replay of clusters[new].append(...) / del clusters[old] (cluster.py:338-345) -> {rep: [member indices in the reference's list order]}."""
+    """Replay of clusters[new].append(...) / del clusters[old] (cluster.py:338-345) -> {rep: [member indices in the reference's list order]}.
+    Plain dict / list replay (small inputs, tests); list_positions() is the array form of the same order."""
     clusters = {i: [i] for i in range(N)}
-    for a, b in joins:
-        clusters[b].extend(clusters[a]); del clusters[a]
+    for aa, bb in joins:
+        for a, b in zip(np.asarray(aa).tolist(), np.asarray(bb).tolist()):
+            clusters[b].extend(clusters[a]); del clusters[a]
     return clusters
+
+
+def list_positions(N, joins):
+    """Position of every read in the read list of its final cluster (the order cluster.py:338-345 builds: a joining representative's whole list
+    is appended to the list of the representative it joins), without replaying lists: the joins form a forest, the final list is its
+    pre-order with children in join order, so  pos(x) = pos(parent) + [size of the parent's list before x's call] + [sizes of the children that
+    joined the same parent earlier in that call]; the sums along the ancestor chains are taken by pointer jumping."""
+    size = np.ones(N, dtype=np.int64); rel = np.zeros(N, dtype=np.int64); parent = np.arange(N, dtype=np.int64)
+    for aa, bb in joins:
+        a = np.asarray(aa, dtype=np.int64); b = np.asarray(bb, dtype=np.int64)
+        if len(a) == 0:
+            continue
+        sa = size[a]
+        o = np.argsort(b, kind="stable"); bs = b[o]; sas = sa[o]
+        csum = np.cumsum(sas) - sas
+        first = np.ones(len(bs), dtype=bool); first[1:] = bs[1:] != bs[:-1]
+        gstart = csum[first][np.cumsum(first) - 1]
+        rel[a[o]] = size[bs] + (csum - gstart)
+        parent[a] = b
+        np.add.at(size, b, sa)
+    pos = rel.copy(); p = parent.copy()
+    while True:
+        gp = p[p]
+        pos = pos + np.where(p != np.arange(N), pos[p], 0)
+        if np.array_equal(gp, p):
+            break
+        p = gp
+    return pos
 
 
 def parallel_clustering(read_array, p_emp_probs, args, api=None):

@@ -1,0 +1,74 @@
+"""CPU: the array path of the CLI (ngspeciesid_amd.fastpath) against the reference-shaped dict / file layer of this package and against the
+reference's own output files, with the oracle as the C-ABI backend (the same comparison runs on the HIP library in tests/test_gpu_cli.py)."""
+import hashlib, os, shutil, tempfile
+import numpy as np
+import pytest
+from oracle_lib import GOLD
+from ngspeciesid_amd import cli, fastpath
+
+
+def _run(api, extra, shaped, fastq=None, monkeypatch=None):
+    out = tempfile.mkdtemp()
+    args = cli.build_parser().parse_args(["--ont", "--fastq", fastq or os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", out] + extra)
+    args.k, args.w = 13, 20
+    if shaped:
+        cli.main_reference_shaped(args)
+    else:
+        fastpath.main(args, api=api)
+    files = {}
+    for root, _, fs in os.walk(out):
+        for f in fs:
+            files[os.path.relpath(os.path.join(root, f), out)] = open(os.path.join(root, f), "rb").read()
+    shutil.rmtree(out)
+    return files
+
+
+@pytest.fixture()
+def oracle_backend(oracle, monkeypatch):
+    from ngspeciesid_amd import runtime
+    monkeypatch.setattr(runtime, "get_api", lambda device=None: oracle)          # the dict layer asks runtime for its backend
+    return oracle
+
+
+@pytest.mark.parametrize("extra", [["--t", "1"], ["--t", "8"], ["--t", "1", "--consensus", "--racon", "--racon_iter", "2"],
+                                   ["--t", "4", "--consensus", "--racon", "--racon_iter", "1", "--abundance_ratio", "0.01"],
+                                   ["--t", "2", "--m", "620", "--s", "40", "--top_reads", "--sample_size", "150"]])
+def test_array_path_writes_the_same_files_as_the_dict_layer(oracle_backend, extra):
+    a = _run(oracle_backend, extra, True); b = _run(oracle_backend, extra, False)
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert a[k] == b[k], k
+    if extra == ["--t", "1"]:                                  # and the reference's own files (tests/golden, written by the reference CLI)
+        assert b["final_clusters.tsv"] == open(os.path.join(GOLD, "sample_h1_t1_final_clusters.tsv"), "rb").read()
+        assert hashlib.md5(b["sorted.fastq"]).hexdigest() == open(os.path.join(GOLD, "sample_h1_t1_sorted.fastq.md5")).read().strip()
+
+
+def test_soft_masked_iupac_and_overlong_reads_do_not_abort(oracle_backend, tmp_path, caplog):
+    """a lower-case / IUPAC base or one over-long read used to abort the run after sorted.fastq was written.  Now: such bases are
+    clustered as upper case / N (the files keep the original letters) and reads beyond NGSID_MAX_READ_LEN stay singletons, both with a warning."""
+    src = open(os.path.join(GOLD, "sample_h1.fastq")).read().split("\n")
+    recs = [src[i:i + 4] for i in range(0, len(src) - 3, 4)]
+    recs[3][1] = recs[3][1][:50].lower() + recs[3][1][50:]                       # soft-masked prefix
+    recs[7][1] = recs[7][1][:20] + "RYKM" + recs[7][1][24:]                      # IUPAC codes
+    long_seq = (recs[0][1] * 30)[:17000]
+    recs.append(["@too_long_read", long_seq, "+", "I" * len(long_seq)])
+    fq = tmp_path / "in.fastq"; fq.write_text("\n".join("\n".join(r) for r in recs) + "\n")
+    import logging
+    with caplog.at_level(logging.WARNING):
+        files = _run(oracle_backend, ["--t", "1"], False, fastq=str(fq))
+    assert "stay singletons" in caplog.text and "clustered as upper case / N" in caplog.text
+    srt = files["sorted.fastq"].decode()
+    assert recs[3][1] in srt and recs[7][1] in srt and long_seq in srt            # original letters in the output
+    lines = files["final_clusters.tsv"].decode().splitlines()
+    ids = {l.split("\t")[1]: int(l.split("\t")[0]) for l in lines}
+    assert sum(1 for l in lines if int(l.split("\t")[0]) == ids["too_long_read"]) == 1          # a singleton
+    ref = _run(oracle_backend, ["--t", "1"], False)
+    big = lambda f: sorted(np.bincount([int(l.split(b"\t")[0]) for l in f["final_clusters.tsv"].splitlines()]).tolist(), reverse=True)[:2]
+    assert big(files) == big(ref)                                                  # the masked / IUPAC reads still join their clusters
+
+
+def test_unsupported_k_is_refused_before_any_output(tmp_path):
+    out = tmp_path / "o"
+    with pytest.raises(SystemExit):
+        cli.cli(["--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", str(out), "--k", "25", "--w", "30"])
+    assert not os.path.exists(out / "sorted.fastq")

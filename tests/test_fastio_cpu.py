@@ -1,0 +1,63 @@
+"""CPU: the host ingest / egress helpers of the library (csrc/host_io.hip through ngspeciesid_amd.fastio) against the package's general reader
+(which follows the reference's readfq) and against plain Python formatting.  No GPU needed: these entry points do no device work."""
+import os
+import numpy as np
+import pytest
+from oracle_lib import GOLD
+from ngspeciesid_amd import fastio
+from ngspeciesid_amd.help_functions import readfq
+
+
+def _general(path):
+    with open(path) as f:
+        return [(a, s, q) for a, (s, q) in readfq(f)]
+
+
+def test_read_fastq_equals_general_reader():
+    path = os.path.join(GOLD, "sample_h1.fastq")
+    names, rs, plain = fastio.read_fastq(path)
+    ref = _general(path)
+    assert plain and rs.n == len(ref) == len(names)
+    for i, (a, s, q) in enumerate(ref):
+        assert names.get(i) == a and rs.get(i) == (s, q)
+
+
+def test_irregular_files_use_the_general_reader(tmp_path):
+    p = tmp_path / "multi.fastq"
+    p.write_text("@r1 desc\nACGT\nAC\n+\nIIII\nII\n@r2\nGG\n+\n##\n")                 # multi-line record
+    names, rs, plain = fastio.read_fastq(str(p))
+    assert not plain and [names.get(i) for i in range(2)] == ["r1 desc", "r2"] and rs.get(0) == ("ACGTAC", "IIIIII") and rs.get(1) == ("GG", "##")
+    p2 = tmp_path / "nonl.fastq"
+    p2.write_text("@a\nACGT\n+\nIIII\n@b\nTT\n+\n!!")                                     # no trailing newline: still the array path
+    names, rs, plain = fastio.read_fastq(str(p2))
+    assert plain and rs.n == 2 and rs.get(1) == ("TT", "!!") and names.get(1) == "b"
+    p3 = tmp_path / "plusq.fastq"
+    p3.write_text("@a\nACGT\n+\n@III\n@b\nTT\n+\n+!\n")                                   # quality strings starting with '@' / '+'
+    names, rs, plain = fastio.read_fastq(str(p3))
+    assert plain and rs.get(0) == ("ACGT", "@III") and rs.get(1) == ("TT", "+!")
+    p4 = tmp_path / "empty.fastq"; p4.write_text("")
+    names, rs, plain = fastio.read_fastq(str(p4))
+    assert rs.n == 0
+
+
+def test_writers(tmp_path):
+    names, rs, _ = fastio.read_fastq(os.path.join(GOLD, "sample_h1.fastq"))
+    idx = np.array([5, 0, 279, 17], dtype=np.uint64)
+    out = str(tmp_path / "o.fastq")
+    fastio.write_fastq(out, idx, names, rs, suffixes=["_1.5", "_22.0", "", "_x"])
+    exp = "".join("@%s%s\n%s\n+\n%s\n" % (names.get(int(i)), sfx, *rs.get(int(i))) for i, sfx in zip(idx, ["_1.5", "_22.0", "", "_x"]))
+    assert open(out).read() == exp
+    fastio.write_fastq(out, idx[:2], names, rs, first_token=True, append=True)
+    exp += "".join("@%s\n%s\n+\n%s\n" % (names.get(int(i)).split()[0], *rs.get(int(i))) for i in idx[:2])
+    assert open(out).read() == exp
+    tsv = str(tmp_path / "o.tsv")
+    fastio.write_tsv(tsv, idx, names, fastio.int_prefixes([0, 0, 7, 1234567]))
+    assert open(tsv).read() == "".join("%d\t%s\n" % (p, names.get(int(i))) for p, i in zip([0, 0, 7, 1234567], idx))
+    b, o = fastio.int_prefixes(np.array([0, 9, 10, 99, 100, 12345678901]))
+    assert [b[int(o[i]):int(o[i + 1])].tobytes().decode() for i in range(6)] == ["0", "9", "10", "99", "100", "12345678901"]
+
+
+def test_normalize_bases():
+    a = np.frombuffer(b"ACGTNacgtnRYKMUu-*xACGT", dtype=np.uint8).copy()
+    ch = fastio.normalize_bases(a)
+    assert a.tobytes() == b"ACGTNACGTNNNNNNNNNNACGT" and ch == 14

@@ -37,6 +37,51 @@ def test_cli_consensus_racon(gpu_api, tmp_path):
     assert os.path.exists(os.path.join(out, "reads_to_consensus_%s.fastq" % cid))
 
 
+def _files(out):
+    res = {}
+    for root, _, fs in os.walk(out):
+        for f in fs:
+            res[os.path.relpath(os.path.join(root, f), out)] = open(os.path.join(root, f), "rb").read()
+    return res
+
+
+@pytest.mark.parametrize("extra", [["--t", "1", "--consensus", "--racon", "--racon_iter", "3"], ["--t", "8", "--consensus", "--racon", "--racon_iter", "2", "--abundance_ratio", "0.01"],
+                                   ["--t", "2", "--m", "620", "--s", "40", "--top_reads", "--sample_size", "150"]])
+def test_cli_array_path_equals_reference_shaped_layer(gpu_api, tmp_path, monkeypatch, extra):
+    """the array path (default) and the dict / file layer that mirrors the reference's Python functions write byte-identical files (HIP backend)"""
+    from ngspeciesid_amd.cli import cli
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    cli(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", a] + extra)
+    monkeypatch.setenv("NGSID_CLI_REFERENCE_SHAPED", "1")
+    cli(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", b] + extra)
+    fa, fb = _files(a), _files(b)
+    assert sorted(fa) == sorted(fb)
+    for k in fa:
+        assert fa[k] == fb[k], k
+
+
+def test_cli_synthetic_100k_consensus_equals_amplicons(gpu_api, tmp_path):
+    """file in -> files out at C2 scale with 5 species: every racon_cl_id_*/consensus.fasta equals a generating amplicon, final_clusters.tsv is pure"""
+    from ngspeciesid_amd import synth, fastio
+    from ngspeciesid_amd._capi import ReadSet
+    from ngspeciesid_amd.cli import cli
+    sp = synth.make_species(5, 750, 0.15, seed=1)
+    rd = synth.make_reads(sp, 100000, mu=17.0, seed=9)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    spc = rd["species"].numpy()
+    names = fastio.Names.from_list(["r%d_sp%d" % (i, spc[i]) for i in range(rs.n)])
+    fq = str(tmp_path / "in.fastq"); fastio.write_fastq(fq, np.arange(rs.n), names, rs)
+    out = str(tmp_path / "out")
+    cli(["--ont", "--fastq", fq, "--outfolder", out, "--t", "1", "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", "0.02"])
+    truths = sorted(s.tobytes().decode() for s in sp)
+    got = sorted(open(os.path.join(out, d, "consensus.fasta")).read().split("\n")[1] for d in os.listdir(out) if d.startswith("racon_cl_id_"))
+    assert got == truths
+    cl = {}
+    for line in open(os.path.join(out, "final_clusters.tsv")):
+        cid, acc = line.rstrip("\n").split("\t"); cl.setdefault(int(cid), set()).add(acc.rsplit("_sp", 1)[1])
+    assert all(len(v) == 1 for k, v in cl.items() if k < 5)
+
+
 @pytest.mark.parametrize("tag,t", [("sample_h1", 8), ("synth2k_d15", 8), ("synth600_d10_q14", 4)])
 def test_tree_merge(gpu_api, tag, t):
     run_tree(gpu_api, tag, t)
