@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-step", action="store_true", help="skip the extra step with stop_when_stable (profiling runs that count per-step traffic)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the file-in -> files-out leg (the drop-in CLI on the same reads, reported as config.cli)")
+    ap.add_argument("--cli-t", type=int, default=1, help="--t of the CLI leg (the reference's batch count; 1 = one clustering pass)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --reads per GPU, an independent set per rank.  strong: ONE global score-sorted set of --reads reads, rank g gets batch g+1 of the "
                          "reference's `--t N` partition (parallelize.batch_list total_nt), so the N-GPU membership is the reference's --t N membership of that set")
@@ -236,6 +238,33 @@ def main():
         dtc = time.perf_counter() - tc
         cpu = {"value": round(ns / dtc, 2), "unit": "reads/s", "cores": 1, "kind": "port",
                "sample": "%d reads strided from the same batch (same params, tile_depth %d), oracle/libngsid_oracle.so, %.1f s" % (ns, args.tile_depth, dtc)}
+    # ---- the drop-in surface: FASTQ file in -> the reference's output files out (python -m ngspeciesid_amd ...), same reads, same flags as C3
+    cli_leg = None
+    if not args.no_cli and world == 1:
+        import shutil, tempfile, argparse as _ap
+        from ngspeciesid_amd import fastio, fastpath, cli as _cli
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        tmp = tempfile.mkdtemp(prefix="ngsid_bench_", dir=base)
+        try:
+            hseq = rd["seq"].cpu().numpy(); hqual = rd["qual"].cpu().numpy(); hoff = rd["off"].cpu().numpy().astype(np.uint64); hsp = rd["species"].cpu().numpy()
+            hrs = ReadSet(hseq, hqual, hoff)
+            perm = np.random.default_rng(3).permutation(n)                      # the file is NOT in score order
+            names = fastio.Names.from_list(["r%d_sp%d" % (i, hsp[i]) for i in range(n)])
+            fq = os.path.join(tmp, "reads.fastq"); fastio.write_fastq(fq, perm, names, hrs)
+            in_bytes = os.path.getsize(fq)
+            outd = os.path.join(tmp, "out"); os.makedirs(outd)
+            cargs = _cli.build_parser().parse_args(["--ont", "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", "0.02"])
+            cargs.k, cargs.w = 13, 20
+            tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl
+            out_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs)
+            got = sorted(m[2] for m in r["centers"])
+            cli_leg = {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "ratio_to_hot_path": round((n / dcl) / reads_per_s, 3), "t": args.cli_t,
+                       "stage_s": {k_: round(v, 3) for k_, v in r["timings"].items()}, "input_fastq_bytes": in_bytes, "output_bytes": out_bytes,
+                       "files_on": "tmpfs (/dev/shm)" if base else "disk (tmp dir)", "consensus_equals_amplicons": got == sorted(truths),
+                       "what": "python -m ngspeciesid_amd --ont --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio 0.02: FASTQ parse, score, sort, sorted.fastq, "
+                               "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % args.cli_t}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), 750 bp ONT", "value": round(reads_per_s, 1), "unit": "reads/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
            "scaling": args.scaling if world > 1 or force_dist else "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic",
@@ -246,6 +275,7 @@ def main():
                       "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),
                       "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok}},
            "roofline": roof, "cpu_baseline": cpu}
+    if cli_leg is not None: out["config"]["cli"] = cli_leg
     if res_stop is not None: out["config"]["with_stable_stop"] = {"reads_per_s": round(n_total / dt_stop, 1), "ms_per_step": round(dt_stop * 1e3, 2), "same_result": stop_same,
                                           "note": "library default stop_when_stable=1 (not used for `value`): a cluster whose polished sequence equals its backbone is not polished again"}
     print(json.dumps(out))

@@ -192,13 +192,19 @@ int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid
  * ngsid_host_gather: dst[dst_off[i] .. +len[i]) = src[src_off[i] .. +len[i]).
  * ngsid_host_normalize_bases: in place, a..z -> A..Z, then anything outside ACGTN -> N; *changed = bytes altered.
  * ngsid_host_write_records: kind 0 = FASTQ records "@name sfx \n seq \n+\n qual \n", kind 1 = TSV lines "pre \t name \n" for reads idx[0..n); sfx / pre are
- *   CSR strings per OUTPUT record (sfx_off NULL = none); first_token != 0 cuts the name at the first blank (consensus.py:213). */
+ *   CSR strings per OUTPUT record (sfx_off NULL = none; per READ, i.e. indexed by idx[j], when sfx_by_read != 0); first_token != 0 cuts the name at the first blank (consensus.py:213). */
 int32_t ngsid_host_fastq_index(const uint8_t* buf, uint64_t len, uint64_t* rec, uint32_t* name_len, uint32_t* seq_len, uint64_t cap_records, uint64_t* n_records);
 int32_t ngsid_host_gather(const uint8_t* src, const uint64_t* src_off, const uint32_t* len, uint64_t n, uint8_t* dst, const uint64_t* dst_off);
 int32_t ngsid_host_normalize_bases(uint8_t* seq, uint64_t len, uint64_t* changed);
+/* ngsid_host_count_foreign_bases: how many bytes ngsid_host_normalize_bases would change.
+ * ngsid_host_repr_doubles: CPython's repr(float) of every value (shortest round-trip digits, Python's fixed / exponent layout), each preceded by
+ *   `prefix` (0 = none), as CSR strings in buf (32 bytes per value must be available) / off[n+1]: the "_score" name suffixes of sorted.fastq
+ *   (get_sorted_fastq_for_cluster.py:176). */
+int32_t ngsid_host_count_foreign_bases(const uint8_t* seq, uint64_t len, uint64_t* count);
+int32_t ngsid_host_repr_doubles(const double* v, uint64_t n, int32_t prefix, uint8_t* buf, uint64_t cap, uint64_t* off, uint64_t* needed);
 int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
                                  const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
-                                 const uint8_t* sfx, const uint64_t* sfx_off, const uint8_t* seq, const uint8_t* qual, const uint64_t* off);
+                                 const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read, const uint8_t* seq, const uint8_t* qual, const uint64_t* off);
 
 /* Measurement hooks (bench.py): when enabled every kernel launch of this ctx is bracketed by HIP events on the
  * ctx's own stream; ngsid_profile_read synchronises and writes "kernel_name launches total_ms\n" lines (and resets). */

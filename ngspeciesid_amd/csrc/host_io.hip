@@ -9,6 +9,8 @@
 #include <thread>
 #include <vector>
 #include <algorithm>
+#include <charconv>
+#include <cmath>
 #include "../../include/ngsid.h"
 
 namespace {
@@ -95,10 +97,10 @@ extern "C" int32_t ngsid_host_normalize_bases(uint8_t* seq, uint64_t len, uint64
 //   kind 0 (FASTQ):  '@' name sfx_j '\n' seq '\n' '+' '\n' qual '\n'
 //   kind 1 (TSV):    pre_j '\t' name '\n'                                  (final_clusters.tsv: pre_j = the cluster's output id)
 // name = names[name_off[i] .. +name_len[i]) truncated at the first white space when first_token != 0; sfx / pre are CSR strings indexed by j
-// (sfx_off == NULL: none).  The file is created (append == 0) or appended to.  Returns NGSID_ERR_ARG when the file cannot be written.
+// (sfx_off == NULL: none), or by the read index idx[j] when sfx_by_read != 0.  The file is created (append == 0) or appended to.  Returns NGSID_ERR_ARG when the file cannot be written.
 extern "C" int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
                                             const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
-                                            const uint8_t* sfx, const uint64_t* sfx_off,
+                                            const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read,
                                             const uint8_t* seq, const uint8_t* qual, const uint64_t* off)
 {
     if (!path || (n && (!idx || !names || !name_off || !name_len))) return NGSID_ERR_ARG;
@@ -114,22 +116,72 @@ extern "C" int32_t ngsid_host_write_records(const char* path, int32_t append, in
             const uint64_t j = c0 + x, i = idx[j]; uint32_t L = name_len[i];
             if (first_token) { const uint8_t* p = names + name_off[i]; uint32_t k = 0; while (k < L && p[k] != ' ' && !(p[k] >= 9 && p[k] <= 13)) ++k;      /* str.split() white space */ L = k; }
             nl[x] = L;
-            const uint64_t sl = sfx_off ? sfx_off[j + 1] - sfx_off[j] : 0;
+            const uint64_t sj = sfx_by_read ? i : j;
+            const uint64_t sl = sfx_off ? sfx_off[sj + 1] - sfx_off[sj] : 0;
             roff[x + 1] = kind == 0 ? 1 + L + sl + 1 + 2 * (off[i + 1] - off[i]) + 1 + 2 + 1 : sl + 1 + L + 1; } });
         for (uint64_t x = 0; x < m; ++x) roff[x + 1] += roff[x];
         out.resize(roff[m]);
         parallel_ranges(m, n_threads(roff[m]), [&](uint64_t a, uint64_t b, int) { for (uint64_t x = a; x < b; ++x) {
             const uint64_t j = c0 + x, i = idx[j]; uint8_t* o = out.data() + roff[x];
-            const uint64_t sl = sfx_off ? sfx_off[j + 1] - sfx_off[j] : 0;
+            const uint64_t sj = sfx_by_read ? i : j;
+            const uint64_t sl = sfx_off ? sfx_off[sj + 1] - sfx_off[sj] : 0;
             if (kind == 0) {
                 const uint64_t l = off[i + 1] - off[i];
-                *o++ = '@'; memcpy(o, names + name_off[i], nl[x]); o += nl[x]; if (sl) { memcpy(o, sfx + sfx_off[j], sl); o += sl; } *o++ = '\n';
+                *o++ = '@'; memcpy(o, names + name_off[i], nl[x]); o += nl[x]; if (sl) { memcpy(o, sfx + sfx_off[sj], sl); o += sl; } *o++ = '\n';
                 memcpy(o, seq + off[i], l); o += l; *o++ = '\n'; *o++ = '+'; *o++ = '\n'; memcpy(o, qual + off[i], l); o += l; *o++ = '\n';
             } else {
-                if (sl) { memcpy(o, sfx + sfx_off[j], sl); o += sl; } *o++ = '\t'; memcpy(o, names + name_off[i], nl[x]); o += nl[x]; *o++ = '\n';
+                if (sl) { memcpy(o, sfx + sfx_off[sj], sl); o += sl; } *o++ = '\t'; memcpy(o, names + name_off[i], nl[x]); o += nl[x]; *o++ = '\n';
             } } });
         if (!out.empty() && fwrite(out.data(), 1, out.size(), f) != out.size()) rc = NGSID_ERR_ARG;
     }
     if (fclose(f) != 0) rc = NGSID_ERR_ARG;
     return rc;
+}
+
+// Number of bases that ngsid_host_normalize_bases would change (no copy needed when it is 0).
+extern "C" int32_t ngsid_host_count_foreign_bases(const uint8_t* seq, uint64_t len, uint64_t* count)
+{
+    if ((!seq && len) || !count) return NGSID_ERR_ARG;
+    const int T = n_threads(len); std::vector<uint64_t> c(T, 0);
+    parallel_ranges(len, T, [&](uint64_t a, uint64_t b, int t) { uint64_t k = 0;
+        for (uint64_t i = a; i < b; ++i) { const uint8_t ch = seq[i]; k += !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N'); } c[t] = k; });
+    uint64_t tot = 0; for (auto v : c) tot += v; *count = tot;
+    return NGSID_OK;
+}
+
+// repr(float) of CPython 3 for every v[i] (the '_score' suffix of sorted.fastq, get_sorted_fastq_for_cluster.py:176): the shortest digit string
+// that round-trips (std::to_chars finds the same digits as CPython's dtoa mode 0), laid out by CPython's rule - fixed notation with at least
+// ".0" when -4 <= decimal exponent < 16, else d.ddde+XX with an exponent of at least two digits; inf / nan as Python prints them.
+// Each string is preceded by `prefix` when prefix != 0.  off[n+1] receives the CSR offsets; returns NGSID_ERR_CAPACITY (and *needed) when
+// buf is too small (32 bytes per value always suffice).
+extern "C" int32_t ngsid_host_repr_doubles(const double* v, uint64_t n, int32_t prefix, uint8_t* buf, uint64_t cap, uint64_t* off, uint64_t* needed)
+{
+    if ((n && (!v || !off)) || (!buf && cap)) return NGSID_ERR_ARG;
+    if (needed) *needed = n * 32;
+    if (cap < n * 32) return NGSID_ERR_CAPACITY;
+    std::vector<uint8_t> len(n);
+    parallel_ranges(n, n_threads(n * 64), [&](uint64_t a, uint64_t b, int) { for (uint64_t i = a; i < b; ++i) {
+        char* o = (char*)buf + i * 32; char* p = o; const double x = v[i];
+        if (prefix) *p++ = (char)prefix;
+        if (std::isnan(x)) { memcpy(p, "nan", 3); p += 3; }
+        else if (std::isinf(x)) { if (x < 0) *p++ = '-'; memcpy(p, "inf", 3); p += 3; }
+        else {
+            char sci[48]; auto r = std::to_chars(sci, sci + 40, x, std::chars_format::scientific); *r.ptr = 0;      // [-]d[.ddd]e[+-]XX, shortest round-trip digits
+            const char* q = sci; if (*q == '-') { *p++ = '-'; ++q; }
+            char dig[24]; int nd = 0; const char* e = q; while (e < r.ptr && *e != 'e') { if (*e != '.') dig[nd++] = *e; ++e; }
+            const int ex = atoi(e + 1);                        // decimal exponent of the first digit
+            if (ex >= -4 && ex < 16) {
+                if (ex >= 0) { for (int k = 0; k <= ex; ++k) *p++ = k < nd ? dig[k] : '0'; *p++ = '.'; if (nd > ex + 1) { for (int k = ex + 1; k < nd; ++k) *p++ = dig[k]; } else *p++ = '0'; }
+                else { *p++ = '0'; *p++ = '.'; for (int k = 0; k < -ex - 1; ++k) *p++ = '0'; for (int k = 0; k < nd; ++k) *p++ = dig[k]; }
+            } else {
+                *p++ = dig[0]; if (nd > 1) { *p++ = '.'; for (int k = 1; k < nd; ++k) *p++ = dig[k]; }
+                *p++ = 'e'; *p++ = ex < 0 ? '-' : '+'; const int ae = ex < 0 ? -ex : ex; char t[8]; int nt = 0; int z = ae; do { t[nt++] = (char)('0' + z % 10); z /= 10; } while (z);
+                if (nt < 2) t[nt++] = '0'; while (nt) *p++ = t[--nt];
+            }
+        }
+        len[i] = (uint8_t)(p - o); } });
+    // compact the 32-byte slots
+    off[0] = 0; for (uint64_t i = 0; i < n; ++i) off[i + 1] = off[i] + len[i];
+    for (uint64_t i = 0; i < n; ++i) if (off[i] != i * 32) memmove(buf + off[i], buf + i * 32, len[i]);
+    return NGSID_OK;
 }

@@ -24,6 +24,17 @@ class Names:
     def get(self, i):
         a = int(self.off[i]); return self.buf[a:a + int(self.len[i])].tobytes().decode()
 
+    def compact(self, idx):
+        """the names idx, in that order, gathered into a buffer of their own"""
+        idx = np.asarray(idx, dtype=np.int64)
+        ln = np.ascontiguousarray(self.len[idx]); so = np.ascontiguousarray(self.off[idx])
+        off = np.zeros(len(idx), dtype=np.uint64)
+        if len(idx):
+            off[1:] = np.cumsum(ln[:-1], dtype=np.uint64)
+        buf = np.empty(int(ln.sum()) if len(idx) else 0, dtype=np.uint8)
+        runtime.load_library().ngsid_host_gather(_p(self.buf), _p(so), _p(ln), C.c_uint64(len(idx)), _p(buf), _p(off))
+        return Names(buf, off, ln)
+
     @staticmethod
     def from_list(strs):
         bs = [s.encode() for s in strs]
@@ -74,6 +85,22 @@ def normalize_bases(seq: np.ndarray) -> int:
     return int(ch.value)
 
 
+def count_foreign_bases(seq: np.ndarray) -> int:
+    ch = C.c_uint64(0)
+    runtime.load_library().ngsid_host_count_foreign_bases(_p(seq), C.c_uint64(len(seq)), C.byref(ch))
+    return int(ch.value)
+
+
+def repr_doubles(values, prefix=""):
+    """CSR (bytes, offsets) of CPython's repr(float) of every value, each preceded by `prefix` (one character or empty)"""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    buf = np.empty(32 * len(v) + 32, dtype=np.uint8); off = np.zeros(len(v) + 1, dtype=np.uint64); need = C.c_uint64(0)
+    rc = runtime.load_library().ngsid_host_repr_doubles(_p(v), C.c_uint64(len(v)), C.c_int32(ord(prefix) if prefix else 0), _p(buf), C.c_uint64(len(buf)), _p(off), C.byref(need))
+    if rc:
+        raise RuntimeError("ngsid_host_repr_doubles failed (%d)" % rc)
+    return buf[:int(off[-1])].copy() if len(v) else np.zeros(1, np.uint8), off
+
+
 def _csr(strs):
     bs = [s if isinstance(s, bytes) else s.encode() for s in strs]
     off = np.zeros(len(bs) + 1, dtype=np.uint64)
@@ -82,13 +109,14 @@ def _csr(strs):
     return (np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(1, np.uint8)), off
 
 
-def write_fastq(path, idx, names: Names, rs: ReadSet, suffixes=None, first_token=False, append=False):
-    """FASTQ records of reads idx (in that order); suffixes[j] is appended to the j-th record's name (the '_score' of sorted.fastq)."""
+def write_fastq(path, idx, names: Names, rs: ReadSet, suffixes=None, first_token=False, append=False, sfx_by_read=False):
+    """FASTQ records of reads idx (in that order); a suffix is appended to each record's name (the '_score' of sorted.fastq): suffixes = list of
+    strings or a CSR (bytes, offsets), one per OUTPUT record, or one per READ (indexed by idx[j]) with sfx_by_read."""
     lib = runtime.load_library()
     idx = np.ascontiguousarray(idx, dtype=np.uint64)
-    sb, so = (None, None) if suffixes is None else _csr(suffixes)
+    sb, so = (None, None) if suffixes is None else (suffixes if isinstance(suffixes, tuple) else _csr(suffixes))
     rc = lib.ngsid_host_write_records(path.encode(), C.c_int32(int(append)), C.c_int32(0), C.c_uint64(len(idx)), _p(idx), _p(names.buf), _p(names.off), _p(names.len),
-                                      C.c_int32(int(first_token)), _p(sb), _p(so), _p(rs.seq), _p(rs.qual), _p(rs.off))
+                                      C.c_int32(int(first_token)), _p(sb), _p(so), C.c_int32(int(sfx_by_read)), _p(rs.seq), _p(rs.qual), _p(rs.off))
     if rc:
         raise OSError("cannot write %s" % path)
 
@@ -99,7 +127,7 @@ def write_tsv(path, idx, names: Names, prefixes, append=False):
     idx = np.ascontiguousarray(idx, dtype=np.uint64)
     pb, po = prefixes if isinstance(prefixes, tuple) else _csr(prefixes)
     rc = lib.ngsid_host_write_records(path.encode(), C.c_int32(int(append)), C.c_int32(1), C.c_uint64(len(idx)), _p(idx), _p(names.buf), _p(names.off), _p(names.len),
-                                      C.c_int32(0), _p(pb), _p(po), None, None, None)
+                                      C.c_int32(0), _p(pb), _p(po), C.c_int32(0), None, None, None)
     if rc:
         raise OSError("cannot write %s" % path)
 

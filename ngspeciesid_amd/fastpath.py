@@ -30,22 +30,22 @@ def _repr_floats(x):
     return [repr(v) for v in np.asarray(x, dtype=np.float64).tolist()]
 
 
-def _string_ranks(names: fastio.Names, idx, suffixes):
-    """dense rank of the strings name[idx[j]] + suffixes[j] under byte-wise comparison (= Python str order for UTF-8), equal strings equal rank:
+def _string_ranks(names: fastio.Names, sfx, idx):
+    """dense rank of the strings name[i] + suffix[i], i in idx, under byte-wise comparison (= Python str order for UTF-8), equal strings equal rank:
     the accession tie-break of cluster.py:79,174.  Fixed-width byte rows + one numpy sort instead of a Python sort of a million strings."""
     import ctypes as C
     n = len(idx)
     if n == 0:
         return np.zeros(0, dtype=np.uint32)
-    sb, so = fastio._csr(suffixes)
-    slen = np.diff(so.astype(np.int64)).astype(np.uint32)
+    sb, so = sfx
+    slen = (so[1:] - so[:-1]).astype(np.uint32)[idx]
     nlen = names.len[idx]
     W = int(nlen.max()) + int(slen.max()) + 1
     buf = np.zeros(n * W, dtype=np.uint8)
     lib = runtime.load_library()
     row = (np.arange(n, dtype=np.uint64) * np.uint64(W))
     lib.ngsid_host_gather(fastio._p(names.buf), fastio._p(np.ascontiguousarray(names.off[idx])), fastio._p(np.ascontiguousarray(nlen)), C.c_uint64(n), fastio._p(buf), fastio._p(row))
-    lib.ngsid_host_gather(fastio._p(sb), fastio._p(np.ascontiguousarray(so[:-1])), fastio._p(slen), C.c_uint64(n), fastio._p(buf), fastio._p(row + nlen.astype(np.uint64)))
+    lib.ngsid_host_gather(fastio._p(sb), fastio._p(np.ascontiguousarray(so[:-1][idx])), fastio._p(np.ascontiguousarray(slen)), C.c_uint64(n), fastio._p(buf), fastio._p(row + nlen.astype(np.uint64)))
     rows = buf.view("S%d" % W)
     o = np.argsort(rows, kind="stable")
     srt = rows[o]
@@ -55,15 +55,30 @@ def _string_ranks(names: fastio.Names, idx, suffixes):
 
 
 class SortedReads:
-    """the content of sorted.fastq in memory: reads in score order, original names + '_score' suffixes"""
+    """the content of sorted.fastq in memory: reads in score order, original names + '_score' suffixes (CSR bytes, one per read)"""
 
     def __init__(self, names, rs, suffixes, score, err=None):
-        self.names, self.rs, self.suffixes, self.score, self.err = names, rs, suffixes, np.asarray(score, dtype=np.float64), err
+        self.names, self.rs, self.score, self.err = names, rs, np.asarray(score, dtype=np.float64), err
+        self.sfx = suffixes if isinstance(suffixes, tuple) else fastio._csr(suffixes)
         self.n = rs.n
 
+    def suffix(self, i):
+        b, o = self.sfx; return b[int(o[i]):int(o[i + 1])].tobytes().decode()
 
-def score_and_sort(args, api):
+    def name_has_blank(self):
+        """per read: does the name contain white space (str.split() would cut it)?  computed once on the compact name buffer"""
+        if getattr(self, "_blank", None) is None:
+            nb = self.names
+            spaces = np.flatnonzero((nb.buf == 32) | ((nb.buf >= 9) & (nb.buf <= 13)))
+            a = nb.off.astype(np.int64); b = a + nb.len.astype(np.int64)
+            self._blank = (np.searchsorted(spaces, b, "left") > np.searchsorted(spaces, a, "left")) if len(spaces) else np.zeros(len(nb), dtype=bool)
+        return self._blank
+
+
+def score_and_sort(args, api, T=None):
     """get_sorted_fastq_for_cluster.main: score, filter, stable sort by score, write sorted.fastq + logfile.txt -> SortedReads"""
+    T = T if T is not None else {}
+    t0 = time()
     out_path = args.outfile
     logf = os.path.join(args.outfolder, "logfile.txt")
     if os.path.isfile(out_path) and getattr(args, "use_old_sorted_file", False):
@@ -75,14 +90,18 @@ def score_and_sort(args, api):
         base = [a.rsplit("_", 1)[0] for a in accs]; sfx = ["_" + a.rsplit("_", 1)[1] for a in accs]
         return SortedReads(fastio.Names.from_list(base), rs, sfx, [float(s[1:]) for s in sfx])
     names, rs, _ = fastio.read_fastq(args.fastq)
+    T["read_fastq"] = time() - t0; t0 = time()
     lens = np.diff(rs.off.astype(np.int64))
     if rs.n and lens.max() > 65535:
         raise SystemExit("a read of %d bases exceeds what the read scorer handles (65 535); filter the input first" % int(lens.max()))
     score, err, keep = api.score_reads(rs, args.k, args.quality_threshold) if rs.n else (np.zeros(0), np.zeros(0), np.zeros(0, np.uint8))
+    T["score"] = time() - t0; t0 = time()
     idx = np.nonzero(keep)[0]
     order = idx[np.argsort(-score[idx], kind="stable")]                   # read_array.sort(key=score, reverse=True) is stable
-    sfx = ["_" + r for r in _repr_floats(score[order])]
+    sfx = fastio.repr_doubles(score[order], prefix="_")                   # "_" + repr(score), as "{0}".format(score) prints a float
+    T["sort"] = time() - t0; t0 = time()
     fastio.write_fastq(out_path, order, names, rs, suffixes=sfx)
+    T["write_sorted_fastq"] = time() - t0; t0 = time()
     logging.debug(f"{len(order)} reads passed quality critera (avg phred Q val over {args.quality_threshold} and length > 2*k) and will be clustered.")
     er = np.sort(err[idx])
     with open(logf, "w") as lf:
@@ -93,10 +112,25 @@ def score_and_sort(args, api):
             lf.write("Mean read error rate:{0}\n".format(float(sum(er.tolist()) / len(er))))
         lf.write("\n")
     sub = subset_reads(rs, order)
-    return SortedReads(fastio.Names(names.buf, names.off[order], names.len[order]), sub, sfx, score[order], err[order])
+    nm = names.compact(order)                       # names of the kept reads in their own small buffer (the file buffer can go)
+    T["gather_sorted"] = time() - t0
+    return SortedReads(nm, sub, sfx, score[order], err[order])
 
 
-def cluster(sr: SortedReads, sel, args, api):
+def normalized_reads(sr: SortedReads):
+    """the read set the kernels see: upper case, everything outside ACGTN as N (the reference compares raw characters).  The copy
+    is dropped when nothing had to change."""
+    if fastio.count_foreign_bases(sr.rs.seq) == 0:
+        return sr.rs
+    seq = sr.rs.seq.copy()
+    changed = fastio.normalize_bases(seq)
+    if changed:
+        logging.warning("%d bases outside A/C/G/T/N (lower case, IUPAC codes, U ...) are clustered as upper case / N; the output files keep the original letters", changed)
+        return ReadSet(seq, sr.rs.qual, sr.rs.off)
+    return sr.rs
+
+
+def cluster(sr: SortedReads, work: ReadSet, sel, args, api):
     """clusters the reads sel (indices into the sorted set, ascending = processing order).
     -> rep_of [n] (sorted index of the final representative, self for reads outside sel), herr [n], pos [n] (position in the cluster's read list),
        counters, acc_id [n] (dense rank of the accession 'name_score', -1 outside sel; None when all accessions are distinct)"""
@@ -109,17 +143,13 @@ def cluster(sr: SortedReads, sel, args, api):
     if too_long.any():
         logging.warning("%d reads are longer than %d bases: they are not clustered and stay singletons (use --m / --s to filter by length)", int(too_long.sum()), MAX_READ_LEN)
         sel = sel[~too_long]
-    sub = subset_reads(sr.rs, sel)
-    work = ReadSet(sub.seq.copy(), sub.qual, sub.off)
-    changed = fastio.normalize_bases(work.seq)
-    if changed:
-        logging.warning("%d bases outside A/C/G/T/N (lower case, IUPAC codes, U ...) are clustered as upper case / N; the output files keep the original letters", changed)
+    work = subset_reads(work, sel)
     prm = cluster_params(k=args.k, w=args.w, min_shared=args.min_shared, min_fraction=args.min_fraction, mapped_threshold=args.mapped_threshold,
                          aligned_threshold=args.aligned_threshold, min_prob_no_hits=args.min_prob_no_hits,
                          symmetric=bool(getattr(args, "symmetric_map_align_thresholds", False)), p_shared=select_p_table(args.k, args.w))
     if np.isnan(select_p_table(args.k, args.w)).all():
         raise KeyError("no rows in the shared-minimizer table for k=%d, w=%d (NGSpeciesID:72-77)" % (args.k, args.w))
-    rank = _string_ranks(sr.names, sel, [sr.suffixes[i] for i in sel.tolist()] if len(sel) != n else sr.suffixes)
+    rank = _string_ranks(sr.names, sr.sfx, sel)
     lens = lens_all[sel]; score = sr.score[sel]
     counters = np.zeros(4, dtype=np.uint64)
     if args.nr_cores > 1:
@@ -171,7 +201,7 @@ def write_cluster_files(args, sr, reps, sizes, herr, file_order, cl_sorted):
     return int((sizes > 1).sum())
 
 
-def consensus_and_polish(args, sr, reps, sizes, goff, list_order, abundance_cutoff, api, acc_id=None):
+def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundance_cutoff, api, acc_id=None, T=None):
     """form_draft_consensus + detect_reverse_complements + polish_sequences on the resident read set; writes the reference's files"""
     nsel = int((sizes >= abundance_cutoff).sum())                          # clusters are in (size, score) order already: the selected ones are a prefix
     singles = int((sizes == 1).sum()) if abundance_cutoff > 1 else 0
@@ -185,8 +215,8 @@ def consensus_and_polish(args, sr, reps, sizes, goff, list_order, abundance_cuto
         os.remove(file)
     if nsel == 0:
         return []
-    work = ReadSet(sr.rs.seq.copy(), sr.rs.qual, sr.rs.off)
-    fastio.normalize_bases(work.seq)
+    T = T if T is not None else {}
+    t0 = time()
     mx = args.max_seqs_for_consensus
     groups = []                                                            # per selected cluster: its reads in list order, truncated (consensus.py:260)
     for c in range(nsel):
@@ -199,6 +229,7 @@ def consensus_and_polish(args, sr, reps, sizes, goff, list_order, abundance_cuto
     node_cap = 22 if long_reads else 0
     drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=8, band=0, node_cap=node_cap, trim=pipeline.DRAFT_TRIM),
                                read_order=np.concatenate(groups).astype(np.uint32))
+    T["draft_consensus"] = time() - t0; t0 = time()
     centers = [[int(sizes[c]), int(reps[c]), drafts[c], [c]] for c in range(nsel)]
     merged = pipeline.detect_reverse_complements(api, centers, args.rc_identity_threshold)
     logging.debug(f"{len(merged)} consensus formed.")
@@ -221,6 +252,7 @@ def consensus_and_polish(args, sr, reps, sizes, goff, list_order, abundance_cuto
         ids = np.concatenate(parts)
         pooled.append(ids)
         _write_pooled(os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(c_id)), ids, sr)
+    T["rc_merge_write_pooled_reads"] = time() - t0; t0 = time()
     if getattr(args, "racon", False) and args.racon_iter >= 0:
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in pooled]))).astype(np.uint64)
         bb = ReadSet.from_strings([m[2] for m in merged])
@@ -237,23 +269,19 @@ def consensus_and_polish(args, sr, reps, sizes, goff, list_order, abundance_cuto
                 f.write(">{0} LN:i:{1} RC:i:{2} XC:f:1.000000\n{3}\n".format(name, len(polished[x]), int(used[x]), polished[x]))
             shutil.copyfile(last, os.path.join(folder, "consensus.fasta"))
             merged[x][2] = polished[x]
+        T["polish"] = time() - t0
     return merged
 
 
 def _write_pooled(path, ids, sr):
     # names in the pooled file = first token of the sorted-file accession "name_score" (consensus.py:213): the suffix belongs to the name, so the
     # cut is applied to name + suffix; names with blanks lose their suffix with everything behind the blank
-    blank = np.zeros(len(ids), dtype=bool)
-    if len(ids):
-        nb = sr.names
-        # a name contains a blank iff its first token is shorter than the name (checked on the few names that do contain one)
-        spaces = np.flatnonzero((nb.buf == 32) | ((nb.buf >= 9) & (nb.buf <= 13)))           # str.split() white space
-        if len(spaces):
-            a = nb.off[ids].astype(np.int64); b = a + nb.len[ids].astype(np.int64)
-            lo = np.searchsorted(spaces, a, "left"); hi = np.searchsorted(spaces, b, "left")
-            blank = hi > lo
-    sfx = [("" if bl else sr.suffixes[int(i)]) for i, bl in zip(ids.tolist(), blank.tolist())]
-    fastio.write_fastq(path, ids, sr.names, sr.rs, suffixes=sfx, first_token=True)
+    blank = sr.name_has_blank()[ids] if len(ids) else np.zeros(0, dtype=bool)
+    if not blank.any():
+        fastio.write_fastq(path, ids, sr.names, sr.rs, suffixes=sr.sfx, first_token=True, sfx_by_read=True)
+    else:
+        sfx = [("" if bl else sr.suffix(int(i))) for i, bl in zip(ids.tolist(), blank.tolist())]
+        fastio.write_fastq(path, ids, sr.names, sr.rs, suffixes=sfx, first_token=True)
 
 
 def main(args, api=None):
@@ -261,8 +289,9 @@ def main(args, api=None):
     T = {}
     t0 = time()
     args.outfile = os.path.join(args.outfolder, "sorted.fastq")
-    sr = score_and_sort(args, api)
-    T["ingest_score_sort"] = time() - t0; t0 = time()
+    sr = score_and_sort(args, api, T)
+    work = normalized_reads(sr)
+    T["normalize"] = time() - t0 - sum(T.values()); t0 = time()
     sel = np.arange(sr.n, dtype=np.int64)
     if args.target_length > 0 and args.target_deviation > 0:
         lens = np.diff(sr.rs.off.astype(np.int64))
@@ -274,7 +303,7 @@ def main(args, api=None):
         sel = sel[np.asarray(sorted(random.sample(range(len(sel)), args.sample_size)), dtype=np.int64)]
     abundance_cutoff = int(args.abundance_ratio * len(sel))
     logging.info(f"Starting Clustering: {len(sel)} reads")
-    rep_of, herr, pos, counters, acc_id = cluster(sr, sel, args, api)
+    rep_of, herr, pos, counters, acc_id = cluster(sr, work, sel, args, api)
     T["cluster"] = time() - t0; t0 = time()
     logging.debug(f"Time elapsed clustering: {T['cluster']}")
     reps, sizes, goff, list_order, file_order, cl_sorted = cluster_table(sr, sel, rep_of, pos)
@@ -287,8 +316,7 @@ def main(args, api=None):
     if args.consensus:
         logging.info("Starting Consensus creation and polishing")
         logging.debug(f"Forming draft consensus with abundance_cutoff >= {abundance_cutoff} ({args.abundance_ratio * 100}% of {len(sel)} reads)")
-        merged = consensus_and_polish(args, sr, reps, sizes, goff, list_order, abundance_cutoff, api, acc_id)
-        T["consensus_polish"] = time() - t0
+        merged = consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundance_cutoff, api, acc_id, T)
         logging.info(f"Finished Consensus creation: {len(merged)} created")
     logging.debug("stage seconds: %s" % {k: round(v, 3) for k, v in T.items()})
     return dict(n_sorted=sr.n, n_clustered=len(sel), clusters=len(reps), centers=merged, timings=T, counters=counters)

@@ -18,7 +18,10 @@ def acc_rank(accs):
 
 
 def subset_reads(rs: ReadSet, idx) -> ReadSet:
-    """Gather reads `idx` of a HOST read set into a new contiguous host read set."""
+    """Gather reads `idx` of a HOST read set into a new contiguous host read set (record copies run in the library's multi-threaded host
+    gather, csrc/host_io.hip; a million reads are memcpy-bound instead of building a 750 M-entry index array)."""
+    import ctypes as C
+    from . import runtime
     idx = np.asarray(idx, dtype=np.int64)
     off = rs.off.astype(np.int64)
     lens = off[idx + 1] - off[idx]
@@ -27,8 +30,15 @@ def subset_reads(rs: ReadSet, idx) -> ReadSet:
     if len(idx) and np.all(np.diff(idx) == 1):           # contiguous slice: plain views
         a, b = int(off[idx[0]]), int(off[idx[-1] + 1])
         return ReadSet(rs.seq[a:b], None if rs.qual is None else rs.qual[a:b], noff)
-    src = np.repeat(off[idx] - noff[:-1].astype(np.int64), lens) + np.arange(total, dtype=np.int64)
-    return ReadSet(rs.seq[src], None if rs.qual is None else rs.qual[src], noff)
+    lib = runtime.load_library()
+    so = np.ascontiguousarray(off[idx].astype(np.uint64)); ln = np.ascontiguousarray(lens.astype(np.uint32)); do = np.ascontiguousarray(noff[:-1])
+    seq = np.empty(total, dtype=np.uint8)
+    lib.ngsid_host_gather(rs.seq.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p), C.c_uint64(len(idx)), seq.ctypes.data_as(C.c_void_p), do.ctypes.data_as(C.c_void_p))
+    qual = None
+    if rs.qual is not None:
+        qual = np.empty(total, dtype=np.uint8)
+        lib.ngsid_host_gather(rs.qual.ctypes.data_as(C.c_void_p), so.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p), C.c_uint64(len(idx)), qual.ctypes.data_as(C.c_void_p), do.ctypes.data_as(C.c_void_p))
+    return ReadSet(seq, qual, noff)
 
 
 def make_cluster_fn(api, rs: ReadSet, rank, prm):

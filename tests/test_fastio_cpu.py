@@ -61,3 +61,22 @@ def test_normalize_bases():
     a = np.frombuffer(b"ACGTNacgtnRYKMUu-*xACGT", dtype=np.uint8).copy()
     ch = fastio.normalize_bases(a)
     assert a.tobytes() == b"ACGTNACGTNNNNNNNNNNACGT" and ch == 14
+
+
+def test_repr_doubles_is_cpythons_repr():
+    """the '_score' suffix of sorted.fastq is "{0}".format(float): the native formatter must print every double exactly like CPython"""
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.random(40000) * 700, rng.random(20000) * 1e-6, rng.random(20000) * 1e20, 10.0 ** rng.integers(-30, 30, 20000) * rng.random(20000),
+                           rng.integers(0, 10 ** 17, 20000).astype(np.float64), np.frombuffer(rng.bytes(8 * 60000), dtype=np.float64),
+                           np.array([0.0, -0.0, 1.0, -1.5, 1e16, 1e15, 9999999999999998.0, 1e-4, 1e-5, 0.0001234, 123456789012345678.0, float("inf"), -float("inf"), float("nan"),
+                                     5e-324, 1.7976931348623157e308, 100.0, 0.1, 1 / 3])])
+    b, o = fastio.repr_doubles(vals, prefix="_")
+    got = [b[int(o[i]):int(o[i + 1])].tobytes().decode() for i in range(len(vals))]
+    assert got == ["_" + repr(v) for v in vals.tolist()]
+    b, o = fastio.repr_doubles([2.5, 1e22])
+    assert b.tobytes().decode() == "2.51e+22" and o.tolist() == [0, 3, 8]
+
+
+def test_count_foreign_bases():
+    a = np.frombuffer(b"ACGTNacgtRYACGT", dtype=np.uint8).copy()
+    assert fastio.count_foreign_bases(a) == 6
