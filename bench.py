@@ -55,7 +55,8 @@ def main():
     ap.add_argument("--tile-depth", type=int, default=8)
     ap.add_argument("--band", type=int, default=0, help="POA band width in columns of the first attempt (64 / 128 / 256); 0 = library default (64 for reads up to 1 024 bases)")
     ap.add_argument("--node-cap", type=int, default=0, help="POA graph capacity in 1/16 of the first sequence length (0 = library default)")
-    ap.add_argument("--cpu-sample", type=int, default=1500)
+    ap.add_argument("--cpu-sample", type=int, default=1500, help="reads per worker process of the cpu_baseline leg")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the cpu_baseline leg (0 = all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-step", action="store_true", help="skip the extra step with stop_when_stable (profiling runs that count per-step traffic)")
     ap.add_argument("--no-cli", action="store_true", help="skip the file-in -> files-out leg (the drop-in CLI on the same reads, reported as config.cli)")
@@ -204,7 +205,7 @@ def main():
         ach = alg_bytes_per_launch / avg_s / 1e9
         traffic = None
         try:    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), valid for the profiled workload size only
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
             if tj.get("workload_reads") == args.reads and dom[0] in tj and world == 1:
                 traffic = int(tj[dom[0]]["hbm_bytes_per_step"] * args.steps / max(cnt, 1))      # per launch, like `achieved`
         except Exception:
@@ -212,8 +213,8 @@ def main():
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic,
                 "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                 "note": "integer DP kernel: VALU-issue bound by construction, HBM fraction is small (DESIGN.md section 4)"}
-        if dom[0] == "k_poa_tile":      # what actually bounds it: instruction issue / the dependent chain of a DP row (SQ counters, committed PMC pass)
-            roof["valu_issue"] = {"frac": 0.41, "measured": "offline", "source": "profiles/r01_pmc_poa_tile_final.txt: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x dispatch cycles) = 41 % at four waves per SIMD; waves wait 60 % of their cycles"}
+        if dom[0] == "k_poa_tile":      # what bounds it is instruction issue along the dependent chain of a DP row: SQ counters are in the committed PMC pass (not measurable from inside this process)
+            roof["sq_counters"] = "profiles/r02_pmc_poa_tile.txt"
         if dom[0] == "k_sg_align":      # what actually bounds it: VALU issue.  17.7 VALU instructions per DP cell and lane (ISA count, k_align16.hip), 64 cells per wave instruction
             prop = torch.cuda.get_device_properties(dev)
             clk = float(getattr(prop, "clock_rate", 2400000)) * 1e3
@@ -222,22 +223,54 @@ def main():
             wi = cells / 64.0 * 17.7 / (ms / 1e3)
             roof["valu_issue"] = {"achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4),
                                   "dp_cells_per_s": round(cells / (ms / 1e3), 0)}
-    # ---- CPU baseline: the oracle (port of the reference CPU path) on a bounded sample of the same workload, 1 core
+    # ---- CPU baseline: the oracle (a scalar port of the same algorithms) on a bounded sample of the same workload: one core, and all host cores
+    #      with one batch per core like the reference's `--t N` worker processes (merge rounds not included: they are O(representatives))
     cpu = None
     if not args.no_cpu_baseline and world == 1:
+        import subprocess, tempfile, shutil
         from oracle_lib import load_oracle
+        from ngspeciesid_amd import parallelize
         orc = load_oracle()
-        ns = min(args.cpu_sample, n)
-        # sample = an evenly strided subset (keeps the score order and the species mix)
-        idx = np.linspace(0, n - 1, ns).astype(np.int64)
+        cores = os.cpu_count() or 1
+        try:
+            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            model = "unknown"
+        per_core = max(200, args.cpu_sample)
+        use = max(1, min(cores, args.cpu_cores if args.cpu_cores > 0 else cores))
+        ns = min(n, per_core * use)
+        idx = np.linspace(0, n - 1, ns).astype(np.int64)          # evenly strided subset: keeps the score order and the species mix
         seq = rd["seq"].cpu().numpy(); qual = rd["qual"].cpu().numpy(); off = rd["off"].cpu().numpy()
-        ss = [seq[off[i]:off[i + 1]].tobytes().decode() for i in idx]; qq = [qual[off[i]:off[i + 1]].tobytes().decode() for i in idx]
-        srs = ReadSet.from_strings(ss, qq)
+        from ngspeciesid_amd.hostutil import subset_reads
+        srs = subset_reads(ReadSet(seq, qual, off.astype(np.uint64)), idx)
+        kwc = {k_: v for k_, v in kw.items() if k_ != "p_shared"}
+        # (a) one core, one batch of `per_core` reads
+        one = subset_reads(srs, np.arange(min(per_core, ns)))
         tc = time.perf_counter()
-        pipeline.run_hot_path(orc, srs, rd["score"][idx], acc_rank=acc_rank[idx], **kw)
-        dtc = time.perf_counter() - tc
-        cpu = {"value": round(ns / dtc, 2), "unit": "reads/s", "cores": 1, "kind": "port",
-               "sample": "%d reads strided from the same batch (same params, tile_depth %d), oracle/libngsid_oracle.so, %.1f s" % (ns, args.tile_depth, dtc)}
+        pipeline.run_hot_path(orc, one, rd["score"][idx][:one.n], acc_rank=acc_rank[idx][:one.n], **kw)
+        dt1 = time.perf_counter() - tc
+        # (b) all cores: one worker process per batch of the reference's total_nt partition
+        tmpd = tempfile.mkdtemp(prefix="ngsid_cpu_")
+        allc = None
+        try:
+            np.savez(os.path.join(tmpd, "s.npz"), seq=srs.seq, qual=srs.qual, off=srs.off, score=rd["score"][idx], acc_rank=acc_rank[idx], p_shared=ptab, kw=json.dumps(kwc))
+            batches = [bb for bb in parallelize.batch_list_total_nt(np.diff(srs.off.astype(np.int64)), use) if bb[1] > bb[0]]
+            tc = time.perf_counter()
+            procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), os.path.join(tmpd, "s.npz"), str(a_), str(b_), os.path.join(tmpd, "o%d.json" % i)],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i, (a_, b_) in enumerate(batches)]
+            for p_ in procs: p_.wait()
+            dta = time.perf_counter() - tc
+            done = [json.load(open(os.path.join(tmpd, "o%d.json" % i))) for i in range(len(batches)) if os.path.exists(os.path.join(tmpd, "o%d.json" % i))]
+            if len(done) == len(batches):
+                allc = {"value": round(ns / dta, 1), "cores": len(batches), "wall_s": round(dta, 1), "slowest_worker_s": round(max(d_["seconds"] for d_ in done), 1)}
+        finally:
+            shutil.rmtree(tmpd, ignore_errors=True)
+        cpu = {"value": allc["value"] if allc else round(one.n / dt1, 2), "unit": "reads/s", "cores": allc["cores"] if allc else 1, "kind": "port",
+               "cpu_model": model, "host_cores": cores,
+               "one_core": {"value": round(one.n / dt1, 2), "reads": int(one.n), "seconds": round(dt1, 1)},
+               "sample": "%d reads strided from the same batch (same params, tile_depth %d): %d per worker process, one process per core running oracle/libngsid_oracle.so "
+                         "(scalar C port of this build's algorithms; the reference's own tools - parasail, spoa, racon - are SIMD codes and are not in the image, see BASELINE.md)"
+                         % (ns, args.tile_depth, per_core)}
     # ---- the drop-in surface: FASTQ file in -> the reference's output files out (python -m ngspeciesid_amd ...), same reads, same flags as C3
     cli_leg = None
     if not args.no_cli and world == 1:
