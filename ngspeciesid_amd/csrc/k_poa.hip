@@ -815,7 +815,9 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             const int ck = jk - (int)(myri & 0xffff);
             const bool loaded = (lane <= top) & ((unsigned)ck < (unsigned)BW);
             const int dk = w.dirblk()[loaded ? lane * BW + ck : 0];
-            const bool good = loaded & (dk == 0) & (((unsigned)(myri >> 56) & 16u) != 0) & (jk >= 1);
+            // a plain diagonal move to the previous rank: direction byte 0 = diagonal through the first in-edge, whose tail is one rank up
+            // (dist0 == 1; true for every chain row and for the near / generic rows whose first predecessor is the previous rank)
+            const bool good = loaded & (dk == 0) & ((((unsigned)myri >> 16) & 0xffu) == 1u) & (jk >= 1);
             const unsigned long long gm = __ballot(good);
             const unsigned long long x = gm << (63 - top);     // lane `top` at bit 63: leading ones = the run
             const int run = (~x) ? __builtin_clzll(~x) : 64;   // <= top + 1 because lanes above `top` never set their bit
