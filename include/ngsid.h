@@ -122,6 +122,15 @@ int32_t ngsid_sg_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const
                              int32_t k, const int32_t* match_id,
                              int32_t* score, int32_t* n_cols, int32_t* n_match, int32_t* region);
 
+/* (a10, boundary 8b) the alignment itself - what parasail hands back as result.cigar (cluster.py:138-144, consensus.py:64-73): for pair p the
+ * columns of the two gapped strings in alignment order, one byte each: '=' equal characters, 'X' different characters, 'I' query only, 'D' target
+ * only; free end gaps are part of it (both sequences are covered), so ops_off[p+1] - ops_off[p] = n_cols of ngsid_sg_align_batch.  ops_off has
+ * n_pairs+1 entries; NGSID_ERR_CAPACITY (+ *needed) when cap is too small (qlen + tlen per pair always suffices). */
+int32_t ngsid_sg_align_cigar_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const ngsid_reads_t* targets,
+                                   const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                                   int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,
+                                   int32_t* score, uint64_t* ops_off, uint8_t* ops, uint64_t cap, uint64_t* needed);
+
 /* (a17) the read->backbone alignment of the polisher in edit-distance mode (ngsid_polish_params_t.aln_mode = 1; racon obtains the
  * same thing from edlib, racon src/overlap.cpp find_breaking_points): pair p aligns all of query q_idx[p] inside target t_idx[p]
  * with unit costs (target ends free).  Rules as in ngsid_polish_params_t.aln_mode.  Outputs per pair (any may be NULL):
@@ -156,6 +165,10 @@ int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const ui
                             const ngsid_poa_params_t* prm,
                             uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed);
 
+/* same + per-base coverage: cov[x] = number of reads (count weight) with a base in the alignment column of consensus base x, CSR-aligned with cons */
+int32_t ngsid_poa_consensus_cov(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint32_t* cov, uint64_t cons_cap, uint64_t* needed);
+
 typedef struct {
     int32_t iters;            /* --racon_iter (NGSpeciesID:212) */
     int32_t window;           /* racon -w 500 */
@@ -182,6 +195,13 @@ typedef struct {
 int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                      const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                      uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used);
+
+/* (8e step 3, boundary 8b) the merge rounds of parallel_clustering (parallelize.py:169-217) on the all-gathered representatives of `n_batches`
+ * shards: reps = host read set with qualities, batch[i] = 1-based shard index of representative i, score / hpc_err / acc_rank as in
+ * ngsid_cluster_greedy.  rep_of[i] = index of the final representative of i.  Every round's clustering is ngsid_cluster_greedy; the schedule
+ * (who meets whom, who keeps its database) is include/ngsid_merge_schedule.h.  Deterministic: every rank computes the same map. */
+int32_t ngsid_merge_representatives(ngsid_ctx* ctx, const ngsid_reads_t* reps, const ngsid_cluster_params_t* prm, const uint32_t* acc_rank,
+                                    const double* score, const double* hpc_err, const int32_t* batch, int32_t n_batches, int32_t* rep_of);
 
 /* (f2) Host-side ingest / egress helpers of the drop-in CLI (no device work, multi-threaded; csrc/host_io.hip).  They replace the per-record
  * Python of readfq (help_functions.py:13-42) and of the writers (get_sorted_fastq_for_cluster.py:174-177, NGSpeciesID:99-120,

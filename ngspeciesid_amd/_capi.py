@@ -167,6 +167,16 @@ class Api:
         if rc: self._err(rc)
         return rep, herr, st, cnt
 
+    def merge_representatives(self, reps: ReadSet, prm: ClusterParams, score, hpc_err, batch, n_batches, acc_rank=None):
+        """merge rounds of parallel_clustering on gathered representatives -> rep_of [R] (index of the final representative)"""
+        R = reps.n
+        rep = np.zeros(R, dtype=np.int32)
+        sc = np.ascontiguousarray(score, dtype=np.float64); he = np.ascontiguousarray(hpc_err, dtype=np.float64); bt = np.ascontiguousarray(batch, dtype=np.int32)
+        ar = None if acc_rank is None else np.ascontiguousarray(acc_rank, dtype=np.uint32)
+        rc = self._call("merge_representatives", C.byref(reps.c), C.byref(prm), _p(ar), _p(sc), _p(he), _p(bt), C.c_int32(int(n_batches)), _p(rep))
+        if rc: self._err(rc)
+        return rep
+
     # ---- (a10,a15)
     def sg_align_batch(self, q: ReadSet, t: ReadSet, q_idx, t_idx, open_, ext=1, match=2, mismatch=-2, k=13, match_id=None):
         q_idx = np.ascontiguousarray(q_idx, dtype=np.uint32); t_idx = np.ascontiguousarray(t_idx, dtype=np.uint32)
@@ -178,6 +188,19 @@ class Api:
                         _p(open_), C.c_int32(ext), C.c_int32(k), _p(mid), _p(score), _p(ncols), _p(nmatch), _p(region))
         if rc: self._err(rc)
         return score, ncols, nmatch, region
+
+    def sg_align_cigar_batch(self, q: ReadSet, t: ReadSet, q_idx, t_idx, open_, ext=1, match=2, mismatch=-2):
+        """-> (score [n], list of column strings over '=XID' in alignment order, one per pair): the alignment parasail returns as a CIGAR"""
+        q_idx = np.ascontiguousarray(q_idx, dtype=np.uint32); t_idx = np.ascontiguousarray(t_idx, dtype=np.uint32)
+        n = len(q_idx)
+        open_ = np.ascontiguousarray(np.broadcast_to(np.asarray(open_, dtype=np.int32), (n,)))
+        ql = np.diff(q.off.astype(np.int64)); tl = np.diff(t.off.astype(np.int64))
+        cap = int((ql[q_idx] + tl[t_idx]).sum()) + 1 if n else 1
+        score = np.zeros(n, dtype=np.int32); off = np.zeros(n + 1, dtype=np.uint64); ops = np.zeros(cap, dtype=np.uint8); needed = C.c_uint64(0)
+        rc = self._call("sg_align_cigar_batch", C.byref(q.c), C.byref(t.c), _p(q_idx), _p(t_idx), C.c_uint64(n), C.c_int32(match), C.c_int32(mismatch),
+                        _p(open_), C.c_int32(ext), _p(score), _p(off), _p(ops), C.c_uint64(cap), C.byref(needed))
+        if rc: self._err(rc)
+        return score, [ops[int(off[p]):int(off[p + 1])].tobytes().decode() for p in range(n)]
 
     def ed_align_batch(self, q: ReadSet, t: ReadSet, q_idx, t_idx, window=500, bp_windows=0):
         """edit-distance (read inside backbone) alignment of the polisher: distance, span[n,4], bp[n,bp_windows,4]"""
@@ -201,6 +224,19 @@ class Api:
         rc = self._call("poa_consensus", C.byref(rs.c), _p(ro), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(coff), _p(cons), C.c_uint64(cap), C.byref(needed))
         if rc: self._err(rc)
         return [cons[int(coff[g]):int(coff[g + 1])].tobytes().decode() for g in range(ng)]
+
+    def poa_consensus_cov(self, rs: ReadSet, grp_off, prm: PoaParams, cap=None, read_order=None):
+        """-> [(consensus string, uint32 coverage array)] per group"""
+        grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
+        ro = None if read_order is None else np.ascontiguousarray(read_order, dtype=np.uint32)
+        ng = len(grp_off) - 1
+        if cap is None:
+            lens = np.diff(rs.off.astype(np.int64)) if rs.mem == MEM_HOST else None
+            cap = int(4 * (lens.max() if lens is not None and len(lens) else 16384) * max(ng, 1) + 1024)
+        coff = np.zeros(ng + 1, dtype=np.uint64); cons = np.zeros(cap, dtype=np.uint8); cov = np.zeros(cap, dtype=np.uint32); needed = C.c_uint64(0)
+        rc = self._call("poa_consensus_cov", C.byref(rs.c), _p(ro), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(coff), _p(cons), _p(cov), C.c_uint64(cap), C.byref(needed))
+        if rc: self._err(rc)
+        return [(cons[int(coff[g]):int(coff[g + 1])].tobytes().decode(), cov[int(coff[g]):int(coff[g + 1])].copy()) for g in range(ng)]
 
     # ---- (a16,a17)
     def polish(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None, read_order=None):

@@ -145,6 +145,8 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
             const int K = J.k; const int mid = J.match_id ? J.match_id[p] : K;
             const uint64_t kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1);
             uint64_t win = 0; int cols = 0, nm = 0, region = 0;
+            uint8_t* opp = J.ops ? J.ops + J.ops_off[p] : nullptr; int oc = 0;      // optional: the alignment columns themselves, in traceback (reverse) order
+            if (opp && lane == 0) { for (int x = n - 1; x > ei; --x) opp[oc++] = 2; for (int x = m - 1; x > ej; --x) opp[oc++] = 3; }
             {   // trailing end gaps (walked first)
                 const int z = (n - 1 - ei) + (m - 1 - ej);
                 const int zl = z < K ? z : K;             // after K zeros the window is all zero
@@ -179,6 +181,7 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
                     const int src = v & 3;
                     if (src == 0) {
                         bit = (qry[i] == tgt[j]);
+                        if (opp && lane == 0) opp[oc++] = bit ? 0 : 1;
                         if (q_end < 0) { q_end = i; t_end = j; }
                         q_beg = i; t_beg = j;
                         if (bpp) {
@@ -188,11 +191,12 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
                         }
                         --i; --j;
                     } else { state = src; emit = 0; }
-                } else if (state == 1) { if (!((v >> 2) & 1)) state = 0; --j; }
-                else { if (!((v >> 3) & 1)) state = 0; --i; }
+                } else if (state == 1) { if (opp && lane == 0) opp[oc++] = 3; if (!((v >> 2) & 1)) state = 0; --j; }
+                else { if (opp && lane == 0) opp[oc++] = 2; if (!((v >> 3) & 1)) state = 0; --i; }
                 if (emit) { win = (win << 1) | (uint64_t)bit; nm += bit; ++cols; if (cols >= K) region += ((int)__popcll(win & kmask) >= mid); }
             }
             if (lane == 0 && bpp && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
+            if (opp && lane == 0) { for (int x = i; x >= 0; --x) opp[oc++] = 2; for (int x = j; x >= 0; --x) opp[oc++] = 3; }
             {   // leading end gaps
                 const int z = (i + 1) + (j + 1);
                 const int zl = z < K ? z : K;
@@ -250,7 +254,7 @@ int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qle
     if (job.npairs > 0xf0000000ull) NGSID_FAIL(ctx, NGSID_ERR_ARG, "more than 2^32 pairs in one aligner call");
     if (max_tlen > NGSID_MAX_READ_LEN || max_qlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in aligner", NGSID_MAX_READ_LEN);
     if (job.k > 64) NGSID_FAIL(ctx, NGSID_ERR_ARG, "window k > 64 unsupported");
-    if (!getenv("NGSID_ALIGN32") && ngsid_align16_applicable(job, max_qlen, max_tlen, max_open)) return ngsid_launch_align16(ctx, job, max_qlen, max_tlen, min_qlen);   // packed int16 path (bit-identical)
+    if (!job.ops && !getenv("NGSID_ALIGN32") && ngsid_align16_applicable(job, max_qlen, max_tlen, max_open)) return ngsid_launch_align16(ctx, job, max_qlen, max_tlen, min_qlen);   // packed int16 path (bit-identical)
     if (max_qlen <= 256) return launch_rpl<4>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 512) return launch_rpl<8>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 768) return launch_rpl<12>(ctx, job, max_qlen, max_tlen);

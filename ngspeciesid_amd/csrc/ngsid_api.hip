@@ -1,5 +1,6 @@
 // ngsid_api.hip - C-ABI entry points that are thin (context, uploads, aligner batch, minimizer CSR, scoring)
 #include "ngsid_internal.h"
+#include "../../include/ngsid_merge_schedule.h"
 #include "../../include/ngsid_tables.h"
 #include <math.h>
 #include <algorithm>
@@ -143,6 +144,56 @@ int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* ou
 }
 
 // ---------------------------------------------------------------------------------------------- (a10,a15)
+// (a10, section 8b) the alignment itself: what parasail returns as result.cigar (cluster.py:138-144, consensus.py:64-73)
+extern "C" int32_t ngsid_sg_align_cigar_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const ngsid_reads_t* targets,
+                                              const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                                              int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,
+                                              int32_t* score, uint64_t* ops_off, uint8_t* ops, uint64_t cap, uint64_t* needed)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!queries || !targets || !ops_off || (n_pairs && (!q_idx || !t_idx || !open))) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    DevReads Q, T;
+    int32_t rc = ngsid_upload_reads(ctx, queries, &Q, false); if (rc) return rc;
+    rc = ngsid_upload_reads(ctx, targets, &T, false); if (rc) return rc;
+    ops_off[0] = 0;
+    if (n_pairs == 0) { if (needed) *needed = 0; return NGSID_OK; }
+    uint32_t mq = 0, mt = 0;
+    std::vector<uint64_t> h_off(n_pairs + 1, 0);
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        if (q_idx[p] >= Q.n || t_idx[p] >= T.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "pair %llu out of range", (unsigned long long)p);
+        const uint32_t ql = (uint32_t)(Q.h_off[q_idx[p] + 1] - Q.h_off[q_idx[p]]), tl = (uint32_t)(T.h_off[t_idx[p] + 1] - T.h_off[t_idx[p]]);
+        mq = std::max(mq, ql); mt = std::max(mt, tl);
+        h_off[p + 1] = h_off[p] + ql + tl;                    // capacity of the pair: every column consumes at least one base
+    }
+    DevBuf<uint32_t> dq, dt; DevBuf<int32_t> dopen, dout; DevBuf<uint64_t> doff; DevBuf<uint8_t> dops;
+    HIPCHK(ctx, dq.alloc(n_pairs)); HIPCHK(ctx, dt.alloc(n_pairs)); HIPCHK(ctx, dopen.alloc(n_pairs)); HIPCHK(ctx, dout.alloc(n_pairs * 4)); HIPCHK(ctx, doff.alloc(n_pairs + 1)); HIPCHK(ctx, dops.alloc(h_off[n_pairs] + 1));
+    HIPCHK(ctx, hipMemcpyAsync(dq.p, q_idx, 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dt.p, t_idx, 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dopen.p, open, 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(doff.p, h_off.data(), 8 * (n_pairs + 1), hipMemcpyHostToDevice, ctx->stream));
+    AlignJob J{};
+    J.qseq = Q.seq; J.qoff = Q.off; J.tseq = T.seq; J.toff = T.off; J.qidx = dq.p; J.tidx = dt.p; J.npairs = n_pairs;
+    J.match = match; J.mismatch = mismatch; J.ext = ext; J.k = 1; J.open = dopen.p; J.match_id = nullptr;
+    J.score = dout.p; J.ncols = dout.p + n_pairs; J.nmatch = nullptr; J.region = nullptr; J.bp = nullptr; J.bp_windows = 0; J.window = 1; J.span = nullptr;
+    J.ops = dops.p; J.ops_off = doff.p;
+    int mo = 0; for (uint64_t p = 0; p < n_pairs; ++p) { if (open[p] < 0) { mo = 1 << 20; break; } mo = std::max(mo, (int)open[p]); }
+    rc = ngsid_launch_align(ctx, J, mq, mt, mo); if (rc) return rc;
+    std::vector<int32_t> h(n_pairs * 2); std::vector<uint8_t> hops(h_off[n_pairs] + 1);
+    HIPCHK(ctx, hipMemcpyAsync(h.data(), dout.p, 8 * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hops.data(), dops.p, h_off[n_pairs], hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (score) memcpy(score, h.data(), 4 * n_pairs);
+    uint64_t total = 0; for (uint64_t p = 0; p < n_pairs; ++p) { total += (uint64_t)h[n_pairs + p]; ops_off[p + 1] = total; }
+    if (needed) *needed = total;
+    if (total > cap || (!ops && total)) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "ops buffer too small: need %llu bytes", (unsigned long long)total);
+    static const uint8_t sym[4] = {'=', 'X', 'I', 'D'};
+    for (uint64_t p = 0; p < n_pairs; ++p) {            // the kernel wrote the columns in traceback order: reverse them into alignment order
+        const uint64_t c = (uint64_t)h[n_pairs + p]; const uint8_t* src = hops.data() + h_off[p]; uint8_t* dst = ops + ops_off[p];
+        for (uint64_t x = 0; x < c; ++x) dst[x] = sym[src[c - 1 - x] & 3];
+    }
+    return NGSID_OK;
+}
+
 extern "C" int32_t ngsid_sg_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* queries, const ngsid_reads_t* targets,
                                         const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
                                         int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,
@@ -405,4 +456,21 @@ extern "C" int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap)
     if (out.size() + 1 > cap) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "profile buffer too small");
     memcpy(buf, out.c_str(), out.size() + 1);
     return NGSID_OK;
+}
+
+// (8e step 3, boundary 8b) the merge rounds of parallel_clustering on the all-gathered representatives (parallelize.py:169-217): schedule in
+// include/ngsid_merge_schedule.h, every round's clustering = ngsid_cluster_greedy on this GPU.  Identical on every rank.
+static int32_t merge_cb(void* user, const ngsid_reads_t* sub, const ngsid_cluster_params_t* prm, const uint32_t* acc_rank, const int32_t* prev_batch, const double* known_err,
+                        int32_t* rep_of_read, double* hpc_err_out, uint8_t* status_out)
+{
+    uint64_t counters[4];
+    return ngsid_cluster_greedy((ngsid_ctx*)user, sub, prm, acc_rank, prev_batch, known_err, rep_of_read, hpc_err_out, status_out, counters);
+}
+extern "C" int32_t ngsid_merge_representatives(ngsid_ctx* ctx, const ngsid_reads_t* reps, const ngsid_cluster_params_t* prm, const uint32_t* acc_rank,
+                                               const double* score, const double* hpc_err, const int32_t* batch, int32_t n_batches, int32_t* rep_of)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!reps || !prm || !rep_of || (reps->n && (!score || !batch))) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    if (reps->mem != NGSID_MEM_HOST || (reps->n && !reps->qual)) NGSID_FAIL(ctx, NGSID_ERR_ARG, "representatives are expected as a host read set with qualities (they are a few KB each)");
+    return ngsid_merge_schedule(merge_cb, ctx, reps, prm, acc_rank, score, hpc_err, batch, n_batches, rep_of);
 }

@@ -132,6 +132,8 @@ struct AlignJob {            // device pointers
     int32_t* bp; int bp_windows; int window; int32_t* span;  // span: per pair {q_begin,q_end,t_begin,t_end} of the aligned part
     // optional indirection (length classes): the k-th work item is pair pair_list[k], and the item count is read from device memory
     const uint32_t* pair_list; const uint32_t* npairs_dev;
+    // optional alignment columns (int32 kernel only): ops + ops_off[p] receives one byte per column in traceback (reverse) order, 0 '=' 1 'X' 2 'I' 3 'D'
+    uint8_t* ops; const uint64_t* ops_off;
 };
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20, uint32_t min_qlen = 0);   // min_qlen: lower bound of the query lengths (lets empty length classes be skipped)
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);

@@ -171,8 +171,25 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- (a13,a14)
+static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                  const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov);
+
 extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                                        const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed)
+{
+    return poa_consensus_impl(ctx, reads, read_order, grp_off, n_groups, prm, cons_off, cons, cons_cap, needed, nullptr);
+}
+
+// same, plus the per-base coverage of the consensus (boundary 8b: "consensus bytes, len, per-base coverage")
+extern "C" int32_t ngsid_poa_consensus_cov(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                           const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint32_t* cov, uint64_t cons_cap, uint64_t* needed)
+{
+    if (ctx && !cov) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null coverage buffer");
+    return poa_consensus_impl(ctx, reads, read_order, grp_off, n_groups, prm, cons_off, cons, cons_cap, needed, cov);
+}
+
+static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                  const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov)
 {
     if (!ctx) return NGSID_ERR_ARG;
     if (!reads || !grp_off || !prm || !cons_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
@@ -187,7 +204,7 @@ extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* read
     HIPCHK(ctx, hipGetLastError());
     std::vector<Unit> units(n_groups);
     for (uint64_t g = 0; g < n_groups; ++g) { units[g].seqs.reserve(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs.push_back(read_order ? read_order[r] : (uint32_t)r); }
-    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= 1024 ? 64 : 128), prm->node_cap, prm->tile_depth, prm->mode, false, prm->trim > 0 ? 1 : 0};
+    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= 1024 ? 64 : 128), prm->node_cap, prm->tile_depth, prm->mode, cov != nullptr, prm->trim > 0 ? 1 : 0};
     std::vector<int> nobb;
     htc.mark("units");
     rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;
@@ -195,7 +212,8 @@ extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* read
     uint64_t total = 0; bool overflow = false; cons_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         const std::string& s = units[g].result;
-        if (total + s.size() <= cons_cap && cons) memcpy(cons + total, s.data(), s.size()); else if (s.size()) overflow = true;
+        if (total + s.size() <= cons_cap && cons) { memcpy(cons + total, s.data(), s.size()); if (cov && units[g].cov.size() == s.size() && !s.empty()) memcpy(cov + total, units[g].cov.data(), 4 * s.size()); else if (cov) for (size_t x = 0; x < s.size(); ++x) cov[total + x] = 0; }
+        else if (s.size()) overflow = true;
         total += s.size(); cons_off[g + 1] = total;
     }
     if (needed) *needed = total;

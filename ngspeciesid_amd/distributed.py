@@ -11,7 +11,6 @@ shard, tile consensuses and window consensuses of the shard's own reads.  Collec
 Reads never move between GPUs.
 """
 from __future__ import annotations
-import pickle
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -20,23 +19,59 @@ from ._capi import ReadSet, cluster_params, poa_params, polish_params, POA_LOCAL
 from .hostutil import subset_reads
 
 
-def all_gather_bytes(blob: bytes, device):
-    """variable-length all-gather: sizes first, then one padded uint8 all_gather (RCCL on GPU, gloo on CPU)."""
+def _pack(obj: dict) -> np.ndarray:
+    """dict of numpy arrays / scalars / lists of strings -> one uint8 buffer: a small JSON header (names, dtypes, shapes) + the raw array bytes"""
+    import json
+    head, chunks = [], []
+    for k, v in obj.items():
+        if isinstance(v, (list, tuple)) and (len(v) == 0 or isinstance(v[0], str)):
+            b = [x.encode() for x in v]; lens = np.array([len(x) for x in b], dtype=np.int64)
+            head.append((k, "strlist", [len(b)])); chunks += [lens.tobytes(), b"".join(b)]
+        elif v is None:
+            head.append((k, "none", []))
+        else:
+            a = np.ascontiguousarray(v)
+            head.append((k, a.dtype.str, list(a.shape))); chunks.append(a.tobytes())
+    h = json.dumps(head).encode()
+    return np.frombuffer(np.array([len(h)], dtype=np.int64).tobytes() + h + b"".join(chunks), dtype=np.uint8)
+
+
+def _unpack(buf: np.ndarray) -> dict:
+    import json
+    hl = int(buf[:8].view(np.int64)[0]); head = json.loads(buf[8:8 + hl].tobytes().decode()); o = 8 + hl; out = {}
+    for k, dt, shape in head:
+        if dt == "none":
+            out[k] = None
+        elif dt == "strlist":
+            n = shape[0]; lens = buf[o:o + 8 * n].view(np.int64); o += 8 * n
+            strs = []
+            for l in lens.tolist():
+                strs.append(buf[o:o + l].tobytes().decode()); o += l
+            out[k] = strs
+        else:
+            cnt = int(np.prod(shape)) if shape else 1; nb = cnt * np.dtype(dt).itemsize
+            a = buf[o:o + nb].view(np.dtype(dt)).reshape(shape).copy(); o += nb
+            out[k] = a if shape else a[()]
+    return out
+
+
+def all_gather_obj(obj: dict, device):
+    """variable-length all-gather of a dict of arrays: the sizes first, then ONE padded uint8 all_gather into a single [world, max] tensor
+    (RCCL on the GPU, gloo on CPU) and one copy of that tensor to the host - the payloads (representatives, partial consensuses) are consumed
+    by host-side schedule code.  No pickling: arrays travel as raw bytes behind a JSON header."""
     world = dist.get_world_size()
+    blob = _pack(obj)
     n = torch.tensor([len(blob)], dtype=torch.int64, device=device)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    mx = int(max(int(s.item()) for s in sizes))
-    buf = torch.zeros(max(mx, 1), dtype=torch.uint8, device=device)
-    if len(blob):
-        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
-    outs = [torch.zeros(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(outs, buf)
-    return [bytes(o[:int(s.item())].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
-
-
-def all_gather_obj(obj, device):
-    return [pickle.loads(b) for b in all_gather_bytes(pickle.dumps(obj, protocol=4), device)]
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, n)
+    sizes = sizes.cpu().numpy()
+    mx = max(int(sizes.max()), 1)
+    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
+    buf[:len(blob)] = torch.from_numpy(blob.copy()).to(device)
+    out = torch.empty(world * mx, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, buf)
+    host = out.cpu().numpy().reshape(world, mx)
+    return [_unpack(host[r, :int(sizes[r])]) for r in range(world)]
 
 
 def _weighted_merge_all(api, partials, counts, band):
@@ -100,10 +135,7 @@ def merge_representatives(api, gathered, prm, world):
     else:
         r_accrank = np.arange(len(r_lidx), dtype=np.uint32)
 
-    def cfn(read_idx, prev_batch, known_err):
-        s = subset_reads(reps_rs, read_idx)
-        return api.cluster_greedy(s, prm, acc_rank=r_accrank[np.asarray(read_idx, dtype=np.int64)], prev_batch=prev_batch, known_err=known_err)
-    rep_of_rep, _, joins = parallelize.tree_cluster(cfn, lens_all, r_score, world, state=(r_batch, r_herr))
+    rep_of_rep = api.merge_representatives(reps_rs, prm, r_score, r_herr, r_batch, world, acc_rank=r_accrank).astype(np.int64)      # ngsid_merge_representatives
     return rep_of_rep, r_owner, r_lidx, r_score, n_total
 
 
@@ -149,7 +181,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
     sub_order = np.concatenate([order[a:b] for a, b in zip(lo, hi)]) if len(cand) else np.zeros(0, np.uint32)
     sub_off = np.concatenate(([0], np.cumsum(hi - lo))).astype(np.uint64)
     partial = api.poa_consensus(rs_local, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, trim=pipeline.DRAFT_TRIM), read_order=sub_order) if len(cand) else []
-    allp = all_gather_obj(dict(cons=partial, cnt=(hi - lo).tolist()), device)
+    allp = all_gather_obj(dict(cons=list(partial), cnt=np.asarray(hi - lo, dtype=np.int64)), device)
     drafts = _weighted_merge_all(api, [[p["cons"][c] for p in allp] for c in range(len(cand))], [[p["cnt"][c] for p in allp] for c in range(len(cand))], band)
     T["consensus"] = T.get("consensus", 0.0) + time.perf_counter() - t0
     # ---- 5. reverse-complement merge (identical on every rank), then polish: per iteration local window consensus + weighted merge
@@ -168,7 +200,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
         p_order = np.concatenate(p_order) if p_order else np.zeros(0, np.uint32)
         bb = ReadSet.from_strings(polished)
         loc, used = api.polish(bb, rs_local, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, trim=polish_trim, stop_when_stable=polish_stop_when_stable), read_order=p_order)
-        allq = all_gather_obj(dict(cons=loc, cnt=[int(u) for u in used]), device)
+        allq = all_gather_obj(dict(cons=list(loc), cnt=np.asarray(used, dtype=np.int64)), device)
         mg = _weighted_merge_all(api, [[q["cons"][c] for q in allq] for c in range(len(merged))], [[q["cnt"][c] for q in allq] for c in range(len(merged))], band)
         polished = [mg[c] or polished[c] for c in range(len(merged))]
     T["polish"] = T.get("polish", 0.0) + time.perf_counter() - t0

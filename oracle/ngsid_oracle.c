@@ -191,6 +191,28 @@ int32_t ongsid_sg_align_cigar(const uint8_t* q, int32_t n, const uint8_t* t, int
     return NGSID_OK;
 }
 
+int32_t ongsid_sg_align_cigar_batch(const ngsid_reads_t* Q, const ngsid_reads_t* T, const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                                    int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,
+                                    int32_t* score, uint64_t* ops_off, uint8_t* ops_out, uint64_t cap, uint64_t* needed) {
+    static const uint8_t sym[4] = { '=', 'X', 'I', 'D' };
+    uint64_t total = 0; int overflow = 0; ops_off[0] = 0;
+    for (uint64_t p = 0; p < n_pairs; ++p) {
+        uint32_t qi = q_idx[p], ti = t_idx[p];
+        const uint8_t* q = Q->seq + Q->off[qi]; int n = (int)(Q->off[qi + 1] - Q->off[qi]);
+        const uint8_t* t = T->seq + T->off[ti]; int m = (int)(T->off[ti + 1] - T->off[ti]);
+        sg_result R; sg_align(q, n, t, m, match, mismatch, open[p], ext, &R);
+        uint8_t* ops = (uint8_t*)malloc((size_t)(n + m + 1));
+        int c = sg_traceback(q, t, &R, ops);
+        if (score) score[p] = R.score;
+        if (total + (uint64_t)c <= cap && ops_out) { for (int x = 0; x < c; ++x) ops_out[total + (uint64_t)x] = sym[ops[c - 1 - x]]; } else if (c) overflow = 1;
+        total += (uint64_t)c; ops_off[p + 1] = total;
+        free(ops); free(R.tb);
+    }
+    if (needed) *needed = total;
+    if (overflow) FAIL(NGSID_ERR_CAPACITY, "ops buffer too small");
+    return NGSID_OK;
+}
+
 int32_t ongsid_sg_align_batch(const ngsid_reads_t* Q, const ngsid_reads_t* T,
                               const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
                               int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,
@@ -557,4 +579,16 @@ int ongsid_i_sg_ops(const uint8_t* q, int n, const uint8_t* t, int m, int match,
     for (int i = 0, j = c - 1; i < j; ++i, --j) { uint8_t x = ops[i]; ops[i] = ops[j]; ops[j] = x; }
     free(R.tb);
     return c;
+}
+
+/* merge rounds on gathered representatives: the shared schedule over the oracle's own clustering */
+#include "../include/ngsid_merge_schedule.h"
+static int32_t o_merge_cb(void* user, const ngsid_reads_t* sub, const ngsid_cluster_params_t* prm, const uint32_t* acc_rank, const int32_t* prev_batch, const double* known_err,
+                          int32_t* rep_of_read, double* hpc_err_out, uint8_t* status_out) {
+    uint64_t counters[4]; (void)user;
+    return ongsid_cluster_greedy(sub, prm, acc_rank, prev_batch, known_err, rep_of_read, hpc_err_out, status_out, counters);
+}
+int32_t ongsid_merge_representatives(const ngsid_reads_t* reps, const ngsid_cluster_params_t* prm, const uint32_t* acc_rank,
+                                     const double* score, const double* hpc_err, const int32_t* batch, int32_t n_batches, int32_t* rep_of) {
+    return ngsid_merge_schedule(o_merge_cb, NULL, reps, prm, acc_rank, score, hpc_err, batch, n_batches, rep_of);
 }

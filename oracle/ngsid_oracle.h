@@ -43,12 +43,19 @@ int32_t ongsid_sg_align_batch(const ngsid_reads_t* queries, const ngsid_reads_t*
                               int32_t k, const int32_t* match_id,
                               int32_t* score, int32_t* n_cols, int32_t* n_match, int32_t* region);
 /* single pair with CIGAR text (=XID, end gaps included) for the parasail-shaped shim */
+int32_t ongsid_merge_representatives(const ngsid_reads_t* reps, const ngsid_cluster_params_t* prm, const uint32_t* acc_rank,
+                                     const double* score, const double* hpc_err, const int32_t* batch, int32_t n_batches, int32_t* rep_of);
+int32_t ongsid_sg_align_cigar_batch(const ngsid_reads_t* queries, const ngsid_reads_t* targets, const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,
+                                    int32_t match, int32_t mismatch, const int32_t* open, int32_t ext,
+                                    int32_t* score, uint64_t* ops_off, uint8_t* ops, uint64_t cap, uint64_t* needed);
 int32_t ongsid_sg_align_cigar(const uint8_t* q, int32_t n, const uint8_t* t, int32_t m,
                               int32_t match, int32_t mismatch, int32_t open, int32_t ext,
                               char* cigar, int32_t cigar_cap, int32_t* score);
 int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                              const ngsid_poa_params_t* prm,
                              uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed);
+int32_t ongsid_poa_consensus_cov(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                 const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint32_t* cov, uint64_t cons_cap, uint64_t* needed);
 int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                       const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                       uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used);

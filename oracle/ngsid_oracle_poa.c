@@ -356,8 +356,19 @@ static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P
    run_tile widens it per tile where a path asks for more, so the choice only decides how much work the first attempt does */
 static int default_band(const ngsid_reads_t* reads) { uint64_t mx = 0; for (uint64_t i = 0; i < reads->n; ++i) { const uint64_t l = reads->off[i + 1] - reads->off[i]; if (l > mx) mx = l; } return mx <= 1024 ? 64 : 128; }
 
+static int32_t poa_consensus_impl(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                  const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov_out);
 int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                              const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed) {
+    return poa_consensus_impl(reads, read_order, grp_off, n_groups, prm, cons_off, cons, cons_cap, needed, NULL);
+}
+int32_t ongsid_poa_consensus_cov(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                 const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint32_t* cov, uint64_t cons_cap, uint64_t* needed) {
+    if (!cov) return NGSID_ERR_ARG;
+    return poa_consensus_impl(reads, read_order, grp_off, n_groups, prm, cons_off, cons, cons_cap, needed, cov);
+}
+static int32_t poa_consensus_impl(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                  const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov_out) {
     pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : default_band(reads), prm->node_cap, prm->trim > 0 };
     uint64_t total = 0; int overflow = 0; cons_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
@@ -368,10 +379,10 @@ int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_or
             seqs[i].s = reads->seq + reads->off[r]; seqs[i].q = reads->qual ? reads->qual + reads->off[r] : NULL; seqs[i].len = (int)(reads->off[r + 1] - reads->off[r]);
             seqs[i].uw = 1; seqs[i].cw = 1; seqs[i].mode = prm->mode; seqs[i].a0 = 0; seqs[i].a1 = -1;
         }
-        uint8_t* c = NULL; int len = run_hierarchy(seqs, ns, NULL, &P, prm->tile_depth, prm->mode, &c, NULL, 0);
-        if (total + (uint64_t)len <= cons_cap) memcpy(cons + total, c, (size_t)len); else overflow = 1;
+        uint8_t* c = NULL; uint32_t* cv = NULL; int len = run_hierarchy(seqs, ns, NULL, &P, prm->tile_depth, prm->mode, &c, cov_out ? &cv : NULL, cov_out != NULL);
+        if (total + (uint64_t)len <= cons_cap) { memcpy(cons + total, c, (size_t)len); if (cov_out) for (int x = 0; x < len; ++x) cov_out[total + (uint64_t)x] = cv ? cv[x] : 0; } else overflow = 1;
         total += (uint64_t)len; cons_off[g + 1] = total;
-        free(c); free(seqs);
+        free(c); free(cv); free(seqs);
     }
     if (needed) *needed = total;
     if (overflow) return NGSID_ERR_CAPACITY;

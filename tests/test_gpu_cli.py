@@ -85,3 +85,9 @@ def test_cli_synthetic_100k_consensus_equals_amplicons(gpu_api, tmp_path):
 @pytest.mark.parametrize("tag,t", [("sample_h1", 8), ("synth2k_d15", 8), ("synth600_d10_q14", 4)])
 def test_tree_merge(gpu_api, tag, t):
     run_tree(gpu_api, tag, t)
+
+
+@pytest.mark.parametrize("tag,t", [("sample_h1", 8), ("synth2k_d15", 8), ("synth600_d10_q14", 4)])
+def test_c_merge_representatives(gpu_api, tag, t):
+    from test_host_parallelize import run_round1_then_c_merge
+    run_round1_then_c_merge(gpu_api, tag, t)

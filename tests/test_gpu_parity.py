@@ -122,3 +122,41 @@ def test_cluster_seeded_merge_round(gpu_api, oracle):
     exp = oracle.cluster_greedy(rs, prm, acc_rank=ar, prev_batch=prev, known_err=he)
     for a, b in zip(got, exp):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_sg_align_cigar_vs_oracle(gpu_api, oracle):
+    """(boundary 8b) the alignment columns ('=XID', free end gaps included) from the HIP aligner == the oracle's, and consistent with the
+    statistics of ngsid_sg_align_batch; the parasail-shaped front returns the same CIGAR as the test shim the goldens were produced with."""
+    rng = np.random.default_rng(12)
+    qs, ts = _rand_pairs(rng, 60, 30, 900)
+    qs += ["ACGT", "A", "", "GATTACAGATTACA", "acgtNNacgt"]; ts += ["ACGT", "C", "ACG", "CCCCGATTACAGATTACATTTT", "ACGTACGT"]
+    q = ReadSet.from_strings(qs); t = ReadSet.from_strings(ts)
+    idx = np.arange(len(qs)); opens = rng.integers(2, 6, len(qs))
+    s1, o1 = gpu_api.sg_align_cigar_batch(q, t, idx, idx, opens)
+    s2, o2 = oracle.sg_align_cigar_batch(q, t, idx, idx, opens)
+    assert np.array_equal(s1, s2) and o1 == o2
+    sc, ncols, nmatch, _ = gpu_api.sg_align_batch(q, t, idx, idx, opens, 1, 2, -2, 13, None)
+    assert np.array_equal(sc, s1) and [len(o) for o in o1] == ncols.tolist() and [o.count("=") for o in o1] == nmatch.tolist()
+    for a, b, o in zip(qs, ts, o1):
+        assert o.count("=") + o.count("X") + o.count("I") == len(a) and o.count("=") + o.count("X") + o.count("D") == len(b)
+    from ngspeciesid_amd import parasail_like
+    r = parasail_like.sg_trace_scan_16(qs[0], ts[0], int(opens[0]), 1, parasail_like.matrix_create("ACGT", 2, -2), api=gpu_api)
+    assert r.score == s1[0] and not r.saturated and r.cigar.decode == parasail_like._Cigar(o1[0]).decode
+
+
+def test_poa_consensus_coverage_vs_oracle(gpu_api, oracle):
+    from ngspeciesid_amd import synth
+    from ngspeciesid_amd._capi import poa_params
+    sp = synth.make_species(3, 400, 0.15, seed=4)
+    seqs, quals, off = [], [], [0]
+    for g in range(3):
+        rd = synth.make_reads([sp[g]], 50, mu=15.0, seed=70 + g)
+        seqs.append(rd["seq"].numpy()); quals.append(rd["qual"].numpy()); off += list(off[-1] + rd["off"].numpy()[1:])
+    rs = ReadSet(np.concatenate(seqs), np.concatenate(quals), np.array(off, dtype=np.uint64))
+    for prm in (poa_params(tile_depth=8, band=64, trim=1), poa_params(tile_depth=0, band=128, node_cap=64), poa_params(tile_depth=8, band=128, trim=0)):
+        a = gpu_api.poa_consensus_cov(rs, [0, 50, 100, 150], prm); b = oracle.poa_consensus_cov(rs, [0, 50, 100, 150], prm)
+        assert [x[0] for x in a] == [x[0] for x in b]
+        for x, y in zip(a, b):
+            assert np.array_equal(x[1], y[1])
+        assert [x[0] for x in a] == gpu_api.poa_consensus(rs, [0, 50, 100, 150], prm)
+        assert all(int(x[1].max()) <= 50 and len(x[1]) == len(x[0]) for x in a)

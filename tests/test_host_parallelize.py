@@ -41,3 +41,30 @@ def run_tree(api, tag, t):
                                    ("synth600_d10_q14", 4), ("synth300_ccs", 4)])
 def test_tree_merge_matches_reference(oracle, tag, t):
     run_tree(oracle, tag, t)
+
+
+def run_round1_then_c_merge(api, tag, t):
+    """round 1 per batch (what every GPU does with its shard) + ngsid_merge_representatives (the C schedule, include/ngsid_merge_schedule.h)
+    must give the reference's --t N membership, like parallelize.tree_cluster does."""
+    from ngspeciesid_amd.hostutil import subset_reads
+    g = _load("cluster_%s.npz" % tag)
+    rs = ReadSet(g["seq"], g["qual"], g["off"])
+    prm = cluster_params(k=int(g["k"]), w=int(g["w"]), p_shared=g["p_table"])
+    rank = acc_rank([str(a) for a in g["acc"]])
+    lens = np.diff(g["off"].astype(np.int64))
+    rep_of = np.arange(rs.n, dtype=np.int64); herr = np.full(rs.n, np.nan); batch = np.zeros(rs.n, dtype=np.int32)
+    for b, (a0, a1) in enumerate(parallelize.batch_list_total_nt(lens, t)):
+        if a1 <= a0:
+            continue
+        idx = np.arange(a0, a1)
+        r, he, st, _ = api.cluster_greedy(subset_reads(rs, idx), prm, acc_rank=rank[idx])
+        rep_of[idx] = idx[r]; herr[idx] = he; batch[idx] = b + 1
+    reps = np.nonzero(rep_of == np.arange(rs.n))[0]
+    m = api.merge_representatives(subset_reads(rs, reps), prm, g["score"][reps], herr[reps], batch[reps], t, acc_rank=rank[reps])
+    final = reps[m][np.searchsorted(reps, rep_of)]
+    assert np.array_equal(final, g["t%d_rep_of" % t]), "membership differs from the reference --t %d" % t
+
+
+@pytest.mark.parametrize("tag,t", [("sample_h1", 2), ("sample_h1", 4), ("sample_h1", 8), ("synth2k_d15", 8), ("synth600_d10_q14", 4), ("synth300_ccs", 4)])
+def test_c_merge_schedule_matches_reference(oracle, tag, t):
+    run_round1_then_c_merge(oracle, tag, t)
