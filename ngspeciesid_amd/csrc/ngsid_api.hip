@@ -189,6 +189,8 @@ extern "C" int32_t ngsid_sg_align_cigar_batch(ngsid_ctx* ctx, const ngsid_reads_
     static const uint8_t sym[4] = {'=', 'X', 'I', 'D'};
     for (uint64_t p = 0; p < n_pairs; ++p) {            // the kernel wrote the columns in traceback order: reverse them into alignment order
         const uint64_t c = (uint64_t)h[n_pairs + p]; const uint8_t* src = hops.data() + h_off[p]; uint8_t* dst = ops + ops_off[p];
+        const uint64_t ql = Q.h_off[q_idx[p] + 1] - Q.h_off[q_idx[p]], tl = T.h_off[t_idx[p] + 1] - T.h_off[t_idx[p]];
+        if (ql == 0 || tl == 0) { for (uint64_t x = 0; x < c; ++x) dst[x] = ql ? 'I' : 'D'; continue; }      // an empty sequence: the kernel has no cell to trace, the other one is all end gap
         for (uint64_t x = 0; x < c; ++x) dst[x] = sym[src[c - 1 - x] & 3];
     }
     return NGSID_OK;

@@ -30,7 +30,8 @@ def _pack(obj: dict) -> np.ndarray:
         elif v is None:
             head.append((k, "none", []))
         else:
-            a = np.ascontiguousarray(v)
+            a = np.asarray(v)
+            if a.ndim: a = np.ascontiguousarray(a)           # (ascontiguousarray would turn a scalar into a 1-element vector)
             head.append((k, a.dtype.str, list(a.shape))); chunks.append(a.tobytes())
     h = json.dumps(head).encode()
     return np.frombuffer(np.array([len(h)], dtype=np.int64).tobytes() + h + b"".join(chunks), dtype=np.uint8)
