@@ -26,7 +26,7 @@ extern "C" {
 
 #define NGSID_OK                 0
 #define NGSID_ERR_NO_DEVICE     -1   /* no HIP device / kernel image not loadable */
-#define NGSID_ERR_ARG           -2   /* bad argument (NULL, k>21, w<k, ...) */
+#define NGSID_ERR_ARG           -2   /* bad argument (NULL, k>32, w<k, ...) */
 #define NGSID_ERR_ALPHABET      -3   /* base outside {A,C,G,T,N} met by the minimizer encoder */
 #define NGSID_ERR_CAPACITY      -4   /* caller buffer too small; required size reported in *needed */
 #define NGSID_ERR_HIP           -5   /* HIP runtime error (text in ngsid_last_error) */
@@ -36,7 +36,8 @@ extern "C" {
 #define NGSID_MEM_HOST   0u
 #define NGSID_MEM_DEVICE 1u
 
-#define NGSID_MAX_K          21      /* 3-bit order-preserving codes (0=end,A,C,G,N,T) in a uint64 */
+#define NGSID_MAX_K          32      /* k <= 21: 3-bit order-preserving k-mer codes (0=end,A,C,G,N,T) in a uint64; 22..32: two-word codes inside the
+                                        library, handed on as dense order-preserving ranks per call (the reference's table has rows for k = 10..30) */
 #define NGSID_MAX_READ_LEN   16384   /* bases per read handled by the LDS-staged kernels */
 
 typedef struct ngsid_ctx ngsid_ctx;
@@ -81,7 +82,8 @@ int32_t ngsid_score_reads(ngsid_ctx* ctx, const ngsid_reads_t* reads, int32_t k,
 /* (a1-a3) replaces the inline HPC (cluster.py:265), get_kmer_minimizers (cluster.py:16-39) and the
  * HPC quality / error-rate block (cluster.py:279-291).  Output is CSR over reads in read order:
  * mz_off[n+1], codes/pos with capacity `cap` entries (NGSID_ERR_CAPACITY + *needed otherwise).
- * codes are 3-bit-per-base order-preserving k-mer codes; pos are positions in the HPC string.
+ * codes are 3-bit-per-base order-preserving k-mer codes for k <= 21; for 22 <= k <= 32 they are the dense ranks of the k-mers among all
+ * minimizers of THIS call (order preserving, equal k-mers equal code; not comparable between calls); pos are positions in the HPC string.
  * hpc_len[i] = HPC length, hpc_err[i] = error rate (sum over quality characters in ascending
  * character code), reads with hpc_len<k get 0 minimizers.
  * codes/pos/mz_off follow reads->mem (device outputs for device inputs); hpc_len/hpc_err are host. */

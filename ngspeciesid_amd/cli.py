@@ -116,8 +116,8 @@ def cli(argv=None):
         args.k, args.w = 13, 20
     if args.medaka or args.primer_file or args.remove_universal_tails:
         logging.error("--medaka / --primer_file / --remove_universal_tails are outside the accelerated hot path (see DESIGN.md); not available."); sys.exit(1)
-    if args.k > 21 or args.k < 1:
-        logging.error('k = %d is outside what the minimizer encoder of this build handles (1..21).' % args.k); sys.exit(1)
+    if args.k > 32 or args.k < 1:
+        logging.error('k = %d is outside what the minimizer encoder of this build handles (1..32; the shared-minimizer table has rows for k = 10..30).' % args.k); sys.exit(1)
     if 100 < args.w or args.w < args.k:
         logging.error('Please specify a window of size larger or equal to k, and smaller than 100.'); sys.exit(1)
     if args.outfolder and not os.path.exists(args.outfolder):

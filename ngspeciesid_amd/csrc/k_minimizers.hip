@@ -1,141 +1,243 @@
 // k_minimizers.hip - (a1-a3) homopolymer compression, minimizer extraction, HPC / raw error rates.
 //
-// Replaces cluster.py:265 (HPC), :16-39 (get_kmer_minimizers), :279-291 (HPC quality + error rate) and the
-// raw-quality mean of :185-188.  One 256-thread workgroup per read; the HPC string and the k-mer codes of
-// the read are staged in LDS (9 bytes per base), window minima are taken from LDS, and the (code,pos)
-// pairs are written compacted to HBM at the read's own base offset (a read of n bases has at most n-k+1
-// minimizers), so no allocation pass or atomics are needed and the layout is deterministic.
-// HBM traffic per read: 2L in (bases + qualities, coalesced), 12 B per minimizer out.
+// Replaces cluster.py:265 (HPC), :16-39 (get_kmer_minimizers), :279-291 (HPC quality + error rate) and the raw-quality mean of :185-188.
+// ONE WAVE PER READ (round 2; round 1 used a 256-thread workgroup with __syncthreads phases, 9.9 ms per million reads):
+//   1. bases + qualities are staged in LDS with coalesced dword loads (2 bytes per base - the only HBM reads of the kernel);
+//   2. run heads by ballot, HPC letters by prefix popcount, best quality of a run by its head lane (runs are short), quality histograms by
+//      LDS atomics; the two error-rate sums run on two lanes over the quality characters that occur, in ascending character code, as ordered
+//      FP64 sums (same rounding as the oracle: skipped terms are exact zeros);
+//   3. k-mer codes (3 bits per letter, left aligned, zero padded past the end) from aligned dword reads of the HPC string;
+//   4. window minima through a sparse table of argmin positions (log2(w-k+1) doubling passes instead of a scan of w-k+1 codes per window),
+//      emission on position change by ballot-ordered compaction, (code, pos) pairs written at the read's own base offset in HBM
+//      (a read of n bases has at most n-k+1 minimizers: no allocation pass, no atomics, deterministic layout).
+// k <= 21 fits one 64-bit code.  22 <= k <= 42 (KW = 2) keeps (hi, lo) pairs - lo = the last 21 letters - and a rename pass afterwards
+// replaces them by their dense rank over the whole launch (order preserving, equal k-mers equal code), so everything downstream still
+// sees 64-bit order-preserving codes.  HBM traffic per read: 2L in, 12 B per minimizer out.
 #include "ngsid_internal.h"
 #include "../../include/ngsid_tables.h"
+#include <hipcub/hipcub.hpp>
 
 __constant__ double c_phred_p[128];
 static bool g_tables_loaded[16] = {false};
 
+#define MZ_LDSP __attribute__((address_space(3)))
+
 __device__ __forceinline__ int enc3(uint8_t c) {
     switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'N': return 4; case 'T': return 5; default: return -1; }
 }
+// four letters (one per byte, values 0..5) -> 12 bits, first letter in the most significant position
+__device__ __forceinline__ unsigned pack4(unsigned w) { return ((w & 7u) << 9) | (((w >> 8) & 7u) << 6) | (((w >> 16) & 7u) << 3) | ((w >> 24) & 7u); }
 
-// exclusive prefix sum of one int per thread over a 256-thread block; returns the exclusive value, *total = block sum
-__device__ __forceinline__ int block_excl_scan256(int v, int* lds_w /*4 ints*/, int* total) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d); if (lane >= d) x += y; }
-    if (lane == 63) lds_w[wv] = x;
-    __syncthreads();
-    int base = 0;
-    for (int i = 0; i < wv; ++i) base += lds_w[i];
-    *total = lds_w[0] + lds_w[1] + lds_w[2] + lds_w[3];
-    __syncthreads();
-    return base + x - v;
+struct Code2 { uint64_t hi, lo; };
+template <int KW> struct CodeT;
+template <> struct CodeT<1> { uint64_t lo; __device__ __forceinline__ bool less(const CodeT<1>& o) const { return lo < o.lo; } };
+template <> struct CodeT<2> { uint64_t hi, lo; __device__ __forceinline__ bool less(const CodeT<2>& o) const { return hi < o.hi || (hi == o.hi && lo < o.lo); } };
+
+// LDS of one wave (bytes): sraw [ML4] | qraw [ML4] | hs [NC + 64] | hist_h, hist_r [2 x 128 int] | am [NC u16, 8-aligned] | lo [NC u64] | hi [NC u64, KW = 2]
+__host__ __device__ inline size_t mz_lds_per_wave(uint32_t maxlen, int W, int KW)
+{
+    const size_t ML4 = ((size_t)maxlen + 7) & ~(size_t)3;
+    const size_t NC = (((size_t)maxlen > (size_t)W ? (size_t)maxlen : (size_t)W) + 4 + 3) & ~(size_t)3;
+    return 2 * ML4 + (NC + 64) + 1024 + NC * 2 + NC * 8 * (size_t)KW;
 }
 
-extern "C" __global__ __launch_bounds__(256)
+template <int KW>
+__global__ __launch_bounds__(256)
 void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t nreads,
-                      int k, int w, uint64_t* __restrict__ out_codes, uint32_t* __restrict__ out_pos, uint32_t* __restrict__ out_cnt,
+                      int k, int w, uint32_t maxlen, uint32_t lds_per_wave,
+                      uint64_t* __restrict__ out_codes, uint64_t* __restrict__ out_hi, uint32_t* __restrict__ out_pos, uint32_t* __restrict__ out_cnt,
                       uint32_t* __restrict__ out_hlen, double* __restrict__ out_herr, double* __restrict__ out_rawerr, int* __restrict__ flag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint64_t r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv;
     if (r >= nreads) return;
+    const int W = w - k + 1;
+    const size_t ML4 = ((size_t)maxlen + 7) & ~(size_t)3;
+    const size_t NC = (((size_t)maxlen > (size_t)W ? (size_t)maxlen : (size_t)W) + 4 + 3) & ~(size_t)3;
+    unsigned char* base_l = smem + (size_t)wv * lds_per_wave;
+    uint8_t* sraw = base_l; uint8_t* qraw = sraw + ML4; uint8_t* hs = qraw + ML4;
+    int* hist_h = (int*)(hs + NC + 64); int* hist_r = hist_h + 128;
+    uint16_t* am = (uint16_t*)(hist_r + 128);
+    uint64_t* clo = (uint64_t*)((unsigned char*)am + NC * 2); uint64_t* chi = clo + NC;
     const uint64_t base = off[r];
     const int n = (int)(off[r + 1] - base);
-    const int tid = threadIdx.x;
-    // LDS carve: [0,1024) hist_hpc(128 int) + hist_raw(128 int); [1024,1024+64) scan scratch + misc; then codes (8B aligned), then hs
-    int* hist_h = (int*)smem; int* hist_r = hist_h + 128;
-    int* scr = hist_r + 128;                 // 16 ints
-    int* am = scr + 16;                      // 257 ints (window argmin exchange), padded to 272
-    double* term_h = (double*)(smem + 1024 + 64 + 272 * 4); double* term_r = term_h + 128;      // per quality character: count x error probability
-    uint64_t* codes = (uint64_t*)(smem + 1024 + 64 + 272 * 4 + 2048);
-    const int W = w - k + 1;
-    const int ncodes_cap = (n > W ? n : W) + 1;
-    uint8_t* hs = (uint8_t*)(codes + ncodes_cap);
     const uint8_t* s = seq + base; const uint8_t* q = qual ? qual + base : nullptr;
+    // wave-private LDS: instructions of one wave execute in order, so a wave barrier + a drained LDS queue orders its own traffic
+    auto lsync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
 
-    if (tid < 128) { hist_h[tid] = 0; hist_r[tid] = 0; }
-    __syncthreads();
+    // ---- 1. stage bases / qualities (dword loads where the read's start allows it), clear the histograms
+    for (int c = lane; c < 256; c += 64) hist_h[c] = 0;
+    {
+        auto stage = [&](const uint8_t* g, uint8_t* l) {
+            const int head = (int)((4 - ((uintptr_t)g & 3)) & 3);          // bytes until the global address is dword aligned
+            for (int i = lane; i < head && i < n; i += 64) l[i] = g[i];
+            const int nd = n > head ? (n - head) >> 2 : 0;
+            for (int d = lane; d < nd; d += 64) {
+                const unsigned wv_ = *(const unsigned*)(g + head + 4 * d); const int o = head + 4 * d;
+                l[o] = (uint8_t)wv_; l[o + 1] = (uint8_t)(wv_ >> 8); l[o + 2] = (uint8_t)(wv_ >> 16); l[o + 3] = (uint8_t)(wv_ >> 24);
+            }
+            for (int i = head + 4 * nd + lane; i < n; i += 64) l[i] = g[i];
+        };
+        stage(s, sraw); if (q) stage(q, qraw);
+    }
+    lsync();
 
-    // ---- phase 1: run heads, HPC string, best quality per run, histograms
-    const int CH = (n + 255) / 256;
-    const int i0 = tid * CH, i1 = min(n, i0 + CH);
-    int heads = 0;
-    for (int i = i0; i < i1; ++i) heads += (i == 0 || s[i] != s[i - 1]);
-    int total_heads;
-    int hidx = block_excl_scan256(heads, scr, &total_heads);
-    for (int i = i0; i < i1; ++i) {
-        if (q) atomicAdd(&hist_r[q[i] & 127], 1);
-        if (i == 0 || s[i] != s[i - 1]) {
-            const uint8_t c = s[i];
-            hs[hidx] = (uint8_t)enc3(c);          // 3-bit letter code, 0xff = outside ACGTN (reported in phase 2)
+    // ---- 2. run heads, HPC letters, best quality per run, histograms
+    int hl = 0; int bad = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane; const bool in = i < n;
+        const uint8_t ch = in ? sraw[i] : 0;
+        const bool head = in && (i == 0 || ch != sraw[i - 1]);
+        const unsigned long long m = __ballot(head);
+        const int idx = hl + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && q) atomicAdd(&hist_r[qraw[i] & 127], 1);
+        if (head) {
+            const int e = enc3(ch); if (e < 0) bad = 1;
+            hs[idx] = (uint8_t)(e < 0 ? 0 : e);
             if (q) {
-                uint8_t best = q[i];
-                for (int j = i + 1; j < n && s[j] == c; ++j) if (c_phred_p[q[j] & 127] < c_phred_p[best & 127]) best = q[j];
+                uint8_t best = qraw[i];
+                for (int j = i + 1; j < n && sraw[j] == ch; ++j) if (c_phred_p[qraw[j] & 127] < c_phred_p[best & 127]) best = qraw[j];
                 atomicAdd(&hist_h[best & 127], 1);
             }
-            ++hidx;
         }
+        hl += __popcll(m);
     }
-    __syncthreads();
-    const int hl = total_heads;
-    // error rates = sum over the quality characters in ascending order of count x p (the order fixes the rounding: ngsid_oracle.c does the same);
-    // the products are formed by 128 threads, the two ordered sums run on two different waves
-    if (tid < 128) { term_h[tid] = (double)hist_h[tid] * c_phred_p[tid]; term_r[tid] = (double)hist_r[tid] * c_phred_p[tid]; }
-    __syncthreads();
-    const double qnan = __longlong_as_double(0x7ff8000000000000ULL);
-    if (tid == 0) {
-        out_hlen[r] = (uint32_t)hl;
-        double sh = 0.0;
-        if (q) { for (int c = 0; c < 128; ++c) sh = sh + term_h[c]; }
-        out_herr[r] = (q && hl > 0) ? sh / (double)hl : qnan;
-    } else if (tid == 64) {
-        double sr = 0.0;
-        if (q) { for (int c = 0; c < 128; ++c) sr = sr + term_r[c]; }
-        out_rawerr[r] = (q && n > 0) ? sr / (double)n : qnan;
+    if (__ballot(bad)) { if (lane == 0) atomicExch(flag, 1 + (int)(r & 0x3fffffff)); }
+    for (int i = hl + lane; i < (int)(NC + 64); i += 64) hs[i] = 0;                       // zero padding past the end: the "end" symbol of truncated k-mers, and room for the dword reads
+    lsync();
+    // error rates: ordered FP64 sums over the quality characters that occur (ascending code), lane 0 = HPC string, lane 1 = raw read
+    {
+        const double qnan = __longlong_as_double(0x7ff8000000000000ULL);
+        double acc = 0.0;
+        const int* hh = lane == 0 ? hist_h : hist_r;
+        if (q) for (int half = 0; half < 2; ++half) {
+            const int c = half * 64 + lane;
+            unsigned long long occ = __ballot(hist_h[c] != 0 || hist_r[c] != 0);
+            while (occ) { const int b = __builtin_ctzll(occ); occ &= occ - 1; const int cc = half * 64 + b; if (lane < 2) acc = acc + (double)hh[cc] * c_phred_p[cc]; }
+        }
+        if (lane == 0) { out_hlen[r] = (uint32_t)hl; out_herr[r] = (q && hl > 0) ? acc / (double)hl : qnan; }
+        else if (lane == 1) out_rawerr[r] = (q && n > 0) ? acc / (double)n : qnan;
     }
-    if (hl < k) { if (tid == 0) out_cnt[r] = 0; return; }
+    if (hl < k) { if (lane == 0) out_cnt[r] = 0; return; }
 
-    // ---- phase 2: k-mer codes (3 bits/base, left aligned, zero padded past the end)
+    // ---- 3. k-mer codes: letters i .. i+k-1 of the HPC string, 3 bits each, first letter most significant, zeros past the end
     const int nk = hl - k + 1;
     const int nc = nk > W ? nk : W;
-    int bad = 0;
-    for (int i = tid; i < nc; i += 256) {
-        uint64_t c = 0;
-        for (int t = 0; t < k; ++t) {
-            int e = 0;
-            if (i + t < hl) { e = hs[i + t]; if (e == 0xff) { bad = 1; e = 0; } }
-            c = (c << 3) | (uint64_t)e;
+    const int nfull = k >> 2, rem = k & 3;
+    for (int i = lane; i < nc; i += 64) {
+        const unsigned* hw = (const unsigned*)(hs + (i & ~3)); const int sh = i & 3;
+        uint64_t lo = 0, hi = 0; unsigned prev = hw[0];
+        for (int t = 0; t <= nfull; ++t) {
+            const unsigned next = hw[t + 1];
+            unsigned wq = __builtin_amdgcn_alignbyte(next, prev, sh);           // bytes i+4t .. i+4t+3
+            prev = next;
+            unsigned bits = 12; unsigned pk = pack4(wq);
+            if (t == nfull) { if (!rem) break; bits = 3u * (unsigned)rem; pk >>= (12u - bits); }
+            if (KW == 2) hi = (hi << bits) | (lo >> (63 - bits));
+            lo = ((lo << bits) | pk) & 0x7fffffffffffffffULL;
         }
-        codes[i] = c;
+        // positions past the end of the string hold zeros already (hs padding); letters beyond hl inside a k-mer are zeros = "end" symbol
+        clo[i] = lo; if (KW == 2) chi[i] = hi;
+        am[i] = (uint16_t)i;
     }
-    if (bad) atomicExch(flag, 1 + (int)(r & 0x3fffffff));
-    __syncthreads();
+    lsync();
 
-    // ---- phase 3: leftmost window minima, emit on position change (ordered compaction, 256 windows per round)
-    const int nwin = nk >= W ? nk - W + 1 : 1;
-    int emitted = 0;
-    if (tid == 0) am[0] = -1;
-    for (int s0 = 0; s0 < nwin; s0 += 256) {
-        const int sidx = s0 + tid;
-        int best = -1;
-        if (sidx < nwin) {
-            best = sidx; uint64_t bc = codes[sidx];
-            for (int j = sidx + 1; j < sidx + W; ++j) { const uint64_t c = codes[j]; if (c < bc) { bc = c; best = j; } }
+    // ---- 4. sparse table of argmin positions: after pass p, am[i] = leftmost minimum of codes[i .. i+2^p) (clipped at nc)
+    auto better = [&](int a, int b) -> int {           // leftmost minimum of two candidates, a's range starts left of b's
+        CodeT<KW> ca, cb; ca.lo = clo[a]; cb.lo = clo[b]; if constexpr (KW == 2) { ca.hi = chi[a]; cb.hi = chi[b]; }
+        return cb.less(ca) ? b : a;
+    };
+    int span = 1;
+    while (span * 2 <= W) {
+        for (int i0 = 0; i0 < nc; i0 += 64) {
+            const int i = i0 + lane; int v = 0;
+            if (i < nc) { v = am[i]; if (i + span < nc) v = better(v, am[i + span]); }
+            lsync();                                    // every lane of the chunk has read before any writes (in place, ascending chunks)
+            if (i < nc) am[i] = (uint16_t)v;
         }
-        __syncthreads();                 // am[0] from the previous round is in place
-        am[tid + 1] = best;
-        __syncthreads();
-        const int prev = am[tid];
-        const int f = (sidx < nwin) && (best != prev);
-        int tot;
-        const int ex = block_excl_scan256(f, scr, &tot);
-        if (f) { out_codes[base + emitted + ex] = codes[best]; out_pos[base + emitted + ex] = (uint32_t)best; }
-        emitted += tot;
-        const int last = am[256];
-        __syncthreads();
-        if (tid == 0) am[0] = last;
+        lsync();
+        span *= 2;
     }
-    if (tid == 0) out_cnt[r] = (uint32_t)emitted;
+    // leftmost window minima, emit on position change (ordered compaction, 64 windows per round)
+    const int nwin = nk >= W ? nk - W + 1 : 1;
+    int emitted = 0, carry = -1;
+    for (int s0 = 0; s0 < nwin; s0 += 64) {
+        const int sidx = s0 + lane; int best = -1;
+        if (sidx < nwin) { best = am[sidx]; if (W > span) best = better(best, am[sidx + W - span]); }
+        int prev = __shfl_up(best, 1); if (lane == 0) prev = carry;
+        const bool f = sidx < nwin && best != prev;
+        const unsigned long long m = __ballot(f);
+        if (f) {
+            const uint64_t o = base + (uint64_t)(emitted + __popcll(m & ((1ull << lane) - 1ull)));
+            out_codes[o] = clo[best]; if (KW == 2) out_hi[o] = chi[best]; out_pos[o] = (uint32_t)best;
+        }
+        emitted += __popcll(m);
+        const int nv = min(64, nwin - s0); carry = __shfl(best, nv - 1);
+    }
+    if (lane == 0) out_cnt[r] = (uint32_t)emitted;
+}
+
+// ---------------------------------------------------------------------------------------------- rename pass for k > 21
+namespace {
+__global__ void k_mz_compact(const uint64_t* __restrict__ off, const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ coff, uint64_t n,
+                             const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, uint64_t* __restrict__ klo, uint64_t* __restrict__ khi, uint32_t* __restrict__ idx)
+{
+    const uint64_t r = blockIdx.x; if (r >= n) return;
+    const uint64_t b = off[r], o = coff[r]; const uint32_t c = cnt[r];
+    for (uint32_t x = threadIdx.x; x < c; x += blockDim.x) { klo[o + x] = lo[b + x]; khi[o + x] = hi[b + x]; idx[o + x] = (uint32_t)(o + x); }
+}
+__global__ void k_gather64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint64_t* __restrict__ dst)
+{ const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[idx[i]]; }
+__global__ void k_mz_flags(const uint64_t* __restrict__ shi, const uint64_t* __restrict__ lo_c, const uint32_t* __restrict__ perm, uint64_t n, uint32_t* __restrict__ fl)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    fl[i] = (i == 0) ? 0u : ((shi[i] != shi[i - 1] || lo_c[perm[i]] != lo_c[perm[i - 1]]) ? 1u : 0u);
+}
+__global__ void k_mz_scatter(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ perm, uint64_t n, uint64_t* __restrict__ out_c)
+{ const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out_c[perm[i]] = (uint64_t)rank[i]; }
+__global__ void k_mz_expand(const uint64_t* __restrict__ off, const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ coff, uint64_t n, const uint64_t* __restrict__ cc, uint64_t* __restrict__ codes)
+{
+    const uint64_t r = blockIdx.x; if (r >= n) return;
+    const uint64_t b = off[r], o = coff[r]; const uint32_t c = cnt[r];
+    for (uint32_t x = threadIdx.x; x < c; x += blockDim.x) codes[b + x] = cc[o + x];
+}
+}  // namespace
+
+// (hi, lo) pairs at the reads' base offsets -> dense, order-preserving ranks written over d_codes (equal k-mers equal code)
+static int32_t mz_rename_wide(ngsid_ctx* ctx, const DevReads& R, uint64_t* d_codes, const uint64_t* d_hi, const uint32_t* d_cnt)
+{
+    const uint64_t n = R.n;
+    DevBuf<uint64_t> coff; HIPCHK(ctx, coff.alloc(n + 1));
+    DevBuf<unsigned char> tmp; size_t tb = 0;
+    // exclusive scan of the counts (as uint64) -> compact offsets; total on the host
+    std::vector<uint32_t> hc(n); HIPCHK(ctx, hipMemcpyAsync(hc.data(), d_cnt, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<uint64_t> ho(n + 1, 0); for (uint64_t i = 0; i < n; ++i) ho[i + 1] = ho[i] + hc[i];
+    const uint64_t M = ho[n];
+    if (M == 0) return NGSID_OK;
+    if (M > 0xfffffff0ull) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "more than 2^32 minimizers in one call with k > 21");
+    HIPCHK(ctx, hipMemcpyAsync(coff.p, ho.data(), 8 * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    DevBuf<uint64_t> klo, khi, k2, shi; DevBuf<uint32_t> idx, p1, p2, fl, rk;
+    HIPCHK(ctx, klo.alloc(M)); HIPCHK(ctx, khi.alloc(M)); HIPCHK(ctx, k2.alloc(M)); HIPCHK(ctx, shi.alloc(M)); HIPCHK(ctx, idx.alloc(M)); HIPCHK(ctx, p1.alloc(M)); HIPCHK(ctx, p2.alloc(M)); HIPCHK(ctx, fl.alloc(M)); HIPCHK(ctx, rk.alloc(M));
+    hipLaunchKernelGGL(k_mz_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, R.off, d_cnt, coff.p, n, d_codes, d_hi, klo.p, khi.p, idx.p);
+    // LSD: stable sort by lo, then stable sort by hi
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, klo.p, k2.p, idx.p, p1.p, (int)M, 0, 63, ctx->stream));
+    HIPCHK(ctx, tmp.alloc(tb));
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, klo.p, k2.p, idx.p, p1.p, (int)M, 0, 63, ctx->stream));
+    const unsigned gb = (unsigned)((M + 255) / 256);
+    hipLaunchKernelGGL(k_gather64, dim3(gb), dim3(256), 0, ctx->stream, khi.p, p1.p, M, k2.p);                       // hi in lo-sorted order
+    size_t tb2 = 0; HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, k2.p, shi.p, p1.p, p2.p, (int)M, 0, 64, ctx->stream));
+    if (tb2 > tb) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, tmp.alloc(tb2)); tb = tb2; }
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb2, k2.p, shi.p, p1.p, p2.p, (int)M, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_mz_flags, dim3(gb), dim3(256), 0, ctx->stream, shi.p, klo.p, p2.p, M, fl.p);
+    size_t tb3 = 0; HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tb3, fl.p, rk.p, (int)M, ctx->stream));
+    if (tb3 > tb) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, tmp.alloc(tb3)); tb = tb3; }
+    HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp.p, tb3, fl.p, rk.p, (int)M, ctx->stream));
+    hipLaunchKernelGGL(k_mz_scatter, dim3(gb), dim3(256), 0, ctx->stream, rk.p, p2.p, M, k2.p);                      // k2[compact index] = rank
+    hipLaunchKernelGGL(k_mz_expand, dim3((unsigned)n), dim3(64), 0, ctx->stream, R.off, d_cnt, coff.p, n, k2.p, d_codes);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NGSID_OK;
 }
 
 int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
@@ -149,12 +251,25 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     }
     if (R.n == 0) return NGSID_OK;
     const int W = w - k + 1;
-    const size_t ncap = (size_t)((int)R.maxlen > W ? (int)R.maxlen : W) + 1;
-    size_t lds = 1024 + 64 + 272 * 4 + 2048 + ncap * 8 + (size_t)R.maxlen + 16;
-    lds = (lds + 15) & ~(size_t)15;
-    if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_hpc_minimizers, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    { ProfScope ps_(ctx, "k_hpc_minimizers"); hipLaunchKernelGGL(k_hpc_minimizers, dim3((unsigned)R.n), dim3(256), lds, ctx->stream,
-                       R.seq, R.qual, R.off, R.n, k, w, d_codes, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag); }
+    const int KW = k <= 21 ? 1 : 2;
+    const size_t lpw = (mz_lds_per_wave(R.maxlen, W, KW) + 15) & ~(size_t)15;
+    int wpb = 4; while (wpb > 1 && lpw * wpb > 64 * 1024) wpb >>= 1;
+    const size_t lds = lpw * wpb;
+    if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "minimizer kernel needs %zu bytes of LDS", lds);
+    const unsigned blocks = (unsigned)((R.n + wpb - 1) / wpb);
+    DevBuf<uint64_t> d_hi;
+    if (KW == 2) HIPCHK(ctx, d_hi.alloc(R.total + 1));
+    {
+        ProfScope ps_(ctx, "k_hpc_minimizers");
+        if (KW == 1) {
+            if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_hpc_minimizers<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_hpc_minimizers<1>, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, R.maxlen, (uint32_t)lpw, d_codes, (uint64_t*)nullptr, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag);
+        } else {
+            if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_hpc_minimizers<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_hpc_minimizers<2>, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, R.maxlen, (uint32_t)lpw, d_codes, d_hi.p, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag);
+        }
+    }
     HIPCHK(ctx, hipGetLastError());
+    if (KW == 2) return mz_rename_wide(ctx, R, d_codes, d_hi.p, d_cnt);
     return NGSID_OK;
 }

@@ -346,7 +346,8 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     HIPCHK(ctx, flag.alloc(1)); HIPCHK(ctx, d_rgroup.alloc(N)); HIPCHK(ctx, d_orient.alloc(N));
     HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_rgroup.p, h_rgroup.data(), 4 * N, hipMemcpyHostToDevice, ctx->stream));
-    rc = ngsid_launch_minimizers(ctx, RD, prm->k, prm->w, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr.p, rawerr.p, flag.p); if (rc) return rc;
+    const int sk = std::min(prm->k, 21), sw = std::max(prm->w, sk);       // strand detection only needs SOME minimizer scheme: one-word codes, comparable between the two launches
+    rc = ngsid_launch_minimizers(ctx, RD, sk, sw, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr.p, rawerr.p, flag.p); if (rc) return rc;
     {
         // backbone fw + rc minimizers through the same kernel, then sorted on the host (a handful of short lists)
         std::vector<std::string> two; for (uint32_t g = 0; g < G; ++g) two.push_back(B[g]); for (uint32_t g = 0; g < G; ++g) two.push_back(revcomp(B[g]));
@@ -356,7 +357,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         DevBuf<uint64_t> bc; DevBuf<uint32_t> bp_, bcnt, bhl; DevBuf<double> be, bw; DevBuf<int> bflag;
         HIPCHK(ctx, bc.alloc(BR.total + 1)); HIPCHK(ctx, bp_.alloc(BR.total + 1)); HIPCHK(ctx, bcnt.alloc(2 * G)); HIPCHK(ctx, bhl.alloc(2 * G)); HIPCHK(ctx, be.alloc(2 * G)); HIPCHK(ctx, bw.alloc(2 * G)); HIPCHK(ctx, bflag.alloc(1));
         HIPCHK(ctx, hipMemsetAsync(bflag.p, 0, sizeof(int), ctx->stream));
-        rc = ngsid_launch_minimizers(ctx, BR, prm->k, prm->w, bc.p, bp_.p, bcnt.p, bhl.p, be.p, bw.p, bflag.p); if (rc) return rc;
+        rc = ngsid_launch_minimizers(ctx, BR, sk, sw, bc.p, bp_.p, bcnt.p, bhl.p, be.p, bw.p, bflag.p); if (rc) return rc;
         std::vector<uint64_t> hc(BR.total + 1); std::vector<uint32_t> hcnt(2 * G), hhl(2 * G); int hf = 0, rf = 0;
         HIPCHK(ctx, hipMemcpyAsync(hc.data(), bc.p, 8 * (BR.total + 1), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), bcnt.p, 4 * 2 * G, hipMemcpyDeviceToHost, ctx->stream));
@@ -367,14 +368,14 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         if (hf || rf) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "base outside ACGTN in %s", hf ? "a backbone" : "a read");
         std::vector<uint64_t> lists, loff(2 * G + 1, 0);
         for (uint32_t i = 0; i < 2 * G; ++i) {
-            const uint32_t c = hhl[i] >= (uint32_t)prm->k ? hcnt[i] : 0;
+            const uint32_t c = hhl[i] >= (uint32_t)sk ? hcnt[i] : 0;
             std::vector<uint64_t> v(hc.begin() + toff[i], hc.begin() + toff[i] + c); std::sort(v.begin(), v.end());
             lists.insert(lists.end(), v.begin(), v.end()); loff[i + 1] = lists.size();
         }
         DevBuf<uint64_t> d_lists, d_loff; HIPCHK(ctx, d_lists.alloc(lists.size() + 1)); HIPCHK(ctx, d_loff.alloc(loff.size()));
         if (!lists.empty()) HIPCHK(ctx, hipMemcpyAsync(d_lists.p, lists.data(), 8 * lists.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_loff.p, loff.data(), 8 * loff.size(), hipMemcpyHostToDevice, ctx->stream));
-        { ProfScope ps_(ctx, "k_strand"); hipLaunchKernelGGL(k_strand, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, RD.off, mzcnt.p, hlen.p, mzcode.p, prm->k, d_rgroup.p, d_lists.p, d_loff.p, G, N, d_orient.p); }
+        { ProfScope ps_(ctx, "k_strand"); hipLaunchKernelGGL(k_strand, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, RD.off, mzcnt.p, hlen.p, mzcode.p, sk, d_rgroup.p, d_lists.p, d_loff.p, G, N, d_orient.p); }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }

@@ -58,16 +58,17 @@ static inline int enc3(uint8_t c) {
  * For len < w the first (only) window holds end-truncated / empty slices (cluster.py:19): codes are
  * left-aligned and zero padded so that a proper prefix sorts before its extensions.
  * Returns count or -1 on alphabet error. codes/pos need capacity max(1, n-k+1). */
-static int minimizers(const uint8_t* hs, int n, int k, int w, uint64_t* codes, uint32_t* pos) {
+typedef unsigned __int128 kcode;       /* 3 bits per letter: k <= 42 */
+static int minimizers_wide(const uint8_t* hs, int n, int k, int w, kcode* codes, uint32_t* pos) {
     int W = w - k + 1, nk = n - k + 1;
     int nc = nk > W ? nk : W;
-    uint64_t* kc = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)nc);
+    kcode* kc = (kcode*)malloc(sizeof(kcode) * (size_t)nc);
     for (int i = 0; i < nc; ++i) {
-        uint64_t c = 0;
+        kcode c = 0;
         for (int t = 0; t < k; ++t) {
             int e = 0;
             if (i + t < n) { e = enc3(hs[i + t]); if (e < 0) { free(kc); return -1; } }
-            c = (c << 3) | (uint64_t)e;
+            c = (c << 3) | (kcode)e;
         }
         kc[i] = c;
     }
@@ -78,6 +79,29 @@ static int minimizers(const uint8_t* hs, int n, int k, int w, uint64_t* codes, u
         if (best != prev) { codes[cnt] = kc[best]; pos[cnt] = (uint32_t)best; ++cnt; prev = best; }
     }
     free(kc);
+    return cnt;
+}
+/* k > 21: the clustering only needs k-mer IDENTITY, so wide codes are interned (first come, first numbered) for the duration of one
+ * cluster_greedy call; the public ongsid_hpc_minimizers hands out order-preserving dense ranks instead (as the library does). */
+typedef struct { kcode key; uint64_t id; int used; } internslot;
+static internslot* g_intern = NULL; static size_t g_intern_cap = 0, g_intern_n = 0;
+static void intern_reset(void) { free(g_intern); g_intern = NULL; g_intern_cap = 0; g_intern_n = 0; }
+static uint64_t intern(kcode c) {
+    if ((g_intern_n + 1) * 2 > g_intern_cap) {
+        size_t nc = g_intern_cap ? g_intern_cap * 2 : 1024; internslot* ns = (internslot*)calloc(nc, sizeof(internslot));
+        for (size_t i = 0; i < g_intern_cap; ++i) if (g_intern[i].used) { size_t h = (size_t)((uint64_t)(g_intern[i].key ^ (g_intern[i].key >> 61)) * 0x9E3779B97F4A7C15ull) & (nc - 1); while (ns[h].used) h = (h + 1) & (nc - 1); ns[h] = g_intern[i]; }
+        free(g_intern); g_intern = ns; g_intern_cap = nc;
+    }
+    size_t h = (size_t)((uint64_t)(c ^ (c >> 61)) * 0x9E3779B97F4A7C15ull) & (g_intern_cap - 1);
+    while (g_intern[h].used) { if (g_intern[h].key == c) return g_intern[h].id; h = (h + 1) & (g_intern_cap - 1); }
+    g_intern[h].used = 1; g_intern[h].key = c; g_intern[h].id = (uint64_t)g_intern_n; return (uint64_t)g_intern_n++;
+}
+static int minimizers(const uint8_t* hs, int n, int k, int w, uint64_t* codes, uint32_t* pos) {
+    int capn = n - k + 1; if (capn < 1) capn = 1;
+    kcode* wc = (kcode*)malloc(sizeof(kcode) * (size_t)capn);
+    int cnt = minimizers_wide(hs, n, k, w, wc, pos);
+    for (int i = 0; i < cnt; ++i) codes[i] = k <= 21 ? (uint64_t)wc[i] : intern(wc[i]);
+    free(wc);
     return cnt;
 }
 
@@ -298,11 +322,14 @@ int32_t ongsid_score_reads(const ngsid_reads_t* reads, int32_t k, double q_thres
 /* ------------------------------------------------------------------------------------------------
  * (a1-a3) batch HPC + minimizers
  * ---------------------------------------------------------------------------------------------- */
+typedef struct { kcode c; uint64_t i; } wrank;
+static int cmp_wrank(const void* a, const void* b) { const wrank* x = (const wrank*)a; const wrank* y = (const wrank*)b; return x->c < y->c ? -1 : (x->c > y->c ? 1 : (x->i < y->i ? -1 : (x->i > y->i))); }
 int32_t ongsid_hpc_minimizers(const ngsid_reads_t* reads, int32_t k, int32_t w,
                               uint64_t* mz_off, uint64_t* codes, uint32_t* pos, uint64_t cap, uint64_t* needed,
                               uint32_t* hpc_len, double* hpc_err) {
     if (k < 1 || k > NGSID_MAX_K || w < k) FAIL(NGSID_ERR_ARG, "bad k/w");
     uint64_t total = 0; int overflow = 0;
+    wrank* wide = NULL; size_t wcap = 0;                 /* k > 21: all wide codes of the call, ranked at the end */
     mz_off[0] = 0;
     for (uint64_t r = 0; r < reads->n; ++r) {
         const uint8_t* s = reads->seq + reads->off[r]; const uint8_t* q = reads->qual ? reads->qual + reads->off[r] : NULL;
@@ -314,18 +341,28 @@ int32_t ongsid_hpc_minimizers(const ngsid_reads_t* reads, int32_t k, int32_t w,
         int cnt = 0;
         if (hl >= k) {
             int capn = hl - k + 1; if (capn < 1) capn = 1;
-            uint64_t* c = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)capn); uint32_t* p = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)capn);
-            cnt = minimizers(hs, hl, k, w, c, p);
-            if (cnt < 0) { free(c); free(p); free(hs); free(hq); FAIL(NGSID_ERR_ALPHABET, "read %llu: base outside ACGTN", (unsigned long long)r); }
-            if (total + (uint64_t)cnt <= cap) { memcpy(codes + total, c, sizeof(uint64_t) * (size_t)cnt); memcpy(pos + total, p, sizeof(uint32_t) * (size_t)cnt); }
-            else overflow = 1;
+            kcode* c = (kcode*)malloc(sizeof(kcode) * (size_t)capn); uint32_t* p = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)capn);
+            cnt = minimizers_wide(hs, hl, k, w, c, p);
+            if (cnt < 0) { free(c); free(p); free(hs); free(hq); free(wide); FAIL(NGSID_ERR_ALPHABET, "read %llu: base outside ACGTN", (unsigned long long)r); }
+            if (total + (uint64_t)cnt <= cap) {
+                memcpy(pos + total, p, sizeof(uint32_t) * (size_t)cnt);
+                if (k <= 21) { for (int x = 0; x < cnt; ++x) codes[total + (uint64_t)x] = (uint64_t)c[x]; }
+                else { if (total + (uint64_t)cnt > wcap) { wcap = (total + (uint64_t)cnt) * 2 + 1024; wide = (wrank*)realloc(wide, sizeof(wrank) * wcap); }
+                       for (int x = 0; x < cnt; ++x) { wide[total + (uint64_t)x].c = c[x]; wide[total + (uint64_t)x].i = total + (uint64_t)x; } }
+            } else overflow = 1;
             free(c); free(p);
         }
         total += (uint64_t)cnt; mz_off[r + 1] = total;
         free(hs); free(hq);
     }
     if (needed) *needed = total;
-    if (overflow) FAIL(NGSID_ERR_CAPACITY, "minimizer buffer too small: need %llu", (unsigned long long)total);
+    if (overflow) { free(wide); FAIL(NGSID_ERR_CAPACITY, "minimizer buffer too small: need %llu", (unsigned long long)total); }
+    if (k > 21 && total) {      /* dense order-preserving ranks over the call */
+        qsort(wide, (size_t)total, sizeof(wrank), cmp_wrank);
+        uint64_t rk = 0;
+        for (uint64_t j = 0; j < total; ++j) { if (j && wide[j].c != wide[j - 1].c) ++rk; codes[wide[j].i] = rk; }
+    }
+    free(wide);
     return NGSID_OK;
 }
 
@@ -383,6 +420,7 @@ int32_t ongsid_cluster_greedy(const ngsid_reads_t* reads, const ngsid_cluster_pa
     if (k < 1 || k > NGSID_MAX_K || w < k) FAIL(NGSID_ERR_ARG, "bad k/w");
     const uint64_t N = reads->n;
     int rc = NGSID_OK;
+    intern_reset();                                   /* k > 21: k-mer ids are per call */
     /* per representative slot data */
     int nrep = 0, caprep = 64;
     int* rep_read = (int*)malloc(sizeof(int) * (size_t)caprep);

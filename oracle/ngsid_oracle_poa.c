@@ -415,7 +415,8 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
         /* ---- strand detection by shared (HPC) minimizers with the initial backbone: replaces minimap2's strand call */
         uint64_t* cf = malloc(sizeof(uint64_t) * (size_t)(Blen + 1)); uint64_t* cr = malloc(sizeof(uint64_t) * (size_t)(Blen + 1)); uint32_t* tp = malloc(sizeof(uint32_t) * (size_t)(Blen + 1));
         uint8_t* Brc = malloc((size_t)Blen + 1); for (int i = 0; i < Blen; ++i) Brc[i] = comp_base(B[Blen - 1 - i]);
-        int nf = ongsid_i_hpc_minimizers(B, Blen, prm->k, prm->w, cf, tp); int nr = ongsid_i_hpc_minimizers(Brc, Blen, prm->k, prm->w, cr, tp);
+        const int sk = prm->k < 21 ? prm->k : 21, sw = prm->w > sk ? prm->w : sk;      /* strand detection: one-word codes (comparable between sequences) */
+        int nf = ongsid_i_hpc_minimizers(B, Blen, sk, sw, cf, tp); int nr = ongsid_i_hpc_minimizers(Brc, Blen, sk, sw, cr, tp);
         if (nf < 0 || nr < 0) { free(B); free(cf); free(cr); free(tp); free(Brc); return NGSID_ERR_ALPHABET; }
         qsort(cf, (size_t)nf, sizeof(uint64_t), cmp_u64); qsort(cr, (size_t)nr, sizeof(uint64_t), cmp_u64);
         int8_t* orient = malloc((size_t)ns + 1); uint8_t** rs = calloc((size_t)ns + 1, sizeof(uint8_t*)); uint8_t** rq = calloc((size_t)ns + 1, sizeof(uint8_t*)); int* rl = malloc(sizeof(int) * ((size_t)ns + 1));
@@ -424,7 +425,7 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
             uint64_t r = read_order ? read_order[grp_off[g] + (uint64_t)i] : grp_off[g] + (uint64_t)i; const uint8_t* s = reads->seq + reads->off[r]; const uint8_t* q = reads->qual ? reads->qual + reads->off[r] : NULL; int n = (int)(reads->off[r + 1] - reads->off[r]);
             rl[i] = n; totlen += n;
             uint64_t* c = malloc(sizeof(uint64_t) * (size_t)(n + 1)); uint32_t* p = malloc(sizeof(uint32_t) * (size_t)(n + 1));
-            int cnt = ongsid_i_hpc_minimizers(s, n, prm->k, prm->w, c, p);
+            int cnt = ongsid_i_hpc_minimizers(s, n, sk, sw, c, p);
             if (cnt < 0) { rc_err = 1; free(c); free(p); orient[i] = -1; continue; }
             int a = 0, b = 0; for (int t = 0; t < cnt; ++t) { a += in_sorted(cf, nf, c[t]); b += in_sorted(cr, nr, c[t]); }
             orient[i] = (a == 0 && b == 0) ? -1 : (b > a ? 1 : 0);

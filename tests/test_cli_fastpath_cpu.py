@@ -70,5 +70,5 @@ def test_soft_masked_iupac_and_overlong_reads_do_not_abort(oracle_backend, tmp_p
 def test_unsupported_k_is_refused_before_any_output(tmp_path):
     out = tmp_path / "o"
     with pytest.raises(SystemExit):
-        cli.cli(["--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", str(out), "--k", "25", "--w", "30"])
+        cli.cli(["--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", str(out), "--k", "40", "--w", "45"])
     assert not os.path.exists(out / "sorted.fastq")

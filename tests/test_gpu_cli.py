@@ -82,7 +82,7 @@ def test_cli_synthetic_100k_consensus_equals_amplicons(gpu_api, tmp_path):
     assert all(len(v) == 1 for k, v in cl.items() if k < 5)
 
 
-@pytest.mark.parametrize("tag,t", [("sample_h1", 8), ("synth2k_d15", 8), ("synth600_d10_q14", 4)])
+@pytest.mark.parametrize("tag,t", [("sample_h1", 8), ("synth2k_d15", 8), ("synth600_d10_q14", 4), ("synth1200_k25", 2), ("synth1200_k30", 2)])
 def test_tree_merge(gpu_api, tag, t):
     run_tree(gpu_api, tag, t)
 

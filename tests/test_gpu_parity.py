@@ -32,6 +32,18 @@ def test_minimizers(gpu_api, oracle, tag, kw):
     assert np.array_equal(got[1], g["codes_%d_%d" % (k, w)])         # and against the reference's own output
 
 
+@pytest.mark.parametrize("kw", [(25, 30), (30, 35), (22, 22), (32, 40)])
+def test_minimizers_k_above_21(gpu_api, oracle, kw):
+    g = _load("minimizers_widek.npz")
+    k, w = kw
+    rs = ReadSet(g["seq"], g["qual"], g["off"])
+    got = gpu_api.hpc_minimizers(rs, k, w); exp = oracle.hpc_minimizers(rs, k, w)
+    for a, b in zip(got[:4], exp[:4]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(got[4], exp[4], equal_nan=True)
+    assert np.array_equal(got[1], g["rank_%d_%d" % (k, w)]) and np.array_equal(got[2], g["pos_%d_%d" % (k, w)])        # the reference's own k-mers
+
+
 def _rand_pairs(rng, n, lmin, lmax, sim=True):
     qs, ts = [], []
     for _ in range(n):
@@ -86,7 +98,7 @@ def test_align_golden(gpu_api):
     assert np.array_equal(region / qlen.astype(np.float64), g["ratio"])
 
 
-@pytest.mark.parametrize("tag", ["sample_h1", "synth2k_d15", "synth600_d10_q14", "synth300_ccs"])
+@pytest.mark.parametrize("tag", ["sample_h1", "synth2k_d15", "synth600_d10_q14", "synth300_ccs", "synth1200_k25", "synth1200_k30"])
 def test_cluster_t1(gpu_api, oracle, tag):
     g = _load("cluster_%s.npz" % tag)
     rs = ReadSet(g["seq"], g["qual"], g["off"])

@@ -38,7 +38,7 @@ def run_tree(api, tag, t):
 
 
 @pytest.mark.parametrize("tag,t", [("sample_h1", 1), ("sample_h1", 2), ("sample_h1", 4), ("sample_h1", 8), ("synth2k_d15", 2), ("synth2k_d15", 8),
-                                   ("synth600_d10_q14", 4), ("synth300_ccs", 4)])
+                                   ("synth600_d10_q14", 4), ("synth300_ccs", 4), ("synth1200_k25", 2), ("synth1200_k30", 2)])
 def test_tree_merge_matches_reference(oracle, tag, t):
     run_tree(oracle, tag, t)
 

@@ -47,7 +47,19 @@ def _acc_rank(acc):
     return rank
 
 
-@pytest.mark.parametrize("tag", ["sample_h1", "synth2k_d15", "synth600_d10_q14", "synth300_ccs"])
+@pytest.mark.parametrize("kw", [(25, 30), (30, 35), (22, 22), (32, 40)])
+def test_minimizers_k_above_21(oracle, kw):
+    """k > 21 (the reference's table goes to k = 30): positions == cluster.get_kmer_minimizers, codes == the dense rank of the reference's k-mer
+    STRINGS among all minimizers of the call (tests/golden/minimizers_widek.npz, oracle/make_golden_widek.py)"""
+    g = _load("minimizers_widek.npz")
+    k, w = kw
+    rs = ReadSet(g["seq"], g["qual"], g["off"])
+    moff, codes, pos, hl, he = oracle.hpc_minimizers(rs, k, w)
+    assert np.array_equal(moff, g["moff_%d_%d" % (k, w)]) and np.array_equal(pos, g["pos_%d_%d" % (k, w)])
+    assert np.array_equal(codes, g["rank_%d_%d" % (k, w)])
+
+
+@pytest.mark.parametrize("tag", ["sample_h1", "synth2k_d15", "synth600_d10_q14", "synth300_ccs", "synth1200_k25", "synth1200_k30"])
 def test_cluster_t1(oracle, tag):
     g = _load("cluster_%s.npz" % tag)
     rs = ReadSet(g["seq"], g["qual"], g["off"])
