@@ -33,12 +33,13 @@ template <int KW> struct CodeT;
 template <> struct CodeT<1> { uint64_t lo; __device__ __forceinline__ bool less(const CodeT<1>& o) const { return lo < o.lo; } };
 template <> struct CodeT<2> { uint64_t hi, lo; __device__ __forceinline__ bool less(const CodeT<2>& o) const { return hi < o.hi || (hi == o.hi && lo < o.lo); } };
 
-// LDS of one wave (bytes): sraw [ML4] | qraw [ML4] | hs [NC + 64] | hist_h, hist_r [2 x 128 int] | am [NC u16, 8-aligned] | lo [NC u64] | hi [NC u64, KW = 2]
+// LDS of one wave (bytes): hs [NC + 64] | am [NC u16] | then EITHER sraw [ML4] | qraw [ML4] | hist_h, hist_r [2 x 128 int] (phases 1-2) OR lo [NC u64] | hi [NC u64, KW = 2] (phases 3-4)
 __host__ __device__ inline size_t mz_lds_per_wave(uint32_t maxlen, int W, int KW)
 {
     const size_t ML4 = ((size_t)maxlen + 7) & ~(size_t)3;
     const size_t NC = (((size_t)maxlen > (size_t)W ? (size_t)maxlen : (size_t)W) + 4 + 3) & ~(size_t)3;
-    return 2 * ML4 + (NC + 64) + 1024 + NC * 2 + NC * 8 * (size_t)KW;
+    const size_t phase12 = 2 * ML4 + 1024, phase34 = NC * 8 * (size_t)KW;      // staged read + histograms | k-mer codes: never live together
+    return (NC + 64) + NC * 2 + (phase12 > phase34 ? phase12 : phase34);
 }
 
 template <int KW>
@@ -56,10 +57,10 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
     const size_t ML4 = ((size_t)maxlen + 7) & ~(size_t)3;
     const size_t NC = (((size_t)maxlen > (size_t)W ? (size_t)maxlen : (size_t)W) + 4 + 3) & ~(size_t)3;
     unsigned char* base_l = smem + (size_t)wv * lds_per_wave;
-    uint8_t* sraw = base_l; uint8_t* qraw = sraw + ML4; uint8_t* hs = qraw + ML4;
-    int* hist_h = (int*)(hs + NC + 64); int* hist_r = hist_h + 128;
-    uint16_t* am = (uint16_t*)(hist_r + 128);
-    uint64_t* clo = (uint64_t*)((unsigned char*)am + NC * 2); uint64_t* chi = clo + NC;
+    uint8_t* hs = base_l; uint16_t* am = (uint16_t*)(hs + NC + 64);
+    unsigned char* un = (unsigned char*)am + NC * 2;                                      // 8-aligned: NC is a multiple of 4, the wave slice of 16
+    uint8_t* sraw = un; uint8_t* qraw = sraw + ML4; int* hist_h = (int*)(un + 2 * ML4); int* hist_r = hist_h + 128;
+    uint64_t* clo = (uint64_t*)un; uint64_t* chi = clo + NC;
     const uint64_t base = off[r];
     const int n = (int)(off[r + 1] - base);
     const uint8_t* s = seq + base; const uint8_t* q = qual ? qual + base : nullptr;
@@ -69,17 +70,22 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
     // ---- 1. stage bases / qualities (dword loads where the read's start allows it), clear the histograms
     for (int c = lane; c < 256; c += 64) hist_h[c] = 0;
     {
+        // the LDS copy starts at the same offset modulo 4 as the global address, so the body moves as aligned dwords on both sides
         auto stage = [&](const uint8_t* g, uint8_t* l) {
             const int head = (int)((4 - ((uintptr_t)g & 3)) & 3);          // bytes until the global address is dword aligned
             for (int i = lane; i < head && i < n; i += 64) l[i] = g[i];
             const int nd = n > head ? (n - head) >> 2 : 0;
-            for (int d = lane; d < nd; d += 64) {
-                const unsigned wv_ = *(const unsigned*)(g + head + 4 * d); const int o = head + 4 * d;
-                l[o] = (uint8_t)wv_; l[o + 1] = (uint8_t)(wv_ >> 8); l[o + 2] = (uint8_t)(wv_ >> 16); l[o + 3] = (uint8_t)(wv_ >> 24);
+            for (int d0 = 0; d0 < nd; d0 += 256) {                                    // four dwords per lane in flight: one HBM round trip per KB
+                unsigned v4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int d = d0 + 64 * u + lane; v4[u] = d < nd ? *(const unsigned*)(g + head + 4 * d) : 0u; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int d = d0 + 64 * u + lane; if (d < nd) *(unsigned*)(l + head + 4 * d) = v4[u]; }
             }
             for (int i = head + 4 * nd + lane; i < n; i += 64) l[i] = g[i];
         };
-        stage(s, sraw); if (q) stage(q, qraw);
+        sraw += (uintptr_t)s & 3; stage(s, sraw);
+        if (q) { qraw += (uintptr_t)q & 3; stage(q, qraw); }
     }
     lsync();
 
@@ -96,8 +102,10 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
             const int e = enc3(ch); if (e < 0) bad = 1;
             hs[idx] = (uint8_t)(e < 0 ? 0 : e);
             if (q) {
-                uint8_t best = qraw[i];
-                for (int j = i + 1; j < n && sraw[j] == ch; ++j) if (c_phred_p[qraw[j] & 127] < c_phred_p[best & 127]) best = qraw[j];
+                // the quality with the LOWEST error probability, first on ties (cluster.py:283).  p(q) = min(10^(-(q-33)/10), 0.79433) is constant up to
+                // '!' (33) and strictly decreasing above it (checked on the table when it is loaded), so p(a) < p(b) <=> max(a,33) > max(b,33)
+                uint8_t best = qraw[i]; int bk = max((int)(best & 127), 33);
+                for (int j = i + 1; j < n && sraw[j] == ch; ++j) { const int kq = max((int)(qraw[j] & 127), 33); if (kq > bk) { bk = kq; best = qraw[j]; } }
                 atomicAdd(&hist_h[best & 127], 1);
             }
         }
@@ -106,15 +114,24 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
     if (__ballot(bad)) { if (lane == 0) atomicExch(flag, 1 + (int)(r & 0x3fffffff)); }
     for (int i = hl + lane; i < (int)(NC + 64); i += 64) hs[i] = 0;                       // zero padding past the end: the "end" symbol of truncated k-mers, and room for the dword reads
     lsync();
-    // error rates: ordered FP64 sums over the quality characters that occur (ascending code), lane 0 = HPC string, lane 1 = raw read
+    // error rates: sum over the quality characters in ascending code of count x p, as ORDERED FP64 sums (zero terms are exact and skipped).  The
+    // products are formed by all lanes (lane c: characters c and 64 + c, table entries in registers), the two sums run side by side in lane 0
+    // (HPC string) and lane 1 (raw read), every term broadcast from its lane by v_readlane
     {
         const double qnan = __longlong_as_double(0x7ff8000000000000ULL);
         double acc = 0.0;
-        const int* hh = lane == 0 ? hist_h : hist_r;
         if (q) for (int half = 0; half < 2; ++half) {
             const int c = half * 64 + lane;
-            unsigned long long occ = __ballot(hist_h[c] != 0 || hist_r[c] != 0);
-            while (occ) { const int b = __builtin_ctzll(occ); occ &= occ - 1; const int cc = half * 64 + b; if (lane < 2) acc = acc + (double)hh[cc] * c_phred_p[cc]; }
+            const int nh = hist_h[c], nr = hist_r[c]; const double pc = c_phred_p[c];
+            const double th = (double)nh * pc, tr = (double)nr * pc;
+            unsigned long long occ = __ballot(nh != 0 || nr != 0);
+            const unsigned thl = (unsigned)__double_as_longlong(th), thh = (unsigned)(__double_as_longlong(th) >> 32), trl = (unsigned)__double_as_longlong(tr), trh = (unsigned)(__double_as_longlong(tr) >> 32);
+            while (occ) {
+                const int b = __builtin_ctzll(occ); occ &= occ - 1;
+                const unsigned a0 = __builtin_amdgcn_readlane(thl, b), a1 = __builtin_amdgcn_readlane(thh, b), b0 = __builtin_amdgcn_readlane(trl, b), b1 = __builtin_amdgcn_readlane(trh, b);
+                const double t = __longlong_as_double((long long)(((unsigned long long)(lane == 0 ? a1 : b1) << 32) | (lane == 0 ? a0 : b0)));
+                acc = acc + t;
+            }
         }
         if (lane == 0) { out_hlen[r] = (uint32_t)hl; out_herr[r] = (q && hl > 0) ? acc / (double)hl : qnan; }
         else if (lane == 1) out_rawerr[r] = (q && n > 0) ? acc / (double)n : qnan;
@@ -246,6 +263,8 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     if (k < 1 || k > NGSID_MAX_K || w < k || w > 255) NGSID_FAIL(ctx, NGSID_ERR_ARG, "k must be in [1,%d] and k <= w <= 255 (k=%d w=%d)", NGSID_MAX_K, k, w);
     if (R.maxlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "read of %u bases exceeds NGSID_MAX_READ_LEN=%d", R.maxlen, NGSID_MAX_READ_LEN);
     if (!g_tables_loaded[ctx->device & 15]) {
+        for (int qc = 0; qc < 127; ++qc)          // the run-quality choice of the kernel compares max(q, 33) instead of table entries: valid iff the table has this shape
+            if (qc < 33 ? NGSID_PHRED_P[qc] != NGSID_PHRED_P[qc + 1] : !(NGSID_PHRED_P[qc] > NGSID_PHRED_P[qc + 1])) NGSID_FAIL(ctx, NGSID_ERR_ARG, "internal: phred table is not constant below '!' and strictly decreasing above");
         HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_phred_p), NGSID_PHRED_P, sizeof(double) * 128));
         g_tables_loaded[ctx->device & 15] = true;
     }
@@ -253,7 +272,7 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     const int W = w - k + 1;
     const int KW = k <= 21 ? 1 : 2;
     const size_t lpw = (mz_lds_per_wave(R.maxlen, W, KW) + 15) & ~(size_t)15;
-    int wpb = 4; while (wpb > 1 && lpw * wpb > 64 * 1024) wpb >>= 1;
+    const int wpb = 1;                   // one wave per workgroup: the LDS slice of a read (8.3 KB at 750 bases) is what bounds the waves per CU (measured: 9.5 ms per 10^6 reads, 10.2 ms with four waves per workgroup)
     const size_t lds = lpw * wpb;
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "minimizer kernel needs %zu bytes of LDS", lds);
     const unsigned blocks = (unsigned)((R.n + wpb - 1) / wpb);

@@ -45,8 +45,8 @@ def test_error_codes(gpu_api, oracle):
             api.cluster_greedy(rs, cluster_params(p_shared=PT))
         assert e.value.code == -3                                                    # NGSID_ERR_ALPHABET
         with pytest.raises(NgsidError) as e:
-            api.cluster_greedy(ReadSet.from_strings(["ACGT" * 30], ["I" * 120]), cluster_params(k=22, w=30, p_shared=PT))
-        assert e.value.code == -2                                                    # k > 21
+            api.cluster_greedy(ReadSet.from_strings(["ACGT" * 30], ["I" * 120]), cluster_params(k=33, w=40, p_shared=PT))
+        assert e.value.code == -2                                                    # k > 32
     # a (k,w) without rows in the empirical table: KeyError in the reference (cluster.py:367) -> NGSID_ERR_NO_PTABLE
     sp = synth.make_species(1, 300, 0.15, seed=2); rd = synth.make_reads(sp, 20, mu=20.0, seed=3)
     rs2 = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
