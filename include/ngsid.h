@@ -228,6 +228,12 @@ int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind,
                                  const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
                                  const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read, const uint8_t* seq, const uint8_t* qual, const uint64_t* off);
 
+/* (f4) infix ("HW") location of a primer inside a consensus end = edlib.align(primer, window, mode="HW", task="locations", k=max_ed,
+ * additionalEqualities=IUPAC)["locations"][0] as barcode_trimmer.find_barcode_locations uses it (barcode_trimmer.py:34-60): *ed = smallest edit
+ * distance or -1 when above max_ed, [*start, *end] (inclusive) = the first end position with that distance and the smallest start ending there. */
+int32_t ngsid_host_infix_locate(const uint8_t* query, int32_t qlen, const uint8_t* target, int32_t tlen, int32_t max_ed, int32_t iupac,
+                                int32_t* ed, int32_t* start, int32_t* end);
+
 /* Measurement hooks (bench.py): when enabled every kernel launch of this ctx is bracketed by HIP events on the
  * ctx's own stream; ngsid_profile_read synchronises and writes "kernel_name launches total_ms\n" lines (and resets). */
 int32_t ngsid_profile_enable(ngsid_ctx* ctx, int32_t on);

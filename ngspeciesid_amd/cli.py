@@ -1,8 +1,8 @@
 """Command line of the reference (NGSpeciesID:187-287) over the MI355X hot path:  python -m ngspeciesid_amd --ont --fastq X --outfolder O --consensus --racon
 
 Same flags and defaults, same output files (sorted.fastq, logfile.txt, final_clusters.tsv, final_cluster_origins.tsv,
-consensus_reference_*.fasta, reads_to_consensus_*.fastq, racon_cl_id_*/consensus.fasta).  --medaka, --primer_file and
---remove_universal_tails are outside the hot path and are refused.
+consensus_reference_*.fasta, reads_to_consensus_*.fastq, racon_cl_id_*/consensus.fasta), including --primer_file /
+--remove_universal_tails (barcode_trimmer.py).  --medaka is outside the hot path and is refused.
 """
 from __future__ import annotations
 import argparse, logging, os, random, shutil, sys, tempfile
@@ -66,6 +66,8 @@ def main_reference_shaped(args):
         logging.info("Starting Consensus creation and polishing")
         work_dir = tempfile.mkdtemp()
         centers = consensus.form_draft_consensus(clusters, representatives, sorted_reads_fastq_file, work_dir, abundance_cutoff, args)
+        if args.primer_file or args.remove_universal_tails:
+            raise NotImplementedError("--primer_file / --remove_universal_tails are implemented in the array path of the CLI (the default; unset NGSID_CLI_REFERENCE_SHAPED)")
         centers_filtered = consensus.detect_reverse_complements(centers, args.rc_identity_threshold)
         consensus.polish_sequences(centers_filtered, args)
         shutil.rmtree(work_dir)
@@ -114,8 +116,8 @@ def cli(argv=None):
         args.k, args.w = 15, 50
     elif args.ont:
         args.k, args.w = 13, 20
-    if args.medaka or args.primer_file or args.remove_universal_tails:
-        logging.error("--medaka / --primer_file / --remove_universal_tails are outside the accelerated hot path (see DESIGN.md); not available."); sys.exit(1)
+    if args.medaka:
+        logging.error("--medaka (neural polisher) is outside the accelerated hot path (see DESIGN.md); use --racon."); sys.exit(1)
     if args.k > 32 or args.k < 1:
         logging.error('k = %d is outside what the minimizer encoder of this build handles (1..32; the shared-minimizer table has rows for k = 10..30).' % args.k); sys.exit(1)
     if 100 < args.w or args.w < args.k:

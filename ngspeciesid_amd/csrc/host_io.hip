@@ -185,3 +185,77 @@ extern "C" int32_t ngsid_host_repr_doubles(const double* v, uint64_t n, int32_t 
     for (uint64_t i = 0; i < n; ++i) if (off[i] != i * 32) memmove(buf + off[i], buf + i * 32, len[i]);
     return NGSID_OK;
 }
+
+// (f4) Infix ("HW") edit-distance location of a primer in a consensus end - what barcode_trimmer.find_barcode_locations gets from
+// edlib.align(primer, center_window, mode="HW", task="locations", k=max_ed, additionalEqualities=IUPAC_map) (barcode_trimmer.py:34-60):
+// unit costs, target ends free; *ed = the smallest edit distance (-1 when it exceeds max_ed), *end = the first (smallest) target position at
+// which an alignment with that distance ends (inclusive), *start = the smallest start of such an alignment ending there (edlib takes the LAST
+// end of the reversed prefix alignment for exactly that reason) - i.e. result["locations"][0].  iupac != 0 adds the reference's equalities
+// (M = A/C, R = A/G, ... N, X = any of ACGT; symmetric, not transitive), case-sensitive like edlib.
+// Bit-parallel (Myers 1999 / Hyyro) over 64-row blocks with per-character match masks; primers of any length.
+namespace {
+bool iupac_eq(uint8_t a, uint8_t b, int iupac)
+{
+    if (a == b) return true;
+    if (!iupac) return false;
+    auto set = [](uint8_t c) -> const char* { switch (c) { case 'M': return "AC"; case 'R': return "AG"; case 'W': return "AT"; case 'S': return "CG"; case 'Y': return "CT"; case 'K': return "GT";
+        case 'V': return "ACG"; case 'H': return "ACT"; case 'D': return "AGT"; case 'B': return "CGT"; case 'X': return "ACGT"; case 'N': return "ACGT"; default: return ""; } };
+    for (const char* p = set(a); *p; ++p) if ((uint8_t)*p == b) return true;
+    for (const char* p = set(b); *p; ++p) if ((uint8_t)*p == a) return true;
+    return false;
+}
+// last-row scores D[qlen][j] for j = 1..tlen of the alignment of q against t with a free start in t (prefix_mode == 0) or anchored at t[0] (1)
+void myers_last_row(const uint8_t* q, int qlen, const uint8_t* t, int tlen, int iupac, int prefix_mode, std::vector<int>& last)
+{
+    const int nb = (qlen + 63) / 64;
+    std::vector<uint64_t> peq((size_t)256 * nb, 0);
+    bool seen[256] = {false};
+    for (int j = 0; j < tlen; ++j) if (!seen[t[j]]) { seen[t[j]] = true; for (int i = 0; i < qlen; ++i) if (iupac_eq(q[i], t[j], iupac)) peq[(size_t)t[j] * nb + i / 64] |= 1ull << (i & 63); }
+    std::vector<uint64_t> Pv(nb, ~0ull), Mv(nb, 0);
+    std::vector<int> score(nb);                                  // score at the last row of every block
+    for (int b = 0; b < nb; ++b) score[b] = std::min(qlen, (b + 1) * 64);
+    last.assign(tlen, 0);
+    const int lastbits = qlen - (nb - 1) * 64;                   // rows in the last block
+    for (int j = 0; j < tlen; ++j) {
+        int hin = prefix_mode ? 1 : 0;                           // horizontal delta entering the top row: 0 = free start in the target, +1 = anchored
+        for (int b = 0; b < nb; ++b) {
+            const uint64_t Eq = peq[(size_t)t[j] * nb + b];
+            uint64_t pv = Pv[b], mv = Mv[b];
+            const uint64_t hinNeg = hin < 0 ? 1ull : 0ull;
+            uint64_t Xv = Eq | mv;
+            const uint64_t Eq2 = Eq | hinNeg;
+            uint64_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
+            uint64_t Ph = mv | ~(Xh | pv);
+            uint64_t Mh = pv & Xh;
+            const int top = (b == nb - 1) ? lastbits - 1 : 63;
+            int hout = 0; if ((Ph >> top) & 1) hout = 1; else if ((Mh >> top) & 1) hout = -1;
+            Ph <<= 1; Mh <<= 1;
+            if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+            Pv[b] = Mh | ~(Xv | Ph); Mv[b] = Ph & Xv;
+            score[b] += hout; hin = hout;
+        }
+        last[j] = score[nb - 1];
+    }
+}
+}  // namespace
+
+extern "C" int32_t ngsid_host_infix_locate(const uint8_t* query, int32_t qlen, const uint8_t* target, int32_t tlen, int32_t max_ed, int32_t iupac,
+                                           int32_t* ed, int32_t* start, int32_t* end)
+{
+    if (!ed || !start || !end || (qlen > 0 && !query) || (tlen > 0 && !target) || qlen < 0 || tlen < 0) return NGSID_ERR_ARG;
+    *ed = -1; *start = -1; *end = -1;
+    if (qlen == 0 || tlen == 0) return NGSID_OK;
+    std::vector<int> last;
+    myers_last_row(query, qlen, target, tlen, iupac, 0, last);
+    int best = qlen;                                           // the empty alignment (all of the primer deleted ...) is not a location: edlib needs an end position
+    int e = -1;
+    for (int j = 0; j < tlen; ++j) if (last[j] < best) { best = last[j]; e = j; }
+    if (e < 0 || (max_ed >= 0 && best > max_ed)) return NGSID_OK;
+    // start: reversed primer against the reversed target prefix, anchored at the end position: the LAST position with the same distance
+    std::vector<uint8_t> rq(query, query + qlen), rt(target, target + e + 1);
+    std::reverse(rq.begin(), rq.end()); std::reverse(rt.begin(), rt.end());
+    std::vector<int> rl; myers_last_row(rq.data(), qlen, rt.data(), e + 1, iupac, 1, rl);
+    int jl = -1; for (int j = 0; j <= e; ++j) if (rl[j] == best) jl = j;
+    *ed = best; *end = e; *start = jl >= 0 ? e - jl : e + 1;     // jl < 0: the alignment consumes no target base before `end` ... cannot happen with best < qlen
+    return NGSID_OK;
+}

@@ -229,8 +229,39 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
     node_cap = 22 if long_reads else 0
     drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=8, band=0, node_cap=node_cap, trim=pipeline.DRAFT_TRIM),
                                read_order=np.concatenate(groups).astype(np.uint32))
-    T["draft_consensus"] = time() - t0; t0 = time()
+    T["draft_consensus"] = time() - t0
     centers = [[int(sizes[c]), int(reps[c]), drafts[c], [c]] for c in range(nsel)]
+    barcodes = None
+    if getattr(args, "primer_file", "") or getattr(args, "remove_universal_tails", False):          # NGSpeciesID:134-142
+        from . import barcode_trimmer
+        barcodes = barcode_trimmer.get_universal_tails() if args.remove_universal_tails else barcode_trimmer.read_barcodes(args.primer_file)
+        logging.debug("Detecting and removing universal tails" if args.remove_universal_tails else "Detecting and removing primers")
+        # The reference trims the drafts, polishes the trimmed sequences (minimap2 clips the primer ends of the reads, which lie outside the
+        # overlap), trims again and re-polishes if something was found.  This build's polisher aligns every read END TO END, so reads that
+        # overhang a trimmed backbone would carry the primers back in as insertions.  Hence: merge decisions and the reference files use the
+        # trimmed drafts, polishing runs on the UNTRIMMED drafts (every read base has a place), and the polished sequences are trimmed once more.
+        full = [c[2] for c in centers]
+        barcode_trimmer.remove_barcodes(centers, barcodes, args)
+        logging.debug("{0} centers formed".format(len(centers)))
+        merged = _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, polish_backbones={c[1]: f for c, f in zip(centers, full)})
+        if barcode_trimmer.remove_barcodes(merged, barcodes, args):
+            for nr, c_id, seq, cs in merged:                                                          # the trimmed result is what the run reports
+                folder = os.path.join(args.outfolder, "racon_cl_id_{0}".format(c_id))
+                if os.path.isdir(folder):
+                    with open(os.path.join(folder, "consensus.fasta"), "w") as f:
+                        f.write(">{0} LN:i:{1}\n{2}\n".format("consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr), len(seq), seq))
+        return merged
+    logging.debug("{0} centers formed".format(len(centers)))
+    return _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T)
+
+
+def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, polish_backbones=None):
+    """detect_reverse_complements + polish_sequences (consensus.py:148-183,186-246): centers = [n_reads, c_id, sequence, cluster indices]"""
+    t0 = time()
+    for folder in glob.glob(os.path.join(args.outfolder, "racon_cl_id_*")):
+        shutil.rmtree(folder)
+    for file in glob.glob(os.path.join(args.outfolder, "consensus_reference_*")):
+        os.remove(file)
     merged = pipeline.detect_reverse_complements(api, centers, args.rc_identity_threshold)
     logging.debug(f"{len(merged)} consensus formed.")
     pooled = []
@@ -252,10 +283,10 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
         ids = np.concatenate(parts)
         pooled.append(ids)
         _write_pooled(os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(c_id)), ids, sr)
-    T["rc_merge_write_pooled_reads"] = time() - t0; t0 = time()
+    T["rc_merge_write_pooled_reads"] = T.get("rc_merge_write_pooled_reads", 0.0) + time() - t0; t0 = time()
     if getattr(args, "racon", False) and args.racon_iter >= 0:
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in pooled]))).astype(np.uint64)
-        bb = ReadSet.from_strings([m[2] for m in merged])
+        bb = ReadSet.from_strings([(polish_backbones or {}).get(m[1], m[2]) for m in merged])
         polished, used = api.polish(bb, work, p_off, polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=8, band=0, node_cap=node_cap, trim=2),
                                     read_order=np.concatenate(pooled).astype(np.uint32))
         for x, (nr, c_id, center, cs) in enumerate(merged):
@@ -269,7 +300,7 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
                 f.write(">{0} LN:i:{1} RC:i:{2} XC:f:1.000000\n{3}\n".format(name, len(polished[x]), int(used[x]), polished[x]))
             shutil.copyfile(last, os.path.join(folder, "consensus.fasta"))
             merged[x][2] = polished[x]
-        T["polish"] = time() - t0
+        T["polish"] = T.get("polish", 0.0) + time() - t0
     return merged
 
 

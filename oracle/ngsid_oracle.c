@@ -630,3 +630,33 @@ int32_t ongsid_merge_representatives(const ngsid_reads_t* reps, const ngsid_clus
                                      const double* score, const double* hpc_err, const int32_t* batch, int32_t n_batches, int32_t* rep_of) {
     return ngsid_merge_schedule(o_merge_cb, NULL, reps, prm, acc_rank, score, hpc_err, batch, n_batches, rep_of);
 }
+
+/* (f4) infix edit-distance location, full DP matrices (restates what the reference gets from edlib HW / task=locations; edlib 1.3.x is not in
+ * the image: PARITY UNPINNED, anchored on barcode_trimmer.py:34-60 and on hand-made cases in tests/test_barcode_trimmer.py) */
+static int o_iupac_eq(uint8_t a, uint8_t b, int iupac) {
+    static const char* codes = "MRWSYKVHDBXN"; static const char* sets[] = { "AC", "AG", "AT", "CG", "CT", "GT", "ACG", "ACT", "AGT", "CGT", "ACGT", "ACGT" };
+    if (a == b) return 1; if (!iupac) return 0;
+    for (int x = 0; x < 2; ++x) { uint8_t c = x ? b : a, d = x ? a : b; const char* p = strchr(codes, c); if (p && c) { const char* st = sets[p - codes]; if (strchr(st, d) && d) return 1; } }
+    return 0;
+}
+int32_t ongsid_host_infix_locate(const uint8_t* q, int32_t n, const uint8_t* t, int32_t m, int32_t max_ed, int32_t iupac, int32_t* ed, int32_t* start, int32_t* end) {
+    *ed = -1; *start = -1; *end = -1;
+    if (n <= 0 || m <= 0) return NGSID_OK;
+    int* D = (int*)malloc(sizeof(int) * (size_t)(n + 1) * (size_t)(m + 1));
+#define DD(i, j) D[(size_t)(i) * (size_t)(m + 1) + (size_t)(j)]
+    for (int j = 0; j <= m; ++j) DD(0, j) = 0;
+    for (int i = 1; i <= n; ++i) { DD(i, 0) = i; for (int j = 1; j <= m; ++j) { int a = DD(i - 1, j - 1) + (o_iupac_eq(q[i - 1], t[j - 1], iupac) ? 0 : 1), b = DD(i - 1, j) + 1, c = DD(i, j - 1) + 1; DD(i, j) = a < b ? (a < c ? a : c) : (b < c ? b : c); } }
+    int best = n, e = -1; for (int j = 1; j <= m; ++j) if (DD(n, j) < best) { best = DD(n, j); e = j - 1; }
+    if (e >= 0 && !(max_ed >= 0 && best > max_ed)) {
+        /* smallest start: suffix DP anchored at the end position: S[i][j] = distance of q[i..n) against t[j..e] */
+        int L = e + 1; int* S = (int*)malloc(sizeof(int) * (size_t)(n + 1) * (size_t)(L + 1));
+#define SS(i, j) S[(size_t)(i) * (size_t)(L + 1) + (size_t)(j)]
+        for (int j = 0; j <= L; ++j) SS(n, j) = L - j;
+        for (int i = n - 1; i >= 0; --i) { SS(i, L) = n - i; for (int j = L - 1; j >= 0; --j) { int a = SS(i + 1, j + 1) + (o_iupac_eq(q[i], t[j], iupac) ? 0 : 1), b = SS(i + 1, j) + 1, c = SS(i, j + 1) + 1; SS(i, j) = a < b ? (a < c ? a : c) : (b < c ? b : c); } }
+        int st = -1; for (int j = 0; j <= e; ++j) if (SS(0, j) == best) { st = j; break; }
+        *ed = best; *end = e; *start = st >= 0 ? st : e + 1;
+        free(S);
+    }
+    free(D);
+    return NGSID_OK;
+}

@@ -43,6 +43,7 @@ int32_t ongsid_sg_align_batch(const ngsid_reads_t* queries, const ngsid_reads_t*
                               int32_t k, const int32_t* match_id,
                               int32_t* score, int32_t* n_cols, int32_t* n_match, int32_t* region);
 /* single pair with CIGAR text (=XID, end gaps included) for the parasail-shaped shim */
+int32_t ongsid_host_infix_locate(const uint8_t* query, int32_t qlen, const uint8_t* target, int32_t tlen, int32_t max_ed, int32_t iupac, int32_t* ed, int32_t* start, int32_t* end);
 int32_t ongsid_merge_representatives(const ngsid_reads_t* reps, const ngsid_cluster_params_t* prm, const uint32_t* acc_rank,
                                      const double* score, const double* hpc_err, const int32_t* batch, int32_t n_batches, int32_t* rep_of);
 int32_t ongsid_sg_align_cigar_batch(const ngsid_reads_t* queries, const ngsid_reads_t* targets, const uint32_t* q_idx, const uint32_t* t_idx, uint64_t n_pairs,

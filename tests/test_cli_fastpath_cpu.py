@@ -72,3 +72,25 @@ def test_unsupported_k_is_refused_before_any_output(tmp_path):
     with pytest.raises(SystemExit):
         cli.cli(["--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", str(out), "--k", "40", "--w", "45"])
     assert not os.path.exists(out / "sorted.fastq")
+
+
+def test_universal_tail_trimming_both_layers(oracle_backend, tmp_path):
+    """(f4) --remove_universal_tails / --primer_file: amplicons flanked by the universal tails; the polished consensus is the amplicon body, cut where the reference cuts (the start cut keeps the last primer base, barcode_trimmer.py:84-98)"""
+    from ngspeciesid_amd import synth, fastio, barcode_trimmer
+    from ngspeciesid_amd._capi import ReadSet
+    tails = barcode_trimmer.get_universal_tails()
+    body = synth.make_species(1, 420, 0.15, seed=8)[0]
+    amp = np.frombuffer((tails["1_F_fw"] + body.tobytes().decode() + tails["2_R_fw"]).encode(), dtype=np.uint8)
+    rd = synth.make_reads([amp], 260, mu=18.0, seed=3)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    fq = str(tmp_path / "in.fastq"); fastio.write_fastq(fq, np.arange(rs.n), fastio.Names.from_list(["r%d" % i for i in range(rs.n)]), rs)
+    pf = tmp_path / "primers.fa"; pf.write_text(">F\n%s\n>R\n%s\n" % (tails["1_F_fw"], tails["2_R_rc"]))
+    for extra in (["--remove_universal_tails"], ["--primer_file", str(pf)]):
+        flags = ["--t", "1", "--consensus", "--racon", "--racon_iter", "2", "--abundance_ratio", "0.1"] + extra
+        b = _run(oracle_backend, flags, False, fastq=fq)
+        ref = [v for k, v in b.items() if k.startswith("consensus_reference_")]
+        assert len(ref) == 1 and ref[0].decode().split("\n")[1] == tails["1_F_fw"][-1] + body.tobytes().decode()      # the (trimmed) draft is exact already
+        cons = [v for k, v in b.items() if k.startswith("racon_cl_id_") and k.endswith("consensus.fasta")]
+        assert len(cons) == 1
+        seq = cons[0].decode().split("\n")[1]
+        assert seq == tails["1_F_fw"][-1] + body.tobytes().decode()
