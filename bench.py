@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--check-membership", action="store_true", help="strong scaling: after the timed region rank 0 replays the `--t N` schedule on one GPU and compares the membership")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): everything native code prints to fd 1 (RCCL's banner, rocm warnings) goes to stderr instead
+    sys.stdout.flush(); json_fd = os.dup(1); os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
     ndev = torch.cuda.device_count()
@@ -313,7 +315,11 @@ def main():
     if cli_leg is not None: out["config"]["cli"] = cli_leg
     if res_stop is not None: out["config"]["with_stable_stop"] = {"reads_per_s": round(n_total / dt_stop, 1), "ms_per_step": round(dt_stop * 1e3, 2), "same_result": stop_same,
                                           "note": "library default stop_when_stable=1 (not used for `value`): a cluster whose polished sequence equals its backbone is not polished again"}
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        try: dist.destroy_process_group()
+        except Exception: pass
 
 
 if __name__ == "__main__":
