@@ -234,6 +234,12 @@ int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind,
 int32_t ngsid_host_infix_locate(const uint8_t* query, int32_t qlen, const uint8_t* target, int32_t tlen, int32_t max_ed, int32_t iupac,
                                 int32_t* ed, int32_t* start, int32_t* end);
 
+/* Scheduling options of a context, for tests and tools: "cluster_block" (reads per speculative block, 0 = adaptive), "ed_band" (Ukkonen band of the
+ * polisher's first aligner launch, 0 = off, -1 = automatic), "ed_win_all", "align32" (force the int32 clustering aligner), "align_noclass" (no
+ * query-length classes), "poa_tiles_per_cu".  RESULTS NEVER DEPEND ON THEM (tests/test_gpu_stress.py runs the parity suites under several
+ * settings); the library reads no environment variable for them. */
+int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value);
+
 /* Measurement hooks (bench.py): when enabled every kernel launch of this ctx is bracketed by HIP events on the
  * ctx's own stream; ngsid_profile_read synchronises and writes "kernel_name launches total_ms\n" lines (and resets). */
 int32_t ngsid_profile_enable(ngsid_ctx* ctx, int32_t on);

@@ -254,7 +254,7 @@ int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qle
     if (job.npairs > 0xf0000000ull) NGSID_FAIL(ctx, NGSID_ERR_ARG, "more than 2^32 pairs in one aligner call");
     if (max_tlen > NGSID_MAX_READ_LEN || max_qlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in aligner", NGSID_MAX_READ_LEN);
     if (job.k > 64) NGSID_FAIL(ctx, NGSID_ERR_ARG, "window k > 64 unsupported");
-    if (!job.ops && !getenv("NGSID_ALIGN32") && ngsid_align16_applicable(job, max_qlen, max_tlen, max_open)) return ngsid_launch_align16(ctx, job, max_qlen, max_tlen, min_qlen);   // packed int16 path (bit-identical)
+    if (!job.ops && !ngsid_opt(ctx, "align32", 0) && ngsid_align16_applicable(job, max_qlen, max_tlen, max_open)) return ngsid_launch_align16(ctx, job, max_qlen, max_tlen, min_qlen);   // packed int16 path (bit-identical)
     if (max_qlen <= 256) return launch_rpl<4>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 512) return launch_rpl<8>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 768) return launch_rpl<12>(ctx, job, max_qlen, max_tlen);

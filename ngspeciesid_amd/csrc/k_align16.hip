@@ -402,7 +402,7 @@ int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_q
 {
     // Large batches with mixed query lengths: split the pairs by query-length class so that every pair runs in the instance with the
     // fewest idle rows (a lane owns 2*RP rows; 750-base reads with a few 800-base ones would otherwise all run with RP = 7).
-    if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !getenv("NGSID_ALIGN_NOCLASS")) {
+    if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !ngsid_opt(ctx, "align_noclass", 0)) {
         const uint64_t n = job.npairs;
         { int32_t rcp = ngsid_partition_pairs(ctx, job); if (rcp) return rcp; }
         // The class launches run CONCURRENTLY (the big class on the context's stream, the others on side streams): a class with a few hundred

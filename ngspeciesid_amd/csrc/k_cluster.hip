@@ -628,7 +628,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     const uint32_t BLK = 262144;              // capacity of the per-block buffers
     uint32_t blk = 32768;
     bool blk_fixed = false;
-    if (const char* e = getenv("NGSID_CLUSTER_BLK")) { const long v = atol(e); if (v >= 64 && v <= (long)BLK) { blk = (uint32_t)v; blk_fixed = true; } }     // dev / test knob: the result must not depend on it
+    { const long v = (long)ngsid_opt(ctx, "cluster_block", 0); if (v >= 64 && v <= (long)BLK) { blk = (uint32_t)v; blk_fixed = true; } }     // dev / test knob: the result must not depend on it
     DevBuf<uint64_t> cnt; uint32_t stride = 0;
     DevBuf<uint32_t> req_q, req_t, req_slot, d_scal; DevBuf<int32_t> req_open, req_mid, req_region;
     HIPCHK(ctx, req_q.alloc(BLK)); HIPCHK(ctx, req_t.alloc(BLK)); HIPCHK(ctx, req_slot.alloc(BLK)); HIPCHK(ctx, req_open.alloc(BLK)); HIPCHK(ctx, req_mid.alloc(BLK)); HIPCHK(ctx, req_region.alloc(BLK));

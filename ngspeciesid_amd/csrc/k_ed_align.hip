@@ -230,16 +230,17 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
     if (max_qlen > NGSID_MAX_READ_LEN || max_tlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in the edit-distance aligner", NGSID_MAX_READ_LEN);
     // band: wide enough for the usual read-to-draft distance, pairs beyond it take the unbanded launch (the result does not depend on it)
     int bandK = 64 + (int)(max_qlen / 32);
-    if (const char* e = getenv("NGSID_ED_BAND")) bandK = atoi(e);
+    const bool band_set = ngsid_opt(ctx, "ed_band", -1) >= 0;
+    if (band_set) bandK = (int)ngsid_opt(ctx, "ed_band", -1);
     const bool win = max_qlen > 1024 && bandK > 0;  // long queries: sliding window of 8 register-resident blocks (band of at most ~380 rows) ...
     bool win16 = false;                             // ... or of 16 (~900 rows) when the reads are so long that a 5 % error rate needs it
     if (win) {
-        if (bandK > 150 && !getenv("NGSID_ED_BAND")) { win16 = true; bandK = std::min(64 + (int)(max_qlen / 16), 400); }
+        if (bandK > 150 && !band_set) { win16 = true; bandK = std::min(64 + (int)(max_qlen / 16), 400); }
         else if (bandK > 150) { win16 = true; bandK = std::min(bandK, 400); }
     }
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
     if (bandK > 0) HIPCHK(ctx, ctx->ed_fail.reserve(job.npairs));
-    if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !getenv("NGSID_ALIGN_NOCLASS")) {
+    if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !ngsid_opt(ctx, "align_noclass", 0)) {
         // mixed lengths: every pair runs in the instance with the fewest register-resident blocks that holds its query
         // (the scratch is sized by the longest query; launches of one call share it, the stream serialises them)
         int32_t rc = ngsid_partition_pairs(ctx, job); if (rc) return rc;
@@ -255,7 +256,7 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
         if (max_qlen > 256 && (rc = launch_ed<8>(ctx, cls(1, 512), std::min<uint32_t>(max_qlen, 512), max_tlen, dist_out, 2, bandK))) return rc;
         // 513-768 bases: the 8-block window instance as well (12 KB of LDS per wave instead of 18 KB: three waves per SIMD instead of two, -8 %);
         // NGSID_ED_WIN_ALL=0 selects the 12-block instance with all blocks resident
-        static const bool win_all = !(getenv("NGSID_ED_WIN_ALL") && atoi(getenv("NGSID_ED_WIN_ALL")) == 0);
+        const bool win_all = ngsid_opt(ctx, "ed_win_all", 1) != 0;
         if (max_qlen > 512 && (rc = (win_all && bandK > 0 && bandK <= 150) ? launch_ed<8, true>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK)
                                                           : launch_ed<12>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK))) return rc;
         if (max_qlen > 768 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4, bandK))) return rc;

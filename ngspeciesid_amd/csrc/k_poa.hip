@@ -1100,7 +1100,7 @@ int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);
     const int wave_cap = BW == 64 ? 4 * POA_W1 : 16;                                  // waves per CU the register budget of the instance allows
     int per_cu = std::max<int>(1, std::min<int>(wave_cap, (int)((160 * 1024) / lds)));
-    if (const char* e = getenv("NGSID_POA_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(e)));      // dev knob
+    if (ngsid_opt(ctx, "poa_tiles_per_cu", 0) > 0) per_cu = std::max(1, std::min(per_cu, (int)ngsid_opt(ctx, "poa_tiles_per_cu", 0)));
     uint32_t nwg = (uint32_t)std::min<uint64_t>(J.nrun, (uint64_t)ctx->n_cu * per_cu);
     const size_t cells = (size_t)J.Vcap * BW;
     const size_t gbytes = poa_graph_bytes(J.Vcap, J.Ecap, J.Lmax);

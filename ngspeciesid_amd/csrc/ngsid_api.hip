@@ -447,6 +447,14 @@ extern "C" int32_t ngsid_profile_enable(ngsid_ctx* ctx, int32_t on)
     prof_collect(ctx); ctx->prof_acc.clear(); ctx->prof = on != 0;
     return NGSID_OK;
 }
+extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value)
+{
+    if (!ctx || !name) return NGSID_ERR_ARG;
+    static const char* known[] = {"cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu"};
+    for (const char* k : known) if (!strcmp(k, name)) { ctx->options[name] = (long long)value; return NGSID_OK; }
+    NGSID_FAIL(ctx, NGSID_ERR_ARG, "unknown option '%s'", name);
+}
+
 extern "C" int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap)
 {
     if (!ctx || !buf || !cap) return NGSID_ERR_ARG;

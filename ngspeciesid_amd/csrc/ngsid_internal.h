@@ -83,10 +83,15 @@ struct ngsid_ctx {
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams: the launches of the small length classes overlap the big one
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     void* pin = nullptr; size_t pin_bytes = 0;     // pinned host staging (device -> host copies of offsets)
+    std::map<std::string, long long> options;     // ngsid_ctx_option
     bool debug_sync = false;
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
 };
+
+// Scheduling options of a context (ngsid_ctx_option): block sizes, kernel instance choice, band of the first attempt.  Set explicitly through the
+// C-ABI by tests and tools - the library reads NO environment variable for them; results never depend on them (the tests run both ways).
+static inline long long ngsid_opt(const ngsid_ctx* ctx, const char* name, long long dflt) { auto it = ctx->options.find(name); return it == ctx->options.end() ? dflt : it->second; }
 
 #define NGSID_FAIL(ctx, code, ...) do { snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); return (code); } while (0)
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \

@@ -37,4 +37,10 @@ def get_api(device: int | None = None) -> Api:
         if rc != 0:
             raise NgsidError(rc, (lib.ngsid_last_error(None) or b"").decode())
         _apis[device] = Api(lib, "ngsid_", ctx)
+        # test / tool hook: NGSID_OPTIONS="ed_band=12,cluster_block=3000" -> ngsid_ctx_option calls on the new context (the LIBRARY reads no environment)
+        for kv in filter(None, os.environ.get("NGSID_OPTIONS", "").split(",")):
+            name, val = kv.split("=")
+            rc = lib.ngsid_ctx_option(ctx, name.strip().encode(), C.c_int64(int(val)))
+            if rc != 0:
+                raise NgsidError(rc, (lib.ngsid_last_error(ctx) or b"").decode())
     return _apis[device]

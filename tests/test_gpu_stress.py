@@ -104,7 +104,7 @@ def test_edit_distance_banded_equals_unbanded_at_scale(pairs, length, err):
 def test_edit_distance_band_does_not_change_results(band):
     """the Ukkonen band of the first launch is exact: with a narrow band most pairs take the unbanded second launch, with a wide one none,
     with 0 the band is off - the oracle comparison must hold for all of them"""
-    _run(3000, 900, 8, tool=TOOL_ED, env={"NGSID_ED_BAND": band})
+    _run(3000, 900, 8, tool=TOOL_ED, env={"NGSID_OPTIONS": "ed_band=%s" % band})
 
 
 @pytest.mark.gpu
@@ -129,8 +129,9 @@ rs = subset_reads(rs0, idx)
 prm = cluster_params(k=13, w=20, p_shared=select_p_table(13, 20))
 ar = np.arange(rs.n, dtype=np.uint32)
 res = []
-for blk in (None, "3000"):
-    if blk: os.environ["NGSID_CLUSTER_BLK"] = blk
+import ctypes as C
+for blk in (0, 3000):
+    assert api.lib.ngsid_ctx_option(api.ctx, b"cluster_block", C.c_int64(blk)) == 0
     rep, herr, st, cnt = api.cluster_greedy(rs, prm, acc_rank=ar)
     res.append((rep.copy(), st.copy(), cnt.copy()))
 assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), "block size changed the result"

@@ -25,9 +25,9 @@ for i in range(n):
 Q = ReadSet.from_strings(qs); TT = ReadSet.from_strings([t.tobytes().decode() for t in T])
 qi = np.arange(n, dtype=np.uint32); ti = np.array(ti, dtype=np.uint32); W = 500; nw = (L + 20 + W - 1) // W
 res = {}
+import ctypes as C
 for band in ("", "0"):
-    if band: os.environ["NGSID_ED_BAND"] = band
-    elif "NGSID_ED_BAND" in os.environ: del os.environ["NGSID_ED_BAND"]
+    assert api.lib.ngsid_ctx_option(api.ctx, b"ed_band", C.c_int64(int(band) if band else -1)) == 0
     for rep in range(2):
         t0 = time.time(); res[band] = api.ed_align_batch(Q, TT, qi, ti, window=W, bp_windows=nw); dt = time.time() - t0
     print("band %-7s %.3fs  mean distance %.1f" % (band or "default", dt, float(res[band][0].mean())), flush=True)

@@ -46,8 +46,9 @@ q = ReadSet.from_strings(qs); t = ReadSet.from_strings(ts)
 idx = np.arange(n, dtype=np.uint32)
 opens = rng.integers(2, 6, n).astype(np.int32); mids = rng.integers(-1, 14, n).astype(np.int32)
 bad = 0
+import ctypes as C
 for env, tag in ((None, "16-bit dispatch"), ("1", "32-bit only")):
-    if env: os.environ["NGSID_ALIGN32"] = env
+    assert api.lib.ngsid_ctx_option(api.ctx, b"align32", C.c_int64(1 if env else 0)) == 0
     t0 = time.time(); got = api.sg_align_batch(q, t, idx, idx, opens, 1, 2, -2, 13, mids); tg = time.time() - t0
     if tag.startswith("16"):
         t0 = time.time(); exp = orc.sg_align_batch(q, t, idx, idx, opens, 1, 2, -2, 13, mids); to = time.time() - t0
