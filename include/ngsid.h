@@ -192,7 +192,8 @@ typedef struct {
 } ngsid_polish_params_t;
 
 /* (a16,a17) replaces run_racon's (minimap2 -> racon) x racon_iter chain (consensus.py:107-126).
- * backbones: one sequence per group (qual ignored); reads grouped like ngsid_poa_consensus.
+ * backbones: one sequence per group (qual ignored); reads grouped like ngsid_poa_consensus; a read may be listed under ONE group only
+ * (NGSID_ERR_ARG otherwise: orientation and window layers are kept per read).
  * n_used[g] (may be NULL) = reads that contributed at least one window layer in the last iteration. */
 int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                      const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,

@@ -336,7 +336,11 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     std::vector<uint32_t> h_rgroup(N, 0xffffffffu); std::vector<uint8_t> tgs(G, 0);
     for (uint32_t g = 0; g < G; ++g) {
         double tot = 0; const uint64_t ns = grp_off[g + 1] - grp_off[g];
-        for (uint64_t x = grp_off[g]; x < grp_off[g + 1]; ++x) { const uint64_t r = read_order ? read_order[x] : x; h_rgroup[r] = g; tot += (double)(RD.h_off[r + 1] - RD.h_off[r]); }
+        for (uint64_t x = grp_off[g]; x < grp_off[g + 1]; ++x) {
+            const uint64_t r = read_order ? read_order[x] : x;
+            if (h_rgroup[r] != 0xffffffffu) NGSID_FAIL(ctx, NGSID_ERR_ARG, "read %llu is listed twice (groups %u and %u): strand and layers are kept per read, list every read under one backbone", (unsigned long long)r, h_rgroup[r], g);
+            h_rgroup[r] = g; tot += (double)(RD.h_off[r + 1] - RD.h_off[r]);
+        }
         tgs[g] = ns > 0 && (tot / (double)ns) > 1000.0;
     }
     ht.mark("group map");

@@ -193,12 +193,9 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
     if racon_iter > 0 and len(merged):
         # every shard polishes the (identical) merged drafts with its own reads, all iterations locally - the orientation, the alignments and
         # the window graphs never leave the GPU - then ONE all-gather of the polished strings and a weighted merge
-        p_order, p_off = [], [0]
-        for m in merged:
-            for c in m[3]:
-                p_order.append(order[lo[c]:hi[c]])
-            p_off.append(sum(len(x) for x in p_order))
-        p_order = np.concatenate(p_order) if p_order else np.zeros(0, np.uint32)
+        lists = pipeline.pooled_read_lists(merged, lambda c: order[lo[c]:hi[c]])
+        p_off = np.concatenate(([0], np.cumsum([len(x) for x in lists])))
+        p_order = np.concatenate(lists) if lists else np.zeros(0, np.uint32)
         bb = ReadSet.from_strings(polished)
         loc, used = api.polish(bb, rs_local, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, trim=polish_trim, stop_when_stable=polish_stop_when_stable), read_order=p_order)
         allq = all_gather_obj(dict(cons=list(loc), cnt=np.asarray(used, dtype=np.int64)), device)

@@ -265,6 +265,7 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
     merged = pipeline.detect_reverse_complements(api, centers, args.rc_identity_threshold)
     logging.debug(f"{len(merged)} consensus formed.")
     pooled = []
+    seen_clusters = set(); polish_lists = []          # the polisher takes a read under one centre only (pipeline.pooled_read_lists): first centre wins
     for nr, c_id, center, cs in merged:
         with open(os.path.join(args.outfolder, "consensus_reference_{0}.fasta".format(c_id)), "w") as f:
             f.write(">{0}\n{1}\n".format("consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr), center))
@@ -282,13 +283,18 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
             parts.append(g)
         ids = np.concatenate(parts)
         pooled.append(ids)
+        fresh = [p for c, p in zip(cs, parts) if c not in seen_clusters]
+        if len(fresh) < len(parts):
+            logging.warning("centre %d: %d cluster(s) were merged into an earlier centre as well; their reads polish that one only", c_id, len(parts) - len(fresh))
+        seen_clusters.update(cs)
+        polish_lists.append(np.concatenate(fresh) if fresh else np.zeros(0, dtype=ids.dtype))
         _write_pooled(os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(c_id)), ids, sr)
     T["rc_merge_write_pooled_reads"] = T.get("rc_merge_write_pooled_reads", 0.0) + time() - t0; t0 = time()
     if getattr(args, "racon", False) and args.racon_iter >= 0:
-        p_off = np.concatenate(([0], np.cumsum([len(x) for x in pooled]))).astype(np.uint64)
+        p_off = np.concatenate(([0], np.cumsum([len(x) for x in polish_lists]))).astype(np.uint64)
         bb = ReadSet.from_strings([(polish_backbones or {}).get(m[1], m[2]) for m in merged])
         polished, used = api.polish(bb, work, p_off, polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=8, band=0, node_cap=node_cap, trim=2),
-                                    read_order=np.concatenate(pooled).astype(np.uint32))
+                                    read_order=np.concatenate(polish_lists).astype(np.uint32))
         for x, (nr, c_id, center, cs) in enumerate(merged):
             logging.debug("running racon on spoa reference {0} using {1} reads for polishing.".format(c_id, len(pooled[x])))
             folder = os.path.join(args.outfolder, "racon_cl_id_{0}".format(c_id))

@@ -80,6 +80,24 @@ def detect_reverse_complements(api: Api, centers, rc_identity_threshold):
     return out
 
 
+def pooled_read_lists(merged, group_reads):
+    """reads polished against every merged centre: the pooled files of consensus.py:208-215.  The reference re-merges centres that were removed
+    already (detect_reverse_complements above), so one cluster can be pooled under two centres; the polisher keeps strand and layers per read, so
+    a read stays with the FIRST centre that lists it (a deviation in that rare case, logged)."""
+    seen = set(); out = []; dup = 0
+    for m in merged:
+        parts = []
+        for ci in m[3]:
+            if ci in seen:
+                dup += 1; continue
+            seen.add(ci); parts.append(group_reads(ci))
+        out.append(np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32))
+    if dup:
+        import logging
+        logging.warning("%d cluster(s) were merged into more than one centre: their reads polish the first of them only", dup)
+    return out
+
+
 def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, w=20, abundance_ratio=0.1,
                  rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=8, band=0, node_cap=0,
                  p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2, polish_aln_mode=2, polish_stop_when_stable=True):
@@ -118,15 +136,14 @@ def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, 
     polished = [m[2] for m in merged]
     if do_polish and racon_iter > 0:
         t0 = time.perf_counter()
-        p_order, p_off = [], [0]
-        for m in merged:
-            for ci in m[3]:                                                     # pooled reads of the merged clusters (consensus.py:208-215)
-                a, b = int(grp_off[ci]), int(grp_off[ci + 1])
-                if max_seqs_for_consensus >= 0:
-                    b = min(b, a + max_seqs_for_consensus)                      # the pooled file is built from the truncated reads_c_id files
-                p_order.append(order[a:b])
-            p_off.append(sum(len(x) for x in p_order))
-        p_order = np.concatenate(p_order)
+        def group_reads(ci):                                                    # pooled reads of the merged clusters (consensus.py:208-215)
+            a, b = int(grp_off[ci]), int(grp_off[ci + 1])
+            if max_seqs_for_consensus >= 0:
+                b = min(b, a + max_seqs_for_consensus)                          # the pooled file is built from the truncated reads_c_id files
+            return order[a:b]
+        lists = pooled_read_lists(merged, group_reads)
+        p_off = np.concatenate(([0], np.cumsum([len(x) for x in lists])))
+        p_order = np.concatenate(lists)
         bb = ReadSet.from_strings([m[2] for m in merged])
         polished, used = api.polish(bb, rs, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=polish_trim, aln_mode=polish_aln_mode, stop_when_stable=polish_stop_when_stable), read_order=p_order)
         T["polish"] = T.get("polish", 0.0) + time.perf_counter() - t0
