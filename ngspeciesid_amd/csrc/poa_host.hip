@@ -269,7 +269,7 @@ __global__ void k_orient(const uint8_t* __restrict__ seq, const uint8_t* __restr
 __global__ __launch_bounds__(256) void k_layers(const uint8_t* __restrict__ oseq, const uint8_t* __restrict__ oqual, const uint64_t* __restrict__ off,
                          const uint32_t* __restrict__ pair_read, const uint32_t* __restrict__ pair_group, uint64_t npairs, int nwinmax,
                          const int32_t* __restrict__ bp, const int32_t* __restrict__ span, const int32_t* __restrict__ blen /* per group */,
-                         int W, double qthr, double ethr, PSeq* __restrict__ lay, uint8_t* __restrict__ valid, int* __restrict__ maxlen_out)
+                         int W, double qthr, double ethr, PSeq* __restrict__ lay, uint16_t* __restrict__ valid /* 0 = no layer, else 1 + its first window position */, int* __restrict__ maxlen_out)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t t = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_layers(const uint8_t* __restrict__ oseq
     const int begin = tf - ws, end = tl - ws; const int offset = (int)(0.01 * (double)wlen);
     PSeq S; S.s = oseq + rb + qf; S.q = oqual ? oqual + rb + qf : nullptr; S.len = len; S.uw = 1; S.cw = 1; S.a0 = begin; S.a1 = end;
     S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI;
-    if (lane == 0) { lay[t] = S; valid[t] = 1; if (len > __atomic_load_n(maxlen_out, __ATOMIC_RELAXED)) atomicMax(maxlen_out, len); }      // (millions of atomics on one word would serialise)
+    if (lane == 0) { lay[t] = S; valid[t] = (uint16_t)((begin < 0 ? 0 : (begin > 65533 ? 65533 : begin)) + 1); if (len > __atomic_load_n(maxlen_out, __ATOMIC_RELAXED)) atomicMax(maxlen_out, len); }      // (millions of atomics on one word would serialise)
 }
 
 std::string revcomp(const std::string& s) { std::string r(s.size(), 'N'); for (size_t i = 0; i < s.size(); ++i) { char c = s[s.size() - 1 - i]; r[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; } return r; }
@@ -394,7 +394,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     static thread_local PinVec<uint32_t> pair_read, pair_group; pair_read.clear(); pair_group.clear();
     for (uint64_t x = 0; x < grp_off[n_groups]; ++x) { const uint64_t r = read_order ? read_order[x] : x; if (h_orient[r] != 255) { pair_read.push_back((uint32_t)r); pair_group.push_back(h_rgroup[r]); } }
     uint64_t NP = pair_read.size();
-    DevBuf<uint32_t> d_pair_read, d_pair_group; DevBuf<int32_t> d_open, d_span, d_blen; DevBuf<int32_t>& d_bp = ctx->pol_bp; DevBuf<uint8_t>& d_lay_raw = ctx->pol_lay; DevBuf<uint8_t>& d_valid = ctx->pol_valid;
+    DevBuf<uint32_t> d_pair_read, d_pair_group; DevBuf<int32_t> d_open, d_span, d_blen; DevBuf<int32_t>& d_bp = ctx->pol_bp; DevBuf<uint8_t>& d_lay_raw = ctx->pol_lay; DevBuf<uint16_t>& d_valid = ctx->pol_valid;
     HIPCHK(ctx, d_pair_read.alloc(NP)); HIPCHK(ctx, d_pair_group.alloc(NP)); HIPCHK(ctx, d_open.alloc(NP)); HIPCHK(ctx, d_span.alloc(NP * 4)); HIPCHK(ctx, d_blen.alloc(G));
     if (NP) { HIPCHK(ctx, hipMemcpyAsync(d_pair_read.p, pair_read.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d_pair_group.p, pair_group.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream));
               HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)d_open.p, prm->aln_open, NP, ctx->stream)); }
@@ -423,7 +423,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         HIPCHK(ctx, hipMemcpyAsync(d_blen.p, blen.data(), 4 * G, hipMemcpyHostToDevice, ctx->stream));
         for (uint32_t g = 0; g < G; ++g) if (!stable[g]) used[g] = 0;
         std::vector<Unit> units; std::vector<PSeq> bbs; std::vector<int> bb_len; std::vector<std::pair<uint32_t, int>> unit_gw;
-        static thread_local PinVec<uint8_t> h_valid; int max_layer = 1;
+        static thread_local PinVec<uint16_t> h_valid; int max_layer = 1;
         HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
         if (NP) {
             HIPCHK(ctx, d_bp.reserve(NP * (uint64_t)nwinmax * 4)); HIPCHK(ctx, d_lay_raw.reserve(sizeof(PSeq) * NP * (uint64_t)nwinmax)); HIPCHK(ctx, d_valid.reserve(NP * (uint64_t)nwinmax));
@@ -441,7 +441,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             HIPCHK(ctx, hipGetLastError());
             h_valid.resize(T);
             HIPCHK(ctx, hipMemcpyAsync(&max_layer, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(h_valid.data(), d_valid.p, T, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(h_valid.data(), d_valid.p, 2 * T, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
         ht.mark("align + layers + valid copy");
@@ -456,13 +456,30 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             // lists sized for the worst case, filled through raw cursors (two million appends per iteration), trimmed afterwards
             std::vector<uint32_t*> cur(units.size(), nullptr);
             for (uint32_t g = 0; g < G; ++g) for (uint32_t wdx = 0; wdx < unw[g]; ++wdx) { auto& v = units[ubase[g] + wdx].seqs; v.resize(npg[g]); cur[ubase[g] + wdx] = v.data(); }
-            const uint32_t* pg = pair_group.data(); const uint8_t* hv0 = h_valid.data();
+            const uint32_t* pg = pair_group.data(); const uint16_t* hv0 = h_valid.data();
             for (uint64_t p = 0; p < NP; ++p) {
-                const uint32_t g = pg[p]; const uint8_t* hv = hv0 + p * (uint64_t)nwinmax; const uint32_t nwg = unw[g], ub = ubase[g]; uint32_t any = 0;
+                const uint32_t g = pg[p]; const uint16_t* hv = hv0 + p * (uint64_t)nwinmax; const uint32_t nwg = unw[g], ub = ubase[g]; uint32_t any = 0;
                 for (uint32_t wdx = 0; wdx < nwg; ++wdx) { const uint32_t v = hv[wdx] != 0; *cur[ub + wdx] = (uint32_t)(p * (uint64_t)nwinmax + wdx); cur[ub + wdx] += v; any |= v; }
                 used[g] += any;
             }
             for (size_t u = 0; u < units.size(); ++u) if (cur[u]) units[u].seqs.resize((size_t)(cur[u] - units[u].seqs.data()));
+            // racon adds the layers of a window in the order of their first window position (src/window.cpp: rank sorted by positions_.first);
+            // ties keep the read order (stable)
+            {
+                static thread_local std::vector<uint32_t> tmpv; std::vector<uint32_t> cnt;
+                for (size_t u = 0; u < units.size(); ++u) {
+                    auto& v = units[u].seqs; if (v.size() < 2) continue;
+                    uint32_t kmax = 0; bool sorted = true;
+                    for (size_t x = 0; x < v.size(); ++x) { const uint32_t kx = hv0[v[x]]; kmax = std::max(kmax, kx); if (x && hv0[v[x - 1]] > kx) sorted = false; }
+                    if (sorted) continue;
+                    cnt.assign((size_t)kmax + 2, 0);                      // counting sort (keys are window positions): linear and stable
+                    for (uint32_t id : v) cnt[hv0[id] + 1]++;
+                    for (size_t k2 = 1; k2 < cnt.size(); ++k2) cnt[k2] += cnt[k2 - 1];
+                    tmpv.resize(v.size());
+                    for (uint32_t id : v) tmpv[cnt[hv0[id]]++] = id;
+                    std::copy(tmpv.begin(), tmpv.end(), v.begin());
+                }
+            }
         }
         std::vector<size_t> nlayers(units.size());
         for (size_t u = 0; u < units.size(); ++u) {

@@ -479,6 +479,11 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
                 free(wf);
                 used += (uint64_t)contributed;
             }
+            /* racon adds the layers of a window in the order of their first window position (src/window.cpp), ties in read order (stable) */
+            for (int wdx = 0; wdx < nwin; ++wdx) {
+                layervec* L = &LV[wdx];
+                for (int x = 1; x < L->n; ++x) { pseq key = L->v[x]; int y = x - 1; while (y >= 0 && L->v[y].a0 > key.a0) { L->v[y + 1] = L->v[y]; --y; } L->v[y + 1] = key; }      /* insertion sort: lists are nearly sorted */
+            }
             /* ---- window consensuses */
             uint8_t* NB = malloc((size_t)Blen * 3 + 1024); int nb = 0, nbcap = Blen * 3 + 1024;
             for (int wdx = 0; wdx < nwin; ++wdx) {
