@@ -262,7 +262,10 @@ def main():
             tc = time.perf_counter()
             procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), os.path.join(tmpd, "s%d.npz" % i), "0", str(b_ - a_), os.path.join(tmpd, "o%d.json" % i)],
                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i, (a_, b_) in enumerate(batches)]
-            for p_ in procs: p_.wait()
+            deadline = time.perf_counter() + 120.0           # bounded leg: workers still running after two minutes are stopped (by PID) and the leg reports nothing
+            for p_ in procs:
+                try: p_.wait(timeout=max(0.1, deadline - time.perf_counter()))
+                except subprocess.TimeoutExpired: p_.kill(); p_.wait()
             dta = time.perf_counter() - tc
             done = [json.load(open(os.path.join(tmpd, "o%d.json" % i))) for i in range(len(batches)) if os.path.exists(os.path.join(tmpd, "o%d.json" % i))]
             if len(done) == len(batches):

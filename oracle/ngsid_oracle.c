@@ -11,6 +11,11 @@
 #include "../include/ngsid_tables.h"
 
 static char g_err[512] = "";
+#include <malloc.h>
+/* The restatement allocates its DP matrices per alignment (hundreds of KB each): with glibc's defaults every one of them is an mmap / page-fault /
+ * munmap cycle, which collapses when a few hundred worker processes do it at once (bench.py cpu_baseline, all host cores).  Keep freed blocks. */
+__attribute__((constructor)) static void ongsid_malloc_setup(void) { mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 512 << 20); mallopt(M_TOP_PAD, 64 << 20); }
+
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
 uint32_t ongsid_abi_version(void) { return 1u; }
