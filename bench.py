@@ -234,12 +234,22 @@ def main():
         from ngspeciesid_amd import parallelize
         orc = load_oracle()
         cores = os.cpu_count() or 1
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores          # what this process may actually run on ...
+        try:                                                                                           # ... and the container's CPU quota (cgroup v2 / v1)
+            q = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q[0] != "max": usable = min(usable, max(1, int(float(q[0]) / float(q[1]))))
+        except Exception:
+            try:
+                qq = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); pp = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if qq > 0: usable = min(usable, max(1, qq // pp))
+            except Exception:
+                pass
         try:
             model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
         except Exception:
             model = "unknown"
         per_core = max(200, args.cpu_sample)
-        use = max(1, min(cores, args.cpu_cores if args.cpu_cores > 0 else cores))
+        use = max(1, min(usable, args.cpu_cores if args.cpu_cores > 0 else usable))
         ns = min(n, per_core * use)
         idx = np.linspace(0, n - 1, ns).astype(np.int64)          # evenly strided subset: keeps the score order and the species mix
         seq = rd["seq"].cpu().numpy(); qual = rd["qual"].cpu().numpy(); off = rd["off"].cpu().numpy()
@@ -273,9 +283,9 @@ def main():
         finally:
             shutil.rmtree(tmpd, ignore_errors=True)
         cpu = {"value": allc["value"] if allc else round(one.n / dt1, 2), "unit": "reads/s", "cores": allc["cores"] if allc else 1, "kind": "port",
-               "cpu_model": model, "host_cores": cores,
+               "cpu_model": model, "host_cores": cores, "usable_cores": usable,
                "one_core": {"value": round(one.n / dt1, 2), "reads": int(one.n), "seconds": round(dt1, 1)}, "all_cores": allc,
-               "sample": "%d reads strided from the same batch (same params, tile_depth %d): %d per worker process, one process per logical core (start-up of the interpreters included in the wall time) running oracle/libngsid_oracle.so "
+               "sample": "%d reads strided from the same batch (same params, tile_depth %d): %d per worker process, one process per usable core (affinity mask / cgroup quota; start-up of the interpreters included in the wall time) running oracle/libngsid_oracle.so "
                          "(scalar C port of this build's algorithms; the reference's own tools - parasail, spoa, racon - are SIMD codes and are not in the image, see BASELINE.md)"
                          % (ns, args.tile_depth, per_core)}
     # ---- the drop-in surface: FASTQ file in -> the reference's output files out (python -m ngspeciesid_amd ...), same reads, same flags as C3
