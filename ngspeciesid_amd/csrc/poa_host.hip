@@ -250,6 +250,12 @@ void k_strand(const uint64_t* __restrict__ off, const uint32_t* __restrict__ mzc
     if (lane == 0) orient[r] = (a == 0 && b == 0) ? 255 : (b > a ? 1 : 0);
 }
 
+// Polishing windows of a backbone of Bl bases: W bases each; a last window shorter than W/10 is merged into the one before it.  (racon keeps it:
+// only layers of at least 0.02 W bases enter a window, so a 7-base tail window is built from the reads that carry INSERTIONS there and the
+// consensus gains bases - seen on 5 007-base amplicons.)  Window w covers [w * W, w == nwin - 1 ? Bl : (w + 1) * W).
+__host__ __device__ __forceinline__ int polish_nwin(int Bl, int W) { const int raw = Bl <= W ? 1 : (Bl + W - 1) / W; const int tail = Bl - (raw - 1) * W; return (raw >= 2 && tail < W / 10) ? raw - 1 : raw; }
+__host__ __device__ __forceinline__ int polish_wlen(int Bl, int W, int w) { return w == polish_nwin(Bl, W) - 1 ? Bl - w * W : W; }
+
 __device__ __forceinline__ uint8_t comp_base(uint8_t c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
 
 __global__ void k_orient(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t n,
@@ -280,8 +286,14 @@ __global__ __launch_bounds__(256) void k_layers(const uint8_t* __restrict__ oseq
     if (qb < 0) return;
     const int qs = qe - qb + 1, ts = te - tb + 1; const int mn = qs < ts ? qs : ts, mx = qs < ts ? ts : qs;
     if (1.0 - (double)mn / (double)mx > ethr) return;
+    const int Bl = blen[pair_group[p]]; const int nw = polish_nwin(Bl, W);
+    if (wdx >= nw) return;
     const int32_t* b = bp + (p * (uint64_t)nwinmax + wdx) * 4;
-    const int qf = b[0], ql = b[1], tf = b[2], tl = b[3];
+    int qf = b[0], ql = b[1], tf = b[2], tl = b[3];
+    if (wdx == nw - 1 && wdx + 1 < nwinmax && (Bl + W - 1) / W > nw) {       // merged tail window: the aligner's break points of the two raw windows are joined
+        const int32_t* b2 = b + 4;
+        if (b2[0] >= 0) { if (qf < 0) { qf = b2[0]; tf = b2[2]; } ql = b2[1]; tl = b2[3]; }
+    }
     if (qf < 0) return;
     const int len = ql - qf + 1; if ((double)len < 0.02 * (double)W) return;
     const uint32_t read = pair_read[p]; const uint64_t rb = off[read];
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(256) void k_layers(const uint8_t* __restrict__ oseq
         for (int d = 32; d >= 1; d >>= 1) sq += __shfl_xor(sq, d);
         if ((double)sq / (double)len < qthr) return;
     }
-    const int Bl = blen[pair_group[p]]; const int ws = wdx * W; const int wlen = (Bl - ws) < W ? (Bl - ws) : W;
+    const int ws = wdx * W; const int wlen = polish_wlen(Bl, W, wdx);
     const int begin = tf - ws, end = tl - ws; const int offset = (int)(0.01 * (double)wlen);
     PSeq S; S.s = oseq + rb + qf; S.q = oqual ? oqual + rb + qf : nullptr; S.len = len; S.uw = 1; S.cw = 1; S.a0 = begin; S.a1 = end;
     S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI;
@@ -447,7 +459,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         ht.mark("align + layers + valid copy");
         // ---- units = (group, window) with their layers in read order
         std::vector<std::vector<int>> unit_of(G);
-        for (uint32_t g = 0; g < G; ++g) { if (stable[g]) continue; const int nw = (int)((B[g].size() + W - 1) / W); unit_of[g].assign(nw, -1);
+        for (uint32_t g = 0; g < G; ++g) { if (stable[g]) continue; const int nw = polish_nwin((int)B[g].size(), W); unit_of[g].assign(nw, -1);
             for (int wdx = 0; wdx < nw; ++wdx) { unit_of[g][wdx] = (int)units.size(); units.emplace_back(); unit_gw.push_back({g, wdx}); } }
         {   // layers of every window in pair (= read) order; the units of a group are consecutive, a window holds at most one layer per pair of its group
             std::vector<uint32_t> ubase(G), unw(G), npg(G, 0);
@@ -485,7 +497,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         for (size_t u = 0; u < units.size(); ++u) {
             nlayers[u] = units[u].seqs.size();
             if (units[u].seqs.size() < 2) { units[u].seqs.clear(); units[u].done = true; continue; }          // racon: < 3 sequences incl. backbone -> keep backbone
-            const uint32_t g = unit_gw[u].first; const int ws = unit_gw[u].second * W; const int wlen = std::min<int>(W, (int)B[g].size() - ws);
+            const uint32_t g = unit_gw[u].first; const int ws = unit_gw[u].second * W; const int wlen = polish_wlen((int)B[g].size(), W, unit_gw[u].second);
             PSeq S; S.s = BB.seq + boff[g] + ws; S.q = nullptr; S.len = wlen; S.uw = 0; S.cw = 0; S.mode = NGSID_POA_GLOBAL; S.a0 = 0; S.a1 = -1;
             units[u].bb = (int)bbs.size(); bbs.push_back(S); bb_len.push_back(wlen);
         }
@@ -499,7 +511,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         // ---- new backbones
         std::vector<std::string> NB(G);
         for (size_t u = 0; u < units.size(); ++u) {
-            const uint32_t g = unit_gw[u].first; const int ws = unit_gw[u].second * W; const int wlen = std::min<int>(W, (int)B[g].size() - ws);
+            const uint32_t g = unit_gw[u].first; const int ws = unit_gw[u].second * W; const int wlen = polish_wlen((int)B[g].size(), W, unit_gw[u].second);
             std::string c = units[u].has_result ? units[u].result : std::string();
             if (!c.empty() && prm->trim && (tgs[g] || prm->trim >= 2) && units[u].cov.size() == c.size()) {
                 const uint32_t avg = (uint32_t)(nlayers[u] / 2); int b = 0, e = (int)c.size() - 1;

@@ -401,6 +401,10 @@ static uint8_t comp_base(uint8_t c) { switch (c) { case 'A': return 'T'; case 'C
 typedef struct { pseq* v; int n, cap; } layervec;
 static void lv_push(layervec* L, pseq s) { if (L->n == L->cap) { L->cap = L->cap ? L->cap * 2 : 16; L->v = realloc(L->v, sizeof(pseq) * (size_t)L->cap); } L->v[L->n++] = s; }
 
+/* polishing windows: W bases each, a last window shorter than W/10 is merged into the one before it (see csrc/poa_host.hip polish_nwin) */
+static int polish_nwin(int Bl, int W) { const int raw = Bl <= W ? 1 : (Bl + W - 1) / W; const int tail = Bl - (raw - 1) * W; return (raw >= 2 && tail < W / 10) ? raw - 1 : raw; }
+static int polish_wlen(int Bl, int W, int w) { return w == polish_nwin(Bl, W) - 1 ? Bl - w * W : W; }
+
 int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                       const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used) {
     pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : default_band(reads), prm->node_cap, prm->trim >= 2 };
@@ -440,7 +444,7 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
         const int tgs = ns > 0 && (totlen / (double)ns) > 1000.0;
         uint64_t used = 0;
         for (int it = 0; it < prm->iters; ++it) {
-            const int nwin = (Blen + W - 1) / W;
+            const int nwin = polish_nwin(Blen, W);
             layervec* LV = calloc((size_t)nwin + 1, sizeof(layervec));
             used = 0;
             for (int i = 0; i < ns; ++i) {
@@ -454,7 +458,7 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
                 for (int x = 0; x < c; ++x) {
                     if (ops[x] <= 1) {
                         if (qb < 0) { qb = qi; tb = ti; } qe = qi; te = ti;
-                        int wdx = ti / W; if (wf[wdx * 4] < 0) { wf[wdx * 4] = qi; wf[wdx * 4 + 2] = ti; } wf[wdx * 4 + 1] = qi; wf[wdx * 4 + 3] = ti;
+                        int wdx = ti / W; if (wdx > nwin - 1) wdx = nwin - 1; if (wf[wdx * 4] < 0) { wf[wdx * 4] = qi; wf[wdx * 4 + 2] = ti; } wf[wdx * 4 + 1] = qi; wf[wdx * 4 + 3] = ti;
                         ++qi; ++ti;
                     } else if (ops[x] == 2) ++qi; else ++ti;
                 }
@@ -468,7 +472,7 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
                             int qf = wf[wdx * 4], ql = wf[wdx * 4 + 1], tf = wf[wdx * 4 + 2], tl = wf[wdx * 4 + 3];
                             int len = ql - qf + 1; if ((double)len < 0.02 * (double)W) continue;
                             if (rq[i]) { long sq = 0; for (int x = qf; x <= ql; ++x) sq += (long)rq[i][x] - 33; if ((double)sq / (double)len < prm->quality_threshold) continue; }
-                            int ws = wdx * W, wlen = (Blen - ws) < W ? (Blen - ws) : W;
+                            int ws = wdx * W, wlen = polish_wlen(Blen, W, wdx);
                             int begin = tf - ws, end = tl - ws; int offset = (int)(0.01 * (double)wlen);
                             pseq S; S.s = rs[i] + qf; S.q = rq[i] ? rq[i] + qf : NULL; S.len = len; S.uw = 1; S.cw = 1; S.a0 = begin; S.a1 = end;
                             S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI;
@@ -487,7 +491,7 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
             /* ---- window consensuses */
             uint8_t* NB = malloc((size_t)Blen * 3 + 1024); int nb = 0, nbcap = Blen * 3 + 1024;
             for (int wdx = 0; wdx < nwin; ++wdx) {
-                int ws = wdx * W, wlen = (Blen - ws) < W ? (Blen - ws) : W;
+                int ws = wdx * W, wlen = polish_wlen(Blen, W, wdx);
                 uint8_t* c = NULL; uint32_t* cov = NULL; int len = 0;
                 if (LV[wdx].n >= 2) {
                     pseq bb; bb.s = B + ws; bb.q = NULL; bb.len = wlen; bb.uw = 0; bb.cw = 0; bb.mode = NGSID_POA_GLOBAL; bb.a0 = 0; bb.a1 = -1;

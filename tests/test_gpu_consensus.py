@@ -139,3 +139,19 @@ def test_band_edge_redo_matches_oracle(gpu_api, oracle):
     # the wide insertion is kept where the majority carries it (groups 0, 1, 3) - i.e. the redo found the path through it
     wide = gpu_api.poa_consensus(rs, grp, poa_params(mode=POA_GLOBAL, tile_depth=6, band=64, trim=1))
     assert len(wide[0]) > 630 and len(wide[1]) > 680 and len(wide[2]) < 615
+
+
+@pytest.mark.parametrize("L", [507, 1003, 1549])
+def test_short_tail_window_parity(gpu_api, oracle, L):
+    sp = synth.make_species(2, L, 0.15, seed=22)
+    seqs, quals, off = [], [], [0]
+    for g in range(2):
+        rd = synth.make_reads([sp[g]], 300, mu=15.0, seed=40 + g)
+        seqs.append(rd["seq"].numpy()); quals.append(rd["qual"].numpy()); off += list(off[-1] + rd["off"].numpy()[1:])
+    rs = ReadSet(np.concatenate(seqs), np.concatenate(quals), np.array(off, dtype=np.uint64))
+    bbs = [s.tobytes().decode() for s in sp]
+    for tail in (3, 7, 30, 49, 50, 120):                       # force every tail-window shape, merged (< 50) and not
+        b2 = [b[:(len(b) // 500) * 500 + tail] if len(b) > 500 + tail else b for b in bbs]
+        prm = polish_params(iters=2, k=13, w=20, tile_depth=8, band=0, trim=2)
+        a, ua = gpu_api.polish(ReadSet.from_strings(b2), rs, [0, 300, 600], prm); b, ub = oracle.polish(ReadSet.from_strings(b2), rs, [0, 300, 600], prm)
+        assert a == b and np.array_equal(ua, ub), tail
