@@ -69,3 +69,11 @@ def test_strong_scaling_ranks_on_one_gpu_membership_equals_t_n(world):
     chk = out["config"]["check"]
     assert chk["membership_equals_reference_t_n"] is True
     assert chk["centers"] == 5 and chk["consensus_edit_distance_vs_truth"] == [0, 0, 0, 0, 0] and chk["cluster_purity"] == 1.0
+
+
+def test_long_ont_reads_5kb_five_species(gpu_api):
+    """beyond the BASELINE shapes: 40 k x 5 kb ONT-profile reads (ten polishing windows, amplicon lengths a few bases over a multiple of 500:
+    the merged tail window; 128-column first band): every polished consensus == its amplicon"""
+    sp, rd, rs, res = _run(gpu_api, 40000, 5, 5000, 17.0, 13, 20, 0.02, seed=3)
+    _check_clusters(rd, res, 5, 0.99)
+    _exact(sp, res)
