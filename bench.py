@@ -13,12 +13,12 @@ import numpy as np
 import torch
 
 
-def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device, abundance=None):
+def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device, abundance=None, rc_fraction=0.0):
     """synthetic reads, scored (f1) and physically ordered by score descending (stable) = the greedy order."""
     from ngspeciesid_amd import synth
     from ngspeciesid_amd._capi import ReadSet
     sp = synth.make_species(n_species, L, 0.15, seed=1)
-    rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed, device=device, abundance=abundance)
+    rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed, device=device, abundance=abundance, rc_fraction=rc_fraction)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     torch.cuda.synchronize(device)       # the library runs on its own HIP stream: torch's generator kernels must have finished writing the reads
     score, err, keep = api.score_reads(rs, 13, 7.0)

@@ -77,3 +77,24 @@ def test_long_ont_reads_5kb_five_species(gpu_api):
     sp, rd, rs, res = _run(gpu_api, 40000, 5, 5000, 17.0, 13, 20, 0.02, seed=3)
     _check_clusters(rd, res, 5, 0.99)
     _exact(sp, res)
+
+
+@pytest.mark.parametrize("mu", [17.0, 14.0])
+def test_mixed_strand_reads_are_merged_and_polished(gpu_api, mu):
+    """half of the reads are reverse complements (real ONT data): the reference's flow gives two clusters per species, the rc merge
+    (consensus.py:148-183) joins them, and the pooled reads of both strands polish ONE sequence per species: the amplicon or its reverse complement"""
+    import torch
+    import bench
+    from ngspeciesid_amd import pipeline
+    from ngspeciesid_amd._capi import ReadSet
+    from ngspeciesid_amd.ptable import select_p_table
+    dev = torch.device("cuda", 0)
+    sp, rd = bench.gen_sorted_reads(gpu_api, 200000, 5, 750, mu, seed=13, device=dev, rc_fraction=0.5)
+    rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
+    res = pipeline.run_hot_path(gpu_api, rs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=13, w=20, abundance_ratio=0.02, racon_iter=3,
+                                tile_depth=8, band=0, p_shared=select_p_table(13, 20), polish_stop_when_stable=False)
+    truths = [s.tobytes().decode() for s in sp]
+    both = set(truths) | set(pipeline.revcomp_str(t) for t in truths)
+    assert len(res["centers"]) == 5, [c[0] for c in res["centers"]]
+    assert all(c[3] in both for c in res["centers"]), "a polished consensus is neither an amplicon nor its reverse complement"
+    assert all(c[0] > 30000 for c in res["centers"]) and all(len(c[4]) == 2 for c in res["centers"])          # two clusters (fw + rc) behind every centre
