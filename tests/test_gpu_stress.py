@@ -139,3 +139,12 @@ print("ok", rs.n, len(np.unique(res[0][0])), res[0][2])
 ''' % ROOT
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0, "\n".join(p.stdout.splitlines()[-10:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trials,seed", [(70, 1), (70, 2)])
+def test_whole_pipeline_matches_oracle_on_random_configurations(trials, seed):
+    """the WHOLE hot path (score, cluster, draft, rc merge, polish) on random small read sets - species count, length (incl. 507 / 1003: merged
+    tail window), depth, error profile, strand mix, k/w (13/20, 15/50, 25/30, 30/35, ...), tile depth, band, iterations, early stop: cluster map,
+    counters and every draft / polished sequence identical on the HIP library and the oracle (tools/stress_pipeline.py)"""
+    _run(trials, seed, tool=os.path.join(ROOT, "tools", "stress_pipeline.py"))
