@@ -150,6 +150,7 @@ void k_decide_map(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, u
     const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (it >= it_hi) return;
     const uint32_t read = items[it];
+    if (D.dec[read] != DEC_UNDEC) return;                 // decided in an earlier pass of this block and not affected by the representatives committed since (k_reset_items)
     if (D.hlen[read] < (uint32_t)D.k) { if (lane == 0) { D.dec[read] = DEC_SHORT; D.alnflag[read] = 0; } return; }
     const uint64_t* row = cnt + (uint64_t)(it - row0) * stride;
     int top = 0;
@@ -437,11 +438,20 @@ __global__ void k_db_merge_batch(const uint64_t* __restrict__ oc, const uint32_t
     nc[idx] = code; ns[idx] = slot;
 }
 
-__global__ void k_reset_items(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi)
+// After `nnew` tentative representatives (hit-matrix columns R0 .. R0 + nnew) were committed, only the items that share >= min_shared minimizers
+// with one of them are decided again.  Every other item keeps its decision: a representative below min_shared hits is never a candidate of the
+// mapping stage (cluster.py:82,88), never ties the top count of the alignment stage (:181, top >= min_shared) and does not change the top count,
+// so the walk over the candidates of such an item is the same as before - the argument behind k_first_affected, applied per item.  In noisy read
+// sets (a new representative every ~200 reads) this takes the re-decided items per pass from "the rest of the block" to a few per cent of it.
+__global__ void k_reset_items(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi, uint32_t row0, const uint64_t* __restrict__ cnt, uint32_t stride,
+                              uint32_t R0, uint32_t nnew)
 {
     const uint32_t it = it_lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= it_hi) return;
-    D.dec[items[it]] = DEC_UNDEC;
+    const uint64_t* row = cnt + (uint64_t)(it - row0) * stride + R0;
+    bool affected = false;
+    for (uint32_t t = 0; t < nnew; ++t) affected = affected || (int)(row[t] >> 48) >= D.min_shared;
+    if (affected) D.dec[items[it]] = DEC_UNDEC;
 }
 
 __global__ void k_finalize(ClDev D, uint64_t n, const uint8_t* __restrict__ seeded, int32_t* __restrict__ rep_of, uint8_t* __restrict__ status,
@@ -592,7 +602,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     DevBuf<int32_t> dec, top, cache_slot, cache_region; DevBuf<uint8_t> kind, alnflag, cache_ptr; DevBuf<uint64_t> cur_hi, cur_lo;
     HIPCHK(ctx, dec.alloc(N)); HIPCHK(ctx, top.alloc(N)); HIPCHK(ctx, cache_slot.alloc(N * NCACHE)); HIPCHK(ctx, cache_region.alloc(N * NCACHE));
     HIPCHK(ctx, kind.alloc(N)); HIPCHK(ctx, alnflag.alloc(N)); HIPCHK(ctx, cache_ptr.alloc(N)); HIPCHK(ctx, cur_hi.alloc(N)); HIPCHK(ctx, cur_lo.alloc(N));
-    HIPCHK(ctx, hipMemsetAsync(dec.p, 0xfc, 4 * N, ctx->stream));          // 0xfcfcfcfc is not a valid decision; every processed item is written
+    HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)dec.p, (int)DEC_UNDEC, N, ctx->stream));      // undecided: k_decide_map takes every item with this value
     HIPCHK(ctx, hipMemsetAsync(cache_slot.p, 0xff, 4 * N * NCACHE, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(cache_ptr.p, 0, N, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(alnflag.p, 0, N, ctx->stream));
@@ -719,6 +729,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             cut = std::min(cut, next_c);
             uint32_t c = 0; while (c < T && C[c] < cut) ++c;                 // >= 1: the affected item lies behind C[0]
+            const uint32_t R_before = S.R;
             rc = commit_reps(ctx, S, c, h_po.data()); if (rc) return rc;
             newreps += c;
             tcur = c == T ? std::min<uint32_t>(TMAX, tcur * 2) : std::max<uint32_t>(1, c);      // speculate wider only while it pays
@@ -728,7 +739,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             if (c < T) HIPCHK(ctx, hipMemset2DAsync(cnt.p + (uint64_t)(lo - b0) * stride + S.R, (size_t)stride * 8, 0, (size_t)(T - c) * 8, b1 - lo, ctx->stream));
             refresh();
             if (S.R + 1 > stride) need_full = true;
-            hipLaunchKernelGGL(k_reset_items, dim3((b1 - lo + 255) / 256), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1);
+            hipLaunchKernelGGL(k_reset_items, dim3((b1 - lo + 255) / 256), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, R_before, c);
             HIPCHK(ctx, hipGetLastError());
         }
         b0 = b1;
