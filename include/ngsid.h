@@ -75,7 +75,7 @@ uint32_t    ngsid_abi_version(void);
 
 /* (f1) replaces get_sorted_fastq_for_cluster.calc_score_new / fastq_single_core :23-33,124-155.
  * score[i] = expected number of error-free k-mers, err_rate[i] = mean 10^-(q/10) (no clamp),
- * keep[i] = 0 when len<2k, HPC len<k or 10*-log10(err)<=q_threshold. */
+ * keep[i] = 0 when len<2k, HPC len<k or 10*-log10(err)<=q_threshold.  Limits: k <= 64 (NGSID_ERR_ARG), reads <= 65535 bases (NGSID_ERR_TOO_LONG). */
 int32_t ngsid_score_reads(ngsid_ctx* ctx, const ngsid_reads_t* reads, int32_t k, double q_threshold,
                           double* score, double* err_rate, uint8_t* keep);
 

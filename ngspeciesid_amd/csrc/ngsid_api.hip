@@ -412,7 +412,9 @@ extern "C" int32_t ngsid_score_reads(ngsid_ctx* ctx, const ngsid_reads_t* reads,
 {
     if (!ctx) return NGSID_ERR_ARG;
     if (!reads || !score || !err_rate || !keep || k < 1) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
+    if (k > 64) NGSID_FAIL(ctx, NGSID_ERR_ARG, "score_reads: k = %d exceeds 64 (the quality ring of the kernel)", (int)k);
     DevReads R; int32_t rc = ngsid_upload_reads(ctx, reads, &R, true); if (rc) return rc;
+    if (R.maxlen > 65535u) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "score_reads: a read of %u bases exceeds 65535 (16-bit quality histogram)", R.maxlen);
     if (!g_score_tables[ctx->device & 15]) {
         HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_p_clamped), NGSID_PHRED_P, sizeof(double) * 128));
         HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_p_nomin), NGSID_PHRED_P_NOMIN, sizeof(double) * 128));

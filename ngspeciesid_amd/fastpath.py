@@ -54,6 +54,36 @@ def _string_ranks(names: fastio.Names, sfx, idx):
     return rank
 
 
+class BackgroundWriters:
+    """Output files are written by worker threads while the GPU stages run (the native writers release the GIL).  join() waits for all of them
+    and re-raises the first failure; main() joins before it returns, whatever happens, so the files are complete whenever the call is over."""
+    def __init__(self, workers=4):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=workers); self.futures = []
+
+    def submit(self, fn, *a, **kw):
+        self.futures.append(self.pool.submit(fn, *a, **kw))
+
+    def join(self):
+        futures, self.futures = self.futures, []
+        err = None
+        for f in futures:
+            try:
+                f.result()
+            except BaseException as e:          # keep waiting for the others, report the first
+                err = err or e
+        if err is not None:
+            raise err
+
+
+def _write(args, fn, *a, **kw):
+    bg = getattr(args, "_writers", None)
+    if bg is None:
+        fn(*a, **kw)
+    else:
+        bg.submit(fn, *a, **kw)
+
+
 class SortedReads:
     """the content of sorted.fastq in memory: reads in score order, original names + '_score' suffixes (CSR bytes, one per read)"""
 
@@ -100,7 +130,7 @@ def score_and_sort(args, api, T=None):
     order = idx[np.argsort(-score[idx], kind="stable")]                   # read_array.sort(key=score, reverse=True) is stable
     sfx = fastio.repr_doubles(score[order], prefix="_")                   # "_" + repr(score), as "{0}".format(score) prints a float
     T["sort"] = time() - t0; t0 = time()
-    fastio.write_fastq(out_path, order, names, rs, suffixes=sfx)
+    _write(args, fastio.write_fastq, out_path, order, names, rs, suffixes=sfx)       # 1.5 GB at C3: written while the reads are clustered
     T["write_sorted_fastq"] = time() - t0; t0 = time()
     logging.debug(f"{len(order)} reads passed quality critera (avg phred Q val over {args.quality_threshold} and length > 2*k) and will be clustered.")
     er = np.sort(err[idx])
@@ -192,7 +222,7 @@ def cluster_table(sr, sel, rep_of, pos):
 
 
 def write_cluster_files(args, sr, reps, sizes, herr, file_order, cl_sorted):
-    fastio.write_tsv(os.path.join(args.outfolder, "final_clusters.tsv"), file_order, sr.names, fastio.int_prefixes(cl_sorted))
+    _write(args, lambda: fastio.write_tsv(os.path.join(args.outfolder, "final_clusters.tsv"), file_order, sr.names, fastio.int_prefixes(cl_sorted)))
     with open(os.path.join(args.outfolder, "final_cluster_origins.tsv"), "w") as f:
         for out_id, r in enumerate(reps.tolist()):
             seq, qual = sr.rs.get(r)
@@ -288,7 +318,7 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
             logging.warning("centre %d: %d cluster(s) were merged into an earlier centre as well; their reads polish that one only", c_id, len(parts) - len(fresh))
         seen_clusters.update(cs)
         polish_lists.append(np.concatenate(fresh) if fresh else np.zeros(0, dtype=ids.dtype))
-        _write_pooled(os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(c_id)), ids, sr)
+        _write(args, _write_pooled, os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(c_id)), ids, sr)     # while the polisher runs
     T["rc_merge_write_pooled_reads"] = T.get("rc_merge_write_pooled_reads", 0.0) + time() - t0; t0 = time()
     if getattr(args, "racon", False) and args.racon_iter >= 0:
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in polish_lists]))).astype(np.uint64)
@@ -323,6 +353,23 @@ def _write_pooled(path, ids, sr):
 
 def main(args, api=None):
     api = api or runtime.get_api()
+    args._writers = BackgroundWriters() if not os.environ.get("NGSID_CLI_SYNC_WRITES") else None
+    try:
+        res = _main(args, api)
+    finally:
+        if args._writers is not None:
+            t0 = time()
+            try:
+                args._writers.join()
+            finally:
+                args._writers.pool.shutdown(wait=True); args._writers = None
+            wait = time() - t0
+    res["timings"]["wait_for_writers"] = wait if os.environ.get("NGSID_CLI_SYNC_WRITES") is None else 0.0
+    logging.debug("stage seconds: %s" % {k: round(v, 3) for k, v in res["timings"].items()})
+    return res
+
+
+def _main(args, api):
     T = {}
     t0 = time()
     args.outfile = os.path.join(args.outfolder, "sorted.fastq")
@@ -355,5 +402,4 @@ def main(args, api=None):
         logging.debug(f"Forming draft consensus with abundance_cutoff >= {abundance_cutoff} ({args.abundance_ratio * 100}% of {len(sel)} reads)")
         merged = consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundance_cutoff, api, acc_id, T)
         logging.info(f"Finished Consensus creation: {len(merged)} created")
-    logging.debug("stage seconds: %s" % {k: round(v, 3) for k, v in T.items()})
     return dict(n_sorted=sr.n, n_clustered=len(sel), clusters=len(reps), centers=merged, timings=T, counters=counters)
