@@ -20,11 +20,10 @@
 #include "k_poa.h"
 #include <algorithm>
 
-#define PNEG (-(1 << 28))
 #define SRC_SLOT 63
 #define NONE16 0xFFFFu
 #define HR 8           // DP rows kept in the LDS ring
-#define RPADL 4        // ring row: RPADL guard cells (PNEG) | BW cells | RPADR guard cells, so neighbour reads need no bounds checks
+#define RPADL 4        // ring row: RPADL guard cells (0 = minus infinity, see PBIAS) | BW cells | RPADR guard cells, so neighbour reads need no bounds checks
 #define RPADR 12
 #define DLO_MAX 11     // largest band-start difference to a predecessor a 'near' row may have (<= RPADR - 1)
 #define TBR 32         // direction rows per traceback block
@@ -55,7 +54,7 @@ struct GG {   // graph arrays in the workgroup's HBM scratch: ONE base pointer +
 };
 // LDS working set.  ~10 KB per tile for 750-base reads, so sixteen tiles (four waves per SIMD) are resident per CU.  The hot arrays sit at
 // COMPILE-TIME offsets so the row loop spends no SGPRs on them.  Layout (BW = band width), alignment phases | consensus phase:
-//   [0, HR*RS*4)            hring   ring of DP rows, RS = RPADL + BW + RPADR ints each (guard cells hold PNEG)      | epred (2 bytes per rank)
+//   [0, HR*RS*4)            hring   ring of DP rows, RS = RPADL + BW + RPADR ints each (guard cells hold 0)      | epred (2 bytes per rank)
 //   [.., + TBR*BW)          dirblk  direction rows: staged by the forward pass, block by block for the traceback      | .. sinkbits
 //   [.., + TBR*8)           rblk    row info of the last staged block (hand-over from the forward pass to the traceback)
 //   [C1, ..)                sq      (one pad byte in front, BW behind)
@@ -424,30 +423,34 @@ __device__ __forceinline__ void poa_row_tail_store(l32 ringrow, LDSP uint8_t* ds
     if (CPL == 1) *dst = (uint8_t)dpack; else if (CPL == 2) *(LDSP uint16_t*)dst = (uint16_t)dpack; else *(LDSP unsigned int*)dst = dpack;
 }
 
-// in-row gap chain H[j] = max(Xf[j], H[j-1]+g) as a max-plus prefix scan of y[j] = Xf[j] - j*g, then the final cell values / directions.
-// Unreachable cells are not normalised: they stay below -2^27 while reachable scores stay above -2^20, so every comparison
-// that decides a reachable cell is unaffected (their own direction bytes are never read by the traceback).  Band columns
-// past the end of the sequence (only when L+1 < BW) see the 0xFF padding and can never beat a real cell.
+// Stored cell values.  The cell of band column j is kept as S = H - j*g + PBIAS (H = the score the oracle computes):
+//   * the column skew j*g turns the in-row gap chain H[j] = max(X[j], H[j-1] + g) into a plain prefix maximum, a vertical move into S_up + g, a
+//     diagonal move into S_diag + (s - g) and the free-start terms of the semi-global / source rows into constants: the row loop carries no
+//     per-lane column offsets (only the local mode still needs its floor 0 = PBIAS - j*g);
+//   * the bias makes "minus infinity" = anything near 0, which is what the guard cells hold and what a DPP lane shift leaves in lanes without a
+//     source: reachable cells are PBIAS +- 2^20, unreachable ones stay below 2^20 in magnitude (they are not normalised: every comparison that
+//     decides a reachable cell is unaffected, and their own direction bytes are never read by the traceback).
+// All differences between candidates of one cell are the same as in H space, so every maximum and every tie-break is the oracle's.
+// Band columns past the end of the sequence (only when L+1 < BW) see the 0xFF padding and can never beat a real cell.
+#define PBIAS (1 << 28)
 template <int CPL, bool LOCAL>
-__device__ __forceinline__ unsigned poa_row_finish(const int (&X)[CPL], const int (&Dd)[CPL], int jg0, int gp, int (&hout)[CPL])
+__device__ __forceinline__ unsigned poa_row_finish(const int (&X)[CPL], const int (&Dd)[CPL], int floor0, int gp, int (&hout)[CPL])
 {
-    int exl[CPL]; int run = PNEG * 2;
+    int exl[CPL]; int run = 0;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-        const int xf = LOCAL ? max(X[c], 0) : X[c];
-        const int y = xf - (jg0 + c * gp);
-        exl[c] = run; run = c ? max(run, y) : y;
+        const int xf = LOCAL ? max(X[c], floor0 - c * gp) : X[c];
+        exl[c] = run; run = c ? max(run, xf) : xf;
     }
     const int incl = wave_incl_max_scan(run);
-    const int excl_lane = __builtin_amdgcn_update_dpp(PNEG * 2, incl, 0x138, 0xf, 0xf, false);     // wave_shr:1, lane 0 keeps the identity
+    const int excl_lane = __builtin_amdgcn_update_dpp(0, incl, 0x138, 0xf, 0xf, true);      // wave_shr:1, lane 0 gets 0 = "minus infinity"
     unsigned dpack = 0;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-        const int ex = c ? max(excl_lane, exl[c]) : excl_lane;
+        const int ex = c ? max(excl_lane, exl[c]) : excl_lane;       // best value reachable through the in-row gap chain
         int val = X[c], dd = Dd[c];
-        const int lfv = ex + jg0 + c * gp;                  // best value reachable through the in-row gap chain
-        if (lfv > val) { val = lfv; dd = 2; }
-        if (LOCAL && val <= 0) { val = 0; dd = 3; }
+        if (ex > val) { val = ex; dd = 2; }
+        if (LOCAL && val <= floor0 - c * gp) { val = floor0 - c * gp; dd = 3; }
         hout[c] = val; dpack |= (unsigned)(dd & 0xff) << (8 * c);
     }
     return dpack;
@@ -460,15 +463,14 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
     int nslow = 0;
     constexpr bool LOCAL = MODE == NGSID_POA_LOCAL, semi = MODE == NGSID_POA_SEMI;
     const int L = __builtin_amdgcn_readfirstlane(S.len);
-    int gp = gp_, sm = sm_, sn = sn_;
+    int gp = gp_, sm = sm_ - gp_, sn = sn_ - gp_;         // sm / sn: diagonal increments in S space (s - g)
     const int lane_jg = lane * CPL * gp_;
-    asm volatile("" : "+v"(gp), "+v"(sm), "+v"(sn));      // keep the three score constants in VGPRs (SGPRs are the scarce resource of this kernel);
-                                                          // gp_ stays scalar for the per-row l0 * gap product
-    int bestv = PNEG, bestpk = 0x7fffffff;      // !LOCAL
-    unsigned bkey[CPL];                         // LOCAL: (value << 16) | (0xFFFF - rank) per owned band column; values are >= 0 and < 2^16 (host check)
+    asm volatile("" : "+v"(gp), "+v"(sm), "+v"(sn));      // keep the three score constants in VGPRs (SGPRs are the scarce resource of this kernel)
+    int bestv = PBIAS / 2, bestpk = 0x7fffffff; // !LOCAL (S space; every candidate sits in column L, so the order is the order of H)
+    unsigned bkey[CPL];                         // LOCAL: (H << 16) | (0xFFFF - rank) per owned band column; H is >= 0 and < 2^16 (host check)
     int hprev[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { hprev[c] = PNEG; bkey[c] = 0; }
+    for (int c = 0; c < CPL; ++c) { hprev[c] = 0; bkey[c] = 0; }
     constexpr int RS = BW + RPADL + RPADR;
     const l32 ring0 = w.hring() + RPADL + lane * CPL;
     const l8 stage0 = w.dirblk() + lane * CPL;
@@ -481,7 +483,37 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
     while (r < V) {
         unsigned rlo = __builtin_amdgcn_readlane(clo, r & 63), rhi = __builtin_amdgcn_readlane(chi, r & 63);
         int rfl = rhi >> 24;
-        if (rfl & 16) {
+        if (rfl & 128) {
+            // ---- tight run (see the prepass): n chain rows, band start + 1 per row -> diagonal = own register, up = lane+1's (one DPP);
+            //      nothing to decode per row but the node letter
+            int n = rhi & 0xff, l0 = rlo & 0xffff;
+            do {
+                const int cv = (__builtin_amdgcn_readlane(chi, r & 63) >> 16) & 0xff;
+                int q[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) q[c] = sq0[l0 + c];
+                const int rt = __builtin_amdgcn_update_dpp(0, hprev[0], 0x130, 0xf, 0xf, true);             // lane+1's first column
+                int X[CPL], Dd[CPL];
+                int floor0 = 0;
+                if (LOCAL) { int l0g = l0 * gp_; asm volatile("" : "+s"(l0g)); floor0 = PBIAS - l0g - lane_jg; }
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    const int sc = q[c] == cv ? sm : sn;
+                    const int xu = (c + 1 < CPL ? hprev[c + 1] : rt) + gp; int xd = hprev[c] + sc, ds = 0;
+                    if (semi) { const int sv = sc + PBIAS; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT << 2; } }
+                    X[c] = max(xd, xu); Dd[c] = xu > xd ? 1 : ds;
+                }
+                const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, floor0, gp, hprev);
+                poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * RS, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
+                if (LOCAL) {
+                    const unsigned rk = 0xFFFFu - (unsigned)r;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)(hprev[c] - (floor0 - c * gp)) << 16) | rk);
+                }
+                ++r; ++l0;
+            } while (--n);
+            rfl = 0;                                                           // nothing pending for the rows just done
+        } else if (rfl & 16) {
             // ---- run of chain rows: registers + one DPP per row, LDS only for letters / ring / staged directions
             for (;;) {
                 const int l0 = rlo & 0xffff; const int cv = (rhi >> 16) & 0xff;
@@ -489,36 +521,36 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) q[c] = sq0[l0 + c];          // sq is padded: no bounds branches
                 // Band start moved by one: diag = same register, up = next column; else diag = previous column, up = same.
-                // Lane 0 / 63 get PNEG from the DPP (no source lane), which is exactly the out-of-band value; column 0 never has a diagonal.
+                // Lane 0 / 63 get 0 from the DPP (no source lane), which is the out-of-band value; column 0 never has a diagonal.
                 int up[CPL], dg[CPL];
                 if (rfl & 32) {
-                    const int rt = __builtin_amdgcn_update_dpp(PNEG, hprev[0], 0x130, 0xf, 0xf, false);         // lane+1's first column
+                    const int rt = __builtin_amdgcn_update_dpp(0, hprev[0], 0x130, 0xf, 0xf, true);         // lane+1's first column
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) { up[c] = c + 1 < CPL ? hprev[c + 1] : rt; dg[c] = hprev[c]; }
                 } else {
-                    const int lf = __builtin_amdgcn_update_dpp(PNEG, hprev[CPL - 1], 0x138, 0xf, 0xf, false);   // lane-1's last column
+                    const int lf = __builtin_amdgcn_update_dpp(0, hprev[CPL - 1], 0x138, 0xf, 0xf, true);   // lane-1's last column
 #pragma unroll
                     for (int c = 0; c < CPL; ++c) { up[c] = hprev[c]; dg[c] = c ? hprev[c - 1] : lf; }
                 }
                 int X[CPL], Dd[CPL];
-                int l0g = l0 * gp_; asm volatile("" : "+s"(l0g));      // scalar product (stops the compiler from re-associating it into a per-lane v_mul_lo_u32)
-                const int jg0 = l0g + lane_jg;
+                int floor0 = 0;
+                if (LOCAL) { int l0g = l0 * gp_; asm volatile("" : "+s"(l0g)); floor0 = PBIAS - l0g - lane_jg; }      // scalar product (no per-lane v_mul_lo_u32)
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const int sc = q[c] == cv ? sm : sn;
                     const int xu = up[c] + gp; int xd = dg[c] + sc, ds = 0;
-                    if (semi) { const int sv = jg0 + (c - 1) * gp + sc; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT << 2; } }   // free start in the graph
+                    if (semi) { const int sv = sc + PBIAS; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT << 2; } }   // free start in the graph
                     X[c] = max(xd, xu); Dd[c] = xu > xd ? 1 : ds;
                 }
-                const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, jg0, gp, hprev);
+                const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, floor0, gp, hprev);
                 poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * RS, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
                 if (LOCAL) {
                     const unsigned rk = 0xFFFFu - (unsigned)r;
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)hprev[c] << 16) | rk);
+                    for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)(hprev[c] - (floor0 - c * gp)) << 16) | rk);
                 } else if ((semi || (rfl & 4)) && (unsigned)(L - l0) < (unsigned)BW) {     // end cells: last column, on sinks (any row in semi-global mode)
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) if (l0 + lane * CPL + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
+                    for (int c = 0; c < CPL; ++c) if (l0 + lane * CPL + c == L && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
                 }
                 ++r;
                 if ((rfl & 8) || (r & (TBR - 1)) == 0 || r >= V) break;       // HBM copy / block flush / chunk switch / end: handled below
@@ -540,29 +572,29 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                 for (int c = 0; c <= CPL; ++c) h1[c] = H1[c];
             } else {
 #pragma unroll
-                for (int c = 0; c <= CPL; ++c) h1[c] = PNEG;
+                for (int c = 0; c <= CPL; ++c) h1[c] = 0;
             }
             int X[CPL], Dd[CPL];
-            int l0g = l0 * gp_; asm volatile("" : "+s"(l0g));      // scalar product (stops the compiler from re-associating it into a per-lane v_mul_lo_u32)
-                const int jg0 = l0g + lane_jg;
+            int floor0 = 0;
+            if (LOCAL) { int l0g = l0 * gp_; asm volatile("" : "+s"(l0g)); floor0 = PBIAS - l0g - lane_jg; }
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int sc = ((int)sq0[l0 + c] == cv) ? sm : sn;
                 // first predecessor wins ties (the oracle walks the edge list in order and replaces on strictly greater)
                 const int xu = max(h0[c + 1], h1[c + 1]) + gp, us = h1[c + 1] > h0[c + 1] ? 1 : 0;
                 int xd = max(h0[c], h1[c]) + sc, ds = h1[c] > h0[c] ? 1 : 0;
-                if (semi) { const int sv = jg0 + (c - 1) * gp + sc; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT; } }       // free start in the graph
+                if (semi) { const int sv = sc + PBIAS; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT; } }       // free start in the graph
                 if (xd >= xu) { X[c] = xd; Dd[c] = 0 | (ds << 2); } else { X[c] = xu; Dd[c] = 1 | (us << 2); }
             }
-            const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, jg0, gp, hprev);
+            const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, floor0, gp, hprev);
             poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * RS, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
             if (LOCAL) {
                 const unsigned rk = 0xFFFFu - (unsigned)r;
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)hprev[c] << 16) | rk);
+                for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)(hprev[c] - (floor0 - c * gp)) << 16) | rk);
             } else if ((semi || (rfl & 4)) && (unsigned)(L - l0) < (unsigned)BW) {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) if (l0 + lane * CPL + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
+                for (int c = 0; c < CPL; ++c) if (l0 + lane * CPL + c == L && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
             }
             ++r;
         } else {
@@ -578,7 +610,7 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
             for (int c = 0; c < CPL; ++c) scj[c] = ((int)sq0[l0 + c] == cv) ? sm : sn;
             int Xd[CPL], Dslot[CPL], Xu[CPL], Uslot[CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) { Xd[c] = PNEG; Xu[c] = PNEG; Dslot[c] = 0; Uslot[c] = 0; }
+            for (int c = 0; c < CPL; ++c) { Xd[c] = 0; Xu[c] = 0; Dslot[c] = 0; Uslot[c] = 0; }
             int slot = 0;
             for (int eit = nopred ? NONE16 : __builtin_amdgcn_readfirstlane((int)g.in_first(g.order(r))); eit != NONE16; eit = __builtin_amdgcn_readfirstlane((int)g.e_next_in(eit)), ++slot) {
                 const int pr = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(eit)));
@@ -588,38 +620,39 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                 if ((r - pr) <= HR) {                       // LDS ring
                     const l32 Hp = w.hring() + (size_t)(pr & (HR - 1)) * RS + RPADL;
 #pragma unroll
-                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : PNEG; }
+                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? Hp[pc] : 0; }
                 } else {                                    // far predecessor: HBM copy of the row (flag 8 made the producer store it)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const int32_t* Hq = Hg + (size_t)pr * BW;
 #pragma unroll
-                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? __builtin_nontemporal_load(Hq + pc) : PNEG; }
+                    for (int c = 0; c <= CPL; ++c) { const int pc = pc0 - 1 + c; hp[c] = (pc >= 0 && pc < BW) ? __builtin_nontemporal_load(Hq + pc) : 0; }
                 }
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     const int j = jb + c;
-                    { const int hv = hp[c + 1]; if (hv > PNEG / 2 && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
-                    if (j >= 1) { const int hv = hp[c]; if (hv > PNEG / 2 && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
+                    { const int hv = hp[c + 1]; if (hv > PBIAS / 2 && hv + gp > Xu[c]) { Xu[c] = hv + gp; Uslot[c] = slot; } }
+                    if (j >= 1) { const int hv = hp[c]; if (hv > PBIAS / 2 && hv + scj[c] > Xd[c]) { Xd[c] = hv + scj[c]; Dslot[c] = slot; } }
                 }
             }
             int X[CPL], Dd[CPL];
+            const int floor0 = PBIAS - l0 * gp_ - lane_jg;       // local mode: S of the score 0 in the lane's first column
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int j = jb + c;
-                if (use_src && j >= 1) { const int sv = LOCAL ? 0 : (j - 1) * gp; if (sv + scj[c] > Xd[c]) { Xd[c] = sv + scj[c]; Dslot[c] = SRC_SLOT; } }
-                if (nopred && !semi) { const int sv = LOCAL ? 0 : j * gp; if (sv + gp > Xu[c]) { Xu[c] = sv + gp; Uslot[c] = SRC_SLOT; } }
+                // virtual source: score 0 (local) or j*g (global) in column j, i.e. S = floor (local) / PBIAS (global)
+                if (use_src && j >= 1) { const int sv = (LOCAL ? floor0 - c * gp + gp : PBIAS) + scj[c]; if (sv > Xd[c]) { Xd[c] = sv; Dslot[c] = SRC_SLOT; } }
+                if (nopred && !semi) { const int sv = (LOCAL ? floor0 - c * gp : PBIAS) + gp; if (sv > Xu[c]) { Xu[c] = sv; Uslot[c] = SRC_SLOT; } }
                 if (Xd[c] >= Xu[c]) { X[c] = Xd[c]; Dd[c] = 0 | (Dslot[c] << 2); } else { X[c] = Xu[c]; Dd[c] = 1 | (Uslot[c] << 2); }
             }
-            int l0g = l0 * gp_; asm volatile("" : "+s"(l0g));
-            const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, l0g + lane_jg, gp, hprev);
+            const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, floor0, gp, hprev);
             poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * RS, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
             if (LOCAL) {
                 const unsigned rk = 0xFFFFu - (unsigned)r;
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)hprev[c] << 16) | rk);
+                for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)(hprev[c] - (floor0 - c * gp)) << 16) | rk);
             } else if (semi || (rfl & 4)) {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) if (jb + c == L && hprev[c] > PNEG / 2 && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
+                for (int c = 0; c < CPL; ++c) if (jb + c == L && hprev[c] > bestv) { bestv = hprev[c]; bestpk = (r << 8) | (lane * CPL + c); }
             }
             ++r;
         }
@@ -661,6 +694,7 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
         for (int c = 1; c < CPL; ++c) if (bkey[c] > k) { k = bkey[c]; cc = c; }
         bestv = (int)(k >> 16); bestpk = (int)(((0xFFFFu - (k & 0xFFFFu)) << 8) | (unsigned)(lane * CPL + cc));
     }
+    else bestv = bestv - PBIAS + L * gp_;       // back to H (lanes without a candidate stay far below every real score)
     bestv_out = bestv; bestpk_out = bestpk; nslow_out = nslow;
 }
 
@@ -678,7 +712,8 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     //   flags: 1 no predecessor, 2 irregular (more than two predecessors, or a distance / band shift that does not fit): walk the
     //          edge list in HBM, 4 sink, 8 keep an HBM copy (a successor is > HR rows away),
     //          16 chain row (single predecessor = previous row, band shift 0/1), 32 = that band shift,
-    //          64 near row (one or two predecessors, all within the LDS ring, band shifts 0..DLO_MAX)
+    //          64 near row (one or two predecessors, all within the LDS ring, band shifts 0..DLO_MAX),
+    //          128 first row of a tight run of chain rows (its length replaces dlo0; see the last pass)
     const BandMap bm = band_map(S, st.L0, BW);
     for (int r = lane; r < V; r += 64) { g.need(r) = 0; g.ri(r) = (unsigned long long)(unsigned)band_lo(g.anchor(g.order(r)), bm, BW); }      // pass 1: band starts
     for (int r = lane; r <= V; r += 64) g.marks(r) = 0;
@@ -725,13 +760,32 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     }
     for (int i = lane; i < HR * (RPADL + RPADR); i += 64) {       // guard cells of the ring rows
         const int row = i / (RPADL + RPADR), k = i % (RPADL + RPADR);
-        w.hring()[row * (BW + RPADL + RPADR) + (k < RPADL ? k : BW + k)] = PNEG;
+        w.hring()[row * (BW + RPADL + RPADR) + (k < RPADL ? k : BW + k)] = 0;          // "minus infinity" of the biased cell values
     }
     for (int i = lane; i < L; i += 64) { g.alnode(i) = NONE16; w.sq()[i] = S.s[i]; }
     for (int i = lane; i < BW; i += 64) w.sq()[L + i] = 0xFF;            // pad: columns past the end never match
     if (lane == 0) w.sq()[-1] = 0xFF;
     mem_sync();
-    for (int r = lane; r < V; r += 64) if (g.need(r)) g.ri(r) |= 8ull << 56;
+    // last pass: HBM-copy flag, and the TIGHT runs of the forward pass: consecutive chain rows whose band moves by one column per row, that need
+    // no HBM copy, hold no end cell and lie in one block of direction rows.  The first row of the run carries the number of rows left in the
+    // run (flag 128, count in the dlo0 byte, which chain rows do not use): the forward pass does such a run in a counted loop without decoding
+    // flags row by row.
+    for (int rb = 0; rb < V; rb += 64) {
+        const int r = rb + lane;
+        unsigned long long ri = r < V ? g.ri(r) : 0ull;
+        if (r < V && g.need(r)) ri |= 8ull << 56;
+        const unsigned fl = (unsigned)(ri >> 56);
+        const bool endz = (mode == NGSID_POA_SEMI || (fl & 4)) && (unsigned)(L - (int)(ri & 0xffff)) < (unsigned)BW;
+        const bool tight = r < V && (fl & (16 | 32 | 8)) == (16 | 32) && (mode == NGSID_POA_LOCAL || !endz);
+        const unsigned long long tm = __ballot(tight);
+        if (tight) {
+            const unsigned long long x = ~(tm >> lane);
+            int cr = x ? __builtin_ctzll(x) : 64;
+            cr = min(cr, TBR - (lane & (TBR - 1)));
+            ri = (ri & ~(0xFFFFull << 32)) | ((unsigned long long)cr << 32) | (128ull << 56);
+        }
+        if (r < V) g.ri(r) = ri;
+    }
     mem_sync();
     PH(J, 0, tph);
     // ---------- forward DP, one row per graph node in topological order
