@@ -115,7 +115,8 @@ __device__ __forceinline__ int wave_incl_add_scan(int v)
 
 // Direction bytes (type | slot << 2; slot 0 / 1 = first / second in-edge, SRC_SLOT = virtual source) go to HBM as 4 bits per cell:
 // type | code << 2 with code 0, 1, 2 = slot 0, 1, SRC_SLOT.  Rows with more than two in-edges (row flag 2, a fraction of a percent) can hold
-// other slots: their byte rows are kept in full next to the packed block and patched in when the traceback reloads the block.
+// other slots: their byte rows are kept in full next to the packed block; the traceback, which walks the packed blocks as they are, reads
+// the byte of such a row from there when the path passes through it.
 __device__ __forceinline__ unsigned dir_nib4(unsigned w) { const unsigned t = w & 0x03030303u, sl = (w >> 2) & 0x01010101u, gq = (w >> 7) & 0x01010101u; return t | ((sl & ~gq) << 2) | (gq << 3); }
 __device__ __forceinline__ unsigned dir_pack8(unsigned w0, unsigned w1)
 {
@@ -123,18 +124,7 @@ __device__ __forceinline__ unsigned dir_pack8(unsigned w0, unsigned w1)
     const unsigned c0 = (n0 | (n0 >> 4)) & 0x00FF00FFu, c1 = (n1 | (n1 >> 4)) & 0x00FF00FFu;
     return ((c0 | (c0 >> 8)) & 0xFFFFu) | (((c1 | (c1 >> 8)) & 0xFFFFu) << 16);
 }
-__device__ __forceinline__ unsigned dir_unpack4(unsigned h16)
-{
-    const unsigned c = (h16 | (h16 << 8)) & 0x00FF00FFu, n = (c | (c << 4)) & 0x0F0F0F0Fu;
-    const unsigned t = n & 0x03030303u, s1 = (n >> 2) & 0x01010101u, gq = (n >> 3) & 0x01010101u;
-    return t | (s1 << 2) | (((gq << 6) - gq) << 2);
-}
 __device__ __forceinline__ ngsid_v4u dir_pack32(const ngsid_v4u a, const ngsid_v4u b) { ngsid_v4u o; o.x = dir_pack8(a.x, a.y); o.y = dir_pack8(a.z, a.w); o.z = dir_pack8(b.x, b.y); o.w = dir_pack8(b.z, b.w); return o; }
-__device__ __forceinline__ void dir_unpack32(const ngsid_v4u p, ngsid_v4u& a, ngsid_v4u& b)
-{
-    a.x = dir_unpack4(p.x & 0xFFFFu); a.y = dir_unpack4(p.x >> 16); a.z = dir_unpack4(p.y & 0xFFFFu); a.w = dir_unpack4(p.y >> 16);
-    b.x = dir_unpack4(p.z & 0xFFFFu); b.y = dir_unpack4(p.z >> 16); b.z = dir_unpack4(p.w & 0xFFFFu); b.w = dir_unpack4(p.w >> 16);
-}
 
 #define PH(J, idx, t0) do { if ((J).phase_cycles && lane == 0) { const unsigned long long t1_ = __builtin_readcyclecounter(); atomicAdd(&(J).phase_cycles[idx], t1_ - (t0)); (t0) = t1_; } } while (0)
 
@@ -487,11 +477,15 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
             // ---- tight run (see the prepass): n chain rows, band start + 1 per row -> diagonal = own register, up = lane+1's (one DPP);
             //      nothing to decode per row but the node letter
             int n = rhi & 0xff, l0 = rlo & 0xffff;
+            int q[CPL], qn[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) qn[c] = sq0[l0 + c];
             do {
                 const int cv = (__builtin_amdgcn_readlane(chi, r & 63) >> 16) & 0xff;
-                int q[CPL];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) q[c] = sq0[l0 + c];
+                for (int c = 0; c < CPL; ++c) q[c] = qn[c];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) qn[c] = sq0[l0 + 1 + c];      // letters of the next row: their LDS latency hides behind this row (sq is padded)
                 const int rt = __builtin_amdgcn_update_dpp(0, hprev[0], 0x130, 0xf, 0xf, true);             // lane+1's first column
                 int X[CPL], Dd[CPL];
                 int floor0 = 0;
@@ -684,9 +678,30 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
             const unsigned long long b = r + 64 + lane < V ? g.ri(r + 64 + lane) : 0ull; nlo = (unsigned)b; nhi = (unsigned)(b >> 32);
         }
     }
-    {   // the traceback starts in the last (still staged) block of direction rows: give it the row info of those rows
+    {   // the traceback starts in the last block of direction rows, which is still staged in LDS: give it the row info of those rows and
+        // pack the block in place (4 bits per cell, the layout every other block comes back from HBM in)
         const int cb = (V - 1) & ~63, blk = (V - 1) & ~(TBR - 1), x = cb + lane;
         if (x >= blk && x < V) w.rblk()[x - blk] = (unsigned long long)clo | ((unsigned long long)chi << 32);
+        asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier();
+        constexpr int NP = TBR * BW / 32 / 64;
+        ngsid_v4u pk[NP];
+#pragma unroll
+        for (int xq = 0; xq < NP; ++xq) {
+            const int q = lane + 64 * xq;
+            const ngsid_v4u a = *(LDSP ngsid_v4u*)(w.dirblk() + q * 32), b = *(LDSP ngsid_v4u*)(w.dirblk() + q * 32 + 16);
+            pk[xq] = dir_pack32(a, b);
+        }
+        if (V & (TBR - 1)) {         // a partial block was never flushed: its rows with more than two in-edges go to the byte rows now
+            unsigned long long irr = __ballot(((chi >> 24) & 2u) != 0) & (0xFFFFFFFFull << (blk & 63));
+            while (irr) {
+                const int bq = __builtin_ctzll(irr); irr &= irr - 1;
+                const int row = cb + bq;
+                if (lane < BW / 16) *(ngsid_v4u*)(Dfull + (size_t)row * BW + lane * 16) = *(LDSP ngsid_v4u*)(w.dirblk() + (row & (TBR - 1)) * BW + lane * 16);
+            }
+        }
+        lds_sync();
+#pragma unroll
+        for (int xq = 0; xq < NP; ++xq) *(LDSP ngsid_v4u*)(w.dirblk() + (lane + 64 * xq) * 16) = pk[xq];
     }
     if (LOCAL) {
         unsigned k = bkey[0]; int cc = 0;
@@ -815,14 +830,18 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     //            diagonal moves through chain rows (predecessor = previous rank): lane k speculatively inspects the cell k such moves
     //            ahead, the wave takes the whole leading run at once, and the first other move is decoded from that lane's data.
     if (aligned_any) {
-        int r = bestr, j = (int)(__builtin_amdgcn_readfirstlane((unsigned)g.ri(bestr)) & 0xffff) + bestc;
-        int blk_lo = (V - 1) & ~(TBR - 1);                 // the forward pass left the last (partial) block of direction rows in LDS
-        // lane k keeps the row info of rank blk_lo + k in registers (k < TBR): one LDS read per iteration (the direction byte) instead of two
+        // r, j: wave-uniform (scalar registers: the whole walk is scalar control flow, only the speculative look-ahead is per lane)
+        int r = __builtin_amdgcn_readfirstlane(bestr);
+        int j = (int)(__builtin_amdgcn_readfirstlane((unsigned)g.ri(r)) & 0xffff) + __builtin_amdgcn_readfirstlane(bestc);
+        int blk_lo = (V - 1) & ~(TBR - 1);                 // the forward pass left the last block of direction rows in LDS, packed
+        // lane k keeps the row info of rank blk_lo + k in registers (k < TBR): one LDS read per iteration (the direction nibble) instead of two
         unsigned long long myri = lane < TBR ? w.rblk()[lane] : 0ull;
         int n_reload = 0, n_iter = 0; unsigned long long c_reload = 0;
         // the block below the current one is prefetched into registers while the current one is walked (a reload is an L2 / HBM round trip
-        // of several thousand cycles, the walk of a block takes longer than that)
-        constexpr int NPF = TBR * BW / 32 / 64;                // packed 16-byte pieces per lane and block (piece q = 32 direction bytes)
+        // of several thousand cycles, the walk of a block takes longer than that).  Blocks stay PACKED in LDS (4 bits per cell: type | slot
+        // code << 2): a cell costs one byte read and a shift, a reload one 16-byte LDS store per piece and no unpacking.
+        constexpr int NPF = TBR * BW / 32 / 64;                // packed 16-byte pieces per lane and block
+        const l8 pkblk = w.dirblk();
         ngsid_v4u pf[NPF]; unsigned long long pri = 0ull; int pf_blk = -1;
         auto prefetch = [&](int b) {
             if (b < 0) { pf_blk = -1; return; }
@@ -844,19 +863,8 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 const unsigned long long trl0 = J.phase_cycles ? __builtin_readcyclecounter() : 0;
                 if (blk_lo != pf_blk) prefetch(blk_lo);       // the path jumped further than one block (far predecessor): fetch it now
 #pragma unroll
-                for (int x = 0; x < NPF; ++x) {
-                    ngsid_v4u a, b; dir_unpack32(pf[x], a, b);
-                    l8 dstp = w.dirblk() + (size_t)(lane + 64 * x) * 32;
-                    *(LDSP ngsid_v4u*)dstp = a; *(LDSP ngsid_v4u*)(dstp + 16) = b;
-                }
+                for (int x = 0; x < NPF; ++x) *(LDSP ngsid_v4u*)(pkblk + (size_t)(lane + 64 * x) * 16) = pf[x];
                 myri = pri;
-                {   // rows with more than two in-edges: their full byte rows replace the unpacked ones
-                    unsigned long long irr = __ballot(lane < TBR && (((unsigned)(myri >> 56)) & 2u) != 0);
-                    while (irr) {
-                        const int bq = __builtin_ctzll(irr); irr &= irr - 1;
-                        if (lane < BW / 16) *(LDSP ngsid_v4u*)(w.dirblk() + bq * BW + lane * 16) = ngsid_load16_l2(Dfull + (size_t)(blk_lo + bq) * BW + lane * 16);
-                    }
-                }
                 prefetch(blk_lo - TBR);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -866,17 +874,19 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             const int top = r - blk_lo;                        // 0 .. TBR-1
             const int jk = j - (top - lane);
             // branch-free per-lane part: out-of-block / out-of-band lanes read cell 0 and are masked afterwards
-            const int ck = jk - (int)(myri & 0xffff);
+            const int lok = (int)(myri & 0xffff);
+            const int ck = jk - lok;
             const bool loaded = (lane <= top) & ((unsigned)ck < (unsigned)BW);
-            const int dk = w.dirblk()[loaded ? lane * BW + ck : 0];
-            // a plain diagonal move to the previous rank: direction byte 0 = diagonal through the first in-edge, whose tail is one rank up
-            // (dist0 == 1; true for every chain row and for the near / generic rows whose first predecessor is the previous rank)
-            const bool good = loaded & (dk == 0) & ((((unsigned)myri >> 16) & 0xffu) == 1u) & (jk >= 1);
+            const int pb = pkblk[loaded ? lane * (BW / 2) + (ck >> 1) : 0];
+            const int nib = (pb >> ((ck & 1) * 4)) & 15;
+            // a plain diagonal move to the previous rank: nibble 0 = diagonal through the first in-edge, whose tail is one rank up (dist0 == 1; true
+            // for every chain row and for the near rows whose first predecessor is the previous rank).  Rows with more than two in-edges (flag 2)
+            // keep their real bytes in HBM: never part of a run, decoded below.
+            const bool good = loaded & (nib == 0) & (((unsigned)(myri >> 16) & 0xffu) == 1u) & !((unsigned)(myri >> 56) & 2u) & (jk >= 1);
             const unsigned long long gm = __ballot(good);
             const unsigned long long x = gm << (63 - top);     // lane `top` at bit 63: leading ones = the run
             const int run = (~x) ? __builtin_clzll(~x) : 64;   // <= top + 1 because lanes above `top` never set their bit
             {   // band-edge check (oracle poa_align): a visited cell (the run and the cell it ends on) on a clipped edge of its row's band
-                const int lok = (int)(myri & 0xffff);
                 const bool clipped = ((ck == 0) & (lok > 0)) | ((ck == BW - 1) & (lok + BW - 1 < L));
                 if (__ballot(loaded & (lane >= top - run) & clipped)) edge = 1;
             }
@@ -884,9 +894,15 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             r -= run; j -= run;
             const int nk = top - run;                          // lane holding the next cell of the path
             if (nk < 0) continue;                              // it is in the block below: go round (loads it)
-            const int d = __builtin_amdgcn_readlane(dk, nk);
             const unsigned rlo = __builtin_amdgcn_readlane((unsigned)myri, nk), rhi = __builtin_amdgcn_readlane((unsigned)(myri >> 32), nk);
-            const int type = d & 3, slot = d >> 2;
+            int type, slot;
+            if ((rhi >> 24) & 2) {                             // more than two in-edges: the real direction byte
+                const int d = __builtin_amdgcn_readfirstlane((int)Dfull[(size_t)r * BW + (j - (int)(rlo & 0xffff))]);
+                type = d & 3; slot = d >> 2;
+            } else {
+                const int nb = __builtin_amdgcn_readlane(nib, nk);
+                type = nb & 3; slot = (nb & 8) ? SRC_SLOT : ((nb >> 2) & 1);
+            }
             if (type == 3) break;
             if (type == 2) { --j; continue; }
             if (type == 0) { if (lane == 0) g.alnode(j - 1) = (uint16_t)r; --j; }
