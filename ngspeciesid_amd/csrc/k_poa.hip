@@ -480,8 +480,13 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
             int q[CPL], qn[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; ++c) qn[c] = sq0[l0 + c];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) asm volatile("" : "+v"(qn[c]));      // consumed here: the loop header then carries no pending LDS read, so the
+                                                                              // loop waits for its own prefetch only (lgkmcnt(2)), never for the row stores
+            int cvn = (__builtin_amdgcn_readlane(chi, r & 63) >> 16) & 0xff;
             do {
-                const int cv = (__builtin_amdgcn_readlane(chi, r & 63) >> 16) & 0xff;
+                const int cv = cvn;
+                cvn = (__builtin_amdgcn_readlane(chi, (r + 1) & 63) >> 16) & 0xff;     // next row's letter (an unused lane read at the end of a chunk)
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) q[c] = qn[c];
 #pragma unroll
@@ -800,6 +805,13 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             ri = (ri & ~(0xFFFFull << 32)) | ((unsigned long long)cr << 32) | (128ull << 56);
         }
         if (r < V) g.ri(r) = ri;
+        if (J.phase_cycles) {            // dev instrumentation: row kinds of the forward pass
+            const unsigned f2 = (unsigned)(ri >> 56);
+            const unsigned long long mt = __ballot(tight), mh = __ballot(tight && (lane == 0 || (lane & (TBR - 1)) == 0 || !((tm >> (lane - 1)) & 1))),
+                                     mc = __ballot(r < V && !tight && (f2 & 16)), mn = __ballot(r < V && !(f2 & 16) && (f2 & 64)), mg = __ballot(r < V && !(f2 & (16 | 64)));
+            if (lane == 0) { atomicAdd(&J.phase_cycles[16], (unsigned long long)__popcll(mt)); atomicAdd(&J.phase_cycles[17], (unsigned long long)__popcll(mh)); atomicAdd(&J.phase_cycles[18], (unsigned long long)__popcll(mc));
+                             atomicAdd(&J.phase_cycles[19], (unsigned long long)__popcll(mn)); atomicAdd(&J.phase_cycles[20], (unsigned long long)__popcll(mg)); }
+        }
     }
     mem_sync();
     PH(J, 0, tph);
