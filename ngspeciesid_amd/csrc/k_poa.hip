@@ -756,26 +756,41 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         for (int u = 0; u < 2; ++u) { const bool h1 = e1v[u] != NONE16; lp1[u] = h1 ? (int)(g.ri(p1v[u]) & 0xffff) : 0; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int r = rb + u * 64 + lane; if (r >= V) continue;
+            const int r = rb + u * 64 + lane; const bool ok = r < V;          // (no divergent exits: the run lengths below are a wave ballot)
             const int l0 = l0v[u]; int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
-            if (e0v[u] == NONE16) fl |= 1;
-            else {
-                // band start of a predecessor = low 16 bits of its row info (written by pass 1; a concurrent full rewrite keeps those bits)
-                d0 = r - p0v[u]; dl0 = l0 - lp0[u]; if (d0 > HR) g.need(p0v[u]) = 1;
-                if (e1v[u] != NONE16) {
-                    d1 = r - p1v[u]; dl1 = l0 - lp1[u]; if (d1 > HR) g.need(p1v[u]) = 1;
-                    if (e2v[u] != NONE16) { fl |= 2; for (int e = e2v[u]; e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) g.need(pr) = 1; } }
+            if (ok) {
+                if (e0v[u] == NONE16) fl |= 1;
+                else {
+                    // band start of a predecessor = low 16 bits of its row info (written by pass 1; a concurrent full rewrite keeps those bits)
+                    d0 = r - p0v[u]; dl0 = l0 - lp0[u]; if (d0 > HR) g.need(p0v[u]) = 1;
+                    if (e1v[u] != NONE16) {
+                        d1 = r - p1v[u]; dl1 = l0 - lp1[u]; if (d1 > HR) g.need(p1v[u]) = 1;
+                        if (e2v[u] != NONE16) { fl |= 2; for (int e = e2v[u]; e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) g.need(pr) = 1; } }
+                    }
+                    if (d0 > 255 || d1 > 255 || dl0 < 0 || dl0 > 255 || dl1 < 0 || dl1 > 255) { fl |= 2; d0 = d1 = dl0 = dl1 = 0; }
                 }
-                if (d0 > 255 || d1 > 255 || dl0 < 0 || dl0 > 255 || dl1 < 0 || dl1 > 255) { fl |= 2; d0 = d1 = dl0 = dl1 = 0; }
+                if (ofv[u] == NONE16) fl |= 4;
+                if (!(fl & 3)) {
+                    if (d0 == 1 && d1 == 0 && dl0 <= 1) fl |= 16 | (dl0 << 5);
+                    else if (d0 <= HR && d1 <= HR && dl0 <= DLO_MAX && dl1 <= DLO_MAX) fl |= 64;
+                }
             }
-            if (ofv[u] == NONE16) fl |= 4;
-            if (!(fl & 3)) {
-                if (d0 == 1 && d1 == 0 && dl0 <= 1) fl |= 16 | (dl0 << 5);
-                else if (d0 <= HR && d1 <= HR && dl0 <= DLO_MAX && dl1 <= DLO_MAX) fl |= 64;
+            // TIGHT runs of the forward pass: consecutive chain rows whose band moves by one column per row, that hold no end cell and lie in
+            // one block of direction rows.  Every row of a run carries the number of rows left in it (flag 128, count in the dlo0 byte, which
+            // chain rows do not use): the forward pass does such a run in a counted loop without decoding flags row by row.  Rows that turn
+            // out to need an HBM copy (flag 8) are taken out of their runs by the last pass.
+            const bool endz = (mode == NGSID_POA_SEMI || (fl & 4)) && (unsigned)(L - l0) < (unsigned)BW;
+            const bool tight = ok && (fl & (16 | 32)) == (16 | 32) && (mode == NGSID_POA_LOCAL || !endz);
+            const unsigned long long tm = __ballot(tight);
+            if (tight) {
+                const unsigned long long x = ~(tm >> lane);
+                int cr = x ? __builtin_ctzll(x) : 64;
+                cr = min(cr, TBR - (lane & (TBR - 1)));
+                dl0 = cr; fl |= 128;
             }
-            g.ri(r) = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)d0 << 16) | ((unsigned long long)(unsigned)d1 << 24)
-                       | ((unsigned long long)(unsigned)dl0 << 32) | ((unsigned long long)(unsigned)dl1 << 40)
-                       | ((unsigned long long)(unsigned)cdv[u] << 48) | ((unsigned long long)(unsigned)fl << 56);
+            if (ok) g.ri(r) = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)d0 << 16) | ((unsigned long long)(unsigned)d1 << 24)
+                               | ((unsigned long long)(unsigned)dl0 << 32) | ((unsigned long long)(unsigned)dl1 << 40)
+                               | ((unsigned long long)(unsigned)cdv[u] << 48) | ((unsigned long long)(unsigned)fl << 56);
         }
     }
     for (int i = lane; i < HR * (RPADL + RPADR); i += 64) {       // guard cells of the ring rows
@@ -786,33 +801,35 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     for (int i = lane; i < BW; i += 64) w.sq()[L + i] = 0xFF;            // pad: columns past the end never match
     if (lane == 0) w.sq()[-1] = 0xFF;
     mem_sync();
-    // last pass: HBM-copy flag, and the TIGHT runs of the forward pass: consecutive chain rows whose band moves by one column per row, that need
-    // no HBM copy, hold no end cell and lie in one block of direction rows.  The first row of the run carries the number of rows left in the
-    // run (flag 128, count in the dlo0 byte, which chain rows do not use): the forward pass does such a run in a counted loop without decoding
-    // flags row by row.
+    // last pass: HBM-copy flag (8) of the rows a far successor asked for.  Such a row leaves its tight run: it becomes a plain chain row again
+    // (band shift 1) and the rows of the run before it count up to it only.  Far successors are rare: most chunks have nothing to do.
+    unsigned kinds[5] = {0, 0, 0, 0, 0};
     for (int rb = 0; rb < V; rb += 64) {
         const int r = rb + lane;
-        unsigned long long ri = r < V ? g.ri(r) : 0ull;
-        if (r < V && g.need(r)) ri |= 8ull << 56;
-        const unsigned fl = (unsigned)(ri >> 56);
-        const bool endz = (mode == NGSID_POA_SEMI || (fl & 4)) && (unsigned)(L - (int)(ri & 0xffff)) < (unsigned)BW;
-        const bool tight = r < V && (fl & (16 | 32 | 8)) == (16 | 32) && (mode == NGSID_POA_LOCAL || !endz);
-        const unsigned long long tm = __ballot(tight);
-        if (tight) {
-            const unsigned long long x = ~(tm >> lane);
-            int cr = x ? __builtin_ctzll(x) : 64;
-            cr = min(cr, TBR - (lane & (TBR - 1)));
-            ri = (ri & ~(0xFFFFull << 32)) | ((unsigned long long)cr << 32) | (128ull << 56);
-        }
-        if (r < V) g.ri(r) = ri;
-        if (J.phase_cycles) {            // dev instrumentation: row kinds of the forward pass
-            const unsigned f2 = (unsigned)(ri >> 56);
-            const unsigned long long mt = __ballot(tight), mh = __ballot(tight && (lane == 0 || (lane & (TBR - 1)) == 0 || !((tm >> (lane - 1)) & 1))),
-                                     mc = __ballot(r < V && !tight && (f2 & 16)), mn = __ballot(r < V && !(f2 & 16) && (f2 & 64)), mg = __ballot(r < V && !(f2 & (16 | 64)));
-            if (lane == 0) { atomicAdd(&J.phase_cycles[16], (unsigned long long)__popcll(mt)); atomicAdd(&J.phase_cycles[17], (unsigned long long)__popcll(mh)); atomicAdd(&J.phase_cycles[18], (unsigned long long)__popcll(mc));
-                             atomicAdd(&J.phase_cycles[19], (unsigned long long)__popcll(mn)); atomicAdd(&J.phase_cycles[20], (unsigned long long)__popcll(mg)); }
+        const bool nd = r < V && g.need(r);
+        const unsigned long long nm = __ballot(nd);
+        if (nm || J.phase_cycles) {
+            unsigned long long ri = r < V ? g.ri(r) : 0ull;
+            const bool was_tight = ((unsigned)(ri >> 56) & 128u) != 0;
+            bool changed = false;
+            if (nd) {
+                if (was_tight) ri = (ri & ~((0xFFull << 32) | (128ull << 56))) | (1ull << 32);
+                ri |= 8ull << 56; changed = true;
+            } else if (was_tight) {
+                const unsigned long long up = nm >> lane;                     // bit k: rank r + k needs a copy
+                const int d = up ? __builtin_ctzll(up) : 64, cr = (int)((ri >> 32) & 0xff);
+                if (d < cr) { ri = (ri & ~(0xFFull << 32)) | ((unsigned long long)d << 32); changed = true; }
+            }
+            if (changed) g.ri(r) = ri;
+            if (J.phase_cycles) {            // dev instrumentation: row kinds of the forward pass (counted per alignment, one atomic each)
+                const unsigned f2 = (unsigned)(ri >> 56); const bool tg = r < V && (f2 & 128);
+                const unsigned long long tmk = __ballot(tg);
+                kinds[0] += __popcll(tmk); kinds[1] += __popcll(__ballot(tg && (lane == 0 || (lane & (TBR - 1)) == 0 || !((tmk >> (lane - 1)) & 1) || ((nm >> (lane - 1)) & 1))));
+                kinds[2] += __popcll(__ballot(r < V && !tg && (f2 & 16))); kinds[3] += __popcll(__ballot(r < V && !(f2 & 16) && (f2 & 64))); kinds[4] += __popcll(__ballot(r < V && !(f2 & (16 | 64))));
+            }
         }
     }
+    if (J.phase_cycles && lane == 0) for (int k = 0; k < 5; ++k) atomicAdd(&J.phase_cycles[16 + k], (unsigned long long)kinds[k]);
     mem_sync();
     PH(J, 0, tph);
     // ---------- forward DP, one row per graph node in topological order
