@@ -83,7 +83,7 @@ def form_draft_consensus(clusters, representatives, sorted_reads_fastq_file, wor
                         break
                     seq, qual = reads[acc]
                     rf.write("@{0}\n{1}\n{2}\n{3}\n".format(acc, seq, "+", qual))
-            center = run_spoa(reads_path_name, os.path.join(work_dir, "spoa_tmp.fa"), "spoa", api=api)
+            center = run_spoa(reads_path_name, os.path.join(work_dir, "spoa_tmp.fa"), "spoa", api=api, tile_depth=getattr(args, "poa_tile_depth", DEFAULT_TILE_DEPTH), band=getattr(args, "poa_band", DEFAULT_BAND))
             centers.append([n, c_id, center, reads_path_name])
         elif n == 1:
             singletons += 1
@@ -126,7 +126,7 @@ def polish_sequences(centers, args, api=None):
             logging.debug("running racon on spoa reference {0} using {1} reads for polishing.".format(c_id, nr_reads_used))
             folder = os.path.join(args.outfolder, "racon_cl_id_{0}".format(c_id))
             mkdir_p(folder)
-            run_racon(all_reads_file, spoa_center_file, folder, "1", args.racon_iter, api=api, k=args.k, w=args.w)
+            run_racon(all_reads_file, spoa_center_file, folder, "1", args.racon_iter, api=api, band=getattr(args, "poa_band", DEFAULT_BAND), k=args.k, w=args.w)
             with open(os.path.join(folder, "consensus.fasta")) as cf:
                 centers[i][2] = cf.readlines()[1].strip()
     return centers

@@ -32,7 +32,8 @@ def oracle_backend(oracle, monkeypatch):
 
 @pytest.mark.parametrize("extra", [["--t", "1"], ["--t", "8"], ["--t", "1", "--consensus", "--racon", "--racon_iter", "2"],
                                    ["--t", "4", "--consensus", "--racon", "--racon_iter", "1", "--abundance_ratio", "0.01"],
-                                   ["--t", "2", "--m", "620", "--s", "40", "--top_reads", "--sample_size", "150"]])
+                                   ["--t", "2", "--m", "620", "--s", "40", "--top_reads", "--sample_size", "150"],
+                                   ["--t", "1", "--consensus", "--poa_tile_depth", "0", "--max_seqs_for_consensus", "40", "--poa_band", "128"]])
 def test_array_path_writes_the_same_files_as_the_dict_layer(oracle_backend, extra):
     a = _run(oracle_backend, extra, True); b = _run(oracle_backend, extra, False)
     assert sorted(a) == sorted(b)

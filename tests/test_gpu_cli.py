@@ -37,6 +37,26 @@ def test_cli_consensus_racon(gpu_api, tmp_path):
     assert os.path.exists(os.path.join(out, "reads_to_consensus_%s.fastq" % cid))
 
 
+def test_cli_exact_order_draft_option(gpu_api, tmp_path):
+    """--poa_tile_depth 0 (extension flag): the draft of a cluster is ONE graph built in read order (spoa's order) instead of the depth-8 hierarchy.
+    On sample_h1 (13.6 % read error) with 120 reads per draft both shapes give nearly the same sequence; the cost of the exact order is printed."""
+    import time
+    from ngspeciesid_amd.cli import cli
+    from util_seq import edit_distance
+    seqs = {}
+    for depth in ("8", "0"):
+        out = str(tmp_path / ("out" + depth)); t = time.time()
+        cli(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", out, "--t", "1", "--consensus", "--max_seqs_for_consensus", "120", "--poa_tile_depth", depth])
+        dt = time.time() - t
+        refs = sorted(f for f in os.listdir(out) if f.startswith("consensus_reference_"))
+        assert len(refs) == 1
+        seqs[depth] = open(os.path.join(out, refs[0])).read().split("\n")[1]
+        print("poa_tile_depth %s: %.2f s, draft length %d" % (depth, dt, len(seqs[depth])))
+    d = edit_distance(seqs["8"], seqs["0"])
+    print("edit distance tiled vs exact-order draft:", d)
+    assert d <= 6 and 600 < len(seqs["0"]) < 720
+
+
 def _files(out):
     res = {}
     for root, _, fs in os.walk(out):
