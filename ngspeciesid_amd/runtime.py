@@ -44,3 +44,19 @@ def get_api(device: int | None = None) -> Api:
             if rc != 0:
                 raise NgsidError(rc, (lib.ngsid_last_error(ctx) or b"").decode())
     return _apis[device]
+
+
+def new_api(device: int | None = None, options: dict | None = None) -> Api:
+    """A fresh, uncached context on `device` (own HIP stream, own scratch buffers): concurrent pipelines of one process use one each."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    lib = load_library()
+    ctx = C.c_void_p()
+    rc = lib.ngsid_create(C.c_int32(device), C.c_uint32(0), C.byref(ctx))
+    if rc != 0:
+        raise NgsidError(rc, (lib.ngsid_last_error(None) or b"").decode())
+    for name, val in (options or {}).items():
+        rc = lib.ngsid_ctx_option(ctx, name.encode(), C.c_int64(int(val)))
+        if rc != 0:
+            raise NgsidError(rc, (lib.ngsid_last_error(ctx) or b"").decode())
+    return Api(lib, "ngsid_", ctx)

@@ -18,7 +18,7 @@ rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
 for rep in range(2):
     if rep == 1: api.lib.ngsid_profile_enable(api.ctx, C.c_int32(1))
     T = {}; t0 = time.perf_counter()
-    res = pipeline.run_hot_path(api, rs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=k, w=w, abundance_ratio=ab, racon_iter=3, tile_depth=8, band=128,
+    res = pipeline.run_hot_path(api, rs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=k, w=w, abundance_ratio=ab, racon_iter=3, tile_depth=8, band=0,
                                 p_shared=select_p_table(k, w), timings=T, polish_stop_when_stable=False)
     dt = time.perf_counter() - t0
 buf = C.create_string_buffer(1 << 16); api.lib.ngsid_profile_read(api.ctx, buf, C.c_uint64(len(buf)))
