@@ -241,6 +241,13 @@ int32_t ngsid_host_infix_locate(const uint8_t* query, int32_t qlen, const uint8_
  * settings); the library reads no environment variable for them. */
 int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value);
 
+/* (b, f2) A caller that makes several calls on the SAME reads (the CLI: cluster + draft consensus + polish; NGSpeciesID:88-131 keeps one
+ * sorted read list for all stages) copies them to HBM once: *dev receives a read set with mem = NGSID_MEM_DEVICE whose buffers belong to the
+ * library until ngsid_reads_release (or ngsid_destroy of the last context).  host->qual may be NULL.  The device read set is valid for
+ * every context on the same device. */
+int32_t ngsid_reads_upload(ngsid_ctx* ctx, const ngsid_reads_t* host, ngsid_reads_t* dev);
+int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev);
+
 /* Measurement hooks (bench.py): when enabled every kernel launch of this ctx is bracketed by HIP events on the
  * ctx's own stream; ngsid_profile_read synchronises and writes "kernel_name launches total_ms\n" lines (and resets). */
 int32_t ngsid_profile_enable(ngsid_ctx* ctx, int32_t on);

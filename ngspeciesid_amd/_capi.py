@@ -102,6 +102,19 @@ class ReadSet:
         keep = dict(seq=seq_t, qual=qual_t, off=off_t, n=off_t.numel() - 1)
         return ReadSet(seq_t.data_ptr(), None if qual_t is None else qual_t.data_ptr(), off_t.data_ptr(), MEM_DEVICE, keep)
 
+    def release(self):
+        """device read set made by Api.upload_reads: give the buffers back (idempotent)"""
+        k = self.keep if isinstance(self.keep, dict) else None
+        if self.mem == MEM_DEVICE and k and k.get("api") is not None:
+            api, k["api"] = k["api"], None
+            api._call("reads_release", C.byref(self.c))
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
     def get(self, i):
         a, b = int(self.off[i]), int(self.off[i + 1])
         return self.seq[a:b].tobytes().decode(), (None if self.qual is None else self.qual[a:b].tobytes().decode())
@@ -125,6 +138,16 @@ class Api:
         f = self._fn(name)
         rc = f(self.ctx, *args) if self.has_ctx else f(*args)
         return rc
+
+    def upload_reads(self, rs: "ReadSet") -> "ReadSet":
+        """host read set -> device-resident read set (one PCIe copy for all the calls that follow); backends without the entry point
+        (the test oracle) and read sets that are on the device already are returned as they are"""
+        if rs.mem != MEM_HOST or not hasattr(self.lib, self.prefix + "reads_upload"):
+            return rs
+        out = Reads()
+        rc = self._call("reads_upload", C.byref(rs.c), C.byref(out))
+        if rc: self._err(rc)
+        return ReadSet(out.seq, out.qual, out.off, MEM_DEVICE, dict(n=rs.n, api=self, host=rs))
 
     def _err(self, rc):
         if self.has_ctx:

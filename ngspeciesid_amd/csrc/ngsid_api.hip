@@ -12,7 +12,9 @@ extern "C" const char* ngsid_last_error(ngsid_ctx* ctx) { return ctx ? ctx->err 
 
 // ---------------------------------------------------------------------------------------------- device memory cache
 namespace {
-struct DevPool { std::mutex mu; std::multimap<unsigned long long, void*> free_; size_t cached = 0; int contexts = 0; };
+struct DevPool { std::mutex mu; std::multimap<unsigned long long, void*> free_; size_t cached = 0; int contexts = 0;
+                 struct Upload { size_t bs; void* q; size_t bq; void* off; size_t bo; }; std::map<void*, Upload> uploads;      // read sets handed out by ngsid_reads_upload
+};
 DevPool g_pool;
 const size_t POOL_LIMIT = (size_t)48 << 30;          // bytes kept for reuse; beyond it blocks go back to the driver
 inline size_t pool_class(size_t b) { if (b < 4096) return 4096; int sh = 63 - __builtin_clzll((unsigned long long)b) - 3; size_t m = ((size_t)1 << sh) - 1; return (b + m) & ~m; }
@@ -90,7 +92,14 @@ extern "C" void ngsid_destroy(ngsid_ctx* ctx)
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
     bool last; { std::lock_guard<std::mutex> lk(g_pool.mu); last = --g_pool.contexts <= 0; }
-    if (last) ngsid_pool_release_all();
+    if (last) {
+        {   // read sets nobody released: their buffers go with the last context
+            std::lock_guard<std::mutex> lk(g_pool.mu);
+            for (auto& kv : g_pool.uploads) { (void)hipFree(kv.first); if (kv.second.q) (void)hipFree(kv.second.q); (void)hipFree(kv.second.off); }
+            g_pool.uploads.clear();
+        }
+        ngsid_pool_release_all();
+    }
 }
 
 int32_t ngsid_side_streams(ngsid_ctx* ctx)
@@ -449,6 +458,37 @@ extern "C" int32_t ngsid_profile_enable(ngsid_ctx* ctx, int32_t on)
     prof_collect(ctx); ctx->prof_acc.clear(); ctx->prof = on != 0;
     return NGSID_OK;
 }
+extern "C" int32_t ngsid_reads_upload(ngsid_ctx* ctx, const ngsid_reads_t* host, ngsid_reads_t* dev)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!host || !dev || !host->off || (host->n && !host->seq) || host->mem != NGSID_MEM_HOST) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_upload: a host read set and an output are required");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = host->n, total = host->off[n];
+    void *ds = nullptr, *dq = nullptr, *dof = nullptr; size_t got = 0;
+    HIPCHK(ctx, ngsid_pool_alloc(&ds, total + 16, &got)); const size_t bs = got;
+    HIPCHK(ctx, ngsid_pool_alloc(&dof, sizeof(uint64_t) * (n + 1), &got)); const size_t bo = got;
+    size_t bq = 0;
+    if (host->qual) { HIPCHK(ctx, ngsid_pool_alloc(&dq, total + 16, &got)); bq = got; }
+    if (total) HIPCHK(ctx, hipMemcpyAsync(ds, host->seq, total, hipMemcpyHostToDevice, ctx->stream));
+    if (total && host->qual) HIPCHK(ctx, hipMemcpyAsync(dq, host->qual, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dof, host->off, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.uploads[ds] = {bs, dq, bq, dof, bo}; }
+    dev->seq = (const uint8_t*)ds; dev->qual = (const uint8_t*)dq; dev->off = (const uint64_t*)dof; dev->n = n; dev->mem = NGSID_MEM_DEVICE; dev->_pad = 0;
+    return NGSID_OK;
+}
+
+extern "C" int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!dev || dev->mem != NGSID_MEM_DEVICE) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_release: not a device read set");
+    DevPool::Upload u;
+    { std::lock_guard<std::mutex> lk(g_pool.mu); auto it = g_pool.uploads.find((void*)dev->seq); if (it == g_pool.uploads.end()) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_release: this read set was not made by ngsid_reads_upload (or was released already)"); u = it->second; g_pool.uploads.erase(it); }
+    ngsid_pool_free((void*)dev->seq, u.bs); if (u.q) ngsid_pool_free(u.q, u.bq); ngsid_pool_free(u.off, u.bo);
+    dev->seq = nullptr; dev->qual = nullptr; dev->off = nullptr; dev->n = 0;
+    return NGSID_OK;
+}
+
 extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return NGSID_ERR_ARG;

@@ -57,7 +57,7 @@ def _string_ranks(names: fastio.Names, sfx, idx):
 class BackgroundWriters:
     """Output files are written by worker threads while the GPU stages run (the native writers release the GIL).  join() waits for all of them
     and re-raises the first failure; main() joins before it returns, whatever happens, so the files are complete whenever the call is over."""
-    def __init__(self, workers=4):
+    def __init__(self, workers=8):
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(max_workers=workers); self.futures = []
 
@@ -160,7 +160,7 @@ def normalized_reads(sr: SortedReads):
     return sr.rs
 
 
-def cluster(sr: SortedReads, work: ReadSet, sel, args, api):
+def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None):
     """clusters the reads sel (indices into the sorted set, ascending = processing order).
     -> rep_of [n] (sorted index of the final representative, self for reads outside sel), herr [n], pos [n] (position in the cluster's read list),
        counters, acc_id [n] (dense rank of the accession 'name_score', -1 outside sel; None when all accessions are distinct)"""
@@ -173,7 +173,8 @@ def cluster(sr: SortedReads, work: ReadSet, sel, args, api):
     if too_long.any():
         logging.warning("%d reads are longer than %d bases: they are not clustered and stay singletons (use --m / --s to filter by length)", int(too_long.sum()), MAX_READ_LEN)
         sel = sel[~too_long]
-    work = subset_reads(work, sel)
+    whole = work_dev is not None and len(sel) == n and args.nr_cores <= 1       # every read in one call: the device-resident set as it is
+    work = work_dev if whole else subset_reads(work, sel)
     prm = cluster_params(k=args.k, w=args.w, min_shared=args.min_shared, min_fraction=args.min_fraction, mapped_threshold=args.mapped_threshold,
                          aligned_threshold=args.aligned_threshold, min_prob_no_hits=args.min_prob_no_hits,
                          symmetric=bool(getattr(args, "symmetric_map_align_thresholds", False)), p_shared=select_p_table(args.k, args.w))
@@ -376,6 +377,8 @@ def _main(args, api):
     sr = score_and_sort(args, api, T)
     work = normalized_reads(sr)
     T["normalize"] = time() - t0 - sum(T.values()); t0 = time()
+    work_dev = api.upload_reads(work)               # ONE copy to HBM for the clustering, the draft consensus and the polishing calls
+    T["upload"] = time() - t0; t0 = time()
     sel = np.arange(sr.n, dtype=np.int64)
     if args.target_length > 0 and args.target_deviation > 0:
         lens = np.diff(sr.rs.off.astype(np.int64))
@@ -387,7 +390,7 @@ def _main(args, api):
         sel = sel[np.asarray(sorted(random.sample(range(len(sel)), args.sample_size)), dtype=np.int64)]
     abundance_cutoff = int(args.abundance_ratio * len(sel))
     logging.info(f"Starting Clustering: {len(sel)} reads")
-    rep_of, herr, pos, counters, acc_id = cluster(sr, work, sel, args, api)
+    rep_of, herr, pos, counters, acc_id = cluster(sr, work, sel, args, api, work_dev)
     T["cluster"] = time() - t0; t0 = time()
     logging.debug(f"Time elapsed clustering: {T['cluster']}")
     reps, sizes, goff, list_order, file_order, cl_sorted = cluster_table(sr, sel, rep_of, pos)
@@ -400,6 +403,8 @@ def _main(args, api):
     if args.consensus:
         logging.info("Starting Consensus creation and polishing")
         logging.debug(f"Forming draft consensus with abundance_cutoff >= {abundance_cutoff} ({args.abundance_ratio * 100}% of {len(sel)} reads)")
-        merged = consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundance_cutoff, api, acc_id, T)
+        merged = consensus_and_polish(args, sr, work_dev, reps, sizes, goff, list_order, abundance_cutoff, api, acc_id, T)
         logging.info(f"Finished Consensus creation: {len(merged)} created")
+    if work_dev is not work:
+        work_dev.release()
     return dict(n_sorted=sr.n, n_clustered=len(sel), clusters=len(reps), centers=merged, timings=T, counters=counters)

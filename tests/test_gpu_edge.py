@@ -78,3 +78,33 @@ def test_symmetric_thresholds(gpu_api, oracle):
     a, b = both(gpu_api, oracle, lambda api: api.cluster_greedy(rs, prm))
     for x, y in zip(a, b):
         assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_device_resident_read_set_and_second_context(gpu_api, oracle):
+    """ngsid_reads_upload: one copy to HBM serves several calls and several contexts; results equal the host read set's; a second context
+    (own stream and scratch) working from another host thread at the same time gives the same answers."""
+    import threading
+    from ngspeciesid_amd import runtime
+    sp = synth.make_species(3, 500, 0.15, seed=5)
+    rd = synth.make_reads(sp, 3000, mu=17.0, seed=9)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    prm = cluster_params(k=13, w=20, p_shared=PT)
+    dev = gpu_api.upload_reads(rs)
+    assert dev is not rs and dev.n == rs.n
+    a = gpu_api.cluster_greedy(rs, prm); b = gpu_api.cluster_greedy(dev, prm)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    groups = [np.nonzero(a[0] == r)[0].astype(np.uint32) for r in np.unique(a[0]) if (a[0] == r).sum() >= 50]
+    off = np.concatenate(([0], np.cumsum([len(g) for g in groups]))).astype(np.uint64); ro = np.concatenate(groups)
+    pp = poa_params(mode=0, match=5, mismatch=-4, gap=-2, tile_depth=8, band=64, trim=1)
+    ref = gpu_api.poa_consensus(rs, off, pp, read_order=ro)
+    api2 = runtime.new_api(0)
+    out = [None, None]
+    def work(k, api):
+        out[k] = [api.poa_consensus(dev, off, pp, read_order=ro) for _ in range(3)]
+    th = [threading.Thread(target=work, args=(0, gpu_api)), threading.Thread(target=work, args=(1, api2))]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert all(x == ref for x in out[0]) and all(x == ref for x in out[1])
+    api2.lib.ngsid_destroy(api2.ctx)
+    dev.release(); dev.release()                       # idempotent
+    with pytest.raises(NgsidError):
+        gpu_api._err(gpu_api._call("reads_release", __import__("ctypes").byref(rs.c)))          # a host read set is refused
