@@ -2,6 +2,8 @@
 // and ngsid_polish (a16,a17).  Mirrors oracle/ngsid_oracle_poa.c: run_hierarchy / ongsid_poa_consensus / ongsid_polish.
 #include "ngsid_internal.h"
 #include "k_poa.h"
+#include <thread>
+#include <atomic>
 #include <chrono>
 #include <algorithm>
 #include <vector>
@@ -465,32 +467,63 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
             std::vector<uint32_t> ubase(G), unw(G), npg(G, 0);
             for (uint32_t g = 0; g < G; ++g) { unw[g] = (uint32_t)unit_of[g].size(); ubase[g] = unw[g] ? (uint32_t)unit_of[g][0] : 0; }
             for (uint64_t p = 0; p < NP; ++p) npg[pair_group[p]]++;
-            // lists sized for the worst case, filled through raw cursors (two million appends per iteration), trimmed afterwards
-            std::vector<uint32_t*> cur(units.size(), nullptr);
-            for (uint32_t g = 0; g < G; ++g) for (uint32_t wdx = 0; wdx < unw[g]; ++wdx) { auto& v = units[ubase[g] + wdx].seqs; v.resize(npg[g]); cur[ubase[g] + wdx] = v.data(); }
             const uint32_t* pg = pair_group.data(); const uint16_t* hv0 = h_valid.data();
-            for (uint64_t p = 0; p < NP; ++p) {
-                const uint32_t g = pg[p]; const uint16_t* hv = hv0 + p * (uint64_t)nwinmax; const uint32_t nwg = unw[g], ub = ubase[g]; uint32_t any = 0;
-                for (uint32_t wdx = 0; wdx < nwg; ++wdx) { const uint32_t v = hv[wdx] != 0; *cur[ub + wdx] = (uint32_t)(p * (uint64_t)nwinmax + wdx); cur[ub + wdx] += v; any |= v; }
-                used[g] += any;
-            }
-            for (size_t u = 0; u < units.size(); ++u) if (cur[u]) units[u].seqs.resize((size_t)(cur[u] - units[u].seqs.data()));
+            // pairs come group by group (the caller's read lists); then every (group, window) unit is filled and ordered by its own host thread
+            // from the group's pair range.  Otherwise (never seen) one pass over all pairs.
+            bool by_group = true; std::vector<uint64_t> gbeg(G + 1, 0);
+            for (uint64_t p = 1; p < NP; ++p) if (pg[p] < pg[p - 1]) { by_group = false; break; }
+            if (by_group) { uint64_t acc = 0; for (uint32_t g = 0; g < G; ++g) { gbeg[g] = acc; acc += npg[g]; } gbeg[G] = acc; }
             // racon adds the layers of a window in the order of their first window position (src/window.cpp: rank sorted by positions_.first);
-            // ties keep the read order (stable)
-            {
-                static thread_local std::vector<uint32_t> tmpv; std::vector<uint32_t> cnt;
-                for (size_t u = 0; u < units.size(); ++u) {
-                    auto& v = units[u].seqs; if (v.size() < 2) continue;
-                    uint32_t kmax = 0; bool sorted = true;
-                    for (size_t x = 0; x < v.size(); ++x) { const uint32_t kx = hv0[v[x]]; kmax = std::max(kmax, kx); if (x && hv0[v[x - 1]] > kx) sorted = false; }
-                    if (sorted) continue;
-                    cnt.assign((size_t)kmax + 2, 0);                      // counting sort (keys are window positions): linear and stable
-                    for (uint32_t id : v) cnt[hv0[id] + 1]++;
-                    for (size_t k2 = 1; k2 < cnt.size(); ++k2) cnt[k2] += cnt[k2 - 1];
-                    tmpv.resize(v.size());
-                    for (uint32_t id : v) tmpv[cnt[hv0[id]]++] = id;
-                    std::copy(tmpv.begin(), tmpv.end(), v.begin());
+            // ties keep the read order (stable): counting sort on the window position
+            auto order_unit = [&](std::vector<uint32_t>& v, std::vector<uint32_t>& tmpv, std::vector<uint32_t>& cnt) {
+                if (v.size() < 2) return;
+                uint32_t kmax = 0; bool sorted = true;
+                for (size_t x = 0; x < v.size(); ++x) { const uint32_t kx = hv0[v[x]]; kmax = std::max(kmax, kx); if (x && hv0[v[x - 1]] > kx) sorted = false; }
+                if (sorted) return;
+                cnt.assign((size_t)kmax + 2, 0);
+                for (uint32_t id : v) cnt[hv0[id] + 1]++;
+                for (size_t k2 = 1; k2 < cnt.size(); ++k2) cnt[k2] += cnt[k2 - 1];
+                tmpv.resize(v.size());
+                for (uint32_t id : v) tmpv[cnt[hv0[id]]++] = id;
+                std::copy(tmpv.begin(), tmpv.end(), v.begin());
+            };
+            if (by_group && NP >= 65536) {
+                std::vector<uint64_t> used_g(G, 0);
+                const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+                const size_t ntask = units.size() + G;                          // one task per unit + one per group (reads used)
+                std::atomic<size_t> next_task{0};
+                auto worker = [&]() {
+                    std::vector<uint32_t> tmpv, cnt;
+                    for (;;) {
+                        const size_t t = next_task.fetch_add(1); if (t >= ntask) break;
+                        if (t < units.size()) {
+                            const uint32_t g = unit_gw[t].first, wdx = (uint32_t)unit_gw[t].second;
+                            auto& v = units[t].seqs; v.resize(npg[g]); uint32_t* c = v.data();
+                            for (uint64_t p = gbeg[g]; p < gbeg[g + 1]; ++p) { *c = (uint32_t)(p * (uint64_t)nwinmax + wdx); c += hv0[p * (uint64_t)nwinmax + wdx] != 0; }
+                            v.resize((size_t)(c - v.data()));
+                            order_unit(v, tmpv, cnt);
+                        } else {
+                            const uint32_t g = (uint32_t)(t - units.size()); const uint32_t nwg = unw[g]; uint64_t u = 0;
+                            for (uint64_t p = gbeg[g]; p < gbeg[g + 1]; ++p) { const uint16_t* hv = hv0 + p * (uint64_t)nwinmax; uint32_t any = 0; for (uint32_t wdx = 0; wdx < nwg; ++wdx) any |= hv[wdx] != 0; u += any; }
+                            used_g[g] = u;
+                        }
+                    }
+                };
+                std::vector<std::thread> th; for (unsigned x = 1; x < hw; ++x) th.emplace_back(worker);
+                worker(); for (auto& t : th) t.join();
+                for (uint32_t g = 0; g < G; ++g) used[g] += (uint32_t)used_g[g];
+            } else {
+                // lists sized for the worst case, filled through raw cursors, trimmed afterwards
+                std::vector<uint32_t*> cur(units.size(), nullptr);
+                for (uint32_t g = 0; g < G; ++g) for (uint32_t wdx = 0; wdx < unw[g]; ++wdx) { auto& v = units[ubase[g] + wdx].seqs; v.resize(npg[g]); cur[ubase[g] + wdx] = v.data(); }
+                for (uint64_t p = 0; p < NP; ++p) {
+                    const uint32_t g = pg[p]; const uint16_t* hv = hv0 + p * (uint64_t)nwinmax; const uint32_t nwg = unw[g], ub = ubase[g]; uint32_t any = 0;
+                    for (uint32_t wdx = 0; wdx < nwg; ++wdx) { const uint32_t v = hv[wdx] != 0; *cur[ub + wdx] = (uint32_t)(p * (uint64_t)nwinmax + wdx); cur[ub + wdx] += v; any |= v; }
+                    used[g] += any;
                 }
+                for (size_t u = 0; u < units.size(); ++u) if (cur[u]) units[u].seqs.resize((size_t)(cur[u] - units[u].seqs.data()));
+                std::vector<uint32_t> tmpv, cnt;
+                for (size_t u = 0; u < units.size(); ++u) order_unit(units[u].seqs, tmpv, cnt);
             }
         }
         std::vector<size_t> nlayers(units.size());
