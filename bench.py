@@ -214,7 +214,7 @@ def main():
             traffic = None
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic,
                 "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-                "note": "integer DP kernel: VALU-issue bound by construction, HBM fraction is small (DESIGN.md section 4)"}
+                "note": "integer DP kernel, one wave per tile: bound by the latency of the wave's dependent instruction stream (six waves per SIMD overlap to 2.75x, VALU pipe 60 % busy), not by HBM - the fraction of the HBM roofline is small by construction (DESIGN.md sections 4 and 10)"}
         if dom[0] == "k_poa_tile":      # what bounds it is instruction issue along the dependent chain of a DP row: SQ counters are in the committed PMC pass (not measurable from inside this process)
             roof["sq_counters"] = "profiles/r02_pmc_poa_tile.txt"
         if dom[0] == "k_sg_align":      # what actually bounds it: VALU issue.  17.7 VALU instructions per DP cell and lane (ISA count, k_align16.hip), 64 cells per wave instruction
