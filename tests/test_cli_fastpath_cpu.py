@@ -95,3 +95,13 @@ def test_universal_tail_trimming_both_layers(oracle_backend, tmp_path):
         assert len(cons) == 1
         seq = cons[0].decode().split("\n")[1]
         assert seq == tails["1_F_fw"][-1] + body.tobytes().decode()
+
+
+def test_background_writers_and_synchronous_writes_give_the_same_files(oracle_backend, monkeypatch):
+    """the output files are complete when main() returns, with the writer threads (default) and without (NGSID_CLI_SYNC_WRITES=1)"""
+    flags = ["--t", "2", "--consensus", "--racon", "--racon_iter", "1", "--abundance_ratio", "0.01"]
+    a = _run(oracle_backend, flags, False)
+    monkeypatch.setenv("NGSID_CLI_SYNC_WRITES", "1")
+    b = _run(oracle_backend, flags, False)
+    assert sorted(a) == sorted(b) and all(a[k] == b[k] for k in a)
+    assert any(k.startswith("reads_to_consensus_") for k in a) and "sorted.fastq" in a
