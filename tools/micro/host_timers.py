@@ -1,6 +1,9 @@
+"""dev tool: one pass of the hot path on the bench workload with NGSID_HOST_TIMERS=1 - the library prints the host-side time of every stage
+(job lists, uploads, kernels, downloads per hierarchy level) to stderr."""
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
-os.chdir("/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.chdir(ROOT)
 import numpy as np, torch, bench
 from ngspeciesid_amd import runtime, pipeline
 from ngspeciesid_amd._capi import ReadSet
