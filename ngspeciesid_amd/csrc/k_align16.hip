@@ -10,6 +10,7 @@
 // The systolic skew is two columns per lane: steps = m + 127 per strip.
 #include "ngsid_internal.h"
 #include <algorithm>
+#include <type_traits>
 
 #define NEG16 (-20000)
 // Packed 16-bit VALU ops through inline asm: with plain vector types the compiler "simplifies" the flag arithmetic back into
@@ -90,6 +91,10 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
         int bestRowV = -(1 << 29), bestRowJ = 0;
         int bestColV = -(1 << 29), bestColI = 0x7fffffff;
 
+        // The strip loop is instantiated once per register pair that can hold the LAST query row (wave-uniform own_p): the capture of that row's
+        // cell is then a compile-time choice instead of RP selects per step.
+        auto strips = [&](auto OPc) {
+        constexpr int OWN_P = decltype(OPc)::value;
         for (int sidx = 0; sidx < nstrips; ++sidx) {
             const int i0 = sidx * STRIP + lane * RPL;
             int qc2[RP], nwq2[RP], hl2[RP], e2[RP];
@@ -139,9 +144,10 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
                     if (r < C0) acc0 = (acc0 << 4) | c; else acc1 = (acc1 << 4) | c;                // never crosses a 16-bit half: <= 4 nibbles each
                     hd2 = hl2[r];
                     hl2[r] = (h & am2) | (hl2[r] & ~am2);
-                    e2[r] = (E & am2) | (e2[r] & ~am2);
+                    e2[r] = E;       // not masked: before a lane's first column E only relaxes to H - open = -open (what the first real column computes from
+                                     // the boundary anyway: same value, same 'opened' flag), after its last column E is not used again
                     hu2 = h; f2 = F;
-                    if (r == own_p) cap2 = h;
+                    if (r == OWN_P) cap2 = h;
                 }
                 // traceback word: A cells low dword, B cells high dword (complement nibbles); words of inactive steps are never read
                 const unsigned wA = ((unsigned)acc0 & 0xffffu) | ((unsigned)acc1 << 16), wB = ((unsigned)acc0 >> 16) | ((unsigned)acc1 & 0xffff0000u);
@@ -166,6 +172,17 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
 #pragma unroll
             for (int r = 0; r < RP; ++r) { const int ib = i0 + RP + r; const int v = HI16(hl2[r]); if (ib < n && v > bestColV) { bestColV = v; bestColI = ib; } }
             if (nstrips > 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); }
+        }
+        };
+        switch (own_p) {
+            case 0: strips(std::integral_constant<int, 0>{}); break;
+            case 1: strips(std::integral_constant<int, (RP > 1 ? 1 : 0)>{}); break;
+            case 2: strips(std::integral_constant<int, (RP > 2 ? 2 : 0)>{}); break;
+            case 3: strips(std::integral_constant<int, (RP > 3 ? 3 : 0)>{}); break;
+            case 4: strips(std::integral_constant<int, (RP > 4 ? 4 : 0)>{}); break;
+            case 5: strips(std::integral_constant<int, (RP > 5 ? 5 : 0)>{}); break;
+            case 6: strips(std::integral_constant<int, (RP > 6 ? 6 : 0)>{}); break;
+            default: strips(std::integral_constant<int, (RP > 7 ? 7 : 0)>{}); break;
         }
         // ---- reduce the end cell (first maximum over the last row, then strictly larger over the last column with the lowest row)
         int rowV = bestRowV, rowJ = bestRowJ;
