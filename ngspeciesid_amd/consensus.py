@@ -14,7 +14,7 @@ from . import pipeline
 from ._capi import ReadSet, poa_params, polish_params, POA_LOCAL
 from .help_functions import readfq, mkdir_p
 
-DEFAULT_TILE_DEPTH = 8
+DEFAULT_TILE_DEPTH = pipeline.TILE_DEPTH
 DEFAULT_BAND = 0          # library default: 64 columns for reads up to 1 024 bases, 128 beyond; widened per tile by the band-edge check
 
 
@@ -126,7 +126,7 @@ def polish_sequences(centers, args, api=None):
             logging.debug("running racon on spoa reference {0} using {1} reads for polishing.".format(c_id, nr_reads_used))
             folder = os.path.join(args.outfolder, "racon_cl_id_{0}".format(c_id))
             mkdir_p(folder)
-            run_racon(all_reads_file, spoa_center_file, folder, "1", args.racon_iter, api=api, band=getattr(args, "poa_band", DEFAULT_BAND), k=args.k, w=args.w)
+            run_racon(all_reads_file, spoa_center_file, folder, "1", args.racon_iter, api=api, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else DEFAULT_TILE_DEPTH), band=getattr(args, "poa_band", DEFAULT_BAND), k=args.k, w=args.w)
             with open(os.path.join(folder, "consensus.fasta")) as cf:
                 centers[i][2] = cf.readlines()[1].strip()
     return centers

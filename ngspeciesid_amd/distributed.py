@@ -141,7 +141,7 @@ def merge_representatives(api, gathered, prm, world):
 
 
 def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k=13, w=20, abundance_ratio=0.1, rc_identity_threshold=0.9,
-                     racon_iter=3, tile_depth=8, band=0, p_shared=None, cluster_kwargs=None, do_consensus=True, polish_trim=2, device=None, timings=None, polish_stop_when_stable=True):
+                     racon_iter=3, tile_depth=pipeline.TILE_DEPTH, band=0, p_shared=None, cluster_kwargs=None, do_consensus=True, polish_trim=2, device=None, timings=None, polish_stop_when_stable=True):
     """Runs on every rank; returns dict(final_rep=(rank, local idx) per local read as two arrays, centers=[(n, key, draft, polished)])."""
     import time
     T = timings if timings is not None else {}

@@ -258,7 +258,7 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
     sub_off = np.concatenate(([0], np.cumsum([len(g) for g in groups]))).astype(np.uint64)
     long_reads = bool(np.diff(sr.rs.off.astype(np.int64))[np.concatenate(groups)].max() > 1000)
     node_cap = 22 if long_reads else 0
-    drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=getattr(args, "poa_tile_depth", 8), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=pipeline.DRAFT_TRIM),
+    drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=getattr(args, "poa_tile_depth", pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=pipeline.DRAFT_TRIM),
                                read_order=np.concatenate(groups).astype(np.uint32))
     T["draft_consensus"] = time() - t0
     centers = [[int(sizes[c]), int(reps[c]), drafts[c], [c]] for c in range(nsel)]
@@ -324,7 +324,7 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
     if getattr(args, "racon", False) and args.racon_iter >= 0:
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in polish_lists]))).astype(np.uint64)
         bb = ReadSet.from_strings([(polish_backbones or {}).get(m[1], m[2]) for m in merged])
-        polished, used = api.polish(bb, work, p_off, polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=8, band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=2),
+        polished, used = api.polish(bb, work, p_off, polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=2),
                                     read_order=np.concatenate(polish_lists).astype(np.uint32))
         for x, (nr, c_id, center, cs) in enumerate(merged):
             logging.debug("running racon on spoa reference {0} using {1} reads for polishing.".format(c_id, len(pooled[x])))

@@ -12,6 +12,10 @@ from ._capi import Api, ReadSet, cluster_params, poa_params, polish_params, POA_
 # Draft consensus: coverage-trim the ends of every tile consensus (ngsid_poa_params_t.trim).  spoa itself completes the heaviest bundle to
 # a sink, so its consensus can end in the unsupported tail of a single read, and racon cannot shorten or extend a backbone end; with the
 # trim the drafts of the noisy synthetic sets equal their amplicons before polishing.
+# Reads per exact-order POA tile (draft and polishing windows).  With coverage-trimmed tile consensuses the depth does not matter for the accuracy
+# (exact from 5.6 % to 14.3 % read error at depths 8 / 6 / 5); 6 is the fastest at 1 M reads (depth 8: every second tile ends
+# with an eighth member that no longer fits the edge room and the graphs are largest when the last members are aligned).
+TILE_DEPTH = 6
 DRAFT_TRIM = 1
 
 _COMP = np.zeros(256, dtype=np.uint8)
@@ -99,9 +103,10 @@ def pooled_read_lists(merged, group_reads):
 
 
 def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, w=20, abundance_ratio=0.1,
-                 rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=8, band=0, node_cap=0,
+                 rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=None, band=0, node_cap=0,
                  p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2, polish_aln_mode=2, polish_stop_when_stable=True):
     """Returns dict(rep_of, status, counters, hpc_err, centers=[(n_reads, c_id, draft, polished, groups)])."""
+    tile_depth = TILE_DEPTH if tile_depth is None else tile_depth
     T = timings if timings is not None else {}
     t0 = time.perf_counter()
     prm = cluster_params(k=k, w=w, p_shared=p_shared, **(cluster_kwargs or {}))
