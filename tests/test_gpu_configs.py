@@ -26,7 +26,7 @@ def _run(gpu_api, n, nsp, L, mu, k, w, ab, seed, abundance=None):
     sp, rd = bench.gen_sorted_reads(gpu_api, n, nsp, L, mu, seed=seed, device=dev, abundance=abundance)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     res = pipeline.run_hot_path(gpu_api, rs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=k, w=w, abundance_ratio=ab, racon_iter=3,
-                                tile_depth=8, band=0, p_shared=select_p_table(k, w), polish_stop_when_stable=False)
+                                tile_depth=pipeline.TILE_DEPTH, band=0, p_shared=select_p_table(k, w), polish_stop_when_stable=False)
     return sp, rd, rs, res
 
 
@@ -92,7 +92,7 @@ def test_mixed_strand_reads_are_merged_and_polished(gpu_api, mu):
     sp, rd = bench.gen_sorted_reads(gpu_api, 200000, 5, 750, mu, seed=13, device=dev, rc_fraction=0.5)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     res = pipeline.run_hot_path(gpu_api, rs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=13, w=20, abundance_ratio=0.02, racon_iter=3,
-                                tile_depth=8, band=0, p_shared=select_p_table(13, 20), polish_stop_when_stable=False)
+                                tile_depth=pipeline.TILE_DEPTH, band=0, p_shared=select_p_table(13, 20), polish_stop_when_stable=False)
     truths = [s.tobytes().decode() for s in sp]
     both = set(truths) | set(pipeline.revcomp_str(t) for t in truths)
     assert len(res["centers"]) == 5, [c[0] for c in res["centers"]]

@@ -16,7 +16,7 @@ def test_identical_reads(gpu_api):
 
 
 @pytest.mark.parametrize("cfg", [dict(n=12, L=200, D=0, band=64), dict(n=40, L=500, D=8, band=128), dict(n=40, L=500, D=0, band=128),
-                                 dict(n=100, L=750, D=8, band=128), dict(n=30, L=400, D=4, band=256), dict(n=64, L=1500, D=16, band=128, mu=25.0, node_cap=24)])
+                                 dict(n=100, L=750, D=8, band=128), dict(n=100, L=750, D=6, band=64), dict(n=260, L=750, D=6, band=0, mu=13.0), dict(n=30, L=400, D=4, band=256), dict(n=64, L=1500, D=16, band=128, mu=25.0, node_cap=24)])
 @pytest.mark.parametrize("mode", [POA_LOCAL, POA_GLOBAL])
 def test_poa_vs_oracle(gpu_api, oracle, cfg, mode):
     sp, rd, rs = make_set(cfg["n"], L=cfg["L"], mu=cfg.get("mu", 17.0), seed=5)
@@ -48,12 +48,13 @@ def test_poa_small_capacity_splits(gpu_api, oracle):
     assert gpu_api.poa_consensus(rs, [0, rs.n], prm) == oracle.poa_consensus(rs, [0, rs.n], prm)
 
 
-@pytest.mark.parametrize("cfg", [dict(n=60, L=600, it=1, D=8, rc=0.5), dict(n=120, L=750, it=3, D=8, rc=0.0), dict(n=40, L=1300, it=2, D=8, rc=0.3, mu=25.0), dict(n=30, L=500, it=2, D=0, rc=0.5), dict(n=200, L=750, it=3, D=8, rc=0.0, trim=2), dict(n=64, L=600, it=2, D=4, rc=0.5, trim=2)])
+@pytest.mark.parametrize("cfg", [dict(n=60, L=600, it=1, D=8, rc=0.5), dict(n=120, L=750, it=3, D=8, rc=0.0), dict(n=40, L=1300, it=2, D=8, rc=0.3, mu=25.0), dict(n=30, L=500, it=2, D=0, rc=0.5), dict(n=200, L=750, it=3, D=8, rc=0.0, trim=2), dict(n=64, L=600, it=2, D=4, rc=0.5, trim=2),
+                                 dict(n=200, L=750, it=3, D=6, rc=0.0, trim=2, band=0), dict(n=300, L=750, it=2, D=6, rc=0.5, trim=2, band=0, mu=13.0)])   # D=6, band 0 = what the pipeline ships
 def test_polish_vs_oracle(gpu_api, oracle, cfg):
     sp, rd, rs = make_set(cfg["n"], L=cfg["L"], mu=cfg.get("mu", 17.0), seed=11, rc_fraction=cfg["rc"])
     fw = int(np.nonzero(rd["strand"].numpy() == 0)[0][0])
     bb = ReadSet.from_strings([rs.get(fw)[0]])
-    prm = polish_params(iters=cfg["it"], tile_depth=cfg["D"], band=128, trim=cfg.get("trim", 1))
+    prm = polish_params(iters=cfg["it"], tile_depth=cfg["D"], band=cfg.get("band", 128), trim=cfg.get("trim", 1))
     got, gused = gpu_api.polish(bb, rs, [0, rs.n], prm)
     exp, eused = oracle.polish(bb, rs, [0, rs.n], prm)
     assert got == exp, "len got %d exp %d" % (len(got[0]), len(exp[0]))

@@ -24,7 +24,7 @@ def _run(gpu_api, n, nsp, L, mu, k, w, ab, seed, stop=False):
     sp, rd = bench.gen_sorted_reads(gpu_api, n, nsp, L, mu, seed=seed, device=dev)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     res = pipeline.run_hot_path(gpu_api, rs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=k, w=w, abundance_ratio=ab, racon_iter=3,
-                                tile_depth=8, band=0, p_shared=select_p_table(k, w), polish_stop_when_stable=stop)
+                                tile_depth=pipeline.TILE_DEPTH, band=0, p_shared=select_p_table(k, w), polish_stop_when_stable=stop)      # the depth bench.py / the CLI ship with
     return sp, rd, rs, res
 
 
@@ -50,6 +50,7 @@ def _check_consensus(sp, res, max_ed):
 
 
 def test_c3_one_million_reads_five_species(gpu_api):
+    from ngspeciesid_amd import pipeline
     from ngspeciesid_amd._capi import ReadSet, polish_params
     sp, rd, rs, res = _run(gpu_api, 1000000, 5, 750, 17.0, 13, 20, 0.02, seed=7)
     _check_clusters(rd, res, 5, 0.995)
@@ -63,7 +64,7 @@ def test_c3_one_million_reads_five_species(gpu_api):
         ids = np.concatenate([order[np.searchsorted(srt, g, "left"):np.searchsorted(srt, g, "right")] for g in c[4]])
         p_order.append(ids); p_off.append(p_off[-1] + len(ids))
     bb = ReadSet.from_strings([c[3] for c in res["centers"]])
-    again, used = gpu_api.polish(bb, rs, p_off, polish_params(iters=1, k=13, w=20, tile_depth=8, band=128, trim=2), read_order=np.concatenate(p_order))
+    again, used = gpu_api.polish(bb, rs, p_off, polish_params(iters=1, k=13, w=20, tile_depth=pipeline.TILE_DEPTH, band=128, trim=2), read_order=np.concatenate(p_order))
     assert again == [c[3] for c in res["centers"]], "the polished sequences are not a fixed point of the polisher"
     assert np.all(used >= 0.95 * np.diff(p_off))
     # the early stop is exact at this size too

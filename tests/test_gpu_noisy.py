@@ -21,18 +21,21 @@ from ngspeciesid_amd._capi import ReadSet, poa_params, polish_params, POA_LOCAL
 from ngspeciesid_amd.hostutil import subset_reads
 
 
-@pytest.mark.parametrize("cfg", [(1000000, 14.0, 7), (200000, 14.0, 21), (200000, 13.0, 7), (100000, 13.0, 33), (200000, 12.0, 7), (200000, 10.0, 7)])
+# depth None = pipeline.TILE_DEPTH, the depth the pipeline, the CLI and bench.py ship with ("test what you ship"); depth 8 = the round-2 default
+@pytest.mark.parametrize("cfg", [(1000000, 14.0, 7, None), (200000, 14.0, 21, None), (200000, 13.0, 7, None), (100000, 13.0, 33, None), (200000, 12.0, 7, None), (200000, 10.0, 7, None),
+                                 (200000, 13.0, 7, 8), (200000, 12.0, 7, 8)])
 def test_noisy_whole_path_consensus_equals_amplicon(gpu_api, cfg):
     import torch
     import bench
     from ngspeciesid_amd import pipeline
     from ngspeciesid_amd.ptable import select_p_table
-    n, mu, seed = cfg
+    n, mu, seed, depth = cfg
+    depth = pipeline.TILE_DEPTH if depth is None else depth
     dev = torch.device("cuda", 0)
     sp, rd = bench.gen_sorted_reads(gpu_api, n, 5, 750, mu, seed=seed, device=dev)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     res = pipeline.run_hot_path(gpu_api, rs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=13, w=20, abundance_ratio=0.02, racon_iter=3,
-                                tile_depth=8, band=0, p_shared=select_p_table(13, 20), polish_stop_when_stable=False)
+                                tile_depth=depth, band=0, p_shared=select_p_table(13, 20), polish_stop_when_stable=False)
     truths = sorted(s.tobytes().decode() for s in sp)
     assert len(res["centers"]) == 5
     got = sorted(c[3] for c in res["centers"])
@@ -42,10 +45,13 @@ def test_noisy_whole_path_consensus_equals_amplicon(gpu_api, cfg):
     assert max(min(edit_distance(c[2], t) for t in truths) for c in res["centers"]) <= 3
 
 
+@pytest.mark.parametrize("depth", [None, 8])
 @pytest.mark.parametrize("m", [190000, 47500, 2968])
-def test_polish_removes_unsupported_backbone_overhangs(gpu_api, m):
+def test_polish_removes_unsupported_backbone_overhangs(gpu_api, m, depth):
     """round-1 failure: draft = amplicon + junk tails; with 44 000+ reads (5+ hierarchy levels) the forced global alignment of the upper
     levels dragged tile consensuses through the junk.  Reads are CPU-generated so the oracle can replay the case (oh3 in DESIGN.md)."""
+    from ngspeciesid_amd import pipeline
+    depth = pipeline.TILE_DEPTH if depth is None else depth
     sps = synth.make_species(5, 750, 0.15, seed=1)
     sp = [s for s in sps if s.tobytes().decode().endswith("GTAACGG")]
     truth = sp[0].tobytes().decode()
@@ -54,11 +60,12 @@ def test_polish_removes_unsupported_backbone_overhangs(gpu_api, m):
     sub = subset_reads(rs, np.arange(m))
     for head, tail in (("CC", "GCCATAAATG"), ("", "GCCATAAATG"), ("TTGACA", ""), ("G", "G")):
         bb = head + truth + tail
-        pol, used = gpu_api.polish(ReadSet.from_strings([bb]), sub, [0, m], polish_params(iters=2, k=13, w=20, tile_depth=8, band=128, trim=2, aln_mode=2, stop_when_stable=0))
+        pol, used = gpu_api.polish(ReadSet.from_strings([bb]), sub, [0, m], polish_params(iters=2, k=13, w=20, tile_depth=depth, band=128, trim=2, aln_mode=2, stop_when_stable=0))
         assert pol[0] == truth, "overhang %r / %r survived: ends %s ... %s" % (head, tail, pol[0][:12], pol[0][-20:])
 
 
-def test_tiled_banded_consensus_vs_single_graph_order(gpu_api, oracle):
+@pytest.mark.parametrize("depth", [6, 8])
+def test_tiled_banded_consensus_vs_single_graph_order(gpu_api, oracle, depth):
     G, R = 60, 32
     sp = synth.make_species(G, 750, 0.15, seed=5)
     seqs, quals, off = [], [], [0]
@@ -70,16 +77,16 @@ def test_tiled_banded_consensus_vs_single_graph_order(gpu_api, oracle):
     T = [s.tobytes().decode() for s in sp]
     out = {}
     for trim in (1, 0):
-        a = gpu_api.poa_consensus(rs, grp, poa_params(tile_depth=8, band=128, trim=trim))
+        a = gpu_api.poa_consensus(rs, grp, poa_params(tile_depth=depth, band=128, trim=trim))
         b = gpu_api.poa_consensus(rs, grp, poa_params(tile_depth=0, band=256, node_cap=64, trim=trim))
         if trim == 1:       # the HIP path is the oracle's algorithm, bit for bit, in both settings
-            assert a == oracle.poa_consensus(rs, grp, poa_params(tile_depth=8, band=128, trim=trim))
+            assert a == oracle.poa_consensus(rs, grp, poa_params(tile_depth=depth, band=128, trim=trim))
             assert b == oracle.poa_consensus(rs, grp, poa_params(tile_depth=0, band=256, node_cap=64, trim=trim))
         dab = [edit_distance(x, y) for x, y in zip(a, b)]; da = [edit_distance(x, t) for x, t in zip(a, T)]; db = [edit_distance(y, t) for y, t in zip(b, T)]
         out["trim%d" % trim] = dict(tiled_vs_single_graph=dict(mean=float(np.mean(dab)), max=int(max(dab))), tiled_vs_truth=dict(mean=float(np.mean(da)), max=int(max(da))),
                                     single_graph_vs_truth=dict(mean=float(np.mean(db)), max=int(max(db))))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(dict(groups=G, reads_per_group=R, mu=14.0, length=750, result=out), open(os.path.join(ROOT, "gpurun_out", "r2_tile_vs_exact.json"), "w"), indent=1)
+    json.dump(dict(groups=G, reads_per_group=R, mu=14.0, length=750, tile_depth=depth, result=out), open(os.path.join(ROOT, "gpurun_out", "tile_depth%d_vs_exact.json" % depth), "w"), indent=1)
     # depth 8 / band 128 is at least as close to the truth as the single-graph order, and the two agree to within a few edits per 750 bases
     assert out["trim1"]["tiled_vs_truth"]["mean"] <= out["trim1"]["single_graph_vs_truth"]["mean"] + 0.1
     assert out["trim1"]["tiled_vs_truth"]["max"] <= 1 and out["trim1"]["tiled_vs_single_graph"]["max"] <= 6
