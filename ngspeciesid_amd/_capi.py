@@ -129,6 +129,22 @@ class Api:
         self.lib, self.prefix, self.ctx = lib, prefix, ctx
         self.has_ctx = ctx is not None
 
+    def close(self):
+        """ngsid_destroy: releases the context's stream, side streams, pinned staging and scratch buffers (and, with the last context of the
+        process, the device-memory cache and the read sets uploaded through it).  Contexts from runtime.get_api() are shared and stay open;
+        the ones from runtime.new_api() belong to their caller: close them (or use `with runtime.new_api() as api:`)."""
+        if self.has_ctx and self.ctx is not None:
+            f = getattr(self.lib, self.prefix + "destroy"); f.restype = None
+            f(self.ctx)
+            self.ctx = None; self.has_ctx = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def _fn(self, name):
         f = getattr(self.lib, self.prefix + name)
         f.restype = C.c_int32

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <thread>
+#include <atomic>
 #include <vector>
 #include <algorithm>
 #include <charconv>
@@ -57,18 +58,21 @@ extern "C" int32_t ngsid_host_fastq_index(const uint8_t* buf, uint64_t len, uint
         while (p < e) { const uint8_t* q = (const uint8_t*)memchr(p, '\n', (size_t)(e - p)); if (!q) break; if (k <= nlines) starts[k] = (uint64_t)(q + 1 - buf); ++k; p = q + 1; } });
     if (tail) starts[nlines] = len + 1;                           // virtual newline behind the last line
     const uint64_t nr = nlines / 4;
-    std::vector<int> bad(T, 0);
-    parallel_ranges(nr, n_threads(nr * 64), [&](uint64_t a, uint64_t b, int t) {
+    // one shared flag (the record pass may run with MORE threads than the line passes - short records - so a per-thread array sized by T was
+    // overrun and lost the error); a bad record does not stop its thread: every other record of the range is still indexed
+    std::atomic<int> bad{0};
+    // length of the line [s, nx - 1) without its line terminator: "\n" or "\r\n" (the reference opens the file in text mode, which drops the '\r')
+    auto linelen = [&](uint64_t s, uint64_t nx) -> uint64_t { uint64_t e = nx - 1; if (e > s && e - 1 < len && buf[e - 1] == '\r') --e; return e - s; };
+    parallel_ranges(nr, n_threads(nr * 64), [&](uint64_t a, uint64_t b, int) {
         for (uint64_t r = a; r < b; ++r) {
             const uint64_t s0 = starts[4 * r], s1 = starts[4 * r + 1], s2 = starts[4 * r + 2], s3 = starts[4 * r + 3], s4 = starts[4 * r + 4];
-            if (s0 >= len || buf[s0] != '@' || s2 >= len || buf[s2] != '+') { bad[t] = 1; return; }
-            const uint64_t sl = s2 - 1 - s1, ql = s4 - 1 - s3;
-            if (sl != ql || sl > 0xffffffffull || s1 - 1 - (s0 + 1) > 0xffffffffull) { bad[t] = 1; return; }
+            if (s0 >= len || buf[s0] != '@' || s2 >= len || buf[s2] != '+') { bad.store(1, std::memory_order_relaxed); continue; }
+            const uint64_t sl = linelen(s1, s2), ql = linelen(s3, s4), nl = linelen(s0 + 1, s1);
+            if (sl != ql || sl > 0xffffffffull || nl > 0xffffffffull) { bad.store(1, std::memory_order_relaxed); continue; }
             rec[4 * r] = s0 + 1; rec[4 * r + 1] = s1; rec[4 * r + 2] = s2; rec[4 * r + 3] = s3;
-            name_len[r] = (uint32_t)(s1 - 1 - (s0 + 1)); seq_len[r] = (uint32_t)sl;
+            name_len[r] = (uint32_t)nl; seq_len[r] = (uint32_t)sl;
         } });
-    for (int t = 0; t < (int)bad.size(); ++t) if (bad[t]) return 1;
-    return 0;
+    return bad.load() ? 1 : 0;
 }
 
 // dst[dst_off[i] .. +len[i]) = src[src_off[i] .. +len[i]) for i < n  (CSR gather / scatter of variable-length byte records)

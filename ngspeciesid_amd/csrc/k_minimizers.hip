@@ -34,15 +34,17 @@ template <> struct CodeT<1> { uint64_t lo; __device__ __forceinline__ bool less(
 template <> struct CodeT<2> { uint64_t hi, lo; __device__ __forceinline__ bool less(const CodeT<2>& o) const { return hi < o.hi || (hi == o.hi && lo < o.lo); } };
 
 // LDS of one wave (bytes): hs [NC + 64] | am [NC u16] | then EITHER sraw [ML4] | qraw [ML4] | hist_h, hist_r [2 x 128 int] (phases 1-2) OR lo [NC u64] | hi [NC u64, KW = 2] (phases 3-4)
-__host__ __device__ inline size_t mz_lds_per_wave(uint32_t maxlen, int W, int KW)
+// LEAN (reads whose full layout would not fit the 160 KB of a CU: above ~14 800 bases at k <= 21, ~8 600 at k > 21): no code arrays - every
+// k-mer code is rebuilt from the HPC letters where it is compared or emitted (k / 4 dword reads each), 5 bytes per base instead of 11 / 19.
+__host__ __device__ inline size_t mz_lds_per_wave(uint32_t maxlen, int W, int KW, bool lean = false)
 {
     const size_t ML4 = ((size_t)maxlen + 7) & ~(size_t)3;
     const size_t NC = (((size_t)maxlen > (size_t)W ? (size_t)maxlen : (size_t)W) + 4 + 3) & ~(size_t)3;
-    const size_t phase12 = 2 * ML4 + 1024, phase34 = NC * 8 * (size_t)KW;      // staged read + histograms | k-mer codes: never live together
+    const size_t phase12 = 2 * ML4 + 1024, phase34 = lean ? 0 : NC * 8 * (size_t)KW;      // staged read + histograms | k-mer codes: never live together
     return (NC + 64) + NC * 2 + (phase12 > phase34 ? phase12 : phase34);
 }
 
-template <int KW>
+template <int KW, bool LEAN>
 __global__ __launch_bounds__(256)
 void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t nreads,
                       int k, int w, uint32_t maxlen, uint32_t lds_per_wave,
@@ -142,9 +144,9 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
     const int nk = hl - k + 1;
     const int nc = nk > W ? nk : W;
     const int nfull = k >> 2, rem = k & 3;
-    for (int i = lane; i < nc; i += 64) {
+    auto kmer_code = [&](int i, uint64_t& lo, uint64_t& hi) {
         const unsigned* hw = (const unsigned*)(hs + (i & ~3)); const int sh = i & 3;
-        uint64_t lo = 0, hi = 0; unsigned prev = hw[0];
+        lo = 0; hi = 0; unsigned prev = hw[0];
         for (int t = 0; t <= nfull; ++t) {
             const unsigned next = hw[t + 1];
             unsigned wq = __builtin_amdgcn_alignbyte(next, prev, sh);           // bytes i+4t .. i+4t+3
@@ -154,15 +156,19 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
             if (KW == 2) hi = (hi << bits) | (lo >> (63 - bits));
             lo = ((lo << bits) | pk) & 0x7fffffffffffffffULL;
         }
+    };
+    for (int i = lane; i < nc; i += 64) {
         // positions past the end of the string hold zeros already (hs padding); letters beyond hl inside a k-mer are zeros = "end" symbol
-        clo[i] = lo; if (KW == 2) chi[i] = hi;
+        if (!LEAN) { uint64_t lo, hi; kmer_code(i, lo, hi); clo[i] = lo; if (KW == 2) chi[i] = hi; }
         am[i] = (uint16_t)i;
     }
     lsync();
 
     // ---- 4. sparse table of argmin positions: after pass p, am[i] = leftmost minimum of codes[i .. i+2^p) (clipped at nc)
     auto better = [&](int a, int b) -> int {           // leftmost minimum of two candidates, a's range starts left of b's
-        CodeT<KW> ca, cb; ca.lo = clo[a]; cb.lo = clo[b]; if constexpr (KW == 2) { ca.hi = chi[a]; cb.hi = chi[b]; }
+        CodeT<KW> ca, cb;
+        if (LEAN) { uint64_t l, h; kmer_code(a, l, h); ca.lo = l; if constexpr (KW == 2) ca.hi = h; kmer_code(b, l, h); cb.lo = l; if constexpr (KW == 2) cb.hi = h; }
+        else { ca.lo = clo[a]; cb.lo = clo[b]; if constexpr (KW == 2) { ca.hi = chi[a]; cb.hi = chi[b]; } }
         return cb.less(ca) ? b : a;
     };
     int span = 1;
@@ -187,7 +193,9 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
         const unsigned long long m = __ballot(f);
         if (f) {
             const uint64_t o = base + (uint64_t)(emitted + __popcll(m & ((1ull << lane) - 1ull)));
-            out_codes[o] = clo[best]; if (KW == 2) out_hi[o] = chi[best]; out_pos[o] = (uint32_t)best;
+            if (LEAN) { uint64_t l, h; kmer_code(best, l, h); out_codes[o] = l; if (KW == 2) out_hi[o] = h; }
+            else { out_codes[o] = clo[best]; if (KW == 2) out_hi[o] = chi[best]; }
+            out_pos[o] = (uint32_t)best;
         }
         emitted += __popcll(m);
         const int nv = min(64, nwin - s0); carry = __shfl(best, nv - 1);
@@ -271,8 +279,10 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     if (R.n == 0) return NGSID_OK;
     const int W = w - k + 1;
     const int KW = k <= 21 ? 1 : 2;
-    const size_t lpw = (mz_lds_per_wave(R.maxlen, W, KW) + 15) & ~(size_t)15;
+    size_t lpw = (mz_lds_per_wave(R.maxlen, W, KW) + 15) & ~(size_t)15;
     const int wpb = 1;                   // one wave per workgroup: the LDS slice of a read (8.3 KB at 750 bases) is what bounds the waves per CU (measured: 9.5 ms per 10^6 reads, 10.2 ms with four waves per workgroup)
+    const bool lean = lpw * wpb > 160 * 1024 || ngsid_opt(ctx, "minimizers_lean", 0) != 0;      // long reads: codes rebuilt on the fly (the full layout needs 180 KB at 16 384 bases)
+    if (lean) lpw = (mz_lds_per_wave(R.maxlen, W, KW, true) + 15) & ~(size_t)15;
     const size_t lds = lpw * wpb;
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "minimizer kernel needs %zu bytes of LDS", lds);
     const unsigned blocks = (unsigned)((R.n + wpb - 1) / wpb);
@@ -280,13 +290,13 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     if (KW == 2) HIPCHK(ctx, d_hi.alloc(R.total + 1));
     {
         ProfScope ps_(ctx, "k_hpc_minimizers");
-        if (KW == 1) {
-            if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_hpc_minimizers<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_hpc_minimizers<1>, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, R.maxlen, (uint32_t)lpw, d_codes, (uint64_t*)nullptr, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag);
-        } else {
-            if (lds > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_hpc_minimizers<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_hpc_minimizers<2>, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, R.maxlen, (uint32_t)lpw, d_codes, d_hi.p, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag);
-        }
+        auto go = [&](auto kern, uint64_t* hi_p) -> hipError_t {
+            if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, R.maxlen, (uint32_t)lpw, d_codes, hi_p, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag);
+            return hipSuccess;
+        };
+        if (KW == 1) HIPCHK(ctx, lean ? go(k_hpc_minimizers<1, true>, nullptr) : go(k_hpc_minimizers<1, false>, nullptr));
+        else HIPCHK(ctx, lean ? go(k_hpc_minimizers<2, true>, d_hi.p) : go(k_hpc_minimizers<2, false>, d_hi.p));
     }
     HIPCHK(ctx, hipGetLastError());
     if (KW == 2) return mz_rename_wide(ctx, R, d_codes, d_hi.p, d_cnt);

@@ -274,19 +274,34 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
         full = [c[2] for c in centers]
         barcode_trimmer.remove_barcodes(centers, barcodes, args)
         logging.debug("{0} centers formed".format(len(centers)))
-        merged = _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, polish_backbones={c[1]: f for c, f in zip(centers, full)})
-        if barcode_trimmer.remove_barcodes(merged, barcodes, args):
-            for nr, c_id, seq, cs in merged:                                                          # the trimmed result is what the run reports
+        used = {}
+        merged = _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, polish_backbones={c[1]: f for c, f in zip(centers, full)}, used_out=used)
+        full_pol = {m[1]: m[2] for m in merged}                                                       # polished, untrimmed
+        if barcode_trimmer.remove_barcodes(merged, barcodes, args):                                   # NGSpeciesID:147-152
+            # the reference now runs detect_reverse_complements + polish_sequences again on the trimmed sequences.  Here: the merge decisions are
+            # taken again on the TRIMMED polished sequences; only if they change the set of centres are the merged groups polished again (from the
+            # surviving centre's untrimmed polished sequence, then trimmed) - a group whose centre list did not change would be polished from the
+            # sequence the polisher just returned, i.e. from its own fixed point.
+            again = pipeline.detect_reverse_complements(api, [list(m) for m in merged], args.rc_identity_threshold)
+            if len(again) != len(merged):
+                logging.debug("%d centres merge after trimming: polishing the merged groups again" % (len(merged) - len(again)))
+                used = {}
+                merged = _merge_and_polish(args, sr, work, [list(m) for m in merged], groups, node_cap, api, acc_id, T, polish_backbones=full_pol, used_out=used)
+                barcode_trimmer.remove_barcodes(merged, barcodes, args)
+            for nr, c_id, seq, cs in merged:          # the trimmed result is what the run reports, in the last iteration's file and in consensus.fasta alike (same header tags)
                 folder = os.path.join(args.outfolder, "racon_cl_id_{0}".format(c_id))
                 if os.path.isdir(folder):
-                    with open(os.path.join(folder, "consensus.fasta"), "w") as f:
-                        f.write(">{0} LN:i:{1}\n{2}\n".format("consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr), len(seq), seq))
+                    name = "consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr)
+                    last = os.path.join(folder, "racon_polished_it_{0}.fasta".format(max(args.racon_iter - 1, 0)))
+                    with open(last, "w") as f:
+                        f.write(">{0} LN:i:{1} RC:i:{2} XC:f:1.000000\n{3}\n".format(name, len(seq), int(used.get(c_id, nr)), seq))
+                    shutil.copyfile(last, os.path.join(folder, "consensus.fasta"))
         return merged
     logging.debug("{0} centers formed".format(len(centers)))
     return _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T)
 
 
-def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, polish_backbones=None):
+def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, polish_backbones=None, used_out=None):
     """detect_reverse_complements + polish_sequences (consensus.py:148-183,186-246): centers = [n_reads, c_id, sequence, cluster indices]"""
     t0 = time()
     for folder in glob.glob(os.path.join(args.outfolder, "racon_cl_id_*")):
@@ -337,6 +352,7 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
                 f.write(">{0} LN:i:{1} RC:i:{2} XC:f:1.000000\n{3}\n".format(name, len(polished[x]), int(used[x]), polished[x]))
             shutil.copyfile(last, os.path.join(folder, "consensus.fasta"))
             merged[x][2] = polished[x]
+            if used_out is not None: used_out[c_id] = int(used[x])
         T["polish"] = T.get("polish", 0.0) + time() - t0
     return merged
 

@@ -93,8 +93,12 @@ def test_universal_tail_trimming_both_layers(oracle_backend, tmp_path):
         assert len(ref) == 1 and ref[0].decode().split("\n")[1] == tails["1_F_fw"][-1] + body.tobytes().decode()      # the (trimmed) draft is exact already
         cons = [v for k, v in b.items() if k.startswith("racon_cl_id_") and k.endswith("consensus.fasta")]
         assert len(cons) == 1
-        seq = cons[0].decode().split("\n")[1]
+        hdr, seq = cons[0].decode().split("\n")[:2]
         assert seq == tails["1_F_fw"][-1] + body.tobytes().decode()
+        # the trimmed sequence is what every file of the last iteration reports, with consistent header tags
+        assert " LN:i:%d RC:i:" % len(seq) in hdr and hdr.endswith("XC:f:1.000000")
+        last = [v for k, v in b.items() if k.startswith("racon_cl_id_") and k.endswith("racon_polished_it_1.fasta")]
+        assert last == cons
 
 
 def test_background_writers_and_synchronous_writes_give_the_same_files(oracle_backend, monkeypatch):

@@ -80,3 +80,44 @@ def test_repr_doubles_is_cpythons_repr():
 def test_count_foreign_bases():
     a = np.frombuffer(b"ACGTNacgtRYACGT", dtype=np.uint8).copy()
     assert fastio.count_foreign_bases(a) == 6
+
+
+def test_malformed_short_records_are_rejected_with_many_threads(tmp_path, monkeypatch):
+    """with records shorter than 64 bytes the record pass used more threads than the line pass; its per-thread error array was
+    overrun and a malformed record ('-' for '+') went unnoticed.  1 M 11-byte records, 32 host threads, one bad record near the end."""
+    monkeypatch.setenv("NGSID_HOST_THREADS", "32")
+    n = 1000000
+    rec = b"@r\nAC\n+\nII\n"
+    buf = bytearray(rec * n)
+    bad_at = (n - 7) * len(rec) + 6
+    assert buf[bad_at:bad_at + 1] == b"+"
+    buf[bad_at:bad_at + 1] = b"-"
+    p = tmp_path / "bad.fastq"; p.write_bytes(bytes(buf))
+    import ctypes as C
+    from ngspeciesid_amd import runtime
+    lib = runtime.load_library()
+    a = np.frombuffer(bytes(buf), dtype=np.uint8)
+    cnt = C.c_uint64(0)
+    assert lib.ngsid_host_fastq_index(fastio._p(a), C.c_uint64(len(a)), None, None, None, C.c_uint64(0), C.byref(cnt)) == 0 and cnt.value == n
+    recs = np.zeros(4 * n, dtype=np.uint64); nl = np.zeros(n, dtype=np.uint32); sl = np.zeros(n, dtype=np.uint32)
+    assert lib.ngsid_host_fastq_index(fastio._p(a), C.c_uint64(len(a)), fastio._p(recs), fastio._p(nl), fastio._p(sl), C.c_uint64(n), C.byref(cnt)) == 1
+    assert int((sl == 2).sum()) == n - 1          # every other record was still indexed
+    good = rec * 50000
+    a2 = np.frombuffer(good, dtype=np.uint8)
+    assert lib.ngsid_host_fastq_index(fastio._p(a2), C.c_uint64(len(a2)), fastio._p(recs), fastio._p(nl), fastio._p(sl), C.c_uint64(n), C.byref(cnt)) == 0 and cnt.value == 50000
+
+
+def test_crlf_fastq_reads_like_text_mode(tmp_path):
+    """a CRLF FASTQ kept a trailing '\\r' on every name, sequence and quality line in the array path; the reference (and this package's
+    general reader) open the file in text mode, which drops it."""
+    txt = "@r1 some description\r\nACGTACGT\r\n+\r\nIIIIHHHH\r\n@r2\r\nGGTT\r\n+r2\r\n##!!\r\n@r3\r\nA\r\n+\r\nI"      # last line without a terminator
+    p = tmp_path / "crlf.fastq"; p.write_bytes(txt.encode())
+    names, rs, plain = fastio.read_fastq(str(p))
+    ref = _general(str(p))
+    assert plain and rs.n == 3 == len(ref)
+    for i, (a, s, q) in enumerate(ref):
+        assert names.get(i) == a and rs.get(i) == (s, q), (i, names.get(i), rs.get(i))
+    assert rs.get(0) == ("ACGTACGT", "IIIIHHHH") and names.get(0) == "r1 some description" and rs.get(2) == ("A", "I")
+    p2 = tmp_path / "crlf_end.fastq"; p2.write_bytes((txt + "\r\n").encode())
+    names, rs, plain = fastio.read_fastq(str(p2))
+    assert plain and rs.get(2) == ("A", "I")

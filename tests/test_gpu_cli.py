@@ -111,3 +111,42 @@ def test_tree_merge(gpu_api, tag, t):
 def test_c_merge_representatives(gpu_api, tag, t):
     from test_host_parallelize import run_round1_then_c_merge
     run_round1_then_c_merge(gpu_api, tag, t)
+
+
+def test_cli_primer_and_tail_trimming_hip_equals_oracle_backend(gpu_api, oracle, tmp_path):
+    """(f4) --remove_universal_tails and --primer_file (primers with IUPAC codes) through libngsid_hip.so on the GPU box: every
+    output file equals the run with the oracle as the backend byte for byte, both strands present (rc merge inside the trimming flow), and the
+    reported consensus is the amplicon body cut where the reference cuts (barcode_trimmer.py:84-98)."""
+    import argparse
+    from ngspeciesid_amd import synth, fastio, barcode_trimmer, cli as _cli, fastpath
+    from ngspeciesid_amd._capi import ReadSet
+    tails = barcode_trimmer.get_universal_tails()
+    bodies = synth.make_species(2, 520, 0.15, seed=8)
+    amps = [np.frombuffer((tails["1_F_fw"] + b.tobytes().decode() + tails["2_R_fw"]).encode(), dtype=np.uint8) for b in bodies]
+    rd = synth.make_reads(amps, 1600, mu=16.0, seed=3, rc_fraction=0.5)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    fq = str(tmp_path / "in.fastq"); fastio.write_fastq(fq, np.arange(rs.n), fastio.Names.from_list(["r%d" % i for i in range(rs.n)]), rs)
+    # primer file with IUPAC codes: R = A/G, Y = C/T, N = any (edlib additionalEqualities, barcode_trimmer.py:9-12)
+    f, r = tails["1_F_fw"], tails["2_R_rc"]
+    iu = lambda s: "".join({"A": "R", "C": "Y"}.get(c, c) if i % 5 == 2 else ("N" if i == 7 else c) for i, c in enumerate(s))
+    pf = tmp_path / "primers.fa"; pf.write_text(">F\n%s\n>R\n%s\n" % (iu(f), iu(r)))
+    for extra in (["--remove_universal_tails"], ["--primer_file", str(pf)]):
+        res = {}
+        for name, api in (("hip", gpu_api), ("oracle", oracle)):
+            out = str(tmp_path / ("out_" + name + str(len(extra))))
+            args = _cli.build_parser().parse_args(["--ont", "--fastq", fq, "--outfolder", out, "--t", "1", "--consensus", "--racon", "--racon_iter", "2", "--abundance_ratio", "0.05"] + extra)
+            args.k, args.w = 13, 20
+            os.makedirs(out, exist_ok=True)
+            fastpath.main(args, api=api)
+            res[name] = _files(out)
+        assert sorted(res["hip"]) == sorted(res["oracle"])
+        for k in res["hip"]:
+            assert res["hip"][k] == res["oracle"][k], k
+        cons = sorted(v.decode().split("\n")[1] for k, v in res["hip"].items() if k.startswith("racon_cl_id_") and k.endswith("consensus.fasta"))
+        # fw-oriented centre: the start cut keeps the last base of 1_F_fw; rc-oriented centre (the rc merge keeps the larger cluster's strand): 2_R_rc leads
+        want = set(f[-1] + b.tobytes().decode() for b in bodies) | set(r[-1] + _rc(b.tobytes().decode()) for b in bodies)
+        assert len(cons) == 2 and all(c in want for c in cons), [len(c) for c in cons]
+
+
+def _rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))

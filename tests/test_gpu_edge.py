@@ -104,7 +104,7 @@ def test_device_resident_read_set_and_second_context(gpu_api, oracle):
     th = [threading.Thread(target=work, args=(0, gpu_api)), threading.Thread(target=work, args=(1, api2))]
     [t.start() for t in th]; [t.join() for t in th]
     assert all(x == ref for x in out[0]) and all(x == ref for x in out[1])
-    api2.lib.ngsid_destroy(api2.ctx)
+    api2.close(); api2.close()                         # Api.close() = ngsid_destroy, idempotent
     dev.release(); dev.release()                       # idempotent
     with pytest.raises(NgsidError):
         gpu_api._err(gpu_api._call("reads_release", __import__("ctypes").byref(rs.c)))          # a host read set is refused

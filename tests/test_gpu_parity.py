@@ -44,6 +44,44 @@ def test_minimizers_k_above_21(gpu_api, oracle, kw):
     assert np.array_equal(got[1], g["rank_%d_%d" % (k, w)]) and np.array_equal(got[2], g["pos_%d_%d" % (k, w)])        # the reference's own k-mers
 
 
+@pytest.mark.parametrize("kw", [(13, 20), (25, 30)])
+def test_minimizers_at_the_maximum_read_length(gpu_api, oracle, kw):
+    """the one-wave-per-read layout needs 11 (k <= 21) / 19 (k > 21) LDS bytes per base - more than a CU has at NGSID_MAX_READ_LEN = 16 384.
+    Long reads run the LEAN layout (codes rebuilt from the HPC letters on the fly); same output as the oracle at 16 384, 15 000 and 9 000 bases,
+    next to short reads in the same call."""
+    k, w = kw
+    rng = np.random.default_rng(k)
+    seqs, quals = [], []
+    for L in (16384, 15000, 9000, 700, 16384):
+        a = rng.integers(0, 4, L); rep = rng.random(L) < 0.15; a[1:][rep[1:]] = a[:-1][rep[1:]]          # some homopolymer runs
+        seqs.append("".join("ACGT"[x] for x in a)); quals.append("".join(chr(33 + int(x)) for x in rng.integers(2, 45, L)))
+    rs = ReadSet.from_strings(seqs, quals)
+    got = gpu_api.hpc_minimizers(rs, k, w); exp = oracle.hpc_minimizers(rs, k, w)
+    for nm, a, b in zip(["moff", "codes", "pos", "hpc_len"], got[:4], exp[:4]):
+        assert np.array_equal(a, b), nm
+    assert np.array_equal(got[4], exp[4], equal_nan=True)
+
+
+@pytest.mark.parametrize("kw", [(13, 20), (15, 50), (30, 35)])
+def test_minimizers_lean_layout_equals_the_goldens(kw):
+    """the lean layout forced on ordinary reads (ngsid_ctx_option minimizers_lean=1, a context of its own): the reference's own codes / ranks"""
+    import ctypes as C
+    from ngspeciesid_amd import runtime
+    k, w = kw
+    api = runtime.new_api(options={"minimizers_lean": 1})
+    try:
+        if k <= 21:
+            g = _load("minimizers_sample_h1.npz"); rs = ReadSet(g["seq"], g["qual"], g["off"])
+            got = api.hpc_minimizers(rs, k, w)
+            assert np.array_equal(got[1], g["codes_%d_%d" % (k, w)])
+        else:
+            g = _load("minimizers_widek.npz"); rs = ReadSet(g["seq"], g["qual"], g["off"])
+            got = api.hpc_minimizers(rs, k, w)
+            assert np.array_equal(got[1], g["rank_%d_%d" % (k, w)]) and np.array_equal(got[2], g["pos_%d_%d" % (k, w)])
+    finally:
+        api.close()
+
+
 def _rand_pairs(rng, n, lmin, lmax, sim=True):
     qs, ts = [], []
     for _ in range(n):

@@ -51,3 +51,4 @@ for it in range(3):
         for j, i in enumerate(sets[k]):
             d2[i] = out[k][0][j]; p2[i] = out[k][1][j]
     print("two contexts (per_cu %d): %.3f s  [ctx0 draft %.3f polish %.3f | ctx1 draft %.3f polish %.3f]  same drafts %s same polished %s" % (per_cu, t2, out[0][2], out[0][3], out[1][2], out[1][3], d2 == d1, p2 == p1))
+api2.close()
