@@ -6,6 +6,7 @@ struct PSeq { const uint8_t* s; const uint8_t* q; int32_t len, uw; uint32_t cw; 
 
 struct PoaJobSet {
     const PSeq* seqs; const PSeq* bbs; const uint32_t* seq_idx; const uint32_t* job_off; const int32_t* job_bb; uint32_t njobs; const uint32_t* job_list; uint32_t nrun;   /* job_list != null: this launch runs tiles job_list[0..nrun) (band-edge redo); else all njobs */
+    const uint32_t* nrun_dev;                 /* != null: the number of tiles to run is read from device memory (device-driven hierarchy: no host round trip between levels) */
     int m, n, g, Vcap, Ecap, Lmax, D, node_cap, trim_tiles;       // D = output slots per job
     int32_t* Hglob; uint8_t* dirglob; uint32_t* covglob;           // per resident workgroup scratch (filled by poa_run_jobs)
     uint8_t* out; int32_t* out_len; int32_t* out_span /* (a0, a1) per slot, may be null */; uint64_t* out_cw; uint32_t* out_n; uint32_t* out_cov; uint32_t* dropped; uint32_t* slot_overflow; unsigned long long* phase_cycles;   // optional dev instrumentation (NGSID_POA_PHASES=1)
@@ -13,3 +14,7 @@ struct PoaJobSet {
 
 size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW);
 int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band);
+// device-driven hierarchy: scratch for all three band instances sized once (poa_prepare), then launches that neither allocate nor touch the host
+struct PoaPlan { int Vcap, Ecap, Lmax; uint32_t nwg_main, nwg_redo; int band0; };
+int32_t poa_prepare(ngsid_ctx* ctx, PoaPlan& P, uint32_t max_jobs);
+int32_t poa_launch(ngsid_ctx* ctx, const PoaPlan& P, PoaJobSet J, int band, bool redo, uint32_t* work_ctr);

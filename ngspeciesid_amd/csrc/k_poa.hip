@@ -1132,11 +1132,12 @@ __device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscra
     uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW * 3 / 2;      // packed direction blocks (4 bits per cell) ...
     uint8_t* Dfull = Dg + (size_t)Vc * BW / 2;                            // ... and the byte rows of the ranks with more than two in-edges (sparse)
 
+    const uint32_t nrun_ = J.nrun_dev ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(J.nrun_dev)) : J.nrun;      // (written by an earlier kernel of the stream)
     for (;;) {
         // persistent workgroups pull tiles from a queue (tiles differ a lot in cost: depth, graph growth, splits)
         uint32_t jq = 0; if (lane == 0) jq = atomicAdd(work_ctr, 1u);
         const uint32_t jqi = (uint32_t)__builtin_amdgcn_readfirstlane((int)jq);
-        if (jqi >= J.nrun) break;
+        if (jqi >= nrun_) break;
         const uint32_t job = J.job_list ? J.job_list[jqi] : jqi;          // a redo launch (wider band) runs a list of tiles
         int edge = 0;
         const uint32_t s0 = J.job_off[job], s1 = J.job_off[job + 1];
@@ -1213,6 +1214,55 @@ int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
     if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile1, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
     else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile2, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
     else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile4, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, ctx->poa_ctr.p); }
+    HIPCHK(ctx, hipGetLastError());
+    return NGSID_OK;
+}
+
+// ---- device-driven hierarchy (poa_host.hip): one scratch allocation for the main band and the two wider redo instances, launches without host work
+static int poa_per_cu(ngsid_ctx* ctx, int Vc, int Ec, int Lm, int BW)
+{
+    const size_t lds = poa_lds_bytes(Vc, Ec, Lm, BW);
+    const int wave_cap = BW == 64 ? 4 * POA_W1 : 16;
+    int per_cu = std::max<int>(1, std::min<int>(wave_cap, (int)((160 * 1024) / lds)));
+    if (ngsid_opt(ctx, "poa_tiles_per_cu", 0) > 0) per_cu = std::max(1, std::min(per_cu, (int)ngsid_opt(ctx, "poa_tiles_per_cu", 0)));
+    return per_cu;
+}
+int32_t poa_prepare(ngsid_ctx* ctx, PoaPlan& P, uint32_t max_jobs)
+{
+    const int B0 = P.band0 <= 64 ? 64 : (P.band0 <= 128 ? 128 : 256);
+    P.band0 = B0;
+    if (P.Vcap > 0xFFF0 || P.Ecap > 0xFFF0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA graph capacity exceeds 16-bit indices (sequence too long for the tile engine)");
+    size_t need_h = 0, need_d = 0, need_g = 0;
+    const size_t gbytes = poa_graph_bytes(P.Vcap, P.Ecap, P.Lmax);
+    for (int BW = B0; BW <= 256; BW *= 2) {
+        const size_t lds = poa_lds_bytes(P.Vcap, P.Ecap, P.Lmax, BW);
+        if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);
+        uint32_t nwg;
+        if (BW == B0) { nwg = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(max_jobs, 1u), (uint64_t)ctx->n_cu * poa_per_cu(ctx, P.Vcap, P.Ecap, P.Lmax, BW)); P.nwg_main = nwg; }
+        else { nwg = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(max_jobs, 1u), (uint64_t)ctx->n_cu * std::min(2, poa_per_cu(ctx, P.Vcap, P.Ecap, P.Lmax, BW))); P.nwg_redo = nwg; }       // redone tiles are rare: a small grid keeps the scratch small
+        const size_t cells = (size_t)P.Vcap * BW;
+        need_h = std::max(need_h, nwg * cells); need_d = std::max(need_d, nwg * cells * 3 / 2); need_g = std::max(need_g, nwg * gbytes);
+    }
+    if (B0 == 256) P.nwg_redo = 0;
+    if (ctx->poa_h.n < need_h) HIPCHK(ctx, ctx->poa_h.alloc(need_h));
+    if (ctx->poa_d.n < need_d) HIPCHK(ctx, ctx->poa_d.alloc(need_d));
+    if (ctx->poa_g.n < need_g) HIPCHK(ctx, ctx->poa_g.alloc(need_g));
+    return NGSID_OK;
+}
+int32_t poa_launch(ngsid_ctx* ctx, const PoaPlan& P, PoaJobSet J, int BW, bool redo, uint32_t* work_ctr)
+{
+    if (J.g >= 0) NGSID_FAIL(ctx, NGSID_ERR_ARG, "POA gap score must be negative");
+    if ((long long)J.m * J.Lmax >= 65536 || J.m < 0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA local score range exceeds 16 bits (match %d x length %d)", J.m, J.Lmax);
+    const size_t lds = poa_lds_bytes(J.Vcap, J.Ecap, J.Lmax, BW);
+    if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);      // (the caller checks all three instances before it starts)
+    const uint32_t nwg = redo ? P.nwg_redo : P.nwg_main;
+    if (nwg == 0) return NGSID_OK;
+    const size_t gbytes = poa_graph_bytes(J.Vcap, J.Ecap, J.Lmax);
+    J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = nullptr;
+    ProfScope ps_(ctx, redo ? "k_poa_tile_redo" : "k_poa_tile");
+    if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile1, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, work_ctr); }
+    else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile2, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, work_ctr); }
+    else { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile4, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, work_ctr); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }

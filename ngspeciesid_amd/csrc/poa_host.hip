@@ -36,8 +36,8 @@ struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; i
 
 // Runs all units to completion.  level0: device PSeq array (nseq0 entries) whose max length is maxlen0;
 // bbs: device backbone PSeqs (may be null), maxbb = longest backbone.
-int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
-                      std::vector<Unit>& units, const HierParams& hp)
+int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
+                           std::vector<Unit>& units, const HierParams& hp)
 {
     const PSeq* cur = d_level0; uint32_t cur_maxlen = maxlen0;
     int slots_cap = 0;
@@ -168,6 +168,346 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
     }
     ht.mark("levels >= 1");
     return NGSID_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Device-driven hierarchy (round 3).  The host-driven loop above synchronises after every level (flags, output counts, lengths, weights and
+// spans come back, the host builds the next level's sequence / tile lists and uploads them): 4 - 5 ms of idle GPU per polishing iteration at
+// 1 M reads, and the top levels are a string of millisecond launches with a round trip in between.  Here the level bookkeeping runs in small
+// kernels on the same stream - band-edge redo lists, per-unit output scan, next-level sequence descriptors, next-level tile lists, results
+// of finished units copied to an arena - and the tile kernels read their tile count from device memory.  The host enqueues all levels of a
+// hierarchy at once and synchronises ONCE.  Same results as the host-driven loop (tests run both: ngsid_ctx_option "poa_host_levels").
+// Anything the fixed launch geometry cannot hold (a tile with more outputs than `slots`, a tile consensus much longer than the longest input,
+// more upper-level tiles than planned) sets a flag and the call is repeated by the host-driven loop.
+enum { C_NJOBS = 0 /* 2 words: level parity */, C_NSEQ = 2, C_OVERFLOW = 3, C_RES_USED = 4, C_REDO_TOTAL = 5, C_FLAGS = 8 /* dropped, slot_overflow (2 words) */, C_REDO = 16 /* + 2 * level + stage */, C_MAXLV = 48, C_WORK = C_REDO + 2 * C_MAXLV /* + 3 * level + instance */, C_WORDS = C_WORK + 3 * C_MAXLV };
+
+struct HierDev {
+    uint32_t U; int D, slots, capV, upper_mode, want_cov, Lmax; uint32_t cap_jobs[2];
+    const int32_t* unit_bb; const int32_t* unit_wlen;
+    uint32_t* unit_ncur; uint32_t* unit_job0[2]; uint32_t* unit_njobs[2]; uint32_t* unit_seq0; int32_t* unit_pick; uint32_t* unit_tmp /* njobs_next, nseq_next, res_len of this level: 3 U */;
+    uint32_t* res_off; int32_t* res_len; uint8_t* res; uint32_t* res_cov;
+    uint32_t* ctrl;
+};
+struct LevelDev { PSeq* seqs; uint8_t* out; int32_t* out_len; int32_t* out_span; uint64_t* out_cw; uint32_t* out_n; uint32_t* out_cov; uint32_t* job_off; int32_t* job_bb; uint32_t* job_unit; uint32_t* job_pos; uint32_t* job_list; };
+
+// tiles whose traceback touched a clipped band edge (bit 31 of out_n) -> list for the launch with twice the band
+__global__ __launch_bounds__(256) void k_poa_redo_list(const uint32_t* __restrict__ out_n, const uint32_t* __restrict__ njobs, uint32_t* __restrict__ list, uint32_t* __restrict__ cnt, uint32_t* __restrict__ total)
+{
+    const uint32_t n = *njobs; const int lane = threadIdx.x & 63;
+    for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x) {
+        const uint32_t j = j0 + threadIdx.x;
+        const bool f = j < n && (out_n[j] & 0x80000000u);
+        const unsigned long long m = __ballot(f);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0; if (lane == leader) { base = atomicAdd(cnt, (uint32_t)__popcll(m)); atomicAdd(total, (uint32_t)__popcll(m)); }
+        base = __shfl(base, leader);
+        if (f) list[base + __popcll(m & ((1ull << lane) - 1))] = j;
+    }
+}
+
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* sm /* 8 words */, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+    __syncthreads();
+    if (lane == 63) sm[w] = x;
+    __syncthreads();
+    uint32_t off = 0; for (int k = 0; k < w; ++k) off += sm[k];
+    total = sm[0] + sm[1] + sm[2] + sm[3];
+    return off + x - v;
+}
+
+// one workgroup per unit: output count of the level, position of every tile's outputs among them, fate of the unit
+//   pick: -3 = was finished before, -2 = goes on, -1 = finishes without a result, >= 0 = finishes with the output in that slot
+__global__ __launch_bounds__(256) void k_poa_unit_scan(HierDev H, LevelDev Lv, int par)
+{
+    __shared__ uint32_t sm[8]; __shared__ unsigned long long best_s[4]; __shared__ uint32_t one_slot;
+    const uint32_t u = blockIdx.x; if (u >= H.U || H.ctrl[C_OVERFLOW]) return;
+    const uint32_t j0 = H.unit_job0[par][u], nj = H.unit_njobs[par][u];
+    uint32_t* tmp = H.unit_tmp + 3ull * u;
+    if (nj == 0) {        // finished at an earlier level, or empty from the start
+        if (threadIdx.x == 0) { if (H.unit_pick[u] == -2) H.unit_pick[u] = -1; else if (H.unit_pick[u] >= 0 || H.unit_pick[u] == -1) H.unit_pick[u] = -3; tmp[0] = 0; tmp[1] = 0; tmp[2] = 0; }
+        return;
+    }
+    if (threadIdx.x == 0) one_slot = 0xffffffffu;
+    __syncthreads();
+    uint32_t running = 0;
+    for (uint32_t b = 0; b < nj; b += 256) {
+        const uint32_t x = b + threadIdx.x; const uint32_t j = j0 + x;
+        const uint32_t c = x < nj ? (Lv.out_n[j] & 0x7fffffffu) : 0u;
+        uint32_t tot; const uint32_t ex = block_excl_scan_256(c, sm, tot);
+        if (x < nj) Lv.job_pos[j] = running + ex;
+        if (c) one_slot = j * (uint32_t)H.slots;                  // only read when the unit has exactly one output
+        running += tot;
+        __syncthreads();
+    }
+    const uint32_t T = running, ncur = H.unit_ncur[u];
+    int pick = -2;
+    if (T == 0) pick = -1;
+    else if (T == 1) { __syncthreads(); pick = (int)one_slot; }
+    else if (T >= ncur) {        // no reduction: the output that stands for most reads wins, the first of them on ties (host loop: strictly greater replaces)
+        unsigned long long best = 0ull;      // (cw + 1 capped to 40 bits) << 24 | (0xFFFFFF - order): larger weight first, then the earlier output
+        uint32_t bslot = 0;
+        for (uint32_t x = threadIdx.x; x < nj; x += 256) {
+            const uint32_t j = j0 + x; const uint32_t c = Lv.out_n[j] & 0x7fffffffu; const uint32_t pos = Lv.job_pos[j];
+            for (uint32_t sidx = 0; sidx < c; ++sidx) {
+                unsigned long long cw = Lv.out_cw[(size_t)j * H.slots + sidx]; if (cw > 0xFFFFFFFFFEull) cw = 0xFFFFFFFFFEull;
+                const unsigned long long key = ((cw + 1) << 24) | (unsigned long long)(0xFFFFFFu - ((pos + sidx) & 0xFFFFFFu));
+                if (key > best) { best = key; bslot = j * (uint32_t)H.slots + sidx; }
+            }
+        }
+        // block arg-max (keys are unique: the order is part of the key)
+        unsigned long long kb = best; uint32_t sb = bslot;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const unsigned long long ok = __shfl_xor(kb, d); const uint32_t os = __shfl_xor(sb, d); if (ok > kb) { kb = ok; sb = os; } }
+        if ((threadIdx.x & 63) == 0) { best_s[threadIdx.x >> 6] = kb; sm[4 + (threadIdx.x >> 6)] = sb; }
+        __syncthreads();
+        unsigned long long kk = 0ull; uint32_t ss = 0; for (int k = 0; k < 4; ++k) if (best_s[k] > kk) { kk = best_s[k]; ss = sm[4 + k]; }
+        pick = (int)ss;
+    }
+    if (threadIdx.x == 0) {
+        H.unit_pick[u] = pick;
+        if (pick == -2) { H.unit_ncur[u] = T; tmp[0] = H.D > 0 ? (T + (uint32_t)H.D - 1) / (uint32_t)H.D : 1u; tmp[1] = T; tmp[2] = 0; }
+        else { tmp[0] = 0; tmp[1] = 0; tmp[2] = pick >= 0 ? (uint32_t)Lv.out_len[pick] : 0u; }
+    }
+}
+
+// one workgroup: prefix sums over the units -> first tile / first sequence of every unit at the next level, arena offsets of the results
+__global__ __launch_bounds__(1024) void k_poa_unit_offsets(HierDev H, int par)
+{
+    __shared__ uint32_t wsum[3][16]; __shared__ uint32_t carry[3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (H.ctrl[C_OVERFLOW]) { if (threadIdx.x == 0) H.ctrl[C_NJOBS + (par ^ 1)] = 0; return; }
+    if (threadIdx.x < 3) carry[threadIdx.x] = threadIdx.x == 2 ? H.ctrl[C_RES_USED] : 0u;
+    __syncthreads();
+    for (uint32_t b = 0; b < H.U; b += 1024) {
+        const uint32_t u = b + threadIdx.x; uint32_t v[3] = {0, 0, 0};
+        if (u < H.U) { v[0] = H.unit_tmp[3ull * u]; v[1] = H.unit_tmp[3ull * u + 1]; v[2] = H.unit_tmp[3ull * u + 2]; }
+        uint32_t x[3] = {v[0], v[1], v[2]};
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) for (int k = 0; k < 3; ++k) { const uint32_t y = __shfl_up(x[k], d); if (lane >= d) x[k] += y; }
+        if (lane == 63) for (int k = 0; k < 3; ++k) wsum[k][w] = x[k];
+        __syncthreads();
+        uint32_t off[3], tot[3];
+        for (int k = 0; k < 3; ++k) { off[k] = carry[k]; for (int q = 0; q < w; ++q) off[k] += wsum[k][q]; tot[k] = 0; for (int q = 0; q < 16; ++q) tot[k] += wsum[k][q]; }
+        if (u < H.U) {
+            H.unit_job0[par ^ 1][u] = off[0] + x[0] - v[0]; H.unit_njobs[par ^ 1][u] = v[0];
+            H.unit_seq0[u] = off[1] + x[1] - v[1];
+            if (H.unit_pick[u] >= 0) H.res_off[u] = off[2] + x[2] - v[2];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) carry[threadIdx.x] += tot[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t nj = carry[0], ns = carry[1];
+        H.unit_job0[par ^ 1][H.U] = nj;
+        H.ctrl[C_RES_USED] = carry[2];
+        bool ovf = nj > H.cap_jobs[par ^ 1] || ns > H.cap_jobs[par] * (uint32_t)H.slots || H.ctrl[C_OVERFLOW] != 0 || H.ctrl[C_FLAGS + 1] != 0 || H.ctrl[C_FLAGS + 2] != 0;
+        if (ovf) H.ctrl[C_OVERFLOW] = 1;
+        H.ctrl[C_NJOBS + (par ^ 1)] = ovf ? 0u : nj; H.ctrl[C_NSEQ] = ns;
+    }
+}
+
+// one wave per tile of the level: its outputs become sequences of the next level (units that go on) or the unit's result (copied to the arena)
+__global__ __launch_bounds__(256) void k_poa_fill_next(HierDev H, LevelDev Lv, int par)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t njobs = H.ctrl[C_NJOBS + par];
+    if (H.ctrl[C_OVERFLOW]) return;
+    for (uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); j < njobs; j += gridDim.x * (blockDim.x >> 6)) {
+    const uint32_t u = Lv.job_unit[j]; const int pick = H.unit_pick[u];
+    const uint32_t n = Lv.out_n[j] & 0x7fffffffu;
+    if (pick == -2) {
+        if ((uint32_t)lane < n) {
+            const size_t sl = (size_t)j * H.slots + lane; const uint64_t cw = Lv.out_cw[sl];
+            PSeq S; S.s = Lv.out + sl * (size_t)H.capV; S.q = nullptr; S.len = Lv.out_len[sl];
+            S.uw = cw > (1u << 20) ? (1 << 20) : (int)cw; if (S.uw < 1) S.uw = 1;
+            S.cw = (uint32_t)(cw > 0xffffffffull ? 0xffffffffull : cw); S.mode = H.upper_mode; S.a0 = 0; S.a1 = -1;
+            if (H.unit_bb[u] >= 0) {     // a tile consensus is a layer of the window like the reads it stands for: global only if it spans the window (oracle run_hierarchy)
+                const int wlen = H.unit_wlen[u], offset = (int)(0.01 * (double)wlen), begin = Lv.out_span[2 * sl], end = Lv.out_span[2 * sl + 1];
+                if (end >= begin) { S.a0 = begin; S.a1 = end; S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI; }
+            }
+            if (S.len > H.Lmax) atomicExch(&H.ctrl[C_OVERFLOW], 1u);       // longer than the launch geometry was planned for: the host-driven loop takes over
+            Lv.seqs[H.unit_seq0[u] + Lv.job_pos[j] + (uint32_t)lane] = S;
+        }
+    } else if (pick >= 0 && (uint32_t)pick / (uint32_t)H.slots == j) {
+        const int len = Lv.out_len[pick]; const uint8_t* src = Lv.out + (size_t)pick * H.capV; uint8_t* dst = H.res + H.res_off[u];
+        for (int x = lane; x < len; x += 64) dst[x] = src[x];
+        if (H.want_cov) { const uint32_t* cs = Lv.out_cov + (size_t)pick * H.capV; uint32_t* cd = H.res_cov + H.res_off[u]; for (int x = lane; x < len; x += 64) cd[x] = cs[x]; }
+        if (lane == 0) H.res_len[u] = len;
+    }
+    }
+}
+
+// tile lists of the next level: tile t of a unit takes its sequences [t D, (t + 1) D)
+__global__ __launch_bounds__(256) void k_poa_fill_jobs(HierDev H, LevelDev Nx, int par /* of the level just done */)
+{
+    const uint32_t nj = H.ctrl[C_NJOBS + (par ^ 1)];
+    if (H.ctrl[C_OVERFLOW]) return;
+    const uint32_t* j0 = H.unit_job0[par ^ 1];
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nj; t += gridDim.x * blockDim.x) {
+    uint32_t lo = 0, hi = H.U;                 // last unit whose first tile is <= t (units without tiles share the first tile of their successor and come before it)
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (j0[mid] <= t) lo = mid; else hi = mid; }
+    const uint32_t u = lo, tl = t - j0[u];
+    const uint32_t T = H.unit_ncur[u]; const uint32_t Dl = H.D > 0 ? (uint32_t)H.D : T;
+    Nx.job_off[t] = H.unit_seq0[u] + tl * Dl; Nx.job_bb[t] = H.unit_bb[u]; Nx.job_unit[t] = u;
+    if (t == nj - 1) Nx.job_off[nj] = H.ctrl[C_NSEQ];
+    }
+}
+
+
+// returns NGSID_OK with *done = true when the device-driven hierarchy ran to completion; *done = false: nothing was changed, use the host-driven loop
+int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
+                          std::vector<Unit>& units, const HierParams& hp, bool* done)
+{
+    *done = false;
+    static const bool want_ph = getenv("NGSID_POA_PHASES") != nullptr;       // the phase counters are read per level by the host-driven loop
+    if (want_ph || ngsid_opt(ctx, "poa_host_levels", 0) || units.empty()) return NGSID_OK;
+    const uint32_t U = (uint32_t)units.size();
+    HostTimer ht(ctx->stream, "hierarchy (device levels)");
+    // ---- level-0 tile lists (as in the host-driven loop) + per-unit records
+    static thread_local PinVec<uint32_t> job_off, seq_idx, job_unit, u_u32; static thread_local PinVec<int32_t> job_bb, u_i32;
+    job_off.clear(); job_off.push_back(0); seq_idx.clear(); job_unit.clear(); job_bb.clear();
+    { size_t tot = 0; for (const Unit& Un : units) if (!Un.done) tot += Un.seqs.size(); seq_idx.reserve(tot); }
+    u_u32.assign(3ull * U, 0); u_i32.assign(3ull * U, 0);        // ncur | job0 | njobs   and   bb | wlen | pick
+    uint32_t maxD = 0; int maxbb = 0; bool any_nobb = false; uint64_t maxn = 0;
+    for (uint32_t u = 0; u < U; ++u) {
+        const Unit& Un = units[u];
+        const uint32_t ncur = Un.done ? 0u : (uint32_t)Un.seqs.size();
+        u_u32[u] = ncur; u_u32[U + u] = (uint32_t)job_unit.size(); u_i32[u] = Un.bb; u_i32[U + u] = Un.bb >= 0 ? bb_len[Un.bb] : 0; u_i32[2ull * U + u] = -2;
+        if (ncur) {
+            const uint32_t Dl = hp.D > 0 ? (uint32_t)hp.D : ncur;
+            for (uint32_t a = 0; a < ncur; a += Dl) {
+                const uint32_t b = std::min(ncur, a + Dl);
+                for (uint32_t x = a; x < b; ++x) seq_idx.push_back(Un.seqs[x]);
+                job_off.push_back((uint32_t)seq_idx.size()); job_bb.push_back(Un.bb); job_unit.push_back(u);
+                maxD = std::max(maxD, b - a);
+            }
+            if (Un.bb >= 0) maxbb = std::max(maxbb, bb_len[Un.bb]); else any_nobb = true;
+            maxn = std::max<uint64_t>(maxn, ncur);
+        }
+        u_u32[2ull * U + u] = (uint32_t)job_unit.size() - u_u32[U + u];
+    }
+    const uint32_t njobs0 = (uint32_t)job_unit.size();
+    if (njobs0 == 0) return NGSID_OK;                       // (the host loop marks the empty units)
+    // ---- one launch geometry for all levels: members of the upper levels are tile consensus sequences, planned for up to 5/4 of the longest input
+    const int Lb = std::max<int>((int)maxlen0, maxbb), Lb2 = Lb + Lb / 4 + 16;
+    const int maxL0 = std::max(maxbb, any_nobb ? Lb2 : 1);
+    long long capV = (long long)maxL0 * (hp.node_cap > 0 ? hp.node_cap : 28) / 16; capV = std::max<long long>(capV, maxL0 + 64); capV = std::max<long long>(capV, (long long)Lb2 + 1);
+    capV = (capV + 7) & ~7ll;
+    const int Lmax = (int)(((uint32_t)std::max(Lb2, 1) + 15) & ~15u);
+    const int band0 = hp.band <= 64 ? 64 : (hp.band <= 128 ? 128 : 256);
+    if (capV > 0xFFF0 || 3 * capV / 2 > 0xFFF0 || (long long)hp.m * Lmax >= 65536 || hp.m < 0 || hp.g >= 0) return NGSID_OK;      // the host loop reports what is wrong (or fits where this margin does not)
+    for (int bw = band0; bw <= 256; bw *= 2) if (poa_lds_bytes((int)capV, (int)(3 * capV / 2), Lmax, bw) > 160 * 1024) return NGSID_OK;
+    const int slots = (int)std::min<uint32_t>(maxD, 4);
+    int levels_est = 1; { uint64_t n = maxn; const uint64_t Dd = hp.D > 0 ? (uint64_t)hp.D : maxn; while (n > 1 && levels_est < C_MAXLV - 4) { n = (n + Dd - 1) / std::max<uint64_t>(Dd, 2); ++levels_est; } }
+    levels_est = std::min(levels_est + 1, C_MAXLV - 2);
+    uint32_t cap[2]; cap[0] = njobs0;
+    { const uint64_t e1 = hp.D > 0 ? (njobs0 + (uint64_t)hp.D - 1) / (uint64_t)hp.D * (uint64_t)slots + U : U; cap[1] = (uint32_t)std::min<uint64_t>(njobs0, e1 + e1 / 4 + 1024); }
+    PoaPlan plan{(int)capV, (int)(3 * capV / 2), Lmax, 0, 0, band0};
+    { int32_t rc = poa_prepare(ctx, plan, njobs0); if (rc) return rc; }
+    // ---- buffers
+    const bool need_cov = hp.want_cov || hp.trim_tiles;
+    LevelDev L[2];
+    for (int q = 0; q < 2; ++q) {
+        ngsid_ctx::PoaLevelBufs* B = &ctx->poa_lv[q]; const size_t ns = (size_t)cap[q] * slots;
+        HIPCHK(ctx, B->out.reserve(ns * capV)); HIPCHK(ctx, B->out_len.reserve(ns)); HIPCHK(ctx, B->out_cw.reserve(ns)); HIPCHK(ctx, B->out_span.reserve(ns * 2)); HIPCHK(ctx, B->out_n.reserve(cap[q]));
+        if (need_cov) HIPCHK(ctx, B->out_cov.reserve(ns * capV));
+        HIPCHK(ctx, B->seqs.reserve(sizeof(PSeq) * ns)); HIPCHK(ctx, B->job_off.reserve((size_t)cap[q] + 1)); HIPCHK(ctx, B->job_bb.reserve(cap[q])); HIPCHK(ctx, B->job_list.reserve(cap[q]));
+        HIPCHK(ctx, B->job_unit.reserve(cap[q])); HIPCHK(ctx, B->job_pos.reserve(cap[q]));
+        L[q] = LevelDev{(PSeq*)B->seqs.p, B->out.p, B->out_len.p, B->out_span.p, B->out_cw.p, B->out_n.p, need_cov ? B->out_cov.p : nullptr, B->job_off.p, B->job_bb.p, B->job_unit.p, B->job_pos.p, B->job_list.p};
+    }
+    HIPCHK(ctx, ctx->poa_lv[0].seq_idx.reserve(seq_idx.size()));
+    DevBuf<uint32_t> d_u32, d_ctrl, d_res_off, d_res_cov; DevBuf<int32_t> d_i32, d_res_len; DevBuf<uint8_t> d_res;
+    HIPCHK(ctx, d_u32.alloc(9ull * U + 4)); HIPCHK(ctx, d_i32.alloc(3ull * U)); HIPCHK(ctx, d_ctrl.alloc(C_WORDS)); HIPCHK(ctx, d_res_off.alloc(U)); HIPCHK(ctx, d_res_len.alloc(U));
+    HIPCHK(ctx, d_res.alloc((size_t)U * capV)); if (hp.want_cov) HIPCHK(ctx, d_res_cov.alloc((size_t)U * capV));
+    HierDev H{};
+    H.U = U; H.D = hp.D; H.slots = slots; H.capV = (int)capV; H.upper_mode = hp.upper_mode; H.want_cov = hp.want_cov ? 1 : 0; H.Lmax = Lmax; H.cap_jobs[0] = cap[0]; H.cap_jobs[1] = cap[1];
+    H.unit_bb = d_i32.p; H.unit_wlen = d_i32.p + U; H.unit_pick = d_i32.p + 2ull * U;
+    H.unit_ncur = d_u32.p; H.unit_job0[0] = d_u32.p + U; H.unit_njobs[0] = d_u32.p + 2ull * U + 1; H.unit_job0[1] = d_u32.p + 3ull * U + 1; H.unit_njobs[1] = d_u32.p + 4ull * U + 2; H.unit_seq0 = d_u32.p + 5ull * U + 2; H.unit_tmp = d_u32.p + 6ull * U + 2;
+    H.res_off = d_res_off.p; H.res_len = d_res_len.p; H.res = d_res.p; H.res_cov = hp.want_cov ? d_res_cov.p : nullptr; H.ctrl = d_ctrl.p;
+    HIPCHK(ctx, hipMemsetAsync(d_ctrl.p, 0, sizeof(uint32_t) * C_WORDS, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_res_len.p, 0xff, sizeof(int32_t) * U, ctx->stream));                                    // -1 = no result
+    HIPCHK(ctx, hipMemcpyAsync(H.unit_ncur, u_u32.data(), 4ull * U, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(H.unit_job0[0], u_u32.data() + U, 4ull * U, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(H.unit_njobs[0], u_u32.data() + 2ull * U, 4ull * U, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_i32.p, u_i32.data(), 12ull * U, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(L[0].job_off, job_off.data(), 4 * job_off.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->poa_lv[0].seq_idx.p, seq_idx.data(), 4 * seq_idx.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(L[0].job_bb, job_bb.data(), 4 * job_bb.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(L[0].job_unit, job_unit.data(), 4 * job_unit.size(), hipMemcpyHostToDevice, ctx->stream));
+    static thread_local PinVec<uint32_t> h_nj; h_nj.assign(1, njobs0);
+    HIPCHK(ctx, hipMemcpyAsync(d_ctrl.p + C_NJOBS, h_nj.data(), 4, hipMemcpyHostToDevice, ctx->stream));
+    ht.mark("L0 lists + upload");
+    static thread_local PinVec<uint32_t> h_ctrl; h_ctrl.resize(C_WORDS);
+    int level = 0;
+    for (;;) {
+        const int batch_end = std::min(C_MAXLV - 1, level + (level == 0 ? levels_est : 3));
+        for (; level < batch_end; ++level) {
+            const int par = level & 1; LevelDev& Lv = L[par]; LevelDev& Nx = L[par ^ 1];
+            PoaJobSet J{};
+            J.seqs = level == 0 ? d_level0 : (const PSeq*)Nx.seqs; J.bbs = d_bbs; J.seq_idx = level == 0 ? ctx->poa_lv[0].seq_idx.p : nullptr; J.job_off = Lv.job_off; J.job_bb = Lv.job_bb; J.njobs = cap[par];
+            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles;
+            J.out = Lv.out; J.out_len = Lv.out_len; J.out_cw = Lv.out_cw; J.out_n = Lv.out_n; J.out_cov = Lv.out_cov; J.out_span = Lv.out_span;
+            J.dropped = d_ctrl.p + C_FLAGS; J.slot_overflow = d_ctrl.p + C_FLAGS + 1;
+            J.job_list = nullptr; J.nrun = 0; J.nrun_dev = d_ctrl.p + C_NJOBS + par;
+            int32_t rc = poa_launch(ctx, plan, J, band0, false, d_ctrl.p + C_WORK + 3 * level); if (rc) return rc;
+            int stage = 0;
+            for (int bw = band0 * 2; bw <= 256; bw *= 2, ++stage) {          // band-edge check (oracle run_tile): flagged tiles run again, whole, with twice the band
+                uint32_t* cnt = d_ctrl.p + C_REDO + 2 * level + stage;
+                hipLaunchKernelGGL(k_poa_redo_list, dim3(std::min<uint32_t>((cap[par] + 255) / 256, 1024u)), dim3(256), 0, ctx->stream, Lv.out_n, d_ctrl.p + C_NJOBS + par, Lv.job_list, cnt, d_ctrl.p + C_REDO_TOTAL);
+                PoaJobSet R = J; R.job_list = Lv.job_list; R.nrun_dev = cnt;
+                rc = poa_launch(ctx, plan, R, bw, true, d_ctrl.p + C_WORK + 3 * level + 1 + stage); if (rc) return rc;
+            }
+            hipLaunchKernelGGL(k_poa_unit_scan, dim3(U), dim3(256), 0, ctx->stream, H, Lv, par);
+            hipLaunchKernelGGL(k_poa_unit_offsets, dim3(1), dim3(1024), 0, ctx->stream, H, par);
+            hipLaunchKernelGGL(k_poa_fill_next, dim3(std::min<uint32_t>((cap[par] + 3) / 4, 4096u)), dim3(256), 0, ctx->stream, H, Lv, par);
+            hipLaunchKernelGGL(k_poa_fill_jobs, dim3(std::min<uint32_t>((cap[par ^ 1] + 255) / 256, 1024u)), dim3(256), 0, ctx->stream, H, Nx, par);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        HIPCHK(ctx, hipMemcpyAsync(h_ctrl.data(), d_ctrl.p, 4 * C_WORDS, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_ctrl[C_FLAGS + 2]) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA tile kernel loop guard tripped (code %u)", h_ctrl[C_FLAGS + 2]);
+        if (h_ctrl[C_OVERFLOW] || h_ctrl[C_FLAGS + 1]) { ht.mark("gave up (geometry): host-driven loop"); return NGSID_OK; }
+        if (h_ctrl[C_NJOBS + (level & 1)] == 0) break;                        // every unit has finished
+        if (level >= C_MAXLV - 1) return NGSID_OK;
+    }
+    ctx->poa_redo_tiles += h_ctrl[C_REDO_TOTAL];
+    ht.mark("levels");
+    // ---- results
+    static thread_local PinVec<int32_t> h_len; static thread_local PinVec<uint32_t> h_off, h_cov; static thread_local PinVec<uint8_t> h_res;
+    h_len.resize(U); h_off.resize(U); const size_t used = h_ctrl[C_RES_USED];
+    HIPCHK(ctx, hipMemcpyAsync(h_len.data(), d_res_len.p, 4ull * U, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_off.data(), d_res_off.p, 4ull * U, hipMemcpyDeviceToHost, ctx->stream));
+    h_res.resize(used + 1); if (used) HIPCHK(ctx, hipMemcpyAsync(h_res.data(), d_res.p, used, hipMemcpyDeviceToHost, ctx->stream));
+    if (hp.want_cov) { h_cov.resize(used + 1); if (used) HIPCHK(ctx, hipMemcpyAsync(h_cov.data(), d_res_cov.p, 4 * used, hipMemcpyDeviceToHost, ctx->stream)); }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t u = 0; u < U; ++u) {
+        Unit& Un = units[u]; if (Un.done) continue;
+        Un.done = true; Un.seqs.clear();
+        if (h_len[u] < 0) continue;
+        const int len = h_len[u];
+        Un.result.assign((const char*)h_res.data() + h_off[u], (size_t)len);
+        if (hp.want_cov) Un.cov.assign(h_cov.data() + h_off[u], h_cov.data() + h_off[u] + len);
+        Un.has_result = true;
+    }
+    ht.mark("results");
+    *done = true;
+    return NGSID_OK;
+}
+
+int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
+                      std::vector<Unit>& units, const HierParams& hp)
+{
+    bool done = false;
+    int32_t rc = run_hierarchy_dev(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hp, &done);
+    if (rc || done) return rc;
+    return run_hierarchy_host(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hp);
 }
 
 }  // namespace

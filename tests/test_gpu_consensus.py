@@ -156,3 +156,47 @@ def test_short_tail_window_parity(gpu_api, oracle, L):
         prm = polish_params(iters=2, k=13, w=20, tile_depth=8, band=0, trim=2)
         a, ua = gpu_api.polish(ReadSet.from_strings(b2), rs, [0, 300, 600], prm); b, ub = oracle.polish(ReadSet.from_strings(b2), rs, [0, 300, 600], prm)
         assert a == b and np.array_equal(ua, ub), tail
+
+
+def test_device_driven_levels_equal_host_driven_levels(gpu_api, oracle):
+    """round 3: the hierarchy levels are chained on the device (tile counts, next-level sequence descriptors and tile lists built by small kernels,
+    one synchronisation per hierarchy).  The host-driven loop (ngsid_ctx_option poa_host_levels = 1, also the fall-back when the planned launch
+    geometry does not fit) must give the same bytes: draft consensus with coverage over many groups of very different sizes (1 .. 400 reads,
+    empty groups, more groups than one scan block), polishing with early stop, depth 6 / 8 / 3 / one-tile, band redo."""
+    from ngspeciesid_amd import runtime
+    host = runtime.new_api(options={"poa_host_levels": 1})
+    try:
+        rng = np.random.default_rng(3)
+        sizes = [1, 2, 0, 7, 400, 13, 6, 36, 37, 0, 216, 5] + [int(x) for x in rng.integers(1, 30, 1200)]
+        sp = synth.make_species(len(sizes), 300, 0.15, seed=31)
+        seqs, quals = [], []
+        for g, n in enumerate(sizes):
+            if n == 0: continue
+            rd = synth.make_reads([sp[g]], n, mu=14.0, seed=500 + g)
+            o = rd["off"].numpy()
+            for i in range(n):
+                seqs.append(rd["seq"].numpy()[o[i]:o[i + 1]].tobytes().decode()); quals.append(rd["qual"].numpy()[o[i]:o[i + 1]].tobytes().decode())
+        rs = ReadSet.from_strings(seqs, quals)
+        goff = np.concatenate(([0], np.cumsum(sizes))).astype(np.uint64)
+        for prm in (poa_params(tile_depth=6, band=0, trim=1), poa_params(tile_depth=8, band=128, trim=0), poa_params(tile_depth=3, band=64, trim=1, mode=POA_GLOBAL, match=3, mismatch=-5, gap=-4),
+                    poa_params(tile_depth=0, band=128, node_cap=40)):
+            a = gpu_api.poa_consensus_cov(rs, goff, prm); b = host.poa_consensus_cov(rs, goff, prm)           # [(consensus, coverage)] per group
+            assert [x[0] for x in a] == [y[0] for y in b]
+            assert all(np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+        first = [0, 1, 3, 4]                                   # groups checked against the oracle as well (the whole set would take the scalar oracle minutes)
+        sub_off = np.concatenate(([0], np.cumsum([sizes[g] for g in first]))).astype(np.uint64)
+        order = np.concatenate([np.arange(int(goff[g]), int(goff[g + 1])) for g in first]).astype(np.uint32)
+        prm = poa_params(tile_depth=6, band=0, trim=1)
+        assert gpu_api.poa_consensus(rs, sub_off, prm, read_order=order) == oracle.poa_consensus(rs, sub_off, prm, read_order=order)
+        # polishing: two groups, 3 iterations, early stop on and off
+        big = [4, 10]
+        p_off = np.concatenate(([0], np.cumsum([sizes[g] for g in big]))).astype(np.uint64)
+        p_order = np.concatenate([np.arange(int(goff[g]), int(goff[g + 1])) for g in big]).astype(np.uint32)
+        bb = ReadSet.from_strings([seqs[int(goff[g])] for g in big])
+        for stop in (0, 1):
+            pp = polish_params(iters=3, k=13, w=20, tile_depth=6, band=0, trim=2, stop_when_stable=stop)
+            x, ux = gpu_api.polish(bb, rs, p_off, pp, read_order=p_order); y, uy = host.polish(bb, rs, p_off, pp, read_order=p_order)
+            assert x == y and np.array_equal(ux, uy)
+            assert x == [sp[g].tobytes().decode() for g in big]
+    finally:
+        host.close()
