@@ -13,15 +13,30 @@ import numpy as np
 import torch
 
 
-def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device, abundance=None, rc_fraction=0.0):
+# BASELINE.json configurations: species, read length, quality profile, (k, w), abundance vector and --abundance_ratio.
+# `reads` = reads PER GPU in the default weak-scaling mode (C4 / C5 are quoted on 8 GPUs: 10 M / 8 and 2 M / 8), and `total` = the size of the
+# ONE global set of --scaling strong.  C1 (sample_h1 through the CLI) is a test, not a bench workload.
+CONFIGS = {
+    "c2": dict(reads=100000, total=100000, species=1, length=750, mu=17.0, k=13, w=20, abundance_ratio=0.1, geometric=None, flags="--ont --abundance_ratio 0.1"),
+    "c3": dict(reads=1000000, total=1000000, species=5, length=750, mu=17.0, k=13, w=20, abundance_ratio=0.02, geometric=None, flags="--ont --abundance_ratio 0.02"),
+    "c4": dict(reads=1250000, total=10000000, species=50, length=750, mu=17.0, k=13, w=20, abundance_ratio=0.005, geometric=None, flags="--ont --abundance_ratio 0.005"),
+    "c5": dict(reads=250000, total=2000000, species=20, length=2000, mu=30.0, k=15, w=50, abundance_ratio=0.002, geometric=0.8, flags="--isoseq --abundance_ratio 0.002"),
+}
+
+
+def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device, abundance=None, rc_fraction=0.0, k=13):
     """synthetic reads, scored (f1) and physically ordered by score descending (stable) = the greedy order."""
     from ngspeciesid_amd import synth
     from ngspeciesid_amd._capi import ReadSet
+    tr = (lambda m: (sys.stderr.write("[gen pid %d] %s\n" % (os.getpid(), m)), sys.stderr.flush())) if os.environ.get("NGSID_BENCH_TRACE") else (lambda m: None)
     sp = synth.make_species(n_species, L, 0.15, seed=1)
+    tr("species made")
     rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed, device=device, abundance=abundance, rc_fraction=rc_fraction)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     torch.cuda.synchronize(device)       # the library runs on its own HIP stream: torch's generator kernels must have finished writing the reads
-    score, err, keep = api.score_reads(rs, 13, 7.0)
+    tr("reads made")
+    score, err, keep = api.score_reads(rs, k, 7.0)
+    tr("reads scored")
     keep_idx = np.nonzero(keep)[0]
     perm = keep_idx[np.argsort(-score[keep_idx], kind="stable")]
     off = rd["off"]; lens = (off[1:] - off[:-1])
@@ -48,10 +63,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("NGSID_BENCH_READS", 1000000)), help="reads per GPU")
-    ap.add_argument("--species", type=int, default=5)
-    ap.add_argument("--length", type=int, default=750)
-    ap.add_argument("--mu", type=float, default=17.0)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="BASELINE.json configuration: c2 100 k x 750 bp 1 species | c3 (default, the one `metric` is quoted on) 1 M x 750 bp 5 species | "
+                    "c4 10 M x 750 bp 50 species over 8 GPUs (1.25 M per GPU) | c5 2 M x 2 kb CCS 20 species, geometric abundance, k15/w50 over 8 GPUs (250 k per GPU)")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (weak scaling) or in total (strong scaling); default: the configuration's")
+    ap.add_argument("--species", type=int, default=None)
+    ap.add_argument("--length", type=int, default=None)
+    ap.add_argument("--mu", type=float, default=None)
     ap.add_argument("--tile-depth", type=int, default=6, help="reads per POA tile (library / CLI default 6)")
     ap.add_argument("--band", type=int, default=0, help="POA band width in columns of the first attempt (64 / 128 / 256); 0 = library default (64 for reads up to 1 024 bases)")
     ap.add_argument("--node-cap", type=int, default=0, help="POA graph capacity in 1/16 of the first sequence length (0 = library default)")
@@ -66,6 +83,13 @@ def main():
                          "reference's `--t N` partition (parallelize.batch_list total_nt), so the N-GPU membership is the reference's --t N membership of that set")
     ap.add_argument("--check-membership", action="store_true", help="strong scaling: after the timed region rank 0 replays the `--t N` schedule on one GPU and compares the membership")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.reads is None: args.reads = int(os.environ.get("NGSID_BENCH_READS", cfg["total"] if args.scaling == "strong" else cfg["reads"]))
+    if args.species is None: args.species = cfg["species"]
+    if args.length is None: args.length = cfg["length"]
+    if args.mu is None: args.mu = cfg["mu"]
+    K_, W_, AB_ = cfg["k"], cfg["w"], cfg["abundance_ratio"]
+    abundance = [cfg["geometric"] ** i for i in range(args.species)] if cfg["geometric"] else None
 
     # stdout carries exactly ONE line (the JSON): everything native code prints to fd 1 (RCCL's banner, rocm warnings) goes to stderr instead
     sys.stdout.flush(); json_fd = os.dup(1); os.dup2(2, 1)
@@ -85,16 +109,21 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    _t00 = time.perf_counter()
+    def trace(msg):           # dev aid: NGSID_BENCH_TRACE=1 -> per-rank progress on stderr
+        if os.environ.get("NGSID_BENCH_TRACE"): sys.stderr.write("[bench rank %d %.1fs] %s\n" % (rank, time.perf_counter() - _t00, msg)); sys.stderr.flush()
     from ngspeciesid_amd import runtime, pipeline
     from ngspeciesid_amd._capi import ReadSet
     from ngspeciesid_amd.ptable import select_p_table
+    trace("process group up, creating the context")
     api = runtime.get_api(local)
-    ptab = select_p_table(13, 20)
+    trace("context created")
+    ptab = select_p_table(K_, W_)
     rd_global = None
     if args.scaling == "strong" and (world > 1 or force_dist):
         # every rank builds the same global set (same seed, same device type) and keeps its own `--t N` batch of it
         from ngspeciesid_amd import parallelize
-        sp, rd_global = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7, device=dev)
+        sp, rd_global = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7, device=dev, abundance=abundance, k=K_)
         goff = rd_global["off"]; glens = (goff[1:] - goff[:-1]).cpu().numpy()
         batches = parallelize.batch_list_total_nt(glens, world)
         a, b = batches[rank] if rank < len(batches) else (len(glens), len(glens))
@@ -104,14 +133,15 @@ def main():
         shard_start = a
         if not (args.check_membership and rank == 0): rd_global = None
     else:
-        sp, rd = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7 + rank, device=dev)
+        sp, rd = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7 + rank, device=dev, abundance=abundance, k=K_)
     torch.cuda.synchronize()
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     n = rs.n
+    trace("reads ready: %d local" % n)
     acc_rank = np.asarray(rd["orig"], dtype=np.uint32)            # stand-in for the accession order (unique, deterministic)
     # The headline runs ALL three polishing iterations (stop_when_stable off).  The library's default stops polishing a cluster once an
     # iteration returns its backbone unchanged (identical result, less work); that rate is reported separately as `with_stable_stop`.
-    kw = dict(k=13, w=20, abundance_ratio=0.02, racon_iter=3, tile_depth=args.tile_depth, band=args.band, p_shared=ptab, polish_stop_when_stable=False)
+    kw = dict(k=K_, w=W_, abundance_ratio=AB_, racon_iter=3, tile_depth=args.tile_depth, band=args.band, p_shared=ptab, polish_stop_when_stable=False)
     if args.node_cap and world == 1: kw["node_cap"] = args.node_cap
 
     def step(T=None, **over):
@@ -131,6 +161,7 @@ def main():
 
     for _ in range(args.warmup):
         res = step()
+    trace("warm-up done")
     import ctypes as C
     api.lib.ngsid_profile_enable(api.ctx, C.c_int32(1))
     T = {}
@@ -138,6 +169,7 @@ def main():
     for _ in range(args.steps):
         res = step(T)
     barrier(); dt = time.perf_counter() - t0
+    trace("timed region done: %.2f s, stages %s" % (dt, {k_: round(v, 2) for k_, v in T.items()}))
     buf = C.create_string_buffer(1 << 16)
     api.lib.ngsid_profile_read(api.ctx, buf, C.c_uint64(len(buf)))
     api.lib.ngsid_profile_enable(api.ctx, C.c_int32(0))
@@ -157,7 +189,7 @@ def main():
         n_total = n
     if dist is not None:
         t = torch.tensor([dt_stop], device=comm_dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt_stop = float(t.item())
-    membership_ok = None
+    membership_ok = None; single_same = None
     if args.scaling == "strong" and dist is not None and args.check_membership:
         # N-GPU membership against the reference's `--t N` schedule replayed on ONE GPU (rank 0), outside the timed region
         from ngspeciesid_amd import distributed, parallelize
@@ -166,13 +198,20 @@ def main():
         starts = [x for x, _ in batches]
         mine = np.asarray([starts[o] + l for o, l in zip(res["final_owner"], res["final_lidx"])], dtype=np.int64)
         allm = distributed.all_gather_obj(dict(a=int(shard_start), final=mine), comm_dev)
+        trace("membership gathered")
         if rank == 0:
             final = np.full(len(glens), -1, dtype=np.int64)
             for m_ in allm: final[m_["a"]:m_["a"] + len(m_["final"])] = m_["final"]
             hrs = ReadSet(rd_global["seq"].cpu().numpy(), rd_global["qual"].cpu().numpy(), rd_global["off"].cpu().numpy().astype(np.uint64))
-            fn = make_cluster_fn(api, hrs, np.asarray(rd_global["orig"], dtype=np.uint32), cluster_params(k=13, w=20, p_shared=ptab))
+            fn = make_cluster_fn(api, hrs, np.asarray(rd_global["orig"], dtype=np.uint32), cluster_params(k=K_, w=W_, p_shared=ptab))
             rep_ref, _, _ = parallelize.tree_cluster(fn, glens, np.asarray(rd_global["score"]), world)
             membership_ok = bool(np.array_equal(final, rep_ref))
+            trace("replayed --t N on one GPU: membership %s" % membership_ok)
+            # ... and the sharded consensus against the single-process path on the whole set (one GPU, one clustering pass)
+            grs = ReadSet.from_torch(rd_global["seq"], rd_global["qual"], rd_global["off"])
+            one = pipeline.run_hot_path(api, grs, rd_global["score"], acc_rank=np.asarray(rd_global["orig"], dtype=np.uint32), **kw)
+            single_same = sorted(c[3] for c in one["centers"]) == sorted(c[3] for c in res["centers"])
+            trace("single-process pass done")
     if rank != 0:
         return
     stop_same = None if res_stop is None else [c[3] for c in res_stop["centers"]] == [c[3] for c in res["centers"]]
@@ -184,14 +223,14 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util_seq import edit_distance
     truths = [s.tobytes().decode() for s in sp]
-    ed = []
-    for c in big:
-        ed.append(min(min(edit_distance(c[3][a:len(c[3]) - b if b else None], t) for a in range(4) for b in range(4)) for t in truths))
+    ed = []; tset = set(truths)
+    for c in big:           # exact hits first (50 species x 50 truths x 16 end trims of a row-vectorised edit distance would take minutes)
+        ed.append(0 if c[3] in tset else min(min(edit_distance(c[3][a:len(c[3]) - b if b else None], t) for a in range(4) for b in range(4)) for t in truths))
     # ---- roofline of the dominant kernel (HIP-event times on the library's own stream)
     redo_tiles = kern.pop("poa_band_redo_tiles", (0, 0.0))[0]
     dom = max(kern.items(), key=lambda kv: kv[1][1]) if kern else (None, (0, 0.0))
     f_aln = float(res["counters"][2]) / n
-    L, M = args.length, 118
+    L = args.length; M = int(round(0.21 * 0.75 * L)) if K_ <= 13 else int(round(0.054 * 0.75 * L))          # minimizers per read (118 at 750 bp k13/w20, 80 at 2 kb k15/w50)
     per_read_bytes = {"k_sg_align": 4 * L, "k_poa_tile": 2 * L, "k_hpc_minimizers": 2 * L + 12 * M, "k_count_hits": 12 * M + 8, "k_decide_map": 12 * M + 8, "k_aln_next": 8}
     roof = None
     if dom[0]:
@@ -206,17 +245,27 @@ def main():
         avg_s = ms / 1e3 / max(cnt, 1)
         ach = alg_bytes_per_launch / avg_s / 1e9
         traffic = None
-        try:    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), valid for the profiled workload size only
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-            if tj.get("workload_reads") == args.reads and dom[0] in tj and world == 1:
+        traffic_src = None
+        try:    # HBM bytes per launch from the committed PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, tools/r03_profiles.sh): a counter
+                # pass cannot run inside this process, so the figure is a measurement of the recorded commit on the recorded workload, not of this run
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
+            if tj.get("workload_reads") == args.reads and tj.get("config", "c3") == args.config and dom[0] in tj and world == 1:
                 traffic = int(tj[dom[0]]["hbm_bytes_per_step"] * args.steps / max(cnt, 1))      # per launch, like `achieved`
+                traffic_src = {"file": "profiles/r03_hbm_traffic.json", "measured_at_commit": tj.get("commit"), "launches_per_step_then": tj[dom[0]].get("launches_per_step")}
         except Exception:
             traffic = None
-        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic,
+        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
+                "limited_by": "memory latency under load in the lane-parallel graph phases + VALU issue in the DP rows (not HBM bandwidth): see `issue` and DESIGN.md section 4",
                 "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
                 "note": "integer DP kernel, one wave per tile: bound by the latency of the wave's dependent instruction stream (six waves per SIMD overlap to 2.75x, VALU pipe 60 % busy), not by HBM - the fraction of the HBM roofline is small by construction (DESIGN.md sections 4 and 10)"}
-        if dom[0] == "k_poa_tile":      # what bounds it is instruction issue along the dependent chain of a DP row: SQ counters are in the committed PMC pass (not measurable from inside this process)
-            roof["sq_counters"] = "profiles/r02_pmc_poa_tile.txt"
+        if dom[0] == "k_poa_tile":      # instruction-issue view of the same kernel: SQ counters of a committed PMC pass on THIS workload at the default tile depth (not measurable from inside this process)
+            try:
+                ij = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_poa_tile.json")))
+                if ij.get("workload_reads") == args.reads and ij.get("config", "c3") == args.config:
+                    roof["issue"] = {k_: ij[k_] for k_ in ("valu_per_row", "salu_per_row", "rows", "pipe_busy", "wave_cycles_waiting_frac", "commit") if k_ in ij}
+                    roof["issue"]["file"] = "profiles/r03_pmc_poa_tile.json"
+            except Exception:
+                pass
         if dom[0] == "k_sg_align":      # what actually bounds it: VALU issue.  17.7 VALU instructions per DP cell and lane (ISA count, k_align16.hip), 64 cells per wave instruction
             prop = torch.cuda.get_device_properties(dev)
             clk = float(getattr(prop, "clock_rate", 2400000)) * 1e3
@@ -283,6 +332,8 @@ def main():
         finally:
             shutil.rmtree(tmpd, ignore_errors=True)
         cpu = {"value": allc["value"] if allc else round(one.n / dt1, 2), "unit": "reads/s", "cores": allc["cores"] if allc else 1, "kind": "port",
+               "reference_python_one_core": {"reads_to_clusters_reads_per_s": 294, "get_sorted_fastq_reads_per_s": 6200, "box": "build container, Intel Xeon @ 2.10 GHz, one core, 4 000 reads of this profile (oracle/time_reference.py; BASELINE.md section 5)",
+                                             "note": "the reference's own Python for the CLUSTERING half only (its aligner behind a parasail-shaped shim = the oracle's scalar C aligner); spoa / racon / minimap2 are not in the image, the reference cannot run on the GPU box - a recorded constant, not measured by this run"},
                "cpu_model": model, "host_cores": cores, "usable_cores": usable,
                "one_core": {"value": round(one.n / dt1, 2), "reads": int(one.n), "seconds": round(dt1, 1)}, "all_cores": allc,
                "sample": "%d reads strided from the same batch (same params, tile_depth %d): %d per worker process, one process per usable core (affinity mask / cgroup quota; start-up of the interpreters included in the wall time) running oracle/libngsid_oracle.so "
@@ -303,27 +354,27 @@ def main():
             fq = os.path.join(tmp, "reads.fastq"); fastio.write_fastq(fq, perm, names, hrs)
             in_bytes = os.path.getsize(fq)
             outd = os.path.join(tmp, "out"); os.makedirs(outd)
-            cargs = _cli.build_parser().parse_args(["--ont", "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", "0.02"])
-            cargs.k, cargs.w = 13, 20
+            cargs = _cli.build_parser().parse_args([("--isoseq" if K_ == 15 else "--ont"), "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", str(AB_)])
+            cargs.k, cargs.w = K_, W_
             tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl
             out_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs)
             got = sorted(m[2] for m in r["centers"])
             cli_leg = {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "ratio_to_hot_path": round((n / dcl) / reads_per_s, 3), "t": args.cli_t,
                        "stage_s": {k_: round(v, 3) for k_, v in r["timings"].items()}, "input_fastq_bytes": in_bytes, "output_bytes": out_bytes,
                        "files_on": "tmpfs (/dev/shm)" if base else "disk (tmp dir)", "consensus_equals_amplicons": got == sorted(truths),
-                       "what": "python -m ngspeciesid_amd --ont --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio 0.02: FASTQ parse, score, sort, sorted.fastq, "
-                               "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % args.cli_t}
+                       "what": "python -m ngspeciesid_amd %s --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio %s: FASTQ parse, score, sort, sorted.fastq, "
+                               "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % ("--isoseq" if K_ == 15 else "--ont", args.cli_t, AB_)}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), 750 bp ONT", "value": round(reads_per_s, 1), "unit": "reads/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
            "scaling": args.scaling if world > 1 or force_dist else "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic",
-           "config": {"workload": ("%d synthetic %d bp ONT-profile reads " + ("in total, one `--t N` batch per GPU" if (args.scaling == "strong" and (world > 1 or force_dist)) else "per GPU") + " (mu=%.0f), %d species @15%% divergence, k=13 w=20, cluster + spoa-style POA + racon-style polish x3, abundance_ratio 0.02, POA tile depth %d band %s")
-                      % (args.reads, args.length, args.mu, args.species, args.tile_depth, ("%d" % args.band) if args.band else "64 (library default, widened per tile by the band-edge check)"),
+           "config": {"workload": (args.config.upper() + ": %d synthetic %d bp %s-profile reads " + ("in total, one `--t N` batch per GPU" if (args.scaling == "strong" and (world > 1 or force_dist)) else "per GPU") + " (mu=%.0f), %d species @15%% divergence%s, k=%d w=%d, cluster + spoa-style POA + racon-style polish x3, abundance_ratio %s, POA tile depth %d band %s")
+                      % (args.reads, args.length, "CCS" if args.mu >= 25 else "ONT", args.mu, args.species, (" with geometric abundance %.1f^i" % cfg["geometric"]) if cfg["geometric"] else "", K_, W_, AB_, args.tile_depth, ("%d" % args.band) if args.band else "64 (library default, widened per tile by the band-edge check)"),
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
                       "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()},
                       "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),
-                      "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok}},
+                      "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok, "sharded_consensus_equals_single_process": single_same}},
            "roofline": roof, "cpu_baseline": cpu}
     if cli_leg is not None: out["config"]["cli"] = cli_leg
     if res_stop is not None: out["config"]["with_stable_stop"] = {"reads_per_s": round(n_total / dt_stop, 1), "ms_per_step": round(dt_stop * 1e3, 2), "same_result": stop_same,

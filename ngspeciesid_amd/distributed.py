@@ -75,6 +75,72 @@ def all_gather_obj(obj: dict, device):
     return [_unpack(host[r, :int(sizes[r])]) for r in range(world)]
 
 
+class TorchComm:
+    """the collectives of the sharded path over torch.distributed (backend nccl = RCCL over xGMI on the GPUs, gloo on CPU)"""
+
+    def __init__(self, device=None):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.device = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+
+    def all_gather_obj(self, obj):
+        return all_gather_obj(obj, self.device)
+
+    def all_reduce_sum(self, a):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+
+
+class LocalComm:
+    """N VIRTUAL ranks = N threads of one process (each with its own ngsid context on the same GPU): the composed N-shard path on a one-GPU box.
+    Same payloads as TorchComm (they go through _pack / _unpack); the exchange is a slot list behind a threading.Barrier.  Eight real processes
+    sharing one MI355X stall in the runtime (seen with torch's own generator kernels, before any library call), so the one-GPU emulation of an
+    8-GPU run uses threads; torch.distributed itself is covered by the gloo tests on CPU and the 2- / 4-process runs on one GPU."""
+
+    class Shared:
+        def __init__(self, world):
+            import threading
+            self.world = world; self.barrier = threading.Barrier(world); self.slots = [None] * world
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.world = shared, rank, shared.world
+
+    def _exchange(self, item):
+        sh = self.shared
+        sh.slots[self.rank] = item
+        sh.barrier.wait()
+        out = list(sh.slots)
+        sh.barrier.wait()                      # nobody overwrites a slot before everyone has read
+        return out
+
+    def all_gather_obj(self, obj):
+        return [_unpack(b) for b in self._exchange(_pack(obj))]
+
+    def all_reduce_sum(self, a):
+        parts = self._exchange(np.asarray(a).copy())
+        return np.sum(parts, axis=0)
+
+
+def run_virtual_ranks(world, fn):
+    """fn(comm) on one thread per virtual rank, comm = LocalComm of that rank (ctypes releases the GIL during the library calls, so the shards'
+    GPU work overlaps); returns the results in rank order and re-raises the first real exception (a failed rank aborts the barrier so that
+    the others do not wait for ever)"""
+    import threading
+    shared = LocalComm.Shared(world)
+    res = [None] * world; err = [None] * world
+    def work(r):
+        try:
+            res[r] = fn(LocalComm(shared, r))
+        except BaseException as e:                  # noqa
+            err[r] = e; shared.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    real = [e for e in err if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if real: raise real[0]
+    if any(e is not None for e in err): raise [e for e in err if e is not None][0]
+    return res
+
+
 def _weighted_merge_all(api, partials, counts, band):
     """For every selected cluster: POA of its per-shard partial consensuses; the quality string carries the weight (reads represented,
     scaled to 1..93).  partials[c] / counts[c] = one entry per shard.  All clusters go through ONE library call (one group each)."""
@@ -141,12 +207,12 @@ def merge_representatives(api, gathered, prm, world):
 
 
 def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k=13, w=20, abundance_ratio=0.1, rc_identity_threshold=0.9,
-                     racon_iter=3, tile_depth=pipeline.TILE_DEPTH, band=0, p_shared=None, cluster_kwargs=None, do_consensus=True, polish_trim=2, device=None, timings=None, polish_stop_when_stable=True):
+                     racon_iter=3, tile_depth=pipeline.TILE_DEPTH, band=0, p_shared=None, cluster_kwargs=None, do_consensus=True, polish_trim=2, device=None, timings=None, polish_stop_when_stable=True, comm=None):
     """Runs on every rank; returns dict(final_rep=(rank, local idx) per local read as two arrays, centers=[(n, key, draft, polished)])."""
     import time
     T = timings if timings is not None else {}
-    world, rank = dist.get_world_size(), dist.get_rank()
-    device = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    comm = comm or TorchComm(device)
+    world, rank = comm.world, comm.rank
     prm = cluster_params(k=k, w=w, p_shared=p_shared, **(cluster_kwargs or {}))
     n_local = rs_local.n
     score_local = np.asarray(score_local, dtype=np.float64)
@@ -157,7 +223,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
     # ---- 2. all-gather the representatives, replay the tree merge everywhere
     t0 = time.perf_counter()
     mine, payload = representative_payload(rs_local, rep_local, herr, score_local, acc_rank_local)
-    gathered = all_gather_obj(payload, device)
+    gathered = comm.all_gather_obj(payload)
     rep_of_rep, r_owner, r_lidx, r_score, n_total = merge_representatives(api, gathered, prm, world)
     base = np.concatenate(([0], np.cumsum([len(g["idx"]) for g in gathered])))
     my_gid = np.full(n_local, -1, dtype=np.int64); my_gid[mine] = base[rank] + np.arange(len(mine))
@@ -168,9 +234,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
         return res
     # ---- 3. cluster sizes over all shards
     t0 = time.perf_counter()
-    sizes = torch.from_numpy(np.bincount(final_gid, minlength=len(r_lidx)).astype(np.int64)).to(device)
-    dist.all_reduce(sizes)
-    sizes = sizes.cpu().numpy()
+    sizes = comm.all_reduce_sum(np.bincount(final_gid, minlength=len(r_lidx)).astype(np.int64))
     cutoff = int(abundance_ratio * n_total)
     cand = np.nonzero((sizes >= cutoff) & (sizes > 0))[0]
     cand = cand[np.lexsort((-r_score[cand], -sizes[cand]))]
@@ -182,7 +246,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
     sub_order = np.concatenate([order[a:b] for a, b in zip(lo, hi)]) if len(cand) else np.zeros(0, np.uint32)
     sub_off = np.concatenate(([0], np.cumsum(hi - lo))).astype(np.uint64)
     partial = api.poa_consensus(rs_local, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, trim=pipeline.DRAFT_TRIM), read_order=sub_order) if len(cand) else []
-    allp = all_gather_obj(dict(cons=list(partial), cnt=np.asarray(hi - lo, dtype=np.int64)), device)
+    allp = comm.all_gather_obj(dict(cons=list(partial), cnt=np.asarray(hi - lo, dtype=np.int64)))
     drafts = _weighted_merge_all(api, [[p["cons"][c] for p in allp] for c in range(len(cand))], [[p["cnt"][c] for p in allp] for c in range(len(cand))], band)
     T["consensus"] = T.get("consensus", 0.0) + time.perf_counter() - t0
     # ---- 5. reverse-complement merge (identical on every rank), then polish: per iteration local window consensus + weighted merge
@@ -198,7 +262,7 @@ def sharded_hot_path(api, rs_local: ReadSet, score_local, acc_rank_local=None, k
         p_order = np.concatenate(lists) if lists else np.zeros(0, np.uint32)
         bb = ReadSet.from_strings(polished)
         loc, used = api.polish(bb, rs_local, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, trim=polish_trim, stop_when_stable=polish_stop_when_stable), read_order=p_order)
-        allq = all_gather_obj(dict(cons=list(loc), cnt=np.asarray(used, dtype=np.int64)), device)
+        allq = comm.all_gather_obj(dict(cons=list(loc), cnt=np.asarray(used, dtype=np.int64)))
         mg = _weighted_merge_all(api, [[q["cons"][c] for q in allq] for c in range(len(merged))], [[q["cnt"][c] for q in allq] for c in range(len(merged))], band)
         polished = [mg[c] or polished[c] for c in range(len(merged))]
     T["polish"] = T.get("polish", 0.0) + time.perf_counter() - t0

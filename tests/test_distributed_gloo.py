@@ -67,3 +67,53 @@ def test_two_rank_consensus_agrees_between_ranks():
     one = pipeline.run_hot_path(load_oracle(), ReadSet(g["seq"], g["qual"], g["off"]), g["score"], acc_rank=acc_rank([str(x) for x in g["acc"]]), k=int(g["k"]), w=int(g["w"]),
                                 p_shared=g["p_table"], abundance_ratio=0.1, racon_iter=1, tile_depth=8)
     assert sorted(c[3] for c in one["centers"]) == sorted(seq for n, seq in outs[0]["centers"]), "sharded and single-process consensus differ"
+
+
+def test_four_rank_gloo_membership_equals_reference_t4():
+    """four gloo processes: merged membership == the reference's --t 4 result (the fixture that holds one: the 10 %-divergence
+    "hard" set, where every cross-species read reaches the aligner)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cluster_synth600_d10_q14.npz"))
+    outs = _run("synth600_d10_q14", consensus=False, world=4)
+    final = np.full(len(g["t4_rep_of"]), -1)
+    for o in outs:
+        final[o["a"]:o["b"]] = o["final"]
+    assert np.array_equal(final, g["t4_rep_of"])
+
+
+@pytest.mark.parametrize("world,tag", [(8, "synth2k_d15"), (2, "synth2k_d15"), (4, "synth600_d10_q14")])
+def test_virtual_ranks_membership_and_consensus(oracle, world, tag):
+    """distributed.LocalComm (N virtual ranks = N threads of one process, what the one-GPU emulation of the 8-GPU configurations uses): the same
+    sharded_hot_path, collectives in memory.  Membership == the reference's --t N; every rank reports the same centres; consensus == amplicons."""
+    from util_seq import edit_distance
+    from ngspeciesid_amd import distributed, parallelize, synth
+    from ngspeciesid_amd._capi import ReadSet
+    from ngspeciesid_amd.hostutil import acc_rank, subset_reads
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cluster_%s.npz" % tag))
+    rs = ReadSet(g["seq"], g["qual"], g["off"]); lens = np.diff(g["off"].astype(np.int64))
+    batches = parallelize.batch_list_total_nt(lens, world)
+    ar = acc_rank([str(x) for x in g["acc"]])
+    def fn(comm):
+        a, b = batches[comm.rank]; idx = np.arange(a, b)
+        return distributed.sharded_hot_path(oracle, subset_reads(rs, idx), g["score"][idx], acc_rank_local=ar[idx], k=int(g["k"]), w=int(g["w"]), p_shared=g["p_table"],
+                                            abundance_ratio=0.1, racon_iter=1, tile_depth=6, comm=comm)
+    res = distributed.run_virtual_ranks(world, fn)
+    starts = [s for s, e in batches]
+    final = np.concatenate([np.array([starts[o] + l for o, l in zip(r["final_owner"], r["final_lidx"])], dtype=np.int64) for r in res])
+    assert np.array_equal(final, g["t%d_rep_of" % world])
+    cent = [[(c[0], c[3]) for c in r["centers"]] for r in res]
+    assert all(c == cent[0] for c in cent[1:])
+    if tag != "synth2k_d15":
+        return
+    assert len(cent[0]) == 5
+    truths = [t.tobytes().decode() for t in synth.make_species(5, 750, 0.15, seed=11)]
+    for n, seq in cent[0]:
+        assert min(edit_distance(seq, t) for t in truths) == 0
+
+
+def test_virtual_rank_failure_does_not_hang(oracle):
+    from ngspeciesid_amd import distributed
+    def fn(comm):
+        if comm.rank == 1: raise ValueError("boom")
+        return comm.all_gather_obj(dict(x=np.arange(3)))
+    with pytest.raises(ValueError):
+        distributed.run_virtual_ranks(3, fn)

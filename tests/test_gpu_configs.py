@@ -98,3 +98,75 @@ def test_mixed_strand_reads_are_merged_and_polished(gpu_api, mu):
     assert len(res["centers"]) == 5, [c[0] for c in res["centers"]]
     assert all(c[3] in both for c in res["centers"]), "a polished consensus is neither an amplicon nor its reverse complement"
     assert all(c[0] > 30000 for c in res["centers"]) and all(len(c[4]) == 2 for c in res["centers"])          # two clusters (fw + rc) behind every centre
+
+
+
+@pytest.mark.parametrize("name,total", [("c4", 2400000), ("c5", 2000000)])
+def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total):
+    """what makes C4 / C5 the 8-GPU configurations, composed - eight `--t 8` batches of ONE global set (C4: 8 x 300 k x 750 bp,
+    50 species, abundance_ratio 0.005; C5 at its FULL size: 8 x 250 k x 2 kb CCS, 20 species with geometric abundance 0.8^i, k15/w50, abundance_ratio
+    0.002, the rarest species at ~700 reads per shard) through distributed.sharded_hot_path: representatives all-gathered and merged by
+    ngsid_merge_representatives, cross-shard abundance cutoff by all-reduce, eight weighted partial consensuses per cluster (draft and polished).
+    The eight ranks are eight threads of this process, each with its own ngsid context on the one GPU (distributed.LocalComm: same payloads,
+    exchanged in memory - eight PROCESSES on one MI355X stall in torch's generator kernels before any library call; torch.distributed itself is
+    covered by the 2- / 4-process test above and the gloo tests on CPU).
+    Checks: membership == parallelize.tree_cluster(.., 8) (= the reference's --t 8 schedule), every polished consensus == its amplicon, pure
+    clusters, identical centres on every rank, sharded consensus == the single-process result on the whole set."""
+    import torch, time
+    import bench
+    from ngspeciesid_amd import pipeline, parallelize, distributed, runtime
+    from ngspeciesid_amd._capi import ReadSet, cluster_params
+    from ngspeciesid_amd.hostutil import make_cluster_fn
+    from ngspeciesid_amd.ptable import select_p_table
+    cfg = bench.CONFIGS[name]; world = 8
+    K, W, AB, nsp = cfg["k"], cfg["w"], cfg["abundance_ratio"], cfg["species"]
+    abundance = [cfg["geometric"] ** i for i in range(nsp)] if cfg["geometric"] else None
+    dev = torch.device("cuda", 0)
+    sp, rd = bench.gen_sorted_reads(gpu_api, total, nsp, cfg["length"], cfg["mu"], seed=7, device=dev, abundance=abundance, k=K)
+    goff = rd["off"]; glens = (goff[1:] - goff[:-1]).cpu().numpy()
+    batches = parallelize.batch_list_total_nt(glens, world)
+    assert len(batches) == world
+    ptab = select_p_table(K, W)
+    kw = dict(k=K, w=W, abundance_ratio=AB, racon_iter=3, tile_depth=pipeline.TILE_DEPTH, band=0, p_shared=ptab, polish_stop_when_stable=False)
+    shards = []
+    for a, b in batches:
+        o0, o1 = int(goff[a].item()), int(goff[b].item())
+        shards.append(dict(seq=rd["seq"][o0:o1].clone(), qual=rd["qual"][o0:o1].clone(), off=(goff[a:b + 1] - goff[a]).clone(), score=rd["score"][a:b], orig=np.asarray(rd["orig"][a:b], dtype=np.uint32)))
+    torch.cuda.synchronize()
+    apis = [gpu_api] + [runtime.new_api(0) for _ in range(world - 1)]
+    try:
+        def rank_fn(comm):
+            s_ = shards[comm.rank]
+            rs_ = ReadSet.from_torch(s_["seq"], s_["qual"], s_["off"])
+            T = {}
+            r = distributed.sharded_hot_path(apis[comm.rank], rs_, s_["score"], acc_rank_local=s_["orig"], comm=comm, timings=T, **kw)
+            r["T"] = T
+            return r
+        t0 = time.perf_counter()
+        res = distributed.run_virtual_ranks(world, rank_fn)
+        dt = time.perf_counter() - t0
+    finally:
+        for a_ in apis[1:]: a_.close()
+    # identical centres on every rank
+    cent = [[(c[0], c[1], c[2], c[3]) for c in r["centers"]] for r in res]
+    assert all(c == cent[0] for c in cent[1:])
+    truths = sorted(s.tobytes().decode() for s in sp)
+    assert sorted(c[3] for c in cent[0]) == truths, "%d centres for %d species" % (len(cent[0]), nsp)
+    # membership == the reference's --t 8 schedule replayed on one GPU
+    starts = [a for a, _ in batches]
+    final = np.concatenate([np.asarray([starts[o] + l for o, l in zip(r["final_owner"], r["final_lidx"])], dtype=np.int64) for r in res])
+    hrs = ReadSet(rd["seq"].cpu().numpy(), rd["qual"].cpu().numpy(), rd["off"].cpu().numpy().astype(np.uint64))
+    fn = make_cluster_fn(gpu_api, hrs, np.asarray(rd["orig"], dtype=np.uint32), cluster_params(k=K, w=W, p_shared=ptab))
+    rep_ref, _, _ = parallelize.tree_cluster(fn, glens, np.asarray(rd["score"]), world)
+    assert np.array_equal(final, rep_ref), "sharded membership differs from --t 8 at %d reads" % int((final != rep_ref).sum())
+    spc = rd["species"].cpu().numpy()
+    big = np.isin(final, np.unique(final)[np.argsort(-np.bincount(np.unique(final, return_inverse=True)[1]))[:nsp]])
+    assert np.array_equal(spc[final[big]], spc[big]) and big.mean() > 0.99
+    # sharded consensus == the single-process path on the whole set
+    grs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
+    one = pipeline.run_hot_path(gpu_api, grs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), **kw)
+    assert sorted(c[3] for c in one["centers"]) == sorted(c[3] for c in cent[0])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(dict(config=name, total_reads=int(len(glens)), shards=world, species=nsp, wall_s_eight_shards_sharing_one_gpu=round(dt, 2), stage_s_rank0={k_: round(v, 3) for k_, v in res[0]["T"].items()},
+                   centres=len(cent[0]), membership_equals_t8=True, consensus_equals_amplicons=True, equals_single_process=True),
+              open(os.path.join(ROOT, "gpurun_out", "composed_%s_8_shards_one_gpu.json" % name), "w"), indent=1)
