@@ -205,7 +205,7 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen,
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ed_align<BMAX, WIN>, 64, lds));
     if (occ < 1) occ = 1;
     u64 want = std::min<u64>(nbundles, (u64)occ * ctx->n_cu);
-    const u64 by_mem = std::max<u64>(1, ((size_t)24 << 30) / (per_wave * 16));
+    const u64 by_mem = std::max<u64>(1, std::min<size_t>((size_t)24 << 30, ctx->scratch_budget) / (per_wave * 16));
     want = std::max<u64>(1, std::min(want, by_mem));
     if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.reserve(want * per_wave));
     if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
@@ -248,7 +248,7 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
         auto cls = [&](int c, uint32_t bound) { AlignJob j = job; j.pair_list = ctx->aln_cls.p + (size_t)c * n; j.npairs_dev = ctx->aln_ctr.p + 8 + c; (void)bound; return j; };
         {   // reserve the scratch once, for the class with the largest footprint (16-block instance, longest query)
             const uint32_t mstride = (max_tlen + 63u) & ~63u; const u64 nblocks = std::max<u64>(1, ((u64)max_qlen + 63) / 64); const u64 per_wave = nblocks * mstride * 64;
-            const u64 want = std::max<u64>(1, std::min<u64>((u64)8 * ctx->n_cu, std::max<u64>(1, ((size_t)24 << 30) / (per_wave * 16))));
+            const u64 want = std::max<u64>(1, std::min<u64>((u64)8 * ctx->n_cu, std::max<u64>(1, std::min<size_t>((size_t)24 << 30, ctx->scratch_budget) / (per_wave * 16))));
             if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.reserve(want * per_wave));
             if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
         }

@@ -1232,21 +1232,29 @@ int32_t poa_prepare(ngsid_ctx* ctx, PoaPlan& P, uint32_t max_jobs)
     const int B0 = P.band0 <= 64 ? 64 : (P.band0 <= 128 ? 128 : 256);
     P.band0 = B0;
     if (P.Vcap > 0xFFF0 || P.Ecap > 0xFFF0) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA graph capacity exceeds 16-bit indices (sequence too long for the tile engine)");
-    size_t need_h = 0, need_d = 0, need_g = 0;
     const size_t gbytes = poa_graph_bytes(P.Vcap, P.Ecap, P.Lmax);
-    for (int BW = B0; BW <= 256; BW *= 2) {
-        const size_t lds = poa_lds_bytes(P.Vcap, P.Ecap, P.Lmax, BW);
-        if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);
-        uint32_t nwg;
-        if (BW == B0) { nwg = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(max_jobs, 1u), (uint64_t)ctx->n_cu * poa_per_cu(ctx, P.Vcap, P.Ecap, P.Lmax, BW)); P.nwg_main = nwg; }
-        else { nwg = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(max_jobs, 1u), (uint64_t)ctx->n_cu * std::min(2, poa_per_cu(ctx, P.Vcap, P.Ecap, P.Lmax, BW))); P.nwg_redo = nwg; }       // redone tiles are rare: a small grid keeps the scratch small
-        const size_t cells = (size_t)P.Vcap * BW;
-        need_h = std::max(need_h, nwg * cells); need_d = std::max(need_d, nwg * cells * 3 / 2); need_g = std::max(need_g, nwg * gbytes);
+    // resident workgroups per CU; halved when the scratch does not fit (several contexts sharing one GPU, very long reads): the persistent
+    // workgroups pull tiles from a queue, so fewer of them only lowers the parallelism
+    for (int shrink = 1;; shrink *= 2) {
+        size_t need_h = 0, need_d = 0, need_g = 0;
+        for (int BW = B0; BW <= 256; BW *= 2) {
+            const size_t lds = poa_lds_bytes(P.Vcap, P.Ecap, P.Lmax, BW);
+            if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "POA tile needs %zu bytes of LDS (> 160 KiB): sequences too long", lds);
+            uint32_t nwg;
+            if (BW == B0) { nwg = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(max_jobs, 1u), std::max<uint64_t>(1, (uint64_t)ctx->n_cu * poa_per_cu(ctx, P.Vcap, P.Ecap, P.Lmax, BW) / shrink)); P.nwg_main = nwg; }
+            else { nwg = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(max_jobs, 1u), std::max<uint64_t>(1, (uint64_t)ctx->n_cu * std::min(2, poa_per_cu(ctx, P.Vcap, P.Ecap, P.Lmax, BW)) / shrink)); P.nwg_redo = nwg; }       // redone tiles are rare: a small grid keeps the scratch small
+            const size_t cells = (size_t)P.Vcap * BW;
+            need_h = std::max(need_h, nwg * cells); need_d = std::max(need_d, nwg * cells * 3 / 2); need_g = std::max(need_g, nwg * gbytes);
+        }
+        if (B0 == 256) P.nwg_redo = 0;
+        hipError_t e = hipSuccess;
+        if (ctx->poa_h.n < need_h) e = ctx->poa_h.alloc(need_h);
+        if (e == hipSuccess && ctx->poa_d.n < need_d) e = ctx->poa_d.alloc(need_d);
+        if (e == hipSuccess && ctx->poa_g.n < need_g) e = ctx->poa_g.alloc(need_g);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || shrink >= 64) HIPCHK(ctx, e);
     }
-    if (B0 == 256) P.nwg_redo = 0;
-    if (ctx->poa_h.n < need_h) HIPCHK(ctx, ctx->poa_h.alloc(need_h));
-    if (ctx->poa_d.n < need_d) HIPCHK(ctx, ctx->poa_d.alloc(need_d));
-    if (ctx->poa_g.n < need_g) HIPCHK(ctx, ctx->poa_g.alloc(need_g));
     return NGSID_OK;
 }
 int32_t poa_launch(ngsid_ctx* ctx, const PoaPlan& P, PoaJobSet J, int BW, bool redo, uint32_t* work_ctr)

@@ -494,6 +494,10 @@ extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t va
     if (!ctx || !name) return NGSID_ERR_ARG;
     static const char* known[] = {"cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "poa_host_levels"};
     for (const char* k : known) if (!strcmp(k, name)) { ctx->options[name] = (long long)value; return NGSID_OK; }
+    if (!strcmp(name, "scratch_budget_mb")) {      // upper bound of the aligners' traceback scratch (default: a quarter of the free HBM at ngsid_create, at most 32 GB): several contexts on one GPU
+        if (value < 64) NGSID_FAIL(ctx, NGSID_ERR_ARG, "scratch_budget_mb must be at least 64");
+        ctx->scratch_budget = (size_t)value << 20; return NGSID_OK;
+    }
     NGSID_FAIL(ctx, NGSID_ERR_ARG, "unknown option '%s'", name);
 }
 

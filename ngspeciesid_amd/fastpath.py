@@ -409,6 +409,21 @@ def _main(args, api):
     rep_of, herr, pos, counters, acc_id = cluster(sr, work, sel, args, api, work_dev)
     T["cluster"] = time() - t0; t0 = time()
     logging.debug(f"Time elapsed clustering: {T['cluster']}")
+    if getattr(args, "strand_aware", False) and len(sel) == sr.n:
+        # extension (strand.py): reverse-complement clusters are joined here, before the cluster files are written and before any consensus work
+        from . import strand
+        prm = cluster_params(k=args.k, w=args.w, min_shared=args.min_shared, min_fraction=args.min_fraction, mapped_threshold=args.mapped_threshold,
+                             aligned_threshold=args.aligned_threshold, min_prob_no_hits=args.min_prob_no_hits,
+                             symmetric=bool(getattr(args, "symmetric_map_align_thresholds", False)), p_shared=select_p_table(args.k, args.w))
+        rep_of, flip, pos, sinfo = strand.strand_merge(api, work, rep_of, sr.score, prm, min_size=max(2, abundance_cutoff // 2), pos=pos)
+        logging.debug("strand-aware merge: %d of %d candidate clusters joined their reverse complement" % (sinfo["merged"], sinfo["candidates"]))
+        if flip.any():
+            work = strand.orient_reads(work, flip)
+            if work_dev is not None and work_dev.mem != work.mem: work_dev.release()
+            work_dev = api.upload_reads(work)
+        T["strand_merge"] = time() - t0; t0 = time()
+    elif getattr(args, "strand_aware", False):
+        logging.warning("--strand_aware needs all reads clustered (no --m / --s / --sample_size selection): ignored")
     reps, sizes, goff, list_order, file_order, cl_sorted = cluster_table(sr, sel, rep_of, pos)
     nontrivial = write_cluster_files(args, sr, reps, sizes, herr, file_order, cl_sorted)
     T["write_clusters"] = time() - t0; t0 = time()

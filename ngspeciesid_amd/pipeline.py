@@ -104,8 +104,10 @@ def pooled_read_lists(merged, group_reads):
 
 def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, w=20, abundance_ratio=0.1,
                  rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=None, band=0, node_cap=0,
-                 p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2, polish_aln_mode=2, polish_stop_when_stable=True):
-    """Returns dict(rep_of, status, counters, hpc_err, centers=[(n_reads, c_id, draft, polished, groups)])."""
+                 p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2, polish_aln_mode=2, polish_stop_when_stable=True,
+                 strand_aware=False):
+    """Returns dict(rep_of, status, counters, hpc_err, centers=[(n_reads, c_id, draft, polished, groups)]); with strand_aware (extension, off by
+    default: strand.py) also flip [n] = reads that were reverse-complemented for the consensus stages, and rep_of is the merged membership."""
     tile_depth = TILE_DEPTH if tile_depth is None else tile_depth
     T = timings if timings is not None else {}
     t0 = time.perf_counter()
@@ -113,10 +115,18 @@ def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, 
     rep_of, herr, status, counters = api.cluster_greedy(rs, prm, acc_rank=acc_rank)
     T["cluster"] = T.get("cluster", 0.0) + time.perf_counter() - t0
     res = dict(rep_of=rep_of, status=status, counters=counters, hpc_err=herr, centers=[])
+    n = rs.n
+    if strand_aware:
+        from . import strand
+        t0 = time.perf_counter()
+        rep_of, flip, _, sinfo = strand.strand_merge(api, rs, rep_of, score, prm, min_size=max(2, int(abundance_ratio * n) // 2))
+        if flip.any():
+            rs = strand.orient_reads(rs, flip)                                   # the consensus stages see every cluster in one orientation
+        res.update(rep_of=rep_of, flip=flip, strand_info=sinfo)
+        T["strand_merge"] = T.get("strand_merge", 0.0) + time.perf_counter() - t0
     if not do_consensus:
         return res
     t0 = time.perf_counter()
-    n = rs.n
     reps, order, grp_off, counts = clusters_from_rep(rep_of)
     cutoff = int(abundance_ratio * n)                                           # NGSpeciesID:65
     sel = select_centers(reps, counts, score, cutoff)

@@ -133,7 +133,7 @@ def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total):
         o0, o1 = int(goff[a].item()), int(goff[b].item())
         shards.append(dict(seq=rd["seq"][o0:o1].clone(), qual=rd["qual"][o0:o1].clone(), off=(goff[a:b + 1] - goff[a]).clone(), score=rd["score"][a:b], orig=np.asarray(rd["orig"][a:b], dtype=np.uint32)))
     torch.cuda.synchronize()
-    apis = [gpu_api] + [runtime.new_api(0) for _ in range(world - 1)]
+    apis = [gpu_api] + [runtime.new_api(0, {"scratch_budget_mb": 6144}) for _ in range(world - 1)]      # eight contexts share one GPU's memory here
     try:
         def rank_fn(comm):
             s_ = shards[comm.rank]
@@ -161,12 +161,13 @@ def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total):
     assert np.array_equal(final, rep_ref), "sharded membership differs from --t 8 at %d reads" % int((final != rep_ref).sum())
     spc = rd["species"].cpu().numpy()
     big = np.isin(final, np.unique(final)[np.argsort(-np.bincount(np.unique(final, return_inverse=True)[1]))[:nsp]])
-    assert np.array_equal(spc[final[big]], spc[big]) and big.mean() > 0.99
+    purity = float((spc[final[big]] == spc[big]).mean())
+    assert purity > 0.9999 and big.mean() > 0.99, (purity, big.mean())          # (the membership itself is pinned above; a handful of noisy reads join another species' cluster in the reference's --t 8 schedule too)
     # sharded consensus == the single-process path on the whole set
     grs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     one = pipeline.run_hot_path(gpu_api, grs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), **kw)
     assert sorted(c[3] for c in one["centers"]) == sorted(c[3] for c in cent[0])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(dict(config=name, total_reads=int(len(glens)), shards=world, species=nsp, wall_s_eight_shards_sharing_one_gpu=round(dt, 2), stage_s_rank0={k_: round(v, 3) for k_, v in res[0]["T"].items()},
-                   centres=len(cent[0]), membership_equals_t8=True, consensus_equals_amplicons=True, equals_single_process=True),
+                   centres=len(cent[0]), purity_of_the_large_clusters=purity, membership_equals_t8=True, consensus_equals_amplicons=True, equals_single_process=True),
               open(os.path.join(ROOT, "gpurun_out", "composed_%s_8_shards_one_gpu.json" % name), "w"), indent=1)
