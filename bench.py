@@ -118,6 +118,9 @@ def main():
     trace("process group up, creating the context")
     api = runtime.get_api(local)
     trace("context created")
+    if world > ndev:      # dev aid (ranks sharing one GPU): the aligners' scratch budget is sized for a GPU of one's own by default
+        import ctypes as _C
+        api.lib.ngsid_ctx_option(api.ctx, b"scratch_budget_mb", _C.c_int64(max(2048, 32768 // world)))
     ptab = select_p_table(K_, W_)
     rd_global = None
     if args.scaling == "strong" and (world > 1 or force_dist):

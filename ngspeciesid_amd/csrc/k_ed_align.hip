@@ -193,6 +193,20 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
     }
 }
 
+// Traceback scratch of `want` resident waves; when the device is short of memory (other contexts / processes on the same GPU) the number of
+// resident waves is halved until the block fits - the persistent waves pull pairs from a queue, so fewer of them only lower the parallelism.
+static int32_t ed_reserve(ngsid_ctx* ctx, u64& want, u64 per_wave)
+{
+    for (;;) {
+        if (ctx->ed_tb.n >= want * per_wave) return NGSID_OK;
+        hipError_t e = ctx->ed_tb.reserve(want * per_wave);
+        if (e == hipSuccess) return NGSID_OK;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || want <= 64) HIPCHK(ctx, e);
+        want = std::max<u64>(64, want / 2);
+    }
+}
+
 template <int BMAX, bool WIN = false>
 static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out, uint32_t ctr_slot = 14, int bandK = 0)
 {
@@ -207,7 +221,7 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen,
     u64 want = std::min<u64>(nbundles, (u64)occ * ctx->n_cu);
     const u64 by_mem = std::max<u64>(1, std::min<size_t>((size_t)24 << 30, ctx->scratch_budget) / (per_wave * 16));
     want = std::max<u64>(1, std::min(want, by_mem));
-    if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.reserve(want * per_wave));
+    { int32_t rr = ed_reserve(ctx, want, per_wave); if (rr) return rr; }
     if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
     HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), ctx->stream));
@@ -249,8 +263,8 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
         {   // reserve the scratch once, for the class with the largest footprint (16-block instance, longest query)
             const uint32_t mstride = (max_tlen + 63u) & ~63u; const u64 nblocks = std::max<u64>(1, ((u64)max_qlen + 63) / 64); const u64 per_wave = nblocks * mstride * 64;
             const u64 want = std::max<u64>(1, std::min<u64>((u64)8 * ctx->n_cu, std::max<u64>(1, std::min<size_t>((size_t)24 << 30, ctx->scratch_budget) / (per_wave * 16))));
-            if (ctx->ed_tb.n < want * per_wave) HIPCHK(ctx, ctx->ed_tb.reserve(want * per_wave));
-            if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
+            u64 w2 = want; { int32_t rr = ed_reserve(ctx, w2, per_wave); if (rr) return rr; }
+            if (ctx->ed_h.n < w2 * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(w2 * (u64)mstride * 64));
         }
         if ((rc = launch_ed<4>(ctx, cls(0, 256), std::min<uint32_t>(max_qlen, 256), max_tlen, dist_out, 1, bandK))) return rc;
         if (max_qlen > 256 && (rc = launch_ed<8>(ctx, cls(1, 512), std::min<uint32_t>(max_qlen, 512), max_tlen, dist_out, 2, bandK))) return rc;

@@ -32,7 +32,7 @@ template <typename T> struct DevBuf {
         if (p) { ngsid_pool_free(p, abytes); p = nullptr; }
         n = count; if (!count) count = 1;
         void* q = nullptr; hipError_t e = ngsid_pool_alloc(&q, count * sizeof(T), &abytes);
-        p = (T*)q; cap = e == hipSuccess ? abytes / sizeof(T) : 0; return e;
+        p = (T*)q; cap = e == hipSuccess ? abytes / sizeof(T) : 0; if (e != hipSuccess) { p = nullptr; n = 0; abytes = 0; } return e;
     }
     // grow-only, contents not kept: for scratch that is reused call after call
     hipError_t reserve(size_t count) { if (p && count <= cap) { n = count; return hipSuccess; } return alloc(count + count / 8); }
