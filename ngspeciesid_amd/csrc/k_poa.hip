@@ -375,15 +375,23 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
         for (int d = 32; d >= 1; d >>= 1) { b = min(b, __shfl_xor(b, d)); e = max(e, __shfl_xor(e, d)); }
         if (b < e && b != 0x7fffffff) {
             span_b = b; span_e = e;
-            const int m2 = e - b + 1;
-            if (b > 0) for (int c0 = 0; c0 < m2; c0 += 64) {
+            // upper levels (trim_tiles & 2, members = weighted tile consensuses): between the kept ends every base whose column carries less than a THIRD of the
+            // merged weight goes as well (oracle EMIT: the heaviest bundle maximises the SUM of the edge weights of a path, so a k-base insertion of the weight w
+            // beats the direct edge W of the rest when (k + 1) w > W - a third for one base, a seventh for five).  Level-0 tiles keep spoa's / racon's behaviour.
+            // Ordered in-place compaction, 64 positions per round (an output index never exceeds the input index).
+            const uint32_t thr3 = (J.trim_tiles & 2) ? (uint32_t)(st.cw_sum / 3) : 0u;
+            const int m2 = e - b + 1; int kept = 0;
+            for (int c0 = 0; c0 < m2; c0 += 64) {
                 const int x = c0 + lane; uint8_t ch = 0; uint32_t cv = 0;
                 if (x < m2) { ch = dst[b + x]; cv = dcov[b + x]; }
+                const bool keep = x < m2 && cv >= thr3;
+                const unsigned long long km = __ballot(keep);
                 mem_sync();
-                if (x < m2) { dst[x] = ch; dcov[x] = cv; }
+                if (keep) { const int o = kept + __popcll(km & ((1ull << lane) - 1ull)); dst[o] = ch; dcov[o] = cv; }
+                kept += __popcll(km);
                 mem_sync();
             }
-            n = m2;
+            n = kept;
         }
     }
     if (lane == 0) {

@@ -28,6 +28,7 @@ template <typename T> struct DevBuf {
     DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { if (p) ngsid_pool_free(p, abytes); }
     size_t cap = 0, abytes = 0;
+    void release() { if (p) { ngsid_pool_free(p, abytes); p = nullptr; } n = 0; cap = 0; abytes = 0; }
     hipError_t alloc(size_t count) {
         if (p) { ngsid_pool_free(p, abytes); p = nullptr; }
         n = count; if (!count) count = 1;

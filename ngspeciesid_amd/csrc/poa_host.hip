@@ -85,7 +85,7 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
             HIPCHK(ctx, hipMemsetAsync(d_flags.p, 0, 16, ctx->stream));
             PoaJobSet J{};
             J.seqs = cur; J.bbs = d_bbs; J.seq_idx = d_seq_idx.p; J.job_off = d_job_off.p; J.job_bb = d_job_bb.p; J.njobs = njobs;
-            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles;
+            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles | ((level > 0 && hp.trim_tiles) ? 2 : 0);
             J.out = Lv->out.p; J.out_len = Lv->out_len.p; J.out_cw = Lv->out_cw.p; J.out_n = Lv->out_n.p; J.out_cov = need_cov ? Lv->out_cov.p : nullptr; J.out_span = Lv->out_span.p;
             J.dropped = d_flags.p; J.slot_overflow = d_flags.p + 1;
             DevBuf<unsigned long long> d_ph; static const bool want_ph = getenv("NGSID_POA_PHASES") != nullptr;
@@ -382,10 +382,11 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
         u_u32[u] = ncur; u_u32[U + u] = (uint32_t)job_unit.size(); u_i32[u] = Un.bb; u_i32[U + u] = Un.bb >= 0 ? bb_len[Un.bb] : 0; u_i32[2ull * U + u] = -2;
         if (ncur) {
             const uint32_t Dl = hp.D > 0 ? (uint32_t)hp.D : ncur;
+            const uint32_t base = (uint32_t)seq_idx.size();
+            seq_idx.insert(seq_idx.end(), Un.seqs.begin(), Un.seqs.end());          // the unit's sequences in one block copy: its tiles are consecutive slices of it
             for (uint32_t a = 0; a < ncur; a += Dl) {
                 const uint32_t b = std::min(ncur, a + Dl);
-                for (uint32_t x = a; x < b; ++x) seq_idx.push_back(Un.seqs[x]);
-                job_off.push_back((uint32_t)seq_idx.size()); job_bb.push_back(Un.bb); job_unit.push_back(u);
+                job_off.push_back(base + b); job_bb.push_back(Un.bb); job_unit.push_back(u);
                 maxD = std::max(maxD, b - a);
             }
             if (Un.bb >= 0) maxbb = std::max(maxbb, bb_len[Un.bb]); else any_nobb = true;
@@ -452,7 +453,7 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
             const int par = level & 1; LevelDev& Lv = L[par]; LevelDev& Nx = L[par ^ 1];
             PoaJobSet J{};
             J.seqs = level == 0 ? d_level0 : (const PSeq*)Nx.seqs; J.bbs = d_bbs; J.seq_idx = level == 0 ? ctx->poa_lv[0].seq_idx.p : nullptr; J.job_off = Lv.job_off; J.job_bb = Lv.job_bb; J.njobs = cap[par];
-            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles;
+            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles | ((level > 0 && hp.trim_tiles) ? 2 : 0);
             J.out = Lv.out; J.out_len = Lv.out_len; J.out_cw = Lv.out_cw; J.out_n = Lv.out_n; J.out_cov = Lv.out_cov; J.out_span = Lv.out_span;
             J.dropped = d_ctrl.p + C_FLAGS; J.slot_overflow = d_ctrl.p + C_FLAGS + 1;
             J.job_list = nullptr; J.nrun = 0; J.nrun_dev = d_ctrl.p + C_NJOBS + par;
@@ -545,7 +546,10 @@ static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, co
     if (RD.n) hipLaunchKernelGGL(k_make_pseq_reads, dim3((unsigned)((RD.n + 255) / 256)), dim3(256), 0, ctx->stream, RD.seq, RD.qual, RD.off, RD.n, prm->mode, d_seqs.p);
     HIPCHK(ctx, hipGetLastError());
     std::vector<Unit> units(n_groups);
-    for (uint64_t g = 0; g < n_groups; ++g) { units[g].seqs.reserve(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs.push_back(read_order ? read_order[r] : (uint32_t)r); }
+    for (uint64_t g = 0; g < n_groups; ++g) {
+        if (read_order) units[g].seqs.assign(read_order + grp_off[g], read_order + grp_off[g + 1]);
+        else { units[g].seqs.resize(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs[r - grp_off[g]] = (uint32_t)r; }
+    }
     HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= 1024 ? 64 : 128), prm->node_cap, prm->tile_depth, prm->mode, cov != nullptr, prm->trim > 0 ? 1 : 0};
     std::vector<int> nobb;
     htc.mark("units");

@@ -119,6 +119,10 @@ def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total):
     from ngspeciesid_amd._capi import ReadSet, cluster_params
     from ngspeciesid_amd.hostutil import make_cluster_fn
     from ngspeciesid_amd.ptable import select_p_table
+    import gc
+    import ctypes as C0
+    gc.collect(); torch.cuda.empty_cache()            # eight contexts' working sets have to fit beside what earlier tests left cached in this process
+    gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"release_scratch", C0.c_int64(1))
     cfg = bench.CONFIGS[name]; world = 8
     K, W, AB, nsp = cfg["k"], cfg["w"], cfg["abundance_ratio"], cfg["species"]
     abundance = [cfg["geometric"] ** i for i in range(nsp)] if cfg["geometric"] else None
