@@ -12,6 +12,11 @@ struct PoaJobSet {
     uint8_t* out; int32_t* out_len; int32_t* out_span /* (a0, a1) per slot, may be null */; uint64_t* out_cw; uint32_t* out_n; uint32_t* out_cov; uint32_t* dropped; uint32_t* slot_overflow; unsigned long long* phase_cycles;   // optional dev instrumentation (NGSID_POA_PHASES=1)
 };
 
+// Tiles of a level: n sequences in tiles of D in order; a remainder of fewer than (D + 1) / 2 sequences does not get a tile of its own but joins the last full tile
+// (round 3: the one- and two-member remainder tiles were the weak spot of the hierarchy - a single heavy minority member can carry its insertions through them).
+// Tile t covers [t D, t == ntiles - 1 ? n : (t + 1) D).  Mirrors oracle/ngsid_oracle_poa.c: ntiles_of.
+__host__ __device__ inline uint32_t poa_ntiles(uint32_t n, uint32_t D) { if (n == 0) return 0; if (D == 0 || n <= D) return 1; const uint32_t r = n % D; return (r != 0 && r < (D + 1) / 2) ? n / D : (n + D - 1) / D; }
+
 size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW);
 int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band);
 // device-driven hierarchy: scratch for all three band instances sized once (poa_prepare), then launches that neither allocate nor touch the host

@@ -53,9 +53,9 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
             Unit& U = units[u]; if (U.done) continue;
             const uint32_t ncur = (uint32_t)U.seqs.size();
             if (ncur == 0) { U.done = true; continue; }
-            const uint32_t Dl = hp.D > 0 ? (uint32_t)hp.D : ncur;
-            for (uint32_t a = 0; a < ncur; a += Dl) {
-                const uint32_t b = std::min(ncur, a + Dl);
+            const uint32_t Dl = hp.D > 0 ? (uint32_t)hp.D : ncur; const uint32_t nt = poa_ntiles(ncur, Dl);
+            for (uint32_t t = 0; t < nt; ++t) {
+                const uint32_t a = t * Dl, b = t + 1 == nt ? ncur : a + Dl;
                 for (uint32_t x = a; x < b; ++x) seq_idx.push_back(U.seqs[x]);
                 job_off.push_back((uint32_t)seq_idx.size()); job_bb.push_back(U.bb); job_unit.push_back((uint32_t)u);
                 maxD = std::max(maxD, b - a);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_poa_unit_scan(HierDev H, LevelDev Lv, i
     }
     if (threadIdx.x == 0) {
         H.unit_pick[u] = pick;
-        if (pick == -2) { H.unit_ncur[u] = T; tmp[0] = H.D > 0 ? (T + (uint32_t)H.D - 1) / (uint32_t)H.D : 1u; tmp[1] = T; tmp[2] = 0; }
+        if (pick == -2) { H.unit_ncur[u] = T; tmp[0] = H.D > 0 ? poa_ntiles(T, (uint32_t)H.D) : 1u; tmp[1] = T; tmp[2] = 0; }
         else { tmp[0] = 0; tmp[1] = 0; tmp[2] = pick >= 0 ? (uint32_t)Lv.out_len[pick] : 0u; }
     }
 }
@@ -384,8 +384,9 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
             const uint32_t Dl = hp.D > 0 ? (uint32_t)hp.D : ncur;
             const uint32_t base = (uint32_t)seq_idx.size();
             seq_idx.insert(seq_idx.end(), Un.seqs.begin(), Un.seqs.end());          // the unit's sequences in one block copy: its tiles are consecutive slices of it
-            for (uint32_t a = 0; a < ncur; a += Dl) {
-                const uint32_t b = std::min(ncur, a + Dl);
+            const uint32_t nt = poa_ntiles(ncur, Dl);
+            for (uint32_t t = 0; t < nt; ++t) {
+                const uint32_t a = t * Dl, b = t + 1 == nt ? ncur : a + Dl;
                 job_off.push_back(base + b); job_bb.push_back(Un.bb); job_unit.push_back(u);
                 maxD = std::max(maxD, b - a);
             }

@@ -324,6 +324,10 @@ static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* 
     }
 }
 
+/* tiles of a level: n sequences in tiles of D in order; a remainder of fewer than (D + 1) / 2 sequences joins the last full tile instead of forming a tile of its own
+   (one- and two-member remainder tiles were the weak spot of the hierarchy: one heavy minority member carries its insertions through them); tile t = [t D, t == ntiles - 1 ? n : (t + 1) D) */
+static int ntiles_of(int n, int D) { if (n <= 0) return 0; if (D <= 0 || n <= D) return 1; int r = n % D; return (r != 0 && r < (D + 1) / 2) ? n / D : (n + D - 1) / D; }
+
 /* hierarchy: level 0 = the given sequences; tiles of D in order; repeat on the tile consensuses until one is left */
 static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P, int D, int upper_mode, uint8_t** cons, uint32_t** cov, int want_cov) {
     pseq* cur = seqs; int ncur = ns; uint8_t** owned = NULL; int nowned = 0; int level = 0;
@@ -331,10 +335,10 @@ static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P
     if (ns == 0) return 0;
     for (;;) {
         int Dl = D > 0 ? D : ncur;
-        int ntiles = (ncur + Dl - 1) / Dl;
+        int ntiles = ntiles_of(ncur, Dl);
         pout* outs = malloc(sizeof(pout) * (size_t)(ncur + 1)); int nout = 0;
         pprm PL = *P; if (level > 0 && P->trim_tiles) PL.trim_tiles |= 2;      /* upper levels: minority-insertion rule of EMIT */
-        for (int t = 0; t < ntiles; ++t) { int a = t * Dl, b = a + Dl < ncur ? a + Dl : ncur; nout += run_tile(cur + a, b - a, backbone, &PL, outs + nout, want_cov && ntiles == 1); }
+        for (int t = 0; t < ntiles; ++t) { int a = t * Dl, b = t + 1 == ntiles ? ncur : a + Dl; nout += run_tile(cur + a, b - a, backbone, &PL, outs + nout, want_cov && ntiles == 1); }
         if (getenv("ODBG_HIER") && backbone && backbone->len < atoi(getenv("ODBG_HIER"))) {      /* dev aid: tile outputs of a short (last) window, level by level */
             int nshort = 0, nlong = 0, nsemi = 0; const int wl = backbone->len;
             for (int i = 0; i < nout; ++i) { if (outs[i].a1 < wl - 1) ++nshort; if (outs[i].len > wl + 2) ++nlong; if (!(outs[i].a0 < (int)(0.01 * wl) && outs[i].a1 > wl - (int)(0.01 * wl))) ++nsemi; }
