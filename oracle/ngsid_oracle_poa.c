@@ -24,7 +24,11 @@
  *     exact-order POA; tile consensuses (weighted by the reads they stand for) are merged by the same
  *     procedure, level by level.  tile_depth<=0 means one tile = plain spoa order for the whole group;
  *   - a graph that would exceed its node capacity is closed (its consensus is emitted) and a new graph is
- *     started with the sequence that did not fit.
+ *     started with the sequence that did not fit;
+ *   - (round 3) a level's last tile takes a remainder of fewer than (D + 1) / 2 sequences along (ntiles_of), and tile
+ *     consensuses of the UPPER levels drop interior bases whose column carries less than a third of the merged weight
+ *     (EMIT, trim_tiles & 2): the heaviest bundle maximises the SUM of edge weights, so in a tile of two or three heavy
+ *     members a minority's k-base insertion wins once (k + 1) w > W - it would never in one graph of all reads.
  */
 #include <stdint.h>
 #include <stdlib.h>
