@@ -36,15 +36,18 @@ template <> struct CodeT<2> { uint64_t hi, lo; __device__ __forceinline__ bool l
 // LDS of one wave (bytes): hs [NC + 64] | am [NC u16] | then EITHER sraw [ML4] | qraw [ML4] | hist_h, hist_r [2 x 128 int] (phases 1-2) OR lo [NC u64] | hi [NC u64, KW = 2] (phases 3-4)
 // LEAN (reads whose full layout would not fit the 160 KB of a CU: above ~14 800 bases at k <= 21, ~8 600 at k > 21): no code arrays - every
 // k-mer code is rebuilt from the HPC letters where it is compared or emitted (k / 4 dword reads each), 5 bytes per base instead of 11 / 19.
-__host__ __device__ inline size_t mz_lds_per_wave(uint32_t maxlen, int W, int KW, bool lean = false)
+// REG (round 3; windows of up to 16 k-mers, k <= 21 - the ONT default k13 / w20 has 8): no code array and no argmin array either.  The window minima are formed in REGISTERS:
+// 64 consecutive k-mer codes, one per lane, rebuilt from the HPC letters; log2(window) doubling steps with lane shifts (the leftmost-minimum sparse table of the stored layout,
+// without the table); a chunk yields 64 - (window - 1) windows.  3.5 KB of LDS per 800-base read instead of 8.9 KB: the waves per CU are no longer bound by LDS.
+__host__ __device__ inline size_t mz_lds_per_wave(uint32_t maxlen, int W, int KW, int mode = 0 /* 0 stored, 1 lean, 2 reg */)
 {
     const size_t ML4 = ((size_t)maxlen + 7) & ~(size_t)3;
     const size_t NC = (((size_t)maxlen > (size_t)W ? (size_t)maxlen : (size_t)W) + 4 + 3) & ~(size_t)3;
-    const size_t phase12 = 2 * ML4 + 1024, phase34 = lean ? 0 : NC * 8 * (size_t)KW;      // staged read + histograms | k-mer codes: never live together
-    return (NC + 64) + NC * 2 + (phase12 > phase34 ? phase12 : phase34);
+    const size_t phase12 = 2 * ML4 + 1024, phase34 = mode ? 0 : NC * 8 * (size_t)KW;      // staged read + histograms | k-mer codes: never live together
+    return (NC + 64) + (mode == 2 ? 0 : NC * 2) + (phase12 > phase34 ? phase12 : phase34);
 }
 
-template <int KW, bool LEAN>
+template <int KW, int MODE>
 __global__ __launch_bounds__(256)
 void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t nreads,
                       int k, int w, uint32_t maxlen, uint32_t lds_per_wave,
@@ -52,6 +55,7 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
                       uint32_t* __restrict__ out_hlen, double* __restrict__ out_herr, double* __restrict__ out_rawerr, int* __restrict__ flag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool LEAN = MODE == 1, REG = MODE == 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv;
     if (r >= nreads) return;
@@ -60,7 +64,7 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
     const size_t NC = (((size_t)maxlen > (size_t)W ? (size_t)maxlen : (size_t)W) + 4 + 3) & ~(size_t)3;
     unsigned char* base_l = smem + (size_t)wv * lds_per_wave;
     uint8_t* hs = base_l; uint16_t* am = (uint16_t*)(hs + NC + 64);
-    unsigned char* un = (unsigned char*)am + NC * 2;                                      // 8-aligned: NC is a multiple of 4, the wave slice of 16
+    unsigned char* un = (unsigned char*)am + (REG ? 0 : NC * 2);                          // 8-aligned: NC is a multiple of 4, the wave slice of 16 (REG: no argmin array)
     uint8_t* sraw = un; uint8_t* qraw = sraw + ML4; int* hist_h = (int*)(un + 2 * ML4); int* hist_r = hist_h + 128;
     uint64_t* clo = (uint64_t*)un; uint64_t* chi = clo + NC;
     const uint64_t base = off[r];
@@ -157,6 +161,42 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
             lo = ((lo << bits) | pk) & 0x7fffffffffffffffULL;
         }
     };
+    const int nwin = nk >= W ? nk - W + 1 : 1;
+    if constexpr (REG) {
+        // ---- 3 + 4 in registers (KW == 1, W <= 16): lane l of a chunk holds the code of k-mer b + l (positions past nc: +infinity); after the doubling steps it holds the
+        //      leftmost minimum of [b + l, b + l + W) - valid for the first 64 - (W - 1) lanes, which are the windows of this chunk.  Ties keep the left candidate.
+        const int S = 64 - (W - 1);
+        int emitted = 0, carry = -1;
+        for (int b = 0; b < nwin; b += S) {
+            const int p = b + lane;
+            uint64_t code = ~0ull; int pos = p;
+            if (p < nc) { uint64_t lo, hi; kmer_code(p, lo, hi); code = lo; }
+            int span = 1;
+            while (span * 2 <= W) {
+                const uint64_t oc = __shfl_down((unsigned long long)code, span); const int op = __shfl_down(pos, span);
+                if (lane + span < 64 && oc < code) { code = oc; pos = op; }
+                span *= 2;
+            }
+            if (W > span) {
+                const int d = W - span;
+                const uint64_t oc = __shfl_down((unsigned long long)code, d); const int op = __shfl_down(pos, d);
+                if (lane + d < 64 && oc < code) { code = oc; pos = op; }
+            }
+            const int sidx = b + lane; const bool valid = lane < S && sidx < nwin;
+            const int best = valid ? pos : -1;
+            int prev = __shfl_up(best, 1); if (lane == 0) prev = carry;
+            const bool f = valid && best != prev;
+            const unsigned long long m = __ballot(f);
+            if (f) {
+                const uint64_t o = base + (uint64_t)(emitted + __popcll(m & ((1ull << lane) - 1ull)));
+                out_codes[o] = code; out_pos[o] = (uint32_t)best;
+            }
+            emitted += __popcll(m);
+            const int nv = min(S, nwin - b); carry = __shfl(best, nv - 1);
+        }
+        if (lane == 0) out_cnt[r] = (uint32_t)emitted;
+        return;
+    }
     for (int i = lane; i < nc; i += 64) {
         // positions past the end of the string hold zeros already (hs padding); letters beyond hl inside a k-mer are zeros = "end" symbol
         if (!LEAN) { uint64_t lo, hi; kmer_code(i, lo, hi); clo[i] = lo; if (KW == 2) chi[i] = hi; }
@@ -183,7 +223,6 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
         span *= 2;
     }
     // leftmost window minima, emit on position change (ordered compaction, 64 windows per round)
-    const int nwin = nk >= W ? nk - W + 1 : 1;
     int emitted = 0, carry = -1;
     for (int s0 = 0; s0 < nwin; s0 += 64) {
         const int sidx = s0 + lane; int best = -1;
@@ -281,8 +320,13 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     const int KW = k <= 21 ? 1 : 2;
     size_t lpw = (mz_lds_per_wave(R.maxlen, W, KW) + 15) & ~(size_t)15;
     const int wpb = 1;                   // one wave per workgroup: the LDS slice of a read (8.3 KB at 750 bases) is what bounds the waves per CU (measured: 9.5 ms per 10^6 reads, 10.2 ms with four waves per workgroup)
-    const bool lean = lpw * wpb > 160 * 1024 || ngsid_opt(ctx, "minimizers_lean", 0) != 0;      // long reads: codes rebuilt on the fly (the full layout needs 180 KB at 16 384 bases)
-    if (lean) lpw = (mz_lds_per_wave(R.maxlen, W, KW, true) + 15) & ~(size_t)15;
+    // layout: 2 = registers (windows of up to 16 k-mers, one-word codes), 1 = lean (long reads: the stored layout needs 180 KB at 16 384 bases), 0 = stored;
+    // ngsid_ctx_option "minimizers_mode" (1 stored, 2 lean, 3 registers) / "minimizers_lean" pick one for tests - same output from all three
+    int mode = (KW == 1 && W <= 16) ? 2 : 0;
+    const long long want = ngsid_opt(ctx, "minimizers_mode", 0);
+    if (want == 1) mode = 0; else if (want == 2 || ngsid_opt(ctx, "minimizers_lean", 0) != 0) mode = 1; else if (want == 3 && KW == 1 && W <= 32) mode = 2;
+    if (mode == 0 && lpw * wpb > 160 * 1024) mode = 1;
+    if (mode) lpw = (mz_lds_per_wave(R.maxlen, W, KW, mode) + 15) & ~(size_t)15;
     const size_t lds = lpw * wpb;
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "minimizer kernel needs %zu bytes of LDS", lds);
     const unsigned blocks = (unsigned)((R.n + wpb - 1) / wpb);
@@ -295,8 +339,8 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, R.maxlen, (uint32_t)lpw, d_codes, hi_p, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag);
             return hipSuccess;
         };
-        if (KW == 1) HIPCHK(ctx, lean ? go(k_hpc_minimizers<1, true>, nullptr) : go(k_hpc_minimizers<1, false>, nullptr));
-        else HIPCHK(ctx, lean ? go(k_hpc_minimizers<2, true>, d_hi.p) : go(k_hpc_minimizers<2, false>, d_hi.p));
+        if (KW == 1) HIPCHK(ctx, mode == 2 ? go(k_hpc_minimizers<1, 2>, nullptr) : mode == 1 ? go(k_hpc_minimizers<1, 1>, nullptr) : go(k_hpc_minimizers<1, 0>, nullptr));
+        else HIPCHK(ctx, mode == 1 ? go(k_hpc_minimizers<2, 1>, d_hi.p) : go(k_hpc_minimizers<2, 0>, d_hi.p));
     }
     HIPCHK(ctx, hipGetLastError());
     if (KW == 2) return mz_rename_wide(ctx, R, d_codes, d_hi.p, d_cnt);

@@ -82,6 +82,33 @@ def test_minimizers_lean_layout_equals_the_goldens(kw):
         api.close()
 
 
+@pytest.mark.parametrize("kw", [(13, 20), (21, 21), (13, 40), (12, 43), (5, 5), (16, 31)])
+def test_minimizer_layouts_agree(gpu_api, oracle, kw):
+    """round 3: three layouts of the minimizer kernel - window minima in registers (the default for windows of up to 16 k-mers), the stored sparse table, the lean
+    long-read layout - give the oracle's output, on the reference's goldens where they exist and on reads around the chunk boundaries of the register layout"""
+    from ngspeciesid_amd import runtime
+    k, w = kw
+    g = _load("minimizers_sample_h1.npz")
+    rng = np.random.default_rng(k * 100 + w)
+    extra = []
+    for L in list(range(k, k + 4)) + [w - 1, w, w + 1, 57 + k - 1, 58 + k - 1, 64 + k, 2 * 57 + k, 750, 3000]:
+        if L < 1: continue
+        a = rng.integers(0, 4, L); extra.append(("".join("ACGT"[x] for x in a), "".join(chr(33 + int(x)) for x in rng.integers(2, 45, L))))
+    extra.append(("AC" * 200, "I" * 400)); extra.append(("A" * 300, "5" * 300)); extra.append(("ACGTN" * 60, "+" * 300))
+    base = ReadSet(g["seq"], g["qual"], g["off"])
+    rs = ReadSet.from_strings([base.get(i)[0] for i in range(base.n)] + [e[0] for e in extra], [base.get(i)[1] for i in range(base.n)] + [e[1] for e in extra])
+    exp = oracle.hpc_minimizers(rs, k, w)
+    for mode in (0, 1, 2, 3):
+        api = gpu_api if mode == 0 else runtime.new_api(options={"minimizers_mode": mode})
+        try:
+            got = api.hpc_minimizers(rs, k, w)
+        finally:
+            if mode: api.close()
+        for nm, a, b in zip(["moff", "codes", "pos", "hpc_len"], got[:4], exp[:4]):
+            assert np.array_equal(a, b), (mode, nm)
+        assert np.array_equal(got[4], exp[4], equal_nan=True)
+
+
 def _rand_pairs(rng, n, lmin, lmax, sim=True):
     qs, ts = [], []
     for _ in range(n):
