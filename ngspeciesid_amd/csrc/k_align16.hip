@@ -199,9 +199,13 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         // ---- traceback (uniform over the wave), identical bookkeeping to k_sg_align; only the word addressing / nibble layout differ
-        if (J.bp) for (int x = lane; x < J.bp_windows * 4; x += 64) J.bp[p * (uint64_t)J.bp_windows * 4 + x] = -1;
+        // The fields of the job description that only the traceback needs are read from the kernel-argument segment HERE, through a pointer the compiler cannot see
+        // through: kept in SGPRs across the step loops they pushed loop-invariant exec masks into VGPR lanes (18 v_readlane reloads per DP step, 8 % of its VALU work).
+        const AlignJob* Jt = (const AlignJob*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(Jt));
+        if (Jt->bp) for (int x = lane; x < Jt->bp_windows * 4; x += 64) Jt->bp[p * (uint64_t)Jt->bp_windows * 4 + x] = -1;
         {
-            const int K = J.k; const int mid = J.match_id ? J.match_id[p] : K;
+            const int K = Jt->k; const int mid = Jt->match_id ? Jt->match_id[p] : K;
             const uint64_t kmask = (K >= 64) ? ~0ull : ((1ull << K) - 1);
             uint64_t win = 0; int cols = 0, nm = 0, region = 0;
             {
@@ -213,12 +217,12 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
             int i = ei, j = ej, state = 0;
             int q_end = -1, t_end = -1, q_beg = -1, t_beg = -1;
             int cw = -1, w_qf = 0, w_ql = 0, w_tf = 0, w_tl = 0;
-            int32_t* bpp = J.bp ? J.bp + p * (uint64_t)J.bp_windows * 4 : nullptr;
+            int32_t* bpp = Jt->bp ? Jt->bp + p * (uint64_t)Jt->bp_windows * 4 : nullptr;
             int blk_s = -1, blk_g = -1, blk_hi = -1;
             // polishing window of the current column, tracked incrementally (no divisions in the loop): [ws, ws + window), index wsn
-            int wsn = bpp ? j / J.window : 0, ws = bpp ? wsn * J.window : 0;
+            int wsn = bpp ? j / Jt->window : 0, ws = bpp ? wsn * Jt->window : 0;
             while (i >= 0 && j >= 0) {
-                if (bpp) while (j < ws) { ws -= J.window; --wsn; }
+                if (bpp) while (j < ws) { ws -= Jt->window; --wsn; }
                 {   // make sure the block of traceback words around the current cell is in LDS (64 steps x one group of 8 lanes)
                     const int sidx = i / STRIP; const int il = i - sidx * STRIP; const int l = il / RPL; const int rr = il - l * RPL;
                     const int tau = j + 2 * l + rr / RP; const int grp = l >> 3;
@@ -271,12 +275,12 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
                     q_beg = i - run + 1; t_beg = j - run + 1;
                     if (bpp) {
                         const int wn = wsn;
-                        if (wn != cw) { if (lane == 0 && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = i; w_tl = j; }
+                        if (wn != cw) { if (lane == 0 && cw >= 0 && cw < Jt->bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = i; w_tl = j; }
                         w_qf = i - run + 1; w_tf = j - run + 1;
                     }
                     i -= run; j -= run;
                     if (i < 0 || j < 0) break;
-                    if (bpp) while (j < ws) { ws -= J.window; --wsn; }
+                    if (bpp) while (j < ws) { ws -= Jt->window; --wsn; }
                 }
                 if (run == 64 || !((__ballot(inb) >> run) & 1)) continue;     // next cell outside the loaded block: go round (reloads)
                 const int v = __builtin_amdgcn_readlane(vk, run);
@@ -288,7 +292,7 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
                         q_beg = i; t_beg = j;
                         if (bpp) {
                             const int wn = wsn;
-                            if (wn != cw) { if (lane == 0 && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = i; w_tl = j; }
+                            if (wn != cw) { if (lane == 0 && cw >= 0 && cw < Jt->bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = i; w_tl = j; }
                             w_qf = i; w_tf = j;
                         }
                         --i; --j;
@@ -297,7 +301,7 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
                 else { if (!((v >> 3) & 1)) state = 0; --i; }
                 if (emit) { win = (win << 1) | (uint64_t)bit; nm += bit; ++cols; if (cols >= K) region += ((int)__popcll(win & kmask) >= mid); }
             }
-            if (lane == 0 && bpp && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
+            if (lane == 0 && bpp && cw >= 0 && cw < Jt->bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
             {
                 const int z = (i + 1) + (j + 1);
                 const int zl = z < K ? z : K;
@@ -306,11 +310,11 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
             }
             if (cols < K) region = (nm >= mid) ? 1 : 0;
             if (lane == 0) {
-                if (J.score) J.score[p] = best;
-                if (J.ncols) J.ncols[p] = cols;
-                if (J.nmatch) J.nmatch[p] = nm;
-                if (J.region) J.region[p] = region;
-                if (J.span) { J.span[p * 4 + 0] = q_beg; J.span[p * 4 + 1] = q_end; J.span[p * 4 + 2] = t_beg; J.span[p * 4 + 3] = t_end; }
+                if (Jt->score) Jt->score[p] = best;
+                if (Jt->ncols) Jt->ncols[p] = cols;
+                if (Jt->nmatch) Jt->nmatch[p] = nm;
+                if (Jt->region) Jt->region[p] = region;
+                if (Jt->span) { Jt->span[p * 4 + 0] = q_beg; Jt->span[p * 4 + 1] = q_end; Jt->span[p * 4 + 2] = t_beg; Jt->span[p * 4 + 3] = t_end; }
             }
         }
         __builtin_amdgcn_wave_barrier();
