@@ -164,6 +164,7 @@ __device__ void tile_add_first(const GG& g, const PSeq& S, TS& st, int lane)
         g.out_first(i) = g.out_last(i) = (i + 1 < S.len) ? (uint16_t)i : (uint16_t)NONE16;
         if (i > 0) { const int e = i - 1; g.e_tail(e) = (uint16_t)(i - 1); g.e_head(e) = (uint16_t)i; g.e_next_in(e) = NONE16; g.e_next_out(e) = NONE16; g.e_w(e) = wtof(S, i - 1) + wtof(S, i); }
     }
+    for (int i = lane; i <= st.capV; i += 64) { if (i < st.capV) g.need(i) = 0; g.marks(i) = 0; }      // invariant of tile_align_add: all zero between alignments
     st.V = S.len; st.E = S.len > 0 ? S.len - 1 : 0; st.L0 = S.len; st.cw_sum += S.cw;
     mem_sync();
 }
@@ -743,37 +744,34 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     //          64 near row (one or two predecessors, all within the LDS ring, band shifts 0..DLO_MAX),
     //          128 first row of a tight run of chain rows (its length replaces dlo0; see the last pass)
     const BandMap bm = band_map(S, st.L0, BW);
-    for (int r = lane; r < V; r += 64) { g.need(r) = 0; g.ri(r) = (unsigned long long)(unsigned)band_lo(g.anchor(g.order(r)), bm, BW); }      // pass 1: band starts
-    for (int r = lane; r <= V; r += 64) g.marks(r) = 0;
-    mem_sync();
-    // pass 2, two 64-rank chunks per iteration: the loads of both chunks are issued before either is consumed, so the dependent chain
-    // order -> in-edge -> tail -> rank -> band start (L2 / HBM latency each) is paid once for 128 ranks
+    // One pass, two 64-rank chunks per iteration: the loads of both chunks are issued before either is consumed, so the dependent chain
+    // order -> in-edge -> tail -> rank / anchor (L2 / HBM latency each) is paid once for 128 ranks.  The band start of a predecessor is
+    // recomputed from its anchor (a load that travels with the rank lookup) instead of being read back from a first pass over all ranks.
+    // need[] (HBM-copy requests) and marks[] (phase D) are all zero here: the tile start clears them and their readers clear what they find.
+    bool setneed = false;
     for (int rb = 0; rb < V; rb += 128) {
         int vv[2], e0v[2], e1v[2], p0v[2], p1v[2], l0v[2], lp0[2], lp1[2], e2v[2], ofv[2], cdv[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; vv[u] = r < V ? (int)g.order(r) : 0; }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; const bool ok = r < V; e0v[u] = ok ? (int)g.in_first(vv[u]) : NONE16; l0v[u] = ok ? (int)(g.ri(r) & 0xffff) : 0; ofv[u] = ok ? (int)g.out_first(vv[u]) : 0; cdv[u] = ok ? (int)g.code(vv[u]) : 0; }
+        for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; const bool ok = r < V; e0v[u] = ok ? (int)g.in_first(vv[u]) : NONE16; l0v[u] = ok ? (int)g.anchor(vv[u]) : 0; ofv[u] = ok ? (int)g.out_first(vv[u]) : 0; cdv[u] = ok ? (int)g.code(vv[u]) : 0; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const bool h = e0v[u] != NONE16; p0v[u] = h ? (int)g.e_tail(e0v[u]) : 0; e1v[u] = h ? (int)g.e_next_in(e0v[u]) : NONE16; }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const bool h0 = e0v[u] != NONE16, h1 = e1v[u] != NONE16; p0v[u] = h0 ? (int)g.rank(p0v[u]) : 0; p1v[u] = h1 ? (int)g.e_tail(e1v[u]) : 0; e2v[u] = h1 ? (int)g.e_next_in(e1v[u]) : NONE16; }
+        for (int u = 0; u < 2; ++u) { const bool h0 = e0v[u] != NONE16, h1 = e1v[u] != NONE16; lp0[u] = h0 ? (int)g.anchor(p0v[u]) : 0; p0v[u] = h0 ? (int)g.rank(p0v[u]) : 0; p1v[u] = h1 ? (int)g.e_tail(e1v[u]) : 0; e2v[u] = h1 ? (int)g.e_next_in(e1v[u]) : NONE16; }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const bool h0 = e0v[u] != NONE16, h1 = e1v[u] != NONE16; lp0[u] = h0 ? (int)(g.ri(p0v[u]) & 0xffff) : 0; p1v[u] = h1 ? (int)g.rank(p1v[u]) : 0; }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const bool h1 = e1v[u] != NONE16; lp1[u] = h1 ? (int)(g.ri(p1v[u]) & 0xffff) : 0; }
+        for (int u = 0; u < 2; ++u) { const bool h1 = e1v[u] != NONE16; lp1[u] = h1 ? (int)g.anchor(p1v[u]) : 0; p1v[u] = h1 ? (int)g.rank(p1v[u]) : 0; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int r = rb + u * 64 + lane; const bool ok = r < V;          // (no divergent exits: the run lengths below are a wave ballot)
-            const int l0 = l0v[u]; int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
+            const int l0 = band_lo(l0v[u], bm, BW); int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
             if (ok) {
                 if (e0v[u] == NONE16) fl |= 1;
                 else {
-                    // band start of a predecessor = low 16 bits of its row info (written by pass 1; a concurrent full rewrite keeps those bits)
-                    d0 = r - p0v[u]; dl0 = l0 - lp0[u]; if (d0 > HR) g.need(p0v[u]) = 1;
+                    d0 = r - p0v[u]; dl0 = l0 - band_lo(lp0[u], bm, BW); if (d0 > HR) { g.need(p0v[u]) = 1; setneed = true; }
                     if (e1v[u] != NONE16) {
-                        d1 = r - p1v[u]; dl1 = l0 - lp1[u]; if (d1 > HR) g.need(p1v[u]) = 1;
-                        if (e2v[u] != NONE16) { fl |= 2; for (int e = e2v[u]; e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) g.need(pr) = 1; } }
+                        d1 = r - p1v[u]; dl1 = l0 - band_lo(lp1[u], bm, BW); if (d1 > HR) { g.need(p1v[u]) = 1; setneed = true; }
+                        if (e2v[u] != NONE16) { fl |= 2; for (int e = e2v[u]; e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) { g.need(pr) = 1; setneed = true; } } }
                     }
                     if (d0 > 255 || d1 > 255 || dl0 < 0 || dl0 > 255 || dl1 < 0 || dl1 > 255) { fl |= 2; d0 = d1 = dl0 = dl1 = 0; }
                 }
@@ -801,6 +799,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                                | ((unsigned long long)(unsigned)cdv[u] << 48) | ((unsigned long long)(unsigned)fl << 56);
         }
     }
+    const bool anyneed = __ballot(setneed) != 0ull;
     for (int i = lane; i < HR * (RPADL + RPADR); i += 64) {       // guard cells of the ring rows
         const int row = i / (RPADL + RPADR), k = i % (RPADL + RPADR);
         w.hring()[row * (BW + RPADL + RPADR) + (k < RPADL ? k : BW + k)] = 0;          // "minus infinity" of the biased cell values
@@ -808,14 +807,16 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     for (int i = lane; i < L; i += 64) { g.alnode(i) = NONE16; w.sq()[i] = S.s[i]; }
     for (int i = lane; i < BW; i += 64) w.sq()[L + i] = 0xFF;            // pad: columns past the end never match
     if (lane == 0) w.sq()[-1] = 0xFF;
-    mem_sync();
     // last pass: HBM-copy flag (8) of the rows a far successor asked for.  Such a row leaves its tight run: it becomes a plain chain row again
     // (band shift 1) and the rows of the run before it count up to it only.  Far successors are rare: most chunks have nothing to do.
     unsigned kinds[5] = {0, 0, 0, 0, 0};
+    if (anyneed || J.phase_cycles) mem_sync();
+    if (anyneed || J.phase_cycles)
     for (int rb = 0; rb < V; rb += 64) {
         const int r = rb + lane;
         const bool nd = r < V && g.need(r);
         const unsigned long long nm = __ballot(nd);
+        if (nd) g.need(r) = 0;
         if (nm || J.phase_cycles) {
             unsigned long long ri = r < V ? g.ri(r) : 0ull;
             const bool was_tight = ((unsigned)(ri >> 56) & 128u) != 0;
@@ -957,6 +958,12 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     // ---------- A: rank -> node, then the existing node per position: the aligned node if the letter matches, else a sibling (same column)
     //             with that letter whose rank lies strictly between the previous aligned position's node and this one (oracle
     //             g_add_alignment: keeps the order topological without a re-sort)
+    // Per 64-position chunk phase A leaves a summary in LDS (the DP ring is free now): the mask of positions that need a NEW node, the aligned
+    // node of the chunk's last aligned position and the node CHOSEN for its first aligned position (reused sibling or the aligned node).
+    // Phase C then only touches the chunks that create nodes and takes its carries (nearest aligned position before / after) from the summaries.
+    const lu64 ch_new = POA_LDS(lu64, 0);                                   // [nch]
+    const l16 ch_last = POA_LDS(l16, 8u * (unsigned)((L + 63) / 64));      // [nch] aligned node of the last aligned position, NONE16 = none
+    const l16 ch_first = ch_last + (L + 63) / 64;                          // [nch] node chosen for the first aligned position, NONE16 = none
     int nnew = 0;
     {
         int carry = -1;                                   // rank of the aligned node of the nearest aligned position before the chunk
@@ -977,15 +984,22 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 const int psrc = lt ? 63 - __clzll(lt) : 0;
                 const int pv = __shfl(ar, psrc);
                 const int prev_rank = lt ? pv : carry;
+                int chosen = NONE16; const int v = vv[u];
                 if (i < L) {
-                    const uint8_t ch = w.sq()[i]; int found = NONE16; const int v = vv[u];
+                    const uint8_t ch = w.sq()[i]; int found = NONE16;
                     if (ar != NONE16) {
                         if (cdv[u] == ch) found = v;
                         else for (int x = g.ring(v); x != v; x = g.ring(x)) if (g.code(x) == ch) { const int ru = g.rank(x); if (ru > prev_rank && ru < ar) { found = x; break; } }
+                        chosen = found != NONE16 ? found : v;
                     }
                     g.alnode(i) = (uint16_t)v; g.nodeof(i) = (uint16_t)found; isnew = found == NONE16;
                 }
-                nnew += __popcll(__ballot(isnew));
+                const unsigned long long mn = __ballot(isnew);
+                nnew += __popcll(mn);
+                if (ib + u * 64 < L) {
+                    const int fc = __shfl(chosen, ma ? __ffsll((long long)ma) - 1 : 0), lv = __shfl(v, ma ? 63 - __clzll(ma) : 0);
+                    if (lane == 0) { const int c = (ib >> 6) + u; ch_new[c] = mn; ch_first[c] = (uint16_t)(ma ? fc : NONE16); ch_last[c] = (uint16_t)(ma ? lv : NONE16); }
+                }
                 if (ma) { const int hl = 63 - __clzll(ma); carry = __shfl(ar, hl); }
             }
         }
@@ -993,53 +1007,56 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     if (J.phase_cycles) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(g.alnode(i) + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&J.phase_cycles[10], (unsigned long long)nnew); atomicAdd(&J.phase_cycles[11], sm_); } }
     mem_sync();
     if (V + nnew > st.capV || st.E + L > st.capE) return 2;      // oracle g_add_alignment capacity rule
-    // ---------- B: ref(i) = node chosen for the first aligned position >= i (reverse carry scan); new nodes go immediately before it
-    {
-        int carry = NONE16;
-        for (int i0 = ((L - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
-            const int i = i0 + lane; int a = (i < L) ? g.alnode(i) : NONE16;
-            if (a != NONE16 && g.nodeof(i) != NONE16) a = g.nodeof(i);          // the node chosen for an aligned position (reused sibling or the aligned node)
-            const unsigned long long m = __ballot(a != NONE16);
-            const unsigned long long ge = m & (~0ull << lane);
-            const int src = ge ? __ffsll((long long)ge) - 1 : 0;
-            const int val = __shfl(a, src);
-            if (i < L) g.ref(i) = (uint16_t)(ge ? val : carry);
-            if (m) { const int first = __ffsll((long long)m) - 1; carry = __shfl(a, first); }
-        }
-    }
-    mem_sync();
     // ---------- C: create nodes (ids in sequence order).  anchor: nearest aligned position at or before i, else after, else a0.
+    //             A new node goes immediately before rf = the node chosen for the first aligned position >= i (end of the order if there is none).
     //             The k-th new node is inserted before old rank ins (V = end; non-decreasing in k): it lands on rank ins + k, and marks[ins]
-    //             counts it so that phase D can shift the old nodes with one prefix sum.
-    {
+    //             counts it so that phase D can shift the old nodes with one prefix sum.  Chunks without new nodes cost two LDS reads.
+    int ins_min = V;
+    if (nnew) {
+        const int nch = (L + 63) / 64;
         int base = V, lastal = NONE16;
-        for (int i0 = 0; i0 < L; i0 += 64) {
-            const int i = i0 + lane; const int a = (i < L) ? g.alnode(i) : NONE16; const bool isnew = (i < L) && g.nodeof(i) == NONE16;
-            const unsigned long long ma = __ballot(a != NONE16);
-            const unsigned long long le = ma & (~0ull >> (63 - lane));
-            const int src = le ? 63 - __clzll(le) : 0;
-            const int lv = __shfl(a, src);
-            const int la = le ? lv : lastal;
-            const unsigned long long mn = __ballot(isnew);
-            const int before = __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-            if (isnew) {
-                const int y = base + before; const int rf = g.ref(i);
-                const int anc = la != NONE16 ? g.anchor(la) : (rf != NONE16 ? g.anchor(rf) : (S.a1 < S.a0 ? 0 : S.a0));
-                g.code(y) = w.sq()[i]; g.anchor(y) = (uint16_t)anc; g.in_first(y) = g.in_last(y) = g.out_first(y) = g.out_last(y) = NONE16; g.cov(y) = 0;
-                if (a != NONE16) { g.ring(y) = g.ring(a); g.ring(a) = (uint16_t)y; } else g.ring(y) = (uint16_t)y;
-                g.nodeof(i) = (uint16_t)y;
-                const int ins = rf != NONE16 ? (int)g.rank(rf) : V;
-                g.tmpo(ins + (y - V)) = (uint16_t)y; atomicAdd(&g.marks(ins), 1u);
+        for (int c = 0; c < nch; ++c) {
+            const unsigned long long mn = ch_new[c];
+            if (mn) {
+                const int i = c * 64 + lane; const bool isnew = (mn >> lane) & 1ull;
+                const int a = (i < L) ? (int)g.alnode(i) : NONE16; const int nf = (i < L) ? (int)g.nodeof(i) : NONE16;
+                const int chosen = a != NONE16 ? (nf != NONE16 ? nf : a) : NONE16;
+                const unsigned long long ma = __ballot(a != NONE16);
+                const unsigned long long le = ma & (~0ull >> (63 - lane));
+                const int lv = __shfl(a, le ? 63 - __clzll(le) : 0);
+                const int la = le ? lv : lastal;
+                const unsigned long long ge = ma & (~0ull << lane);
+                const int rv = __shfl(chosen, ge ? __ffsll((long long)ge) - 1 : 0);
+                int nxt = NONE16;                                  // node chosen for the first aligned position after the chunk
+                for (int c2 = c + 1; c2 < nch; ++c2) { const int f = ch_first[c2]; if (f != NONE16) { nxt = f; break; } }
+                const int rf = ge ? rv : nxt;
+                const int before = __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                if (isnew) {
+                    const int y = base + before;
+                    const int anc = la != NONE16 ? g.anchor(la) : (rf != NONE16 ? g.anchor(rf) : (S.a1 < S.a0 ? 0 : S.a0));
+                    g.code(y) = w.sq()[i]; g.anchor(y) = (uint16_t)anc; g.in_first(y) = g.in_last(y) = g.out_first(y) = g.out_last(y) = NONE16; g.cov(y) = 0;
+                    if (a != NONE16) { g.ring(y) = g.ring(a); g.ring(a) = (uint16_t)y; } else g.ring(y) = (uint16_t)y;
+                    g.nodeof(i) = (uint16_t)y;
+                    const int ins = rf != NONE16 ? (int)g.rank(rf) : V;
+                    g.tmpo(ins + (y - V)) = (uint16_t)y; atomicAdd(&g.marks(ins), 1u);
+                    ins_min = min(ins_min, ins);
+                }
+                base += __popcll(mn);
             }
-            base += __popcll(mn);
-            if (ma) { const int hl = 63 - __clzll(ma); lastal = __shfl(a, hl); }
+            const int lc = ch_last[c];
+            if (lc != NONE16) lastal = lc;
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ins_min = min(ins_min, __shfl_xor(ins_min, d));
+        ins_min = __builtin_amdgcn_readfirstlane(ins_min);
     }
     mem_sync();
-    // ---------- D: ranks.  old node at rank p -> p + #{new nodes inserted before a rank <= p} (prefix sum of marks); new nodes were placed in C
-    {
+    // ---------- D: ranks.  old node at rank p -> p + #{new nodes inserted before a rank <= p} (prefix sum of marks); new nodes were placed in C.
+    //             Ranks before the first insertion point keep their place; marks[] is left all zero for the next alignment.
+    if (nnew) {
+        const int p0 = ins_min & ~127;
         int carry = 0;
-        for (int pb = 0; pb < V; pb += 128) {
+        for (int pb = p0; pb < V; pb += 128) {
             int mv[2], ov[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) { const int p = pb + u * 64 + lane; mv[u] = p < V ? (int)g.marks(p) : 0; ov[u] = p < V ? (int)g.order(p) : 0; }
@@ -1048,19 +1065,21 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 const int p = pb + u * 64 + lane;
                 const int incl = wave_incl_add_scan(mv[u]) + carry;
                 if (p < V) g.tmpo(p + incl) = (uint16_t)ov[u];
+                if (mv[u]) g.marks(p) = 0;
                 carry = __builtin_amdgcn_readlane(incl, 63);
             }
         }
+        if (lane == 0) g.marks(V) = 0;
         mem_sync();
-        for (int rb = 0; rb < V + nnew; rb += 128) {
+        for (int rb = p0; rb < V + nnew; rb += 128) {
             int tv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; tv[u] = r < V + nnew ? (int)g.tmpo(r) : 0; }
 #pragma unroll
             for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; if (r < V + nnew) { g.order(r) = (uint16_t)tv[u]; g.rank(tv[u]) = (uint16_t)r; } }
         }
+        mem_sync();
     }
-    mem_sync();
     // ---------- E: coverage and edges (edge ids in sequence order)
     {
         int ebase = st.E;
