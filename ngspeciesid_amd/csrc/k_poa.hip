@@ -74,6 +74,14 @@ struct LLT {
     LDSP unsigned int* sinkbits;
 };
 __host__ __device__ inline size_t poa_al16(size_t b) { return (b + 15) & ~(size_t)15; }
+// A per-position u16 array of the alignment being merged (aligned rank / node, chosen node): in LDS when the sequence is short enough for the
+// regions that are free at that time (the DP ring during the traceback and the merge, the direction block during the merge), else in the
+// workgroup's HBM scratch.  `lds` is wave-uniform: every access is one scalar branch.
+struct SeqU16 {
+    LDSP uint16_t* l; uint16_t* gm; bool lds;
+    __device__ __forceinline__ int get(int i) const { return lds ? (int)l[i] : (int)gm[i]; }
+    __device__ __forceinline__ void set(int i, int v) const { if (lds) l[i] = (uint16_t)v; else gm[i] = (uint16_t)v; }
+};
 
 // Single-wave workgroup: LDS instructions of one wave execute in issue order, so ordering LDS traffic between lanes only needs the
 // compiler not to reorder and the LDS queue to drain - no s_barrier and no wait on outstanding HBM stores.
@@ -804,7 +812,10 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         const int row = i / (RPADL + RPADR), k = i % (RPADL + RPADR);
         w.hring()[row * (BW + RPADL + RPADR) + (k < RPADL ? k : BW + k)] = 0;          // "minus infinity" of the biased cell values
     }
-    for (int i = lane; i < L; i += 64) { g.alnode(i) = NONE16; w.sq()[i] = S.s[i]; }
+    // alnode[] / nodeof[] of this alignment: LDS when they fit (ring: 2 bytes x L, direction block: 2 bytes x L, chunk summaries in the row-info block)
+    const bool seq_lds = (unsigned)L * 2u <= (unsigned)(HR * (BW + RPADL + RPADR) * 4) && (unsigned)L * 2u <= (unsigned)(TBR * BW) && (unsigned)((L + 63) / 64) * 12u <= (unsigned)(TBR * 8);
+    const SeqU16 alnode = { POA_LDS(l16, LLT<BW>::HRING), &g.alnode(0), seq_lds }, nodeof = { POA_LDS(l16, LLT<BW>::DIRBLK), &g.nodeof(0), seq_lds };
+    for (int i = lane; i < L; i += 64) { if (!seq_lds) g.alnode(i) = NONE16; w.sq()[i] = S.s[i]; }
     for (int i = lane; i < BW; i += 64) w.sq()[L + i] = 0xFF;            // pad: columns past the end never match
     if (lane == 0) w.sq()[-1] = 0xFF;
     // last pass: HBM-copy flag (8) of the rows a far successor asked for.  Such a row leaves its tight run: it becomes a plain chain row again
@@ -867,6 +878,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     //            a time from HBM into LDS.  alnode[] receives RANKS here.  The walk is serial, but most of it is runs of plain
     //            diagonal moves through chain rows (predecessor = previous rank): lane k speculatively inspects the cell k such moves
     //            ahead, the wave takes the whole leading run at once, and the first other move is decoded from that lane's data.
+    if (seq_lds) { for (int i = lane; i < L; i += 64) alnode.l[i] = NONE16; lds_sync(); }      // (the ring is free now)
     if (aligned_any) {
         // r, j: wave-uniform (scalar registers: the whole walk is scalar control flow, only the speculative look-ahead is per lane)
         int r = __builtin_amdgcn_readfirstlane(bestr);
@@ -928,7 +940,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 const bool clipped = ((ck == 0) & (lok > 0)) | ((ck == BW - 1) & (lok + BW - 1 < L));
                 if (__ballot(loaded & (lane >= top - run) & clipped)) edge = 1;
             }
-            if ((lane <= top) & (lane > top - run)) g.alnode(jk - 1) = (uint16_t)(blk_lo + lane);      // `run` diagonal moves, each to the previous rank
+            if ((lane <= top) & (lane > top - run)) alnode.set(jk - 1, blk_lo + lane);      // `run` diagonal moves, each to the previous rank
             r -= run; j -= run;
             const int nk = top - run;                          // lane holding the next cell of the path
             if (nk < 0) continue;                              // it is in the block below: go round (loads it)
@@ -943,7 +955,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             }
             if (type == 3) break;
             if (type == 2) { --j; continue; }
-            if (type == 0) { if (lane == 0) g.alnode(j - 1) = (uint16_t)r; --j; }
+            if (type == 0) { if (lane == 0) alnode.set(j - 1, r); --j; }
             if (slot == SRC_SLOT) break;
             int pr;
             if (!((rhi >> 24) & 2) && slot <= 1) pr = r - (int)(slot == 0 ? ((rlo >> 16) & 0xff) : (rlo >> 24));
@@ -953,7 +965,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[7], (unsigned long long)n_iter); atomicAdd(&J.phase_cycles[13], (unsigned long long)n_reload); atomicAdd(&J.phase_cycles[14], c_reload); }
         edge_out |= edge;
     }
-    mem_sync();                                       // alnode[] (HBM) is read by other lanes next
+    if (seq_lds) lds_sync(); else mem_sync();         // alnode[] is read by other lanes next
     PH(J, 2, tph);
     // ---------- A: rank -> node, then the existing node per position: the aligned node if the letter matches, else a sibling (same column)
     //             with that letter whose rank lies strictly between the previous aligned position's node and this one (oracle
@@ -961,8 +973,9 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     // Per 64-position chunk phase A leaves a summary in LDS (the DP ring is free now): the mask of positions that need a NEW node, the aligned
     // node of the chunk's last aligned position and the node CHOSEN for its first aligned position (reused sibling or the aligned node).
     // Phase C then only touches the chunks that create nodes and takes its carries (nearest aligned position before / after) from the summaries.
-    const lu64 ch_new = POA_LDS(lu64, 0);                                   // [nch]
-    const l16 ch_last = POA_LDS(l16, 8u * (unsigned)((L + 63) / 64));      // [nch] aligned node of the last aligned position, NONE16 = none
+    const unsigned ch_base = seq_lds ? LLT<BW>::RBLK : 0u;                  // (the ring and the direction block hold alnode[] / nodeof[] then)
+    const lu64 ch_new = POA_LDS(lu64, ch_base);                             // [nch]
+    const l16 ch_last = POA_LDS(l16, ch_base + 8u * (unsigned)((L + 63) / 64));      // [nch] aligned node of the last aligned position, NONE16 = none
     const l16 ch_first = ch_last + (L + 63) / 64;                          // [nch] node chosen for the first aligned position, NONE16 = none
     int nnew = 0;
     {
@@ -970,7 +983,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         for (int ib = 0; ib < L; ib += 128) {             // two chunks per iteration: both chunks' loads are in flight together
             int arv[2], vv[2], cdv[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const int i = ib + u * 64 + lane; arv[u] = (i < L) ? (int)g.alnode(i) : NONE16; }
+            for (int u = 0; u < 2; ++u) { const int i = ib + u * 64 + lane; arv[u] = (i < L) ? alnode.get(i) : NONE16; }
 #pragma unroll
             for (int u = 0; u < 2; ++u) vv[u] = arv[u] != NONE16 ? (int)g.order(arv[u]) : NONE16;
 #pragma unroll
@@ -992,7 +1005,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                         else for (int x = g.ring(v); x != v; x = g.ring(x)) if (g.code(x) == ch) { const int ru = g.rank(x); if (ru > prev_rank && ru < ar) { found = x; break; } }
                         chosen = found != NONE16 ? found : v;
                     }
-                    g.alnode(i) = (uint16_t)v; g.nodeof(i) = (uint16_t)found; isnew = found == NONE16;
+                    alnode.set(i, v); nodeof.set(i, found); isnew = found == NONE16;
                 }
                 const unsigned long long mn = __ballot(isnew);
                 nnew += __popcll(mn);
@@ -1004,8 +1017,8 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             }
         }
     }
-    if (J.phase_cycles) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(g.alnode(i) + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&J.phase_cycles[10], (unsigned long long)nnew); atomicAdd(&J.phase_cycles[11], sm_); } }
-    mem_sync();
+    if (J.phase_cycles) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(alnode.get(i) + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&J.phase_cycles[10], (unsigned long long)nnew); atomicAdd(&J.phase_cycles[11], sm_); } }
+    if (seq_lds) lds_sync(); else mem_sync();
     if (V + nnew > st.capV || st.E + L > st.capE) return 2;      // oracle g_add_alignment capacity rule
     // ---------- C: create nodes (ids in sequence order).  anchor: nearest aligned position at or before i, else after, else a0.
     //             A new node goes immediately before rf = the node chosen for the first aligned position >= i (end of the order if there is none).
@@ -1019,7 +1032,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             const unsigned long long mn = ch_new[c];
             if (mn) {
                 const int i = c * 64 + lane; const bool isnew = (mn >> lane) & 1ull;
-                const int a = (i < L) ? (int)g.alnode(i) : NONE16; const int nf = (i < L) ? (int)g.nodeof(i) : NONE16;
+                const int a = (i < L) ? alnode.get(i) : NONE16; const int nf = (i < L) ? nodeof.get(i) : NONE16;
                 const int chosen = a != NONE16 ? (nf != NONE16 ? nf : a) : NONE16;
                 const unsigned long long ma = __ballot(a != NONE16);
                 const unsigned long long le = ma & (~0ull >> (63 - lane));
@@ -1036,7 +1049,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                     const int anc = la != NONE16 ? g.anchor(la) : (rf != NONE16 ? g.anchor(rf) : (S.a1 < S.a0 ? 0 : S.a0));
                     g.code(y) = w.sq()[i]; g.anchor(y) = (uint16_t)anc; g.in_first(y) = g.in_last(y) = g.out_first(y) = g.out_last(y) = NONE16; g.cov(y) = 0;
                     if (a != NONE16) { g.ring(y) = g.ring(a); g.ring(a) = (uint16_t)y; } else g.ring(y) = (uint16_t)y;
-                    g.nodeof(i) = (uint16_t)y;
+                    nodeof.set(i, y);
                     const int ins = rf != NONE16 ? (int)g.rank(rf) : V;
                     g.tmpo(ins + (y - V)) = (uint16_t)y; atomicAdd(&g.marks(ins), 1u);
                     ins_min = min(ins_min, ins);
@@ -1086,7 +1099,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         for (int ib = 0; ib < L; ib += 128) {             // two chunks per iteration (independent: every node of the path is touched by one position only)
             int av[2], bv[2], e0v[2], h0v[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const int i = ib + u * 64 + lane; bv[u] = i < L ? (int)g.nodeof(i) : NONE16; av[u] = (i < L && i > 0) ? (int)g.nodeof(i - 1) : NONE16; }
+            for (int u = 0; u < 2; ++u) { const int i = ib + u * 64 + lane; bv[u] = i < L ? nodeof.get(i) : NONE16; av[u] = (i < L && i > 0) ? nodeof.get(i - 1) : NONE16; }
 #pragma unroll
             for (int u = 0; u < 2; ++u) e0v[u] = av[u] != NONE16 ? (int)g.out_first(av[u]) : NONE16;
 #pragma unroll
