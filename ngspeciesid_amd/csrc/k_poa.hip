@@ -134,7 +134,9 @@ __device__ __forceinline__ unsigned dir_pack8(unsigned w0, unsigned w1)
 }
 __device__ __forceinline__ ngsid_v4u dir_pack32(const ngsid_v4u a, const ngsid_v4u b) { ngsid_v4u o; o.x = dir_pack8(a.x, a.y); o.y = dir_pack8(a.z, a.w); o.z = dir_pack8(b.x, b.y); o.w = dir_pack8(b.z, b.w); return o; }
 
-#define PH(J, idx, t0) do { if ((J).phase_cycles && lane == 0) { const unsigned long long t1_ = __builtin_readcyclecounter(); atomicAdd(&(J).phase_cycles[idx], t1_ - (t0)); (t0) = t1_; } } while (0)
+// phase counters (NGSID_POA_PHASES): 256 slots of 24 counters, one slot per workgroup modulo 256, so that the instrumentation's atomics do not serialise
+#define PHS(J) ((J).phase_cycles + (blockIdx.x & 255u) * 24u)
+#define PH(J, idx, t0) do { if ((J).phase_cycles && lane == 0) { const unsigned long long t1_ = __builtin_readcyclecounter(); atomicAdd(&PHS(J)[idx], t1_ - (t0)); (t0) = t1_; } } while (0)
 
 struct TS { int V, E, L0, members, nout, capV, capE; unsigned long long cw_sum; };
 
@@ -407,7 +409,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
         J.out_len[slot] = n; J.out_cw[slot] = st.cw_sum;
         if (J.out_span) { J.out_span[2 * slot] = n > 0 ? (int32_t)g.anchor(g.order(g.tmpo(poff + span_b))) : 0; J.out_span[2 * slot + 1] = n > 0 ? (int32_t)g.anchor(g.order(g.tmpo(poff + span_e))) : -1; }
     }
-    if (J.phase_cycles && lane == 0) atomicAdd(&J.phase_cycles[12], (unsigned long long)n);
+    if (J.phase_cycles && lane == 0) atomicAdd(&PHS(J)[12], (unsigned long long)n);
     mem_sync();
     PH(J, 4, tph);
     st.nout += 1;
@@ -821,14 +823,15 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     // last pass: HBM-copy flag (8) of the rows a far successor asked for.  Such a row leaves its tight run: it becomes a plain chain row again
     // (band shift 1) and the rows of the run before it count up to it only.  Far successors are rare: most chunks have nothing to do.
     unsigned kinds[5] = {0, 0, 0, 0, 0};
-    if (anyneed || J.phase_cycles) mem_sync();
-    if (anyneed || J.phase_cycles)
+    const bool ph_detail = J.phase_cycles && J.phase_detail;
+    if (anyneed || ph_detail) mem_sync();
+    if (anyneed || ph_detail)
     for (int rb = 0; rb < V; rb += 64) {
         const int r = rb + lane;
         const bool nd = r < V && g.need(r);
         const unsigned long long nm = __ballot(nd);
         if (nd) g.need(r) = 0;
-        if (nm || J.phase_cycles) {
+        if (nm || ph_detail) {
             unsigned long long ri = r < V ? g.ri(r) : 0ull;
             const bool was_tight = ((unsigned)(ri >> 56) & 128u) != 0;
             bool changed = false;
@@ -841,7 +844,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 if (d < cr) { ri = (ri & ~(0xFFull << 32)) | ((unsigned long long)d << 32); changed = true; }
             }
             if (changed) g.ri(r) = ri;
-            if (J.phase_cycles) {            // dev instrumentation: row kinds of the forward pass (counted per alignment, one atomic each)
+            if (ph_detail) {            // dev instrumentation: row kinds of the forward pass (counted per alignment, one atomic each)
                 const unsigned f2 = (unsigned)(ri >> 56); const bool tg = r < V && (f2 & 128);
                 const unsigned long long tmk = __ballot(tg);
                 kinds[0] += __popcll(tmk); kinds[1] += __popcll(__ballot(tg && (lane == 0 || (lane & (TBR - 1)) == 0 || !((tmk >> (lane - 1)) & 1) || ((nm >> (lane - 1)) & 1))));
@@ -849,7 +852,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             }
         }
     }
-    if (J.phase_cycles && lane == 0) for (int k = 0; k < 5; ++k) atomicAdd(&J.phase_cycles[16 + k], (unsigned long long)kinds[k]);
+    if (ph_detail && lane == 0) for (int k = 0; k < 5; ++k) atomicAdd(&PHS(J)[16 + k], (unsigned long long)kinds[k]);
     mem_sync();
     PH(J, 0, tph);
     // ---------- forward DP, one row per graph node in topological order
@@ -858,7 +861,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     if (local) poa_forward<CPL, NGSID_POA_LOCAL>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     else if (mode == NGSID_POA_SEMI) poa_forward<CPL, NGSID_POA_SEMI>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     else poa_forward<CPL, NGSID_POA_GLOBAL>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
-    if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[5], (unsigned long long)V); atomicAdd(&J.phase_cycles[6], (unsigned long long)nslow); }
+    if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[5], (unsigned long long)V); atomicAdd(&PHS(J)[6], (unsigned long long)nslow); }
     mem_sync();                                       // direction rows must have landed before the traceback pulls them back
     PH(J, 1, tph);
     // ---------- best end cell: max value, ties -> lowest rank, then lowest column
@@ -868,7 +871,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         if (ov > bestv || (ov == bestv && opk < bestpk)) { bestv = ov; bestpk = opk; }
     }
     const int bestr = bestpk == 0x7fffffff ? -1 : (bestpk >> 8), bestc = bestpk & 0xff;
-    if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[8], (unsigned long long)(unsigned)bestv); atomicAdd(&J.phase_cycles[9], (unsigned long long)(unsigned)bestpk); }
+    if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[8], (unsigned long long)(unsigned)bestv); atomicAdd(&PHS(J)[9], (unsigned long long)(unsigned)bestpk); }
     bool aligned_any = true;
     if (bestr < 0 || (mode == NGSID_POA_LOCAL && bestv <= 0)) {
         if (mode != NGSID_POA_LOCAL) return 0;
@@ -962,7 +965,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             else { int e = g.in_first(g.order(r)); for (int t = 0; t < slot; ++t) e = g.e_next_in(e); pr = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(e))); }
             r = pr;
         }
-        if (J.phase_cycles && lane == 0) { atomicAdd(&J.phase_cycles[7], (unsigned long long)n_iter); atomicAdd(&J.phase_cycles[13], (unsigned long long)n_reload); atomicAdd(&J.phase_cycles[14], c_reload); }
+        if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[7], (unsigned long long)n_iter); atomicAdd(&PHS(J)[13], (unsigned long long)n_reload); atomicAdd(&PHS(J)[14], c_reload); }
         edge_out |= edge;
     }
     if (seq_lds) lds_sync(); else mem_sync();         // alnode[] is read by other lanes next
@@ -1017,7 +1020,7 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             }
         }
     }
-    if (J.phase_cycles) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(alnode.get(i) + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&J.phase_cycles[10], (unsigned long long)nnew); atomicAdd(&J.phase_cycles[11], sm_); } }
+    if (ph_detail) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(alnode.get(i) + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&PHS(J)[10], (unsigned long long)nnew); atomicAdd(&PHS(J)[11], sm_); } }
     if (seq_lds) lds_sync(); else mem_sync();
     if (V + nnew > st.capV || st.E + L > st.capE) return 2;      // oracle g_add_alignment capacity rule
     // ---------- C: create nodes (ids in sequence order).  anchor: nearest aligned position at or before i, else after, else a0.
