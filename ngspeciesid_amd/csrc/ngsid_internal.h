@@ -73,6 +73,7 @@ struct ngsid_ctx {
     DevBuf<int32_t> bnd;      // aligner strip boundary rows
     DevBuf<uint32_t> aln_ctr; // aligner work-queue counters (one per launch in flight) + length-class counts
     DevBuf<uint32_t> aln_cls; // pair lists of the length classes
+    DevBuf<uint32_t> aln_pint, aln_psorted; DevBuf<uint8_t> aln_pbin;   // paired aligner (k_align16p.hip): bin counters / offsets, pairs sorted by bin, bin of every class entry
     DevBuf<ngsid_v4u_t> ed_tb; // traceback vectors of the edit-distance aligner
     DevBuf<int8_t> ed_h;       // its horizontal deltas between block groups
     DevBuf<uint32_t> ed_fail;  // pairs beyond the band of the first launch
@@ -145,6 +146,8 @@ int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qle
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
 int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t min_qlen = 0);
 int32_t ngsid_side_streams(ngsid_ctx* ctx);          // creates ctx->side / events on first use
+int32_t ngsid_paired_tb_words(ngsid_ctx* ctx, int cls, uint64_t npairs, uint32_t max_tlen, uint64_t* words);      // k_align16p.hip: two pairs per wave for the classes 2 and 3
+int32_t ngsid_launch_paired_class(ngsid_ctx* ctx, const AlignJob& job, int cls, uint32_t max_tlen, hipStream_t st, uint64_t* tb);
 int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job);      // query-length classes {<=256, <=512, <=768, <=896, rest}: lists in ctx->aln_cls, counts in ctx->aln_ctr[8..12]
 int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out);   // k_ed_align.hip (uses qseq..npairs, bp, bp_windows, window, span)
 

@@ -1,0 +1,85 @@
+"""The two-pairs-per-wave instance of the int16 aligner (csrc/k_align16p.hip; classes of 513 - 896 query bases in batches of >= 4 096 pairs).
+It must return exactly what the one-pair kernel (ngsid_ctx_option align_paired = 0) and the oracle return: score, alignment columns, matches and the
+k-window region count depend on the traceback tie-breaks, so equality of all four pins the whole alignment.
+"""
+import ctypes as C
+import numpy as np
+import pytest
+from ngspeciesid_amd._capi import ReadSet
+
+pytestmark = pytest.mark.gpu
+LET = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _mutate(rng, s, rate):
+    out = []
+    for c in s:
+        u = rng.random()
+        if u < rate * 0.4: out.append(int(LET[rng.integers(0, 4)]))                     # substitution
+        elif u < rate * 0.7: continue                                                   # deletion
+        elif u < rate: out.append(int(c)); out.append(int(LET[rng.integers(0, 4)]))     # insertion
+        else: out.append(int(c))
+    return np.array(out, dtype=np.uint8)
+
+
+def _make(seed, npairs, nt=24):
+    rng = np.random.default_rng(seed)
+    targets = [LET[rng.integers(0, 4, int(rng.integers(500, 930)))] for _ in range(nt)]
+    targets.append(np.zeros(0, dtype=np.uint8))                                        # an empty target: the degenerate branch of the kernel
+    qs, qi, ti = [], [], []
+    for p in range(npairs):
+        t = int(rng.integers(0, nt))
+        base = targets[t] if rng.random() < 0.8 else targets[int(rng.integers(0, nt))]  # 20 % unrelated pairs
+        q = _mutate(rng, base, float(rng.choice([0.02, 0.1, 0.2])))
+        lo = int(rng.integers(0, 40)); hi = len(q) - int(rng.integers(0, 40))
+        q = q[lo:max(hi, lo + 520)][:896]
+        if len(q) < 513: q = np.concatenate([q, LET[rng.integers(0, 4, 513 - len(q))]])
+        if rng.random() < 0.05: q = q.copy(); q[rng.integers(0, len(q), 3)] = ord("N")   # wildcards
+        if rng.random() < 0.05: q = q.copy(); q[: len(q) // 3] |= 0x20                    # lower case (raw-character identity differs from the score's)
+        qs.append(q); qi.append(p); ti.append(t if rng.random() > 0.002 else nt)
+    Q = ReadSet(np.concatenate(qs), None, np.concatenate(([0], np.cumsum([len(x) for x in qs]))).astype(np.uint64))
+    T = ReadSet(np.concatenate(targets), None, np.concatenate(([0], np.cumsum([len(x) for x in targets]))).astype(np.uint64))
+    opens = rng.integers(2, 6, npairs).astype(np.int32)
+    return Q, T, np.array(qi, dtype=np.uint32), np.array(ti, dtype=np.uint32), opens
+
+
+def _opt(api, name, v):
+    assert api.lib.ngsid_ctx_option(api.ctx, name, C.c_int64(v)) == 0
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_paired_kernel_equals_one_pair_kernel_and_oracle(gpu_api, oracle, seed):
+    Q, T, qi, ti, opens = _make(seed, 6000)
+    try:
+        _opt(gpu_api, b"align_paired", 1)
+        a = gpu_api.sg_align_batch(Q, T, qi, ti, opens, k=13)
+        _opt(gpu_api, b"align_paired", 0)
+        b = gpu_api.sg_align_batch(Q, T, qi, ti, opens, k=13)
+    finally:
+        _opt(gpu_api, b"align_paired", 1)
+    names = ("score", "ncols", "nmatch", "region")
+    for x, y, nm in zip(a, b, names):
+        bad = np.nonzero(x != y)[0]
+        assert len(bad) == 0, "%s differs between the paired and the one-pair kernel at pairs %s (seed %d)" % (nm, bad[:8].tolist(), seed)
+    sub = np.random.default_rng(seed).choice(len(qi), 300, replace=False)
+    o = oracle.sg_align_batch(Q, T, qi[sub], ti[sub], opens[sub], k=13)
+    for x, y, nm in zip(a, o, names):
+        assert np.array_equal(x[sub], y), "%s differs from the oracle (seed %d)" % (nm, seed)
+
+
+def test_paired_kernel_odd_bins_and_single_class(gpu_api):
+    """all queries of one length (one residue bin, odd count: the last item holds one pair) and a batch that only has the 769 - 896 class"""
+    rng = np.random.default_rng(9)
+    t = LET[rng.integers(0, 4, 800)]
+    for qlen, npairs in ((700, 4097), (850, 4099)):
+        qs = [_mutate(rng, t, 0.1)[:qlen] for _ in range(npairs)]
+        qs = [np.concatenate([q, LET[rng.integers(0, 4, qlen - len(q))]]) if len(q) < qlen else q for q in qs]
+        Q = ReadSet(np.concatenate(qs), None, (np.arange(npairs + 1) * qlen).astype(np.uint64)); T = ReadSet(t, None, np.array([0, len(t)], dtype=np.uint64))
+        qi = np.arange(npairs, dtype=np.uint32); ti = np.zeros(npairs, dtype=np.uint32)
+        try:
+            _opt(gpu_api, b"align_paired", 1); a = gpu_api.sg_align_batch(Q, T, qi, ti, 3, k=13)
+            _opt(gpu_api, b"align_paired", 0); b = gpu_api.sg_align_batch(Q, T, qi, ti, 3, k=13)
+        finally:
+            _opt(gpu_api, b"align_paired", 1)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
