@@ -430,7 +430,7 @@ int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_q
         // pairs costs the latency of one pair, which would otherwise be paid once per class and call.  Every launch has its own scratch slice.
         { int32_t rs = ngsid_side_streams(ctx); if (rs) return rs; }
         uint64_t tbo[NCLS + 1] = {0}, bo[NCLS + 1] = {0};
-        // classes 2 and 3 (513 - 896 bases: the ONT amplicon lengths) run two pairs per wave (k_align16p.hip) unless ngsid_ctx_option("align_paired", 0)
+        // the classes up to 896 bases (single strip) run two pairs per wave (k_align16p.hip) unless ngsid_ctx_option("align_paired", 0)
         const bool paired = ngsid_opt(ctx, "align_paired", 1) != 0;
         {
             Launch16 L; const uint32_t qb[NCLS] = {256, 512, 768, 896, max_qlen};
@@ -440,7 +440,7 @@ int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_q
                 else if (c == 3) plan16<7>(ctx, n, q, max_tlen, &L); else plan16<8>(ctx, n, q, max_tlen, &L);
                 const bool used = (c == 0 || max_qlen > qb[c - 1]) && min_qlen <= qb[c];
                 uint64_t words = L.nwaves * L.words, bwords = L.nwaves * 2ull * L.bnd_stride;
-                if (paired && (c == 2 || c == 3)) { int32_t rp = ngsid_paired_tb_words(ctx, c, n, max_tlen, &words); if (rp) return rp; bwords = 0; }
+                if (paired && c <= 3) { int32_t rp = ngsid_paired_tb_words(ctx, c, n, max_tlen, &words); if (rp) return rp; bwords = 0; }
                 tbo[c + 1] = tbo[c] + (used ? words : 0); bo[c + 1] = bo[c] + (used ? bwords : 0);
             }
             if (ctx->tb.n < tbo[NCLS]) HIPCHK(ctx, ctx->tb.reserve(tbo[NCLS]));
@@ -450,8 +450,8 @@ int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_q
         for (int i = 0; i < 4; ++i) HIPCHK(ctx, hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0));
         int32_t rc;
         // class 2 (<= 768 bases, the ONT amplicon lengths) stays on the main stream
-        if (min_qlen <= 256 && (rc = launch_class<2>(ctx, job, 0, max_qlen, max_tlen, ctx->side[0], tbo[0], bo[0]))) return rc;
-        if (max_qlen > 256 && min_qlen <= 512 && (rc = launch_class<4>(ctx, job, 1, max_qlen, max_tlen, ctx->side[1], tbo[1], bo[1]))) return rc;
+        if (min_qlen <= 256 && (rc = paired ? ngsid_launch_paired_class(ctx, job, 0, max_tlen, ctx->side[0], ctx->tb.p + tbo[0]) : launch_class<2>(ctx, job, 0, max_qlen, max_tlen, ctx->side[0], tbo[0], bo[0]))) return rc;
+        if (max_qlen > 256 && min_qlen <= 512 && (rc = paired ? ngsid_launch_paired_class(ctx, job, 1, max_tlen, ctx->side[1], ctx->tb.p + tbo[1]) : launch_class<4>(ctx, job, 1, max_qlen, max_tlen, ctx->side[1], tbo[1], bo[1]))) return rc;
         if (max_qlen > 768 && min_qlen <= 896 && (rc = paired ? ngsid_launch_paired_class(ctx, job, 3, max_tlen, ctx->side[2], ctx->tb.p + tbo[3])
                                                                 : launch_class<7>(ctx, job, 3, max_qlen, max_tlen, ctx->side[2], tbo[3], bo[3]))) return rc;
         if (max_qlen > 896 && (rc = launch_class<8>(ctx, job, 4, max_qlen, max_tlen, ctx->side[3], tbo[4], bo[4]))) return rc;

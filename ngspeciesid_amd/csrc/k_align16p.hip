@@ -362,10 +362,11 @@ static int32_t plan16p(ngsid_ctx* ctx, uint64_t npairs, uint32_t max_tlen, Launc
     L->nwaves = std::max<uint64_t>(1, std::min(want, by_mem));
     return NGSID_OK;
 }
-// traceback words (u64) the paired launch of class `cls` (2: 513 - 768 bases, R = 12; 3: 769 - 896, R = 14) needs for a batch of npairs
+// traceback words (u64) the paired launch of length class `cls` (0: <= 256 bases, R = 4 rows per lane; 1: <= 512, R = 8; 2: <= 768, R = 12; 3: <= 896, R = 14) needs for a batch of npairs
 int32_t ngsid_paired_tb_words(ngsid_ctx* ctx, int cls, uint64_t npairs, uint32_t max_tlen, uint64_t* words)
 {
-    LaunchP L; int32_t rc = cls == 2 ? plan16p<12>(ctx, npairs, max_tlen, &L) : plan16p<14>(ctx, npairs, max_tlen, &L); if (rc) return rc;
+    LaunchP L; int32_t rc = cls == 0 ? plan16p<4>(ctx, npairs, max_tlen, &L) : cls == 1 ? plan16p<8>(ctx, npairs, max_tlen, &L) : cls == 2 ? plan16p<12>(ctx, npairs, max_tlen, &L) : plan16p<14>(ctx, npairs, max_tlen, &L);
+    if (rc) return rc;
     *words = L.nwaves * 2 * L.words_half;
     return NGSID_OK;
 }
@@ -388,16 +389,17 @@ static int32_t launch_paired(ngsid_ctx* ctx, const AlignJob& job, int cls, uint3
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }
-// One length class (2 or 3) of a partitioned batch (class lists of ngsid_partition_pairs in ctx->aln_cls / aln_ctr) through the paired kernel on stream st;
+// One length class (0 - 3) of a partitioned batch (class lists of ngsid_partition_pairs in ctx->aln_cls / aln_ctr) through the paired kernel on stream st;
 // tb = this launch's slice of the traceback scratch (ngsid_paired_tb_words).
 int32_t ngsid_launch_paired_class(ngsid_ctx* ctx, const AlignJob& job, int cls, uint32_t max_tlen, hipStream_t st, uint64_t* tb)
 {
     const uint64_t n = job.npairs;
-    const int slot = cls == 2 ? 0 : 1;
+    const int slot = cls;                                  // the class launches of a call run concurrently: one slice of the scratch each
     const size_t ints = 4 * PBINS + 8;
-    if (ctx->aln_pint.n < 2 * ints) HIPCHK(ctx, ctx->aln_pint.alloc(2 * ints));
-    if (ctx->aln_psorted.n < 2 * n) HIPCHK(ctx, ctx->aln_psorted.reserve(2 * n));
-    if (ctx->aln_pbin.n < 2 * n) HIPCHK(ctx, ctx->aln_pbin.reserve(2 * n));
+    if (ctx->aln_pint.n < 4 * ints) HIPCHK(ctx, ctx->aln_pint.alloc(4 * ints));
+    if (ctx->aln_psorted.n < 4 * n) HIPCHK(ctx, ctx->aln_psorted.reserve(4 * n));
+    if (ctx->aln_pbin.n < 4 * n) HIPCHK(ctx, ctx->aln_pbin.reserve(4 * n));
     uint32_t* ibase = ctx->aln_pint.p + slot * ints; uint32_t* sorted = ctx->aln_psorted.p + (size_t)slot * n; uint8_t* bin_of = ctx->aln_pbin.p + (size_t)slot * n;
-    return cls == 2 ? launch_paired<12>(ctx, job, cls, max_tlen, st, ibase, sorted, bin_of, tb) : launch_paired<14>(ctx, job, cls, max_tlen, st, ibase, sorted, bin_of, tb);
+    return cls == 0 ? launch_paired<4>(ctx, job, cls, max_tlen, st, ibase, sorted, bin_of, tb) : cls == 1 ? launch_paired<8>(ctx, job, cls, max_tlen, st, ibase, sorted, bin_of, tb)
+         : cls == 2 ? launch_paired<12>(ctx, job, cls, max_tlen, st, ibase, sorted, bin_of, tb) : launch_paired<14>(ctx, job, cls, max_tlen, st, ibase, sorted, bin_of, tb);
 }

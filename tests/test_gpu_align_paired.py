@@ -1,4 +1,4 @@
-"""The two-pairs-per-wave instance of the int16 aligner (csrc/k_align16p.hip; classes of 513 - 896 query bases in batches of >= 4 096 pairs).
+"""The two-pairs-per-wave instance of the int16 aligner (csrc/k_align16p.hip; queries of up to 896 bases in batches of >= 4 096 pairs).
 It must return exactly what the one-pair kernel (ngsid_ctx_option align_paired = 0) and the oracle return: score, alignment columns, matches and the
 k-window region count depend on the traceback tie-breaks, so equality of all four pins the whole alignment.
 """
@@ -22,9 +22,9 @@ def _mutate(rng, s, rate):
     return np.array(out, dtype=np.uint8)
 
 
-def _make(seed, npairs, nt=24):
+def _make(seed, npairs, nt=24, lo_len=500, min_q=513):
     rng = np.random.default_rng(seed)
-    targets = [LET[rng.integers(0, 4, int(rng.integers(500, 930)))] for _ in range(nt)]
+    targets = [LET[rng.integers(0, 4, int(rng.integers(lo_len, 930)))] for _ in range(nt)]
     targets.append(np.zeros(0, dtype=np.uint8))                                        # an empty target: the degenerate branch of the kernel
     qs, qi, ti = [], [], []
     for p in range(npairs):
@@ -32,8 +32,8 @@ def _make(seed, npairs, nt=24):
         base = targets[t] if rng.random() < 0.8 else targets[int(rng.integers(0, nt))]  # 20 % unrelated pairs
         q = _mutate(rng, base, float(rng.choice([0.02, 0.1, 0.2])))
         lo = int(rng.integers(0, 40)); hi = len(q) - int(rng.integers(0, 40))
-        q = q[lo:max(hi, lo + 520)][:896]
-        if len(q) < 513: q = np.concatenate([q, LET[rng.integers(0, 4, 513 - len(q))]])
+        q = q[lo:max(hi, lo + min_q + 7)][:896]
+        if len(q) < min_q: q = np.concatenate([q, LET[rng.integers(0, 4, min_q - len(q))]])
         if rng.random() < 0.05: q = q.copy(); q[rng.integers(0, len(q), 3)] = ord("N")   # wildcards
         if rng.random() < 0.05: q = q.copy(); q[: len(q) // 3] |= 0x20                    # lower case (raw-character identity differs from the score's)
         qs.append(q); qi.append(p); ti.append(t if rng.random() > 0.002 else nt)
@@ -47,9 +47,10 @@ def _opt(api, name, v):
     assert api.lib.ngsid_ctx_option(api.ctx, name, C.c_int64(v)) == 0
 
 
-@pytest.mark.parametrize("seed", [3, 4])
-def test_paired_kernel_equals_one_pair_kernel_and_oracle(gpu_api, oracle, seed):
-    Q, T, qi, ti, opens = _make(seed, 6000)
+@pytest.mark.parametrize("seed,lo_len,min_q", [(3, 500, 513), (4, 500, 513), (5, 40, 1), (6, 200, 180)])
+def test_paired_kernel_equals_one_pair_kernel_and_oracle(gpu_api, oracle, seed, lo_len, min_q):
+    """(3, 4): the 513 - 896 classes; (5, 6): all four single-strip classes, incl. queries of a few bases"""
+    Q, T, qi, ti, opens = _make(seed, 6000, lo_len=lo_len, min_q=min_q)
     try:
         _opt(gpu_api, b"align_paired", 1)
         a = gpu_api.sg_align_batch(Q, T, qi, ti, opens, k=13)
