@@ -160,30 +160,55 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
         const int W = J.window > 0 ? J.window : 0x7fffffff;
         int cw = -1, w_qf = 0, w_ql = 0, w_tf = 0, w_tl = 0;
         int wsn = j > 0 ? (j - 1) / W : 0, ws = wsn * W;       // window of the current target position, tracked without divisions
-        while (i > 0) {
-            bool diag = false, up = true;
-            if (j > 0) {
-                int tblk = (i - 1) >> 6;
-                if (WIN) { const int lo_row = (j - 1) + dmin - bandK - 1; tblk -= lo_row > 0 ? (lo_row >> 6) : 0; }      // band-relative storage
-                const ngsid_v4u w = __builtin_nontemporal_load(mytb + (((u64)tblk * mstride + (u64)(j - 1)) * 64 + lane));
-                const int bit = (i - 1) & 63;
-                const u64 dv = ((u64)w.y << 32) | w.x, uv = ((u64)w.w << 32) | w.z;
-                diag = (dv >> bit) & 1; up = (uv >> bit) & 1;
+        // The lanes walk their paths IN LOCKSTEP OVER THE TARGET COLUMNS (round 3): in round jj every lane whose path stands in column jj handles that column (any
+        // number of vertical moves, then one diagonal or horizontal move), so the 64 loads of a round go to the same column - one or two coalesced KB instead of
+        // 64 scattered sectors (the paths of a bundle drift apart by a few columns, which made every lane fetch its own sector) - and the word of the next column
+        // is requested one round ahead, for the block the path most likely reaches.  A path that is at j = 0 only has vertical moves left: nothing to record.
+        auto tb_blk = [&](int ii, int col0) { int tb_ = (ii - 1) >> 6; if (WIN) { const int lo_row = col0 + dmin - bandK - 1; tb_ -= lo_row > 0 ? (lo_row >> 6) : 0; } return tb_; };
+        auto tb_load = [&](int tb_, int col0) { return __builtin_nontemporal_load(mytb + (((u64)tb_ * mstride + (u64)col0) * 64 + lane)); };
+        int jj = i > 0 ? j : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) jj = max(jj, __shfl_xor(jj, d));
+        jj = __builtin_amdgcn_readfirstlane(jj);
+        ngsid_v4u wn; wn.x = wn.y = wn.z = wn.w = 0; int wn_blk = -0x7fffffff;
+        if (i > 0 && j == jj && jj >= 1) { wn_blk = tb_blk(i, jj - 1); wn = tb_load(wn_blk, jj - 1); }
+        for (; jj >= 1; --jj) {
+            if (!__ballot(i > 0 && j > 0)) break;
+            const bool on = i > 0 && j == jj;
+            ngsid_v4u w = wn; int wb = wn_blk;
+            wn_blk = -0x7fffffff;
+            if (jj >= 2) {                  // request the word of column jj - 2 for the next round
+                int gi = 0;
+                if (on && i > 1) gi = i - 1;                         // most moves are diagonal
+                else if (i > 0 && j == jj - 1) gi = i;               // a path that starts in the next round
+                if (gi > 0) { wn_blk = tb_blk(gi, jj - 2); wn = tb_load(wn_blk, jj - 2); }
             }
-            if (diag) {
-                const int qi = i - 1, ti = j - 1;
-                if (q_end < 0) { q_end = qi; t_end = ti; }
-                q_beg = qi; t_beg = ti;
-                if (bpp) {
-                    while (ti < ws) { ws -= W; --wsn; }
-                    const int wn = wsn;
-                    if (wn != cw) { if (cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn; w_ql = qi; w_tl = ti; }
-                    w_qf = qi; w_tf = ti;
+            if (on) {
+                { const int nb = tb_blk(i, jj - 1); if (nb != wb) { w = tb_load(nb, jj - 1); wb = nb; } }
+                for (;;) {
+                    const int bit = (i - 1) & 63;
+                    const u64 dv = ((u64)w.y << 32) | w.x, uv = ((u64)w.w << 32) | w.z;
+                    const bool diag = (dv >> bit) & 1, up = (uv >> bit) & 1;
+                    if (diag) {
+                        const int qi = i - 1, ti = j - 1;
+                        if (q_end < 0) { q_end = qi; t_end = ti; }
+                        q_beg = qi; t_beg = ti;
+                        if (bpp) {
+                            while (ti < ws) { ws -= W; --wsn; }
+                            const int wn_ = wsn;
+                            if (wn_ != cw) { if (cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn_; w_ql = qi; w_tl = ti; }
+                            w_qf = qi; w_tf = ti;
+                        }
+                        --i; --j; break;
+                    }
+                    if (!up) { --j; break; }
+                    --i;
+                    if (i == 0) break;
+                    { const int nb = tb_blk(i, jj - 1); if (nb != wb) { w = tb_load(nb, jj - 1); wb = nb; } }
                 }
-                --i; --j;
-            } else if (up) --i;
-            else --j;
+            }
         }
+        i = 0;
         if (bpp && ok && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
         if (have && ok) {
             if (dist_out) dist_out[p] = best;
