@@ -445,6 +445,18 @@ __device__ __forceinline__ void poa_row_tail_store(l32 ringrow, LDSP uint8_t* ds
 template <int CPL, bool LOCAL>
 __device__ __forceinline__ unsigned poa_row_finish(const int (&X)[CPL], const int (&Dd)[CPL], int floor0, int gp, int (&hout)[CPL])
 {
+    if constexpr (CPL == 1) {
+        // One cell per lane: in S space the in-row gap chain IS the inclusive prefix maximum, so the scan result is the cell's value; the cell was reached through
+        // the chain iff that value differs from its own candidate, and (local mode) it sits on the floor iff the value equals the floor (the floor grows with the
+        // column, so the prefix maximum of the floors is the lane's own).  Same values and directions as the general form below, two instructions less per row.
+        const int xf = LOCAL ? max(X[0], floor0) : X[0];
+        const int incl = wave_incl_max_scan(xf);
+        int dd = Dd[0];
+        if (incl != X[0]) dd = 2;
+        if (LOCAL && incl == floor0) dd = 3;
+        hout[0] = incl;
+        return (unsigned)(dd & 0xff);
+    }
     int exl[CPL]; int run = 0;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
