@@ -260,7 +260,7 @@ def main():
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "limited_by": "memory latency under load in the lane-parallel graph phases + VALU issue in the DP rows (not HBM bandwidth): see `issue` and DESIGN.md section 4",
                 "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-                "note": "integer DP kernel, one wave per tile: the DP rows run at the VALU issue rate of six waves per SIMD (23 - 24 VALU per row in the tight loop), the graph phases between them wait for dependent L2 / HBM round trips (`issue` has the counters of the recorded commit) - not bound by HBM bandwidth, so the fraction of the HBM roofline is small by construction (DESIGN.md sections 4 and 10)"}
+                "note": "integer DP kernel, one wave per tile: the DP rows run at the VALU issue rate of six waves per SIMD (21 - 22 VALU per row in the tight loop), the graph phases between them wait for dependent L2 / HBM round trips (`issue` has the counters of the recorded commit) - not bound by HBM bandwidth, so the fraction of the HBM roofline is small by construction (DESIGN.md sections 4 and 10)"}
         if dom[0] == "k_poa_tile":      # instruction-issue view of the same kernel: SQ counters of a committed PMC pass on THIS workload at the default tile depth (not measurable from inside this process)
             try:
                 ij = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_poa_tile.json")))
