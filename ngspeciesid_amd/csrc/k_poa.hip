@@ -20,6 +20,9 @@
 #include "k_poa.h"
 #include <algorithm>
 
+#ifndef POA_REPEAT
+#define POA_REPEAT 0      // dev timing builds (tools/micro/build_repeat.sh): 1 / 2 / 3 / 4 = run the prepass / forward pass / traceback / emission twice (same results)
+#endif
 #define SRC_SLOT 63
 #define NONE16 0xFFFFu
 #define HR 8           // DP rows kept in the LDS ring
@@ -738,6 +741,10 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
         lds_sync();
 #pragma unroll
         for (int xq = 0; xq < NP; ++xq) *(LDSP ngsid_v4u*)(w.dirblk() + (lane + 64 * xq) * 16) = pk[xq];
+#if POA_REPEAT == 3
+#pragma unroll
+        for (int xq = 0; xq < NP; ++xq) *(ngsid_v4u*)(Dg + (size_t)blk * (BW / 2) + (lane + 64 * xq) * 16) = pk[xq];
+#endif
     }
     if (LOCAL) {
         unsigned k = bkey[0]; int cc = 0;
@@ -770,6 +777,13 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     // order -> in-edge -> tail -> rank / anchor (L2 / HBM latency each) is paid once for 128 ranks.  The band start of a predecessor is
     // recomputed from its anchor (a load that travels with the rank lookup) instead of being read back from a first pass over all ranks.
     // need[] (HBM-copy requests) and marks[] (phase D) are all zero here: the tile start clears them and their readers clear what they find.
+    const bool seq_lds = (unsigned)L * 2u <= (unsigned)(HR * (BW + RPADL + RPADR) * 4) && (unsigned)L * 2u <= (unsigned)(TBR * BW) && (unsigned)((L + 63) / 64) * 12u <= (unsigned)(TBR * 8);
+    const SeqU16 alnode = { POA_LDS(l16, LLT<BW>::HRING), &g.alnode(0), seq_lds }, nodeof = { POA_LDS(l16, LLT<BW>::DIRBLK), &g.nodeof(0), seq_lds };
+    unsigned kinds[5] = {0, 0, 0, 0, 0};
+    const bool ph_detail = J.phase_cycles && J.phase_detail;
+#if POA_REPEAT == 1
+    for (int rep_ = 0; rep_ < 2; ++rep_) {
+#endif
     bool setneed = false;
     for (int rb = 0; rb < V; rb += 128) {
         int vv[2], e0v[2], e1v[2], p0v[2], p1v[2], l0v[2], lp0[2], lp1[2], e2v[2], ofv[2], cdv[2];
@@ -827,15 +841,11 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         w.hring()[row * (BW + RPADL + RPADR) + (k < RPADL ? k : BW + k)] = 0;          // "minus infinity" of the biased cell values
     }
     // alnode[] / nodeof[] of this alignment: LDS when they fit (ring: 2 bytes x L, direction block: 2 bytes x L, chunk summaries in the row-info block)
-    const bool seq_lds = (unsigned)L * 2u <= (unsigned)(HR * (BW + RPADL + RPADR) * 4) && (unsigned)L * 2u <= (unsigned)(TBR * BW) && (unsigned)((L + 63) / 64) * 12u <= (unsigned)(TBR * 8);
-    const SeqU16 alnode = { POA_LDS(l16, LLT<BW>::HRING), &g.alnode(0), seq_lds }, nodeof = { POA_LDS(l16, LLT<BW>::DIRBLK), &g.nodeof(0), seq_lds };
     for (int i = lane; i < L; i += 64) { if (!seq_lds) g.alnode(i) = NONE16; w.sq()[i] = S.s[i]; }
     for (int i = lane; i < BW; i += 64) w.sq()[L + i] = 0xFF;            // pad: columns past the end never match
     if (lane == 0) w.sq()[-1] = 0xFF;
     // last pass: HBM-copy flag (8) of the rows a far successor asked for.  Such a row leaves its tight run: it becomes a plain chain row again
     // (band shift 1) and the rows of the run before it count up to it only.  Far successors are rare: most chunks have nothing to do.
-    unsigned kinds[5] = {0, 0, 0, 0, 0};
-    const bool ph_detail = J.phase_cycles && J.phase_detail;
     if (anyneed || ph_detail) mem_sync();
     if (anyneed || ph_detail)
     for (int rb = 0; rb < V; rb += 64) {
@@ -864,12 +874,19 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             }
         }
     }
+#if POA_REPEAT == 1
+    mem_sync();
+    }
+#endif
     if (ph_detail && lane == 0) for (int k = 0; k < 5; ++k) atomicAdd(&PHS(J)[16 + k], (unsigned long long)kinds[k]);
     mem_sync();
     PH(J, 0, tph);
     // ---------- forward DP, one row per graph node in topological order
     const bool local = mode == NGSID_POA_LOCAL;
     int bestv, bestpk, nslow;
+#if POA_REPEAT == 2
+    for (int rep_ = 0; rep_ < 2; ++rep_)
+#endif
     if (local) poa_forward<CPL, NGSID_POA_LOCAL>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     else if (mode == NGSID_POA_SEMI) poa_forward<CPL, NGSID_POA_SEMI>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     else poa_forward<CPL, NGSID_POA_GLOBAL>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
@@ -893,12 +910,18 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     //            a time from HBM into LDS.  alnode[] receives RANKS here.  The walk is serial, but most of it is runs of plain
     //            diagonal moves through chain rows (predecessor = previous rank): lane k speculatively inspects the cell k such moves
     //            ahead, the wave takes the whole leading run at once, and the first other move is decoded from that lane's data.
+#if POA_REPEAT == 3
+    for (int rep_ = 0; rep_ < 2; ++rep_) {
+#endif
     if (seq_lds) { for (int i = lane; i < L; i += 64) alnode.l[i] = NONE16; lds_sync(); }      // (the ring is free now)
     if (aligned_any) {
         // r, j: wave-uniform (scalar registers: the whole walk is scalar control flow, only the speculative look-ahead is per lane)
         int r = __builtin_amdgcn_readfirstlane(bestr);
         int j = (int)(__builtin_amdgcn_readfirstlane((unsigned)g.ri(r)) & 0xffff) + __builtin_amdgcn_readfirstlane(bestc);
         int blk_lo = (V - 1) & ~(TBR - 1);                 // the forward pass left the last block of direction rows in LDS, packed
+#if POA_REPEAT == 3
+        if (rep_) blk_lo = 0x7fffff00;                     // timing build: the second walk reloads its first block from HBM (the forward pass flushed it)
+#endif
         // lane k keeps the row info of rank blk_lo + k in registers (k < TBR): one LDS read per iteration (the direction nibble) instead of two
         unsigned long long myri = lane < TBR ? w.rblk()[lane] : 0ull;
         int n_reload = 0, n_iter = 0; unsigned long long c_reload = 0;
@@ -917,6 +940,9 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             pf_blk = b;
         };
         int edge = 0;
+#if POA_REPEAT == 3
+        if (rep_) pf_blk = -1; else
+#endif
         prefetch(blk_lo - TBR);
         for (int guard = 0;; ++guard) {
             ++n_iter;
@@ -980,6 +1006,10 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
         if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[7], (unsigned long long)n_iter); atomicAdd(&PHS(J)[13], (unsigned long long)n_reload); atomicAdd(&PHS(J)[14], c_reload); }
         edge_out |= edge;
     }
+#if POA_REPEAT == 3
+    lds_sync();
+    }
+#endif
     if (seq_lds) lds_sync(); else mem_sync();         // alnode[] is read by other lanes next
     PH(J, 2, tph);
     // ---------- A: rank -> node, then the existing node per position: the aligned node if the letter matches, else a sibling (same column)
@@ -1223,6 +1253,9 @@ __device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscra
                 st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.cw_sum = 0;
             }
         }
+#if POA_REPEAT == 4
+        { const int no_ = st.nout; tile_emit(g, w, J, job, st, lane); st.nout = no_; }
+#endif
         tile_emit(g, w, J, job, st, lane);
         if (lane == 0) { J.out_n[job] = (uint32_t)st.nout | (edge ? 0x80000000u : 0u); if (ndrop && J.dropped) atomicAdd(J.dropped, ndrop); }      // bit 31: a traceback touched a clipped band edge
         mem_sync();

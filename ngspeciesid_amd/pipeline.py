@@ -105,7 +105,7 @@ def pooled_read_lists(merged, group_reads):
 def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, w=20, abundance_ratio=0.1,
                  rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=None, band=0, node_cap=0,
                  p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2, polish_aln_mode=2, polish_stop_when_stable=True,
-                 strand_aware=False):
+                 strand_aware=False, draft_trim=None):
     """Returns dict(rep_of, status, counters, hpc_err, centers=[(n_reads, c_id, draft, polished, groups)]); with strand_aware (extension, off by
     default: strand.py) also flip [n] = reads that were reverse-complemented for the consensus stages, and rep_of is the merged membership."""
     tile_depth = TILE_DEPTH if tile_depth is None else tile_depth
@@ -141,7 +141,7 @@ def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, 
             b = min(b, a + max_seqs_for_consensus)                              # consensus.py:260
         sub_order.append(order[a:b]); sub_off.append(sub_off[-1] + (b - a))
     sub_order = np.concatenate(sub_order) if sub_order else np.zeros(0, np.uint32)
-    drafts = api.poa_consensus(rs, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=DRAFT_TRIM),
+    drafts = api.poa_consensus(rs, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=DRAFT_TRIM if draft_trim is None else draft_trim),
                                read_order=sub_order)
     T["consensus"] = T.get("consensus", 0.0) + time.perf_counter() - t0
     t0 = time.perf_counter()
