@@ -199,6 +199,13 @@ int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid
                      const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                      uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used);
 
+/* (a17, boundary 8b(1)) ngsid_polish with the sequence after EVERY iteration = the racon_polished_it_{i}.fasta files run_racon leaves behind
+ * (consensus.py:112-120).  it_off has iters * n_groups + 1 entries; entry it * n_groups + g is group g after iteration it (the last iteration is
+ * what ngsid_polish returns); it_used likewise (may be NULL).  With stop_when_stable the iterations after a group became stable repeat its string. */
+int32_t ngsid_polish_trace(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
+                           const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                           uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used);
+
 /* (8e step 3, boundary 8b) the merge rounds of parallel_clustering (parallelize.py:169-217) on the all-gathered representatives of `n_batches`
  * shards: reps = host read set with qualities, batch[i] = 1-based shard index of representative i, score / hpc_err / acc_rank as in
  * ngsid_cluster_greedy.  rep_of[i] = index of the final representative of i.  Every round's clustering is ngsid_cluster_greedy; the schedule

@@ -45,20 +45,36 @@ def run_spoa(reads, spoa_out_file, spoa_path, api=None, tile_depth=DEFAULT_TILE_
 
 
 def run_racon(reads_to_center, center_file, outfolder, cores, racon_iter, api=None, tile_depth=DEFAULT_TILE_DEPTH, band=DEFAULT_BAND, k=13, w=20, trim=2):
-    """(minimap2 -x map-ont -> racon) x racon_iter (consensus.py:107-126): writes outfolder/consensus.fasta (and the last racon_polished_it_*.fasta)."""
+    """(minimap2 -x map-ont -> racon) x racon_iter (consensus.py:107-126): writes outfolder/racon_polished_it_{i}.fasta for every iteration and consensus.fasta."""
     api = api or runtime.get_api()
     accs, seqs, quals = _read_fastx(reads_to_center)
     caccs, cseqs, _ = _read_fastx(center_file)
     rs = ReadSet.from_strings(seqs, quals if quals and all(q is not None for q in quals) else None)
     node_cap = 0 if max((len(s) for s in seqs), default=0) <= 1000 else 22
-    out, used = api.polish(ReadSet.from_strings([cseqs[0]]), rs, [0, len(seqs)],
-                           polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=trim))
+    prm = polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=trim)
     with open(os.path.join(outfolder, "stdout.txt"), "w") as f:
         f.write("")
-    last = os.path.join(outfolder, "racon_polished_it_{0}.fasta".format(max(racon_iter - 1, 0)))
-    with open(last, "w") as f:
-        f.write(">{0} LN:i:{1} RC:i:{2} XC:f:1.000000\n{3}\n".format(caccs[0].split()[0], len(out[0]), int(used[0]), out[0]))
-    shutil.copyfile(last, os.path.join(outfolder, "consensus.fasta"))
+    name = caccs[0].split()[0]
+    if racon_iter >= 1:
+        its, used = api.polish_trace(ReadSet.from_strings([cseqs[0]]), rs, [0, len(seqs)], prm)
+        write_racon_iteration_files(outfolder, name, [x[0] for x in its], [int(u[0]) for u in used])
+    else:                                                       # no iteration: consensus.fasta is the centre file itself (consensus.py:124)
+        shutil.copyfile(center_file, os.path.join(outfolder, "consensus.fasta"))
+
+
+def write_racon_iteration_files(outfolder, name, seqs, used):
+    """the files run_racon leaves in racon_cl_id_X/ (consensus.py:110-124): racon_polished_it_{i}.fasta after every iteration (racon's header tags),
+    the (empty) stderr files of the two tools, consensus.fasta = the last iteration.  The PAF of minimap2 is not produced: the polisher aligns on
+    the device and keeps no per-read text."""
+    last = None
+    for i, (s, u) in enumerate(zip(seqs, used)):
+        for fn in ("mm2_stderr_it_{0}.txt", "racon_stderr_it_{0}.txt"):
+            open(os.path.join(outfolder, fn.format(i)), "w").close()
+        last = os.path.join(outfolder, "racon_polished_it_{0}.fasta".format(i))
+        with open(last, "w") as f:
+            f.write(">{0} LN:i:{1} RC:i:{2} XC:f:1.000000\n{3}\n".format(name, len(s), u, s))
+    if last is not None:
+        shutil.copyfile(last, os.path.join(outfolder, "consensus.fasta"))
 
 
 def highest_aln_identity(seq, seq2, api=None):

@@ -662,9 +662,41 @@ std::string revcomp(const std::string& s) { std::string r(s.size(), 'N'); for (s
 
 }  // namespace
 
+struct PolishTrace { std::vector<std::string> seq; std::vector<uint64_t> used; };      // [it * G + g]: the backbones after every iteration
+
+static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
+                           const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                           uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used, PolishTrace* trace);
+
 extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                                 const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                                 uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used)
+{
+    return polish_impl(ctx, backbones, reads, read_order, grp_off, n_groups, prm, out_off, out, out_cap, needed, n_used, nullptr);
+}
+
+extern "C" int32_t ngsid_polish_trace(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
+                                      const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                                      uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!prm || !it_off || prm->iters < 1) NGSID_FAIL(ctx, NGSID_ERR_ARG, "ngsid_polish_trace: null argument or iters < 1");
+    PolishTrace tr; std::vector<uint64_t> ooff(n_groups + 1, 0); uint64_t need1 = 0;
+    const int32_t rc = polish_impl(ctx, backbones, reads, read_order, grp_off, n_groups, prm, ooff.data(), nullptr, 0, &need1, nullptr, &tr);
+    if (rc != NGSID_OK && rc != NGSID_ERR_CAPACITY) return rc;           // (the final sequences are the trace's last iteration: no buffer was handed to the inner call)
+    uint64_t total = 0; bool ovf = false; it_off[0] = 0;
+    for (size_t x = 0; x < tr.seq.size(); ++x) {
+        if (it_out && total + tr.seq[x].size() <= it_cap) memcpy(it_out + total, tr.seq[x].data(), tr.seq[x].size()); else if (tr.seq[x].size()) ovf = true;
+        total += tr.seq[x].size(); it_off[x + 1] = total; if (it_used) it_used[x] = tr.used[x];
+    }
+    if (needed) *needed = total;
+    if (ovf) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "trace buffer too small: need %llu bytes", (unsigned long long)total);
+    return NGSID_OK;
+}
+
+static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
+                           const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                           uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used, PolishTrace* trace)
 {
     if (!ctx) return NGSID_ERR_ARG;
     if (!backbones || !reads || !grp_off || !prm || !out_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
@@ -689,6 +721,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     if (N == 0 || G == 0) {
         uint64_t total = 0; out_off[0] = 0; bool ovf = false;
         for (uint32_t g = 0; g < G; ++g) { if (total + B[g].size() <= out_cap && out) memcpy(out + total, B[g].data(), B[g].size()); else if (B[g].size()) ovf = true; total += B[g].size(); out_off[g + 1] = total; if (n_used) n_used[g] = 0; }
+        if (trace) for (int it = 0; it < prm->iters; ++it) for (uint32_t g = 0; g < G; ++g) { trace->seq.push_back(B[g]); trace->used.push_back(0); }
         if (needed) *needed = total; if (ovf) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "output buffer too small"); return NGSID_OK;
     }
     // ---- read -> group map, mean read length per group (TGS/NGS window type)
@@ -902,7 +935,9 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
         }
         for (uint32_t g = 0; g < G; ++g) { if (stable[g]) NB[g] = B[g]; else if (prm->stop_when_stable && NB[g] == B[g]) stable[g] = 1; }
         B.swap(NB);
+        if (trace) for (uint32_t g = 0; g < G; ++g) { trace->seq.push_back(B[g]); trace->used.push_back(used[g]); }
     }
+    if (trace) while (trace->seq.size() < (size_t)prm->iters * G) { const size_t x = trace->seq.size() - G; trace->seq.push_back(trace->seq[x]); trace->used.push_back(trace->used[x]); }      // every group stable: the remaining iterations return the same strings
     uint64_t total = 0; bool ovf = false; out_off[0] = 0;
     for (uint32_t g = 0; g < G; ++g) {
         if (total + B[g].size() <= out_cap && out) memcpy(out + total, B[g].data(), B[g].size()); else if (B[g].size()) ovf = true;

@@ -19,6 +19,7 @@ import shutil
 from time import time
 import numpy as np
 from . import runtime, fastio, parallelize, pipeline
+from . import consensus as consensus_mod
 from ._capi import ReadSet, cluster_params, poa_params, polish_params, POA_LOCAL
 from .hostutil import subset_reads
 from .ptable import select_p_table
@@ -339,18 +340,24 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
     if getattr(args, "racon", False) and args.racon_iter >= 0:
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in polish_lists]))).astype(np.uint64)
         bb = ReadSet.from_strings([(polish_backbones or {}).get(m[1], m[2]) for m in merged])
-        polished, used = api.polish(bb, work, p_off, polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=2),
-                                    read_order=np.concatenate(polish_lists).astype(np.uint32))
+        prm = polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=2)
+        ro = np.concatenate(polish_lists).astype(np.uint32)
+        if args.racon_iter >= 1:                     # every iteration's sequence: run_racon leaves racon_polished_it_{i}.fasta behind (consensus.py:112-120)
+            its, its_used = api.polish_trace(bb, work, p_off, prm, read_order=ro)
+            polished, used = its[-1], its_used[-1]
+        else:
+            its, its_used = [], []
+            polished, used = api.polish(bb, work, p_off, prm, read_order=ro)
         for x, (nr, c_id, center, cs) in enumerate(merged):
             logging.debug("running racon on spoa reference {0} using {1} reads for polishing.".format(c_id, len(pooled[x])))
             folder = os.path.join(args.outfolder, "racon_cl_id_{0}".format(c_id))
             os.makedirs(folder, exist_ok=True)
             open(os.path.join(folder, "stdout.txt"), "w").close()
             name = "consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr)
-            last = os.path.join(folder, "racon_polished_it_{0}.fasta".format(max(args.racon_iter - 1, 0)))
-            with open(last, "w") as f:
-                f.write(">{0} LN:i:{1} RC:i:{2} XC:f:1.000000\n{3}\n".format(name, len(polished[x]), int(used[x]), polished[x]))
-            shutil.copyfile(last, os.path.join(folder, "consensus.fasta"))
+            if its:
+                consensus_mod.write_racon_iteration_files(folder, name, [it[x] for it in its], [int(u[x]) for u in its_used])
+            else:
+                shutil.copyfile(os.path.join(args.outfolder, "consensus_reference_{0}.fasta".format(c_id)), os.path.join(folder, "consensus.fasta"))
             merged[x][2] = polished[x]
             if used_out is not None: used_out[c_id] = int(used[x])
         T["polish"] = T.get("polish", 0.0) + time() - t0

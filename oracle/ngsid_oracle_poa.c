@@ -37,8 +37,7 @@
 #include <math.h>
 #include "ngsid_oracle.h"
 
-#define PNEG (-(1 << 28))
-#define SRC_SLOT 63
+#include "ngsid_oracle_poa_int.h"
 
 /* ---------------------------------------------------------------- graph */
 typedef struct {
@@ -75,12 +74,6 @@ static void g_add_edge(graph* G, int a, int b, int64_t w) {
     if (G->in_last[b] < 0) G->in_first[b] = e; else G->e_next_in[G->in_last[b]] = e; G->in_last[b] = e;
 }
 
-/* one sequence handed to the tile engine */
-typedef struct {
-    const uint8_t* s; const uint8_t* q; int len;   /* q == NULL: uniform weight uw */
-    int uw; uint32_t cw; int mode; int a0, a1;     /* a1 < a0: span = whole first sequence */
-} pseq;
-static inline int wt(const pseq* S, int i) { return S->q ? (int)S->q[i] - 33 : S->uw; }
 
 static void g_add_first(graph* G, const pseq* S) {
     for (int i = 0; i < S->len; ++i) { int v = g_new_node(G, S->s[i], i); G->order[v] = v; G->rank[v] = v; G->cov[v] = S->cw; if (i) g_add_edge(G, v - 1, v, (int64_t)wt(S, i - 1) + wt(S, i)); }
@@ -89,7 +82,6 @@ static void g_add_first(graph* G, const pseq* S) {
 
 /* ---------------------------------------------------------------- banded alignment of one sequence to the graph
  * H[r][c]: r = rank, c = column - lo[r]; columns 0..L (column j = j bases consumed).  Returns path pairs in forward order. */
-typedef struct { int node, pos; } ppair;
 
 static inline int band_lo(const graph* G, const pseq* S, int v, int BW) {
     int a0 = S->a0, a1 = S->a1; if (a1 < a0) { a0 = 0; a1 = G->L0 - 1; }
@@ -265,10 +257,10 @@ static int g_consensus(const graph* G, uint8_t* out, uint32_t* cov_out, int* anc
 }
 
 /* ---------------------------------------------------------------- tile engine: sequences in order -> one or more (consensus, cw) */
-typedef struct { uint8_t* s; uint32_t* cov; int len; uint64_t cw; int a0, a1; /* anchors (coordinates in the first sequence of the graph) of the first / last consensus node */ } pout;
-typedef struct { int m, n, g, band, node_cap, trim_tiles; } pprm;
-
-static int cap_for(int L0, int node_cap) { long c = (long)L0 * (node_cap > 0 ? node_cap : 28) / 16; if (c < L0 + 64) c = L0 + 64; return (int)c; }
+/* which tile engine run_tile uses: 0 = the node-indexed graph below (the definition), 1 = the rank-ordered restatement (ngsid_oracle_poa_rank.c).
+   Both give the same bytes (tests/test_consensus_oracle.py::test_rank_engine_equals_node_engine). */
+static int g_poa_engine = 0;
+int32_t ongsid_debug_poa_engine(int32_t e) { const int old = g_poa_engine; if (e >= 0) g_poa_engine = e; return old; }
 
 /* returns number of outputs appended to outs (caller frees .s/.cov) */
 static int run_tile_band(const pseq* seqs, int ns, const pseq* backbone, const pprm* P, int band, int* edge, pout* outs, int want_cov) {
@@ -321,7 +313,8 @@ static int run_tile_band(const pseq* seqs, int ns, const pseq* backbone, const p
 static int run_tile(const pseq* seqs, int ns, const pseq* backbone, const pprm* P, pout* outs, int want_cov) {
     for (int band = P->band;; band *= 2) {
         int edge = 0;
-        const int nout = run_tile_band(seqs, ns, backbone, P, band, &edge, outs, want_cov);
+        if (getenv("ODBG_ENGINE")) { static int said[2]; if (!said[g_poa_engine != 0]) { said[g_poa_engine != 0] = 1; fprintf(stderr, "[oracle] tile engine %d in use\n", g_poa_engine); } }
+        const int nout = g_poa_engine ? run_tile_band_rank(seqs, ns, backbone, P, band, &edge, outs, want_cov) : run_tile_band(seqs, ns, backbone, P, band, &edge, outs, want_cov);
         if (getenv("ODBG_EDGE")) { static long ntile = 0, nredo = 0; ++ntile; if (edge && band < 256) ++nredo; if ((ntile & 1023) == 0) fprintf(stderr, "tiles %ld redone %ld\n", ntile, nredo); }
         if (!edge || band >= 256) return nout;
         for (int i = 0; i < nout; ++i) { free(outs[i].s); free(outs[i].cov); }
@@ -426,8 +419,37 @@ static void lv_push(layervec* L, pseq s) { if (L->n == L->cap) { L->cap = L->cap
 static int polish_nwin(int Bl, int W) { const int raw = Bl <= W ? 1 : (Bl + W - 1) / W; const int tail = Bl - (raw - 1) * W; return (raw >= 2 && tail < W / 10) ? raw - 1 : raw; }
 static int polish_wlen(int Bl, int W, int w) { return w == polish_nwin(Bl, W) - 1 ? Bl - w * W : W; }
 
+typedef struct { uint8_t** seq; int* len; uint64_t* used; } ptrace;      /* [it * G + g] */
+static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                           const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used, ptrace* tr);
 int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                       const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used) {
+    return polish_impl(backbones, reads, read_order, grp_off, n_groups, prm, out_off, out, out_cap, needed, n_used, NULL);
+}
+/* the sequence after every iteration (include/ngsid.h: ngsid_polish_trace) */
+int32_t ongsid_polish_trace(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                            const ngsid_polish_params_t* prm, uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used) {
+    if (!prm || !it_off || prm->iters < 1) return NGSID_ERR_ARG;
+    const size_t n = (size_t)prm->iters * (size_t)n_groups;
+    ptrace tr; tr.seq = calloc(n + 1, sizeof(uint8_t*)); tr.len = calloc(n + 1, sizeof(int)); tr.used = calloc(n + 1, sizeof(uint64_t));
+    uint64_t* ooff = calloc((size_t)n_groups + 1, sizeof(uint64_t)); uint64_t need1 = 0;
+    int32_t rc = polish_impl(backbones, reads, read_order, grp_off, n_groups, prm, ooff, NULL, 0, &need1, NULL, &tr);
+    free(ooff);
+    if (rc == NGSID_OK || rc == NGSID_ERR_CAPACITY) {
+        uint64_t total = 0; int ovf = 0; it_off[0] = 0; rc = NGSID_OK;
+        for (size_t x = 0; x < n; ++x) {
+            if (it_out && total + (uint64_t)tr.len[x] <= it_cap) memcpy(it_out + total, tr.seq[x], (size_t)tr.len[x]); else if (tr.len[x]) ovf = 1;
+            total += (uint64_t)tr.len[x]; it_off[x + 1] = total; if (it_used) it_used[x] = tr.used[x];
+        }
+        if (needed) *needed = total;
+        if (ovf) rc = NGSID_ERR_CAPACITY;
+    }
+    for (size_t x = 0; x < n; ++x) free(tr.seq[x]);
+    free(tr.seq); free(tr.len); free(tr.used);
+    return rc;
+}
+static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                           const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used, ptrace* tr) {
     pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : default_band(reads), prm->node_cap, prm->trim >= 2 };
     const int W = prm->window > 0 ? prm->window : 500;
     int aln_mode = prm->aln_mode;
@@ -530,6 +552,7 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
                 free(c); free(cov); free(LV[wdx].v);
             }
             free(LV); free(B); B = NB; Blen = nb;
+            if (tr) { const size_t x = (size_t)it * (size_t)n_groups + (size_t)g; tr->seq[x] = malloc((size_t)Blen + 1); memcpy(tr->seq[x], B, (size_t)Blen); tr->len[x] = Blen; tr->used[x] = used; }
         }
         if (n_used) n_used[g] = used;
         if (total + (uint64_t)Blen <= out_cap) memcpy(out + total, B, (size_t)Blen); else overflow = 1;

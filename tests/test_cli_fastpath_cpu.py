@@ -109,3 +109,19 @@ def test_background_writers_and_synchronous_writes_give_the_same_files(oracle_ba
     b = _run(oracle_backend, flags, False)
     assert sorted(a) == sorted(b) and all(a[k] == b[k] for k in a)
     assert any(k.startswith("reads_to_consensus_") for k in a) and "sorted.fastq" in a
+
+
+def test_polished_sample_h1_is_pinned(oracle_backend):
+    """regression pin of the consensus half on the reference's own reads: draft, the sequence after every polishing iteration and consensus.fasta of
+    `--consensus --racon --racon_iter 3` (oracle backend) equal tests/golden/sample_h1_consensus_oracle.json - NOT a reference vector (spoa / racon are
+    absent), the file a rule change has to move; tests/test_gpu_cli.py compares the HIP library with the same file."""
+    import json
+    gold = json.load(open(os.path.join(GOLD, "sample_h1_consensus_oracle.json")))["shipped"]
+    f = _run(oracle_backend, ["--t", "1", "--consensus", "--racon", "--racon_iter", "3"], False)
+    cid = gold["c_id"]
+    assert f["consensus_reference_%d.fasta" % cid].decode().split("\n")[1] == gold["draft"]
+    for i in range(3):
+        assert f["racon_cl_id_%d/racon_polished_it_%d.fasta" % (cid, i)].decode().split("\n")[:2] == gold["it%d" % i]
+        assert "racon_cl_id_%d/racon_stderr_it_%d.txt" % (cid, i) in f and "racon_cl_id_%d/mm2_stderr_it_%d.txt" % (cid, i) in f
+    assert f["racon_cl_id_%d/consensus.fasta" % cid].decode() == gold["consensus_fasta"]
+

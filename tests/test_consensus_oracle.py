@@ -111,3 +111,43 @@ def test_short_tail_window_is_merged(oracle, L):
     noisy_bb = truth[:200] + truth[203:len(truth) - 2] + "A" + truth[-2:]
     pol, used = oracle.polish(ReadSet.from_strings([noisy_bb]), rs, [0, rs.n], polish_params(iters=2, k=13, w=20, tile_depth=8, band=0, trim=2))
     assert pol[0] == truth
+
+
+def _engine(oracle, e):
+    import ctypes
+    return oracle.lib.ongsid_debug_poa_engine(ctypes.c_int32(e))
+
+
+def test_rank_engine_equals_node_engine(oracle):
+    """oracle/ngsid_oracle_poa_rank.c (the tile engine on a rank-ordered graph, the representation of csrc/k_poa.hip) returns the bytes of the node-indexed
+    engine that defines the semantics: drafts (local mode) and polishing windows (global / semi-global layers), several depths incl. one graph per group,
+    noisy reads, graphs that are closed early (small node capacity), narrow bands (band-edge redo), unit weights, both strands, coverage output."""
+    cases = []
+    sp, rd, rs = make_set(90, L=400, mu=13.0, seed=5)
+    for D in (0, 4, 6):
+        for trim in (0, 1):
+            cases.append(("draft", rs, dict(tile_depth=D, band=64, trim=trim)))
+    cases.append(("draft", rs, dict(tile_depth=0, band=64, node_cap=18)))                 # graph closed early, restarted
+    cases.append(("draft", rs, dict(tile_depth=5, band=128, node_cap=20, trim=1)))
+    sp2, rd2, rs2 = make_set(60, L=900, mu=11.0, seed=8)
+    cases.append(("draft", rs2, dict(tile_depth=6, band=64, trim=1)))                     # noisy: band-edge redo, far predecessors
+    cases.append(("draft", ReadSet(rs2.seq, None, rs2.off), dict(tile_depth=0, band=128)))   # unit weights: ties between equal weights
+    sp3, rd3, rs3 = make_set(120, L=1100, mu=14.0, seed=9, rc_fraction=0.5)
+    res = {}
+    for e in (0, 1):
+        old = _engine(oracle, e)
+        try:
+            out = []
+            for kind, r, kw in cases:
+                cc = oracle.poa_consensus_cov(r, [0, r.n // 2, r.n], poa_params(**kw))
+                out.append(([c for c, _ in cc], [v.tolist() for _, v in cc]))
+            for D, trim, it in ((6, 2, 2), (0, 1, 1), (4, 0, 2)):
+                bb = rs3.get(int(np.nonzero(rd3["strand"].numpy() == 0)[0][0]))[0]
+                out.append(oracle.polish(ReadSet.from_strings([bb, sp3[0].tobytes().decode()[:-3]]), rs3, [0, rs3.n // 2, rs3.n], polish_params(iters=it, k=13, w=20, tile_depth=D, band=0, trim=trim, stop_when_stable=0)))
+            res[e] = out
+        finally:
+            _engine(oracle, old)
+    assert len(res[0]) == len(res[1])
+    for a, b in zip(res[0], res[1]):
+        assert a[0] == b[0]
+        assert list(a[1]) == list(b[1])

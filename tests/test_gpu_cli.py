@@ -23,38 +23,70 @@ def test_cli_sample_h1_t1(gpu_api, tmp_path):
 
 
 def test_cli_consensus_racon(gpu_api, tmp_path):
-    """--consensus --racon --racon_iter 3 on sample_h1 (BASELINE config[0]): runs through, writes the reference's output files."""
+    """--consensus --racon --racon_iter 3 on sample_h1 (BASELINE config[0]) through the HIP library: the reference's output files, and the draft and the
+    sequence after EVERY polishing iteration equal, byte for byte, what the oracle returns on these real reads (tests/golden/sample_h1_consensus_oracle.json,
+    oracle/make_golden_consensus.py; tests/test_cli_fastpath_cpu.py pins the oracle itself on the same file)."""
+    import json
     from ngspeciesid_amd.cli import cli
     out = str(tmp_path / "out")
     cli(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", out, "--t", "1", "--consensus", "--racon", "--racon_iter", "3"])
+    gold = json.load(open(os.path.join(GOLD, "sample_h1_consensus_oracle.json")))["shipped"]
     refs = [f for f in os.listdir(out) if f.startswith("consensus_reference_")]
     assert len(refs) == 1                                       # the fw and rc clusters (138 + 115 reads) are merged by detect_reverse_complements
     cid = refs[0][len("consensus_reference_"):-len(".fasta")]
+    assert int(cid) == gold["c_id"]
     hdr, seq = open(os.path.join(out, refs[0])).read().split("\n")[:2]
     assert hdr == ">consensus_cl_id_%s_total_supporting_reads_253" % cid
-    pol = open(os.path.join(out, "racon_cl_id_%s" % cid, "consensus.fasta")).read().split("\n")[1]
-    assert 600 < len(pol) < 720 and set(pol) <= set("ACGTN")
+    assert seq == gold["draft"]
+    folder = os.path.join(out, "racon_cl_id_%s" % cid)
+    for i in range(3):                                          # run_racon's per-iteration files (consensus.py:112-120)
+        assert open(os.path.join(folder, "racon_polished_it_%d.fasta" % i)).read().split("\n")[:2] == gold["it%d" % i]
+        assert os.path.exists(os.path.join(folder, "racon_stderr_it_%d.txt" % i)) and os.path.exists(os.path.join(folder, "mm2_stderr_it_%d.txt" % i))
+    assert open(os.path.join(folder, "consensus.fasta")).read() == gold["consensus_fasta"]
     assert os.path.exists(os.path.join(out, "reads_to_consensus_%s.fastq" % cid))
 
 
+def test_consensus_deviation_from_the_reference_order_mode(gpu_api):
+    """the shipped mode (tiles of 6, trimmed tile consensuses, one-third rule) against the mode that restates the reference's tools (ONE
+    graph per cluster / window in file order, spoa's untrimmed bundle, racon's window rule), POLISHED vs POLISHED, on the reference's own reads and on
+    C3-shaped clusters.  The numbers are those of profiles/r04_consensus_deviation.json (same tool, 2 000 reads per cluster, oracle backend); here 400 reads
+    per cluster at mu = 14 on the HIP library.  On synthetic reads the shipped mode returns the amplicon and every difference between the modes is an error
+    of the reference-order mode; on sample_h1 (no truth known) the two polished sequences differ by 10 interior edits + 21 bases of end overhang."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import r04_consensus_deviation as D
+    from ngspeciesid_amd import synth
+    from ngspeciesid_amd._capi import ReadSet
+    from util_seq import edit_distance, overlap_distance
+    L = open(os.path.join(GOLD, "sample_h1.fastq")).read().split("\n")
+    rs = ReadSet.from_strings([L[i + 1] for i in range(0, len(L) - 3, 4)], [L[i + 3] for i in range(0, len(L) - 3, 4)])
+    A = D.run(gpu_api, rs, 0.1, D.SHIPPED); B = D.run(gpu_api, rs, 0.1, D.REFORDER)
+    assert len(A) == len(B) == 1 and A[0][0] == 253
+    assert edit_distance(A[0][2], B[0][2]) == 31 and overlap_distance(A[0][2], B[0][2]) == 10          # the recorded deviation on real reads (oracle == HIP)
+    sp = synth.make_species(5, 750, 0.15, seed=1)
+    rd = synth.make_reads(sp, 2000, mu=14.0, seed=11)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    truths = [s.tobytes().decode() for s in sp]
+    A = D.run(gpu_api, rs, 0.02, D.SHIPPED); B = D.run(gpu_api, rs, 0.02, D.REFORDER)
+    assert len(A) == len(B) == 5
+    assert sorted(c[2] for c in A) == sorted(truths)                                                   # shipped: every polished sequence IS its amplicon
+    tot = 0
+    for c in B:
+        d = D.best_ed(c[2], truths); tot += d
+        assert d <= 12                                          # reference-order mode: up to 7 edits per 750 bases at 400 reads (window junctions, untrimmed ends)
+    print("reference-order mode vs truth: %d edits over 5 clusters" % tot)
+
+
 def test_cli_exact_order_draft_option(gpu_api, tmp_path):
-    """--poa_tile_depth 0 (extension flag): the draft of a cluster is ONE graph built in read order (spoa's order) instead of the depth-8 hierarchy.
-    On sample_h1 (13.6 % read error) with 120 reads per draft both shapes give nearly the same sequence; the cost of the exact order is printed."""
-    import time
+    """--poa_tile_depth 0 (extension flag): the draft of a cluster is ONE graph built in read order (spoa's order) instead of the depth-6 hierarchy; runs
+    through the CLI and gives the oracle's bytes (the accuracy comparison of the two shapes is test_consensus_deviation_from_the_reference_order_mode)."""
     from ngspeciesid_amd.cli import cli
-    from util_seq import edit_distance
-    seqs = {}
-    for depth in ("8", "0"):
-        out = str(tmp_path / ("out" + depth)); t = time.time()
-        cli(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", out, "--t", "1", "--consensus", "--max_seqs_for_consensus", "120", "--poa_tile_depth", depth])
-        dt = time.time() - t
-        refs = sorted(f for f in os.listdir(out) if f.startswith("consensus_reference_"))
-        assert len(refs) == 1
-        seqs[depth] = open(os.path.join(out, refs[0])).read().split("\n")[1]
-        print("poa_tile_depth %s: %.2f s, draft length %d" % (depth, dt, len(seqs[depth])))
-    d = edit_distance(seqs["8"], seqs["0"])
-    print("edit distance tiled vs exact-order draft:", d)
-    assert d <= 6 and 600 < len(seqs["0"]) < 720
+    out = str(tmp_path / "out0")
+    cli(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", out, "--t", "1", "--consensus", "--max_seqs_for_consensus", "120", "--poa_tile_depth", "0"])
+    refs = sorted(f for f in os.listdir(out) if f.startswith("consensus_reference_"))
+    assert len(refs) == 1
+    seq = open(os.path.join(out, refs[0])).read().split("\n")[1]
+    assert 600 < len(seq) < 720 and set(seq) <= set("ACGT")
 
 
 def _files(out):
