@@ -34,26 +34,37 @@
 #define LDSP __attribute__((address_space(3)))
 typedef LDSP uint16_t* l16; typedef LDSP uint8_t* l8; typedef LDSP int32_t* l32; typedef LDSP long long* l64; typedef LDSP unsigned long long* lu64;
 
-struct GG {   // graph arrays in the workgroup's HBM scratch: ONE base pointer + 32-bit byte offsets derived from three strides, so the
-              // arrays cost 2+3 SGPRs instead of 34 and every access is a saddr+voffset global instruction
-    uint8_t* base; uint32_t s16, s8, se, sl;  // bytes of one u16[Vc+1] array, one u8[Vc] array, one u16[Ec] array, one u16[Lmax] array (16-byte multiples)
-#define GG_U16(name, k) __device__ __forceinline__ uint16_t& name(uint32_t i) const { return *(uint16_t*)(base + ((k) * s16 + 2u * i)); }
-    GG_U16(anchor, 0) GG_U16(in_first, 1) GG_U16(in_last, 2) GG_U16(out_first, 3) GG_U16(out_last, 4) GG_U16(ring, 5) GG_U16(order, 6) GG_U16(rank, 7) GG_U16(tmpo, 8)
-#undef GG_U16
-    __device__ __forceinline__ uint8_t& code(uint32_t i) const { return *(base + (9u * s16 + i)); }
-    __device__ __forceinline__ uint8_t& need(uint32_t i) const { return *(base + (9u * s16 + s8 + i)); }
-#define GG_E16(name, k) __device__ __forceinline__ uint16_t& name(uint32_t i) const { return *(uint16_t*)(base + (9u * s16 + 2u * s8 + (k) * se + 2u * i)); }
-    GG_E16(e_tail, 0) GG_E16(e_head, 1) GG_E16(e_next_in, 2) GG_E16(e_next_out, 3)
-#undef GG_E16
-    __device__ __forceinline__ int32_t& e_w(uint32_t i) const { return *(int32_t*)(base + (9u * s16 + 2u * s8 + 4u * se + 4u * i)); }
-    __device__ __forceinline__ uint32_t& cov(uint32_t i) const { return *(uint32_t*)(base + (9u * s16 + 2u * s8 + 6u * se + 4u * i)); }
-    __device__ __forceinline__ unsigned long long& ri(uint32_t i) const { return *(unsigned long long*)(base + (9u * s16 + 6u * s8 + 6u * se + 8u * i)); }   // per-rank row info of the current alignment
-    __device__ __forceinline__ long long& sc(uint32_t i) const { return *(long long*)(base + (9u * s16 + 14u * s8 + 6u * se + 8u * i)); }                    // heaviest-bundle scores per rank
-    __device__ __forceinline__ uint32_t& marks(uint32_t i) const { return *(uint32_t*)(base + (9u * s16 + 22u * s8 + 6u * se + 4u * i)); }                    // new nodes inserted before old rank i
-    // per sequence position (the alignment being merged): aligned rank / node, chosen existing node, insertion reference
-#define GG_L16(name, k) __device__ __forceinline__ uint16_t& name(uint32_t i) const { return *(uint16_t*)(base + (9u * s16 + 26u * s8 + 6u * se + 16u + (k) * sl + 2u * i)); }
-    GG_L16(alnode, 0) GG_L16(nodeof, 1) GG_L16(ref, 2)
-#undef GG_L16
+struct GG {   // the graph in the workgroup's HBM scratch, every array indexed by the node's TOPOLOGICAL RANK (round 4; oracle/ngsid_oracle_poa_rank.c is the
+              // CPU restatement): no node ids, no edge objects.  ONE base pointer + 32-bit byte offsets derived from a few strides.
+    uint8_t* base; uint32_t s32, s64, s16, s8, se16, se32, sl;   // bytes of one u32[Vc+1] / u64[Vc+1] / u16[Vc+1] / u8[Vc+1] / u16[Ec] / i32[Ec] / u16[Lmax] array (16-byte multiples)
+    // pp: ranks of the tails of the first two in-edges in creation order (p0 | p1 << 16, NONE16 = none); ar: anchor | ring << 16 (ring = rank of the next node
+    // aligned to the same column, itself when alone); ww: weights of those two edges (w0 | w1 << 32); cov: count weight
+    __device__ __forceinline__ uint32_t& pp(uint32_t i) const { return *(uint32_t*)(base + 4u * i); }
+    __device__ __forceinline__ uint16_t& p0(uint32_t i) const { return *(uint16_t*)(base + 4u * i); }
+    __device__ __forceinline__ uint16_t& p1(uint32_t i) const { return *(uint16_t*)(base + 4u * i + 2u); }
+    __device__ __forceinline__ uint32_t& ar(uint32_t i) const { return *(uint32_t*)(base + s32 + 4u * i); }
+    __device__ __forceinline__ uint16_t& anchor(uint32_t i) const { return *(uint16_t*)(base + s32 + 4u * i); }
+    __device__ __forceinline__ uint16_t& ring(uint32_t i) const { return *(uint16_t*)(base + s32 + 4u * i + 2u); }
+    __device__ __forceinline__ uint32_t& cov(uint32_t i) const { return *(uint32_t*)(base + 2u * s32 + 4u * i); }
+    __device__ __forceinline__ unsigned long long& ww(uint32_t i) const { return *(unsigned long long*)(base + 3u * s32 + 8u * i); }
+    __device__ __forceinline__ int32_t& w0(uint32_t i) const { return *(int32_t*)(base + 3u * s32 + 8u * i); }
+    __device__ __forceinline__ int32_t& w1(uint32_t i) const { return *(int32_t*)(base + 3u * s32 + 8u * i + 4u); }
+    __device__ __forceinline__ unsigned long long& ri(uint32_t i) const { return *(unsigned long long*)(base + 3u * s32 + s64 + 8u * i); }   // per-rank row info of the current alignment
+    __device__ __forceinline__ long long& sc(uint32_t i) const { return *(long long*)(base + 3u * s32 + 2u * s64 + 8u * i); }                  // heaviest-bundle scores per rank
+    __device__ __forceinline__ uint16_t& tmpo(uint32_t i) const { return *(uint16_t*)(base + 3u * s32 + 3u * s64 + 2u * i); }                  // ranks of the bundle path
+    __device__ __forceinline__ uint16_t& shiftg(uint32_t i) const { return *(uint16_t*)(base + 3u * s32 + 3u * s64 + s16 + 2u * i); }          // shift[] when it does not fit the LDS
+    // cm: letter | 0x80 when the node has more than two in-edges (overflow list); of: 1 = the node has an out-edge; far: 1 = some successor lies more than HR
+    // ranks behind (the forward pass keeps an HBM copy of the row).  of / far are written by the lane of the SUCCESSOR, cm by the node's own lane.
+    __device__ __forceinline__ uint8_t& cm(uint32_t i) const { return *(base + 3u * s32 + 3u * s64 + 2u * s16 + i); }
+    __device__ __forceinline__ uint8_t& of(uint32_t i) const { return *(base + 3u * s32 + 3u * s64 + 2u * s16 + s8 + i); }
+    __device__ __forceinline__ uint8_t& far(uint32_t i) const { return *(base + 3u * s32 + 3u * s64 + 2u * s16 + 2u * s8 + i); }
+    // third and later in-edges, in creation order
+    __device__ __forceinline__ uint16_t& ov_head(uint32_t i) const { return *(uint16_t*)(base + 3u * s32 + 3u * s64 + 2u * s16 + 3u * s8 + 2u * i); }
+    __device__ __forceinline__ uint16_t& ov_tail(uint32_t i) const { return *(uint16_t*)(base + 3u * s32 + 3u * s64 + 2u * s16 + 3u * s8 + se16 + 2u * i); }
+    __device__ __forceinline__ int32_t& ov_w(uint32_t i) const { return *(int32_t*)(base + 3u * s32 + 3u * s64 + 2u * s16 + 3u * s8 + 2u * se16 + 4u * i); }
+    // per sequence position (the alignment being merged) when the LDS cannot hold them: aligned rank, existing / final rank
+    __device__ __forceinline__ uint16_t& alnode(uint32_t i) const { return *(uint16_t*)(base + 3u * s32 + 3u * s64 + 2u * s16 + 3u * s8 + 2u * se16 + se32 + 2u * i); }
+    __device__ __forceinline__ uint16_t& nodeof(uint32_t i) const { return *(uint16_t*)(base + 3u * s32 + 3u * s64 + 2u * s16 + 3u * s8 + 2u * se16 + se32 + sl + 2u * i); }
 };
 // LDS working set.  ~10 KB per tile for 750-base reads, so sixteen tiles (four waves per SIMD) are resident per CU.  The hot arrays sit at
 // COMPILE-TIME offsets so the row loop spends no SGPRs on them.  Layout (BW = band width), alignment phases | consensus phase:
@@ -141,7 +152,7 @@ __device__ __forceinline__ ngsid_v4u dir_pack32(const ngsid_v4u a, const ngsid_v
 #define PHS(J) ((J).phase_cycles + (blockIdx.x & 255u) * 24u)
 #define PH(J, idx, t0) do { if ((J).phase_cycles && lane == 0) { const unsigned long long t1_ = __builtin_readcyclecounter(); atomicAdd(&PHS(J)[idx], t1_ - (t0)); (t0) = t1_; } } while (0)
 
-struct TS { int V, E, L0, members, nout, capV, capE; unsigned long long cw_sum; };
+struct TS { int V, E, L0, members, nout, capV, capE, nov; unsigned long long cw_sum; };      // nov = entries of the overflow in-edge list
 
 __device__ __forceinline__ int wtof(const PSeq& S, int i) { return S.q ? (int)S.q[i] - 33 : S.uw; }
 
@@ -169,17 +180,28 @@ __device__ __forceinline__ int band_lo(int anchor, const BandMap& m, int BW) {
     return (int)lo;
 }
 
-__device__ void tile_add_first(const GG& g, const PSeq& S, TS& st, int lane)
+__device__ __forceinline__ void tile_add_first(const GG& g, const PSeq& S, TS& st, int lane)
 {
     for (int i = lane; i < S.len; i += 64) {
-        g.code(i) = S.s[i]; g.anchor(i) = (uint16_t)i; g.ring(i) = (uint16_t)i; g.order(i) = (uint16_t)i; g.rank(i) = (uint16_t)i; g.cov(i) = S.cw;
-        g.in_first(i) = g.in_last(i) = (i > 0) ? (uint16_t)(i - 1) : (uint16_t)NONE16;
-        g.out_first(i) = g.out_last(i) = (i + 1 < S.len) ? (uint16_t)i : (uint16_t)NONE16;
-        if (i > 0) { const int e = i - 1; g.e_tail(e) = (uint16_t)(i - 1); g.e_head(e) = (uint16_t)i; g.e_next_in(e) = NONE16; g.e_next_out(e) = NONE16; g.e_w(e) = wtof(S, i - 1) + wtof(S, i); }
+        g.cm(i) = S.s[i]; g.ar(i) = (uint32_t)i | ((uint32_t)i << 16); g.cov(i) = S.cw; g.of(i) = (i + 1 < S.len) ? 1 : 0; g.far(i) = 0;
+        g.pp(i) = ((i > 0) ? (uint32_t)(i - 1) : (uint32_t)NONE16) | ((uint32_t)NONE16 << 16);
+        g.ww(i) = (i > 0) ? (unsigned long long)(unsigned)(wtof(S, i - 1) + wtof(S, i)) : 0ull;
     }
-    for (int i = lane; i <= st.capV; i += 64) { if (i < st.capV) g.need(i) = 0; g.marks(i) = 0; }      // invariant of tile_align_add: all zero between alignments
-    st.V = S.len; st.E = S.len > 0 ? S.len - 1 : 0; st.L0 = S.len; st.cw_sum += S.cw;
+    st.V = S.len; st.E = S.len > 0 ? S.len - 1 : 0; st.L0 = S.len; st.cw_sum += S.cw; st.nov = 0;
     mem_sync();
+}
+
+// overflow in-edges (third and later, creation order): index of the first entry at or after `from` whose head is rank r, or -1.  Wave-uniform arguments and
+// result; 64 entries per round (the list holds a handful of entries: 0.7 % of the rows have more than two in-edges).
+__device__ __forceinline__ int ov_next(const GG& g, int nov, int r, int from, int lane)
+{
+    for (int x0 = from & ~63; x0 < nov; x0 += 64) {
+        const int x = x0 + lane;
+        const bool hit = x >= from && x < nov && (int)g.ov_head(x) == r;
+        const unsigned long long m = __ballot(hit);
+        if (m) return x0 + __builtin_ctzll(m);
+    }
+    return -1;
 }
 
 // one pass of the heaviest-bundle recurrence over ranks [rb, V) in RANK space.  Per 64-rank chunk every lane fetches the first two
@@ -193,7 +215,7 @@ __device__ __forceinline__ long long uniform64(long long v)
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 template <int BW>
-__device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int completion, int lane)
+__device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int nov, int rb, int completion, int lane)
 {
     int best = -1; long long best_sv = 0;
     int prev_r = -2; long long prev_sv = 0;                   // score of the rank handled last (register copy of sc[prev_r])
@@ -202,23 +224,17 @@ __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int com
         const int r = r0 + lane;
         unsigned tt = NONE16 | (NONE16 << 16), fl = 0; int w0 = 0, w1 = 0;
         if (r < V) {
-            const int v = g.order(r); const int e0 = g.in_first(v);
-            unsigned t0 = NONE16, t1 = NONE16;
-            if (e0 != NONE16) {
-                t0 = g.rank(g.e_tail(e0)); w0 = g.e_w(e0);
-                const int e1 = g.e_next_in(e0);
-                if (e1 != NONE16) { t1 = g.rank(g.e_tail(e1)); w1 = g.e_w(e1); if (g.e_next_in(e1) != NONE16) fl = 1; }
-            }
-            tt = t0 | (t1 << 16);
-            if (!completion && g.out_first(v) == NONE16) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
+            tt = g.pp(r); const unsigned long long wv = g.ww(r); w0 = (int)(unsigned)wv; w1 = (int)(unsigned)(wv >> 32);
+            if (g.cm(r) & 0x80) fl = 1;
+            if (!completion && !g.of(r)) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
         }
         const int cnt = min(64, V - r0);
         for (int x = 0; x < cnt; ++x) {
             const int rr = r0 + x; long long sv = -1; int pv = NONE16;
             const unsigned tx = __builtin_amdgcn_readlane(tt, x);
+            const int ta = tx & 0xffff, tb = tx >> 16;
+            const long long wa = (int)__builtin_amdgcn_readlane(w0, x), wb = (int)__builtin_amdgcn_readlane(w1, x);
             if (!__builtin_amdgcn_readlane(fl, x)) {
-                const int ta = tx & 0xffff, tb = tx >> 16;
-                const long long wa = (int)__builtin_amdgcn_readlane(w0, x), wb = (int)__builtin_amdgcn_readlane(w1, x);
                 bool ha = ta != NONE16, hb = tb != NONE16, ka = false, kb = false; long long sa = 0, sb = 0;
                 if (completion) {
                     if (ha) { sa = SC(ta); ka = true; if (sa == -1) ha = false; }
@@ -235,13 +251,17 @@ __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int com
                     if (take) { sv = wb; pv = tb; }
                 }
                 if (pv != NONE16) sv += (pv == ta) ? (ka ? sa : SC(ta)) : (kb ? sb : SC(tb));
-            } else {        // more than two in-edges: walk the list in HBM
-                const int v = g.order(rr);
+            } else {        // more than two in-edges: the inline pair, then the overflow entries of the rank, in creation order
                 long long spv = 0;
-                for (int e = __builtin_amdgcn_readfirstlane((int)g.in_first(v)); e != NONE16; e = __builtin_amdgcn_readfirstlane((int)g.e_next_in(e))) {
-                    const int t = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(e))); const long long st_ = SC(t);
+                for (int k = 0; k < 2; ++k) {
+                    const int t = k ? tb : ta; const long long ww = k ? wb : wa; const long long st_ = SC(t);
                     if (completion && st_ == -1) continue;
-                    const long long ww = __builtin_amdgcn_readfirstlane(g.e_w(e));
+                    if (sv < ww || (sv == ww && pv != NONE16 && spv <= st_)) { sv = ww; pv = t; spv = st_; }
+                }
+                for (int e = ov_next(g, nov, rr, 0, lane); e >= 0; e = ov_next(g, nov, rr, e + 1, lane)) {
+                    const int t = __builtin_amdgcn_readfirstlane((int)g.ov_tail(e)); const long long st_ = SC(t);
+                    if (completion && st_ == -1) continue;
+                    const long long ww = __builtin_amdgcn_readfirstlane(g.ov_w(e));
                     if (sv < ww || (sv == ww && pv != NONE16 && spv <= st_)) { sv = ww; pv = t; spv = st_; }
                 }
                 if (pv != NONE16) sv += spv;
@@ -262,37 +282,34 @@ __device__ int bundle_pass(const GG& g, const LLT<BW>& w, int V, int rb, int com
 // (6 rounds of lane shuffles), predecessors before the chunk come from LDS.  A chunk ends in front of the first hard rank whose
 // candidates lie inside it; that rank opens the next chunk with all its candidates final.  Same results as bundle_pass(.., 0, 0, ..).
 template <int BW>
-__device__ int bundle_pass_parallel(const GG& g, const LLT<BW>& w, int V, int lane)
+__device__ int bundle_pass_parallel(const GG& g, const LLT<BW>& w, int V, int nov, int lane)
 {
     int best = -1; long long best_sv = 0;
     int r0 = 0;
     while (r0 < V) {
         const int r = r0 + lane; const bool valid = r < V;
-        int t0 = NONE16, t1 = NONE16, w0 = 0, w1 = 0, v = 0; bool many = false;
+        int t0 = NONE16, t1 = NONE16, w0 = 0, w1 = 0; bool many = false;
         if (valid) {
-            v = g.order(r); const int e0 = g.in_first(v);
-            if (e0 != NONE16) {
-                t0 = g.rank(g.e_tail(e0)); w0 = g.e_w(e0);
-                const int e1 = g.e_next_in(e0);
-                if (e1 != NONE16) { t1 = g.rank(g.e_tail(e1)); w1 = g.e_w(e1); many = g.e_next_in(e1) != NONE16; }
-            }
-            if (g.out_first(v) == NONE16) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
+            const uint32_t ppv = g.pp(r); const unsigned long long wv = g.ww(r);
+            t0 = ppv & 0xffff; t1 = ppv >> 16; w0 = (int)(unsigned)wv; w1 = (int)(unsigned)(wv >> 32);
+            many = (g.cm(r) & 0x80) != 0;
+            if (!g.of(r)) atomicOr((unsigned int*)&w.sinkbits[r >> 5], 1u << (r & 31));
         }
         const bool hard = valid && (many || (t1 != NONE16 && w0 == w1));
-        // candidates of a hard rank inside the chunk?  (with more than two in-edges: be conservative, look at the first two only if both
-        // are early, else treat as inside - such ranks are rare)
+        // candidates of a hard rank inside the chunk?  (with more than two in-edges: treat as inside - such ranks are rare)
         const bool inside = hard && (many ? true : (t0 >= r0 || t1 >= r0));
-        unsigned long long cm = __ballot(inside && lane > 0);
+        unsigned long long cm_ = __ballot(inside && lane > 0);
         // a rank with many in-edges at lane 0 has all candidates before the chunk by definition
-        const int n = min(min(64, V - r0), cm ? __ffsll((long long)cm) - 1 : 64);
+        const int n = min(min(64, V - r0), cm_ ? __ffsll((long long)cm_) - 1 : 64);
         const bool act = lane < n;
         int pv = NONE16; long long val = -1, extv = 0; int ptr = -1;
         if (act) {
             long long wv = -1;
-            if (many) {                                   // lane 0 only: walk the list, all tails are final
+            if (many) {                                   // lane 0 only: the inline pair, then the overflow entries in creation order; all tails are final
                 long long spv = 0;
-                for (int e = g.in_first(v); e != NONE16; e = g.e_next_in(e)) {
-                    const int t = g.rank(g.e_tail(e)); const long long st_ = g.sc(t); const long long ww = g.e_w(e);
+                for (int k = 0; k < 2; ++k) { const int t = k ? t1 : t0; const long long st_ = g.sc(t); const long long ww = k ? w1 : w0; if (wv < ww || (wv == ww && pv != NONE16 && spv <= st_)) { wv = ww; pv = t; spv = st_; } }
+                for (int e = 0; e < nov; ++e) if ((int)g.ov_head(e) == r) {
+                    const int t = g.ov_tail(e); const long long st_ = g.sc(t); const long long ww = g.ov_w(e);
                     if (wv < ww || (wv == ww && pv != NONE16 && spv <= st_)) { wv = ww; pv = t; spv = st_; }
                 }
             } else if (t0 != NONE16) {
@@ -328,7 +345,7 @@ __device__ int bundle_pass_parallel(const GG& g, const LLT<BW>& w, int V, int la
 
 // heaviest bundle + branch completion (oracle g_consensus)
 template <int BW>
-__device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uint32_t job, TS& st, int lane)
+__device__ __forceinline__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uint32_t job, TS& st, int lane)
 {
     if (st.V == 0 || st.members == 0) return;
     if (st.nout >= J.D) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow, 1u); return; }   // host retries with more output slots
@@ -340,18 +357,29 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     mem_sync();
     for (int x = lane; x < (V + 31) / 32; x += 64) w.sinkbits[x] = 0;
     lds_sync();
-    int mx = bundle_pass_parallel(g, w, V, lane);
+    const int nov = st.nov;
+    int mx = bundle_pass_parallel(g, w, V, nov, lane);
     unsigned long long tph2 = tph;
     for (int guard = 0; !((w.sinkbits[mx >> 5] >> (mx & 31)) & 1u); ++guard) {
         if (guard > V) { if (lane == 0 && J.slot_overflow) atomicExch(J.slot_overflow + 1, 2u); break; }   // cannot happen: each completion pass starts further down
         const int start = mx;
-        if (lane == 0) {
-            const int sv = g.order(start);
-            for (int e = g.out_first(sv); e != NONE16; e = g.e_next_out(e))
-                for (int f = g.in_first(g.e_head(e)); f != NONE16; f = g.e_next_in(f)) if (g.e_tail(f) != sv) g.sc(g.rank(g.e_tail(f))) = -1;
+        // every other in-edge tail of the successors of `start` is taken out (oracle g_consensus).  Lane-parallel over the ranks behind start: a rank is a
+        // successor if start is among its in-edge tails (inline pair or overflow entries)
+        for (int h0 = start + 1; h0 < V; h0 += 64) {
+            const int h = h0 + lane;
+            if (h < V) {
+                const uint32_t ppv = g.pp(h); const int t0 = ppv & 0xffff, t1 = ppv >> 16; const bool many = (g.cm(h) & 0x80) != 0;
+                bool succ = t0 == start || t1 == start;
+                if (many && !succ) for (int e = 0; e < nov; ++e) if ((int)g.ov_head(e) == h && (int)g.ov_tail(e) == start) succ = true;
+                if (succ) {
+                    if (t0 != NONE16 && t0 != start) g.sc(t0) = -1;
+                    if (t1 != NONE16 && t1 != start) g.sc(t1) = -1;
+                    if (many) for (int e = 0; e < nov; ++e) if ((int)g.ov_head(e) == h && (int)g.ov_tail(e) != start) g.sc(g.ov_tail(e)) = -1;
+                }
+            }
         }
         mem_sync();
-        const int m2 = bundle_pass(g, w, V, start + 1, 1, lane);
+        const int m2 = bundle_pass(g, w, V, nov, start + 1, 1, lane);
         if (m2 < 0) break;
         mx = m2;
     }
@@ -376,7 +404,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     mem_sync();
     PH(J, 15, tph2);
     for (int i = lane; i < n; i += 64) {
-        const int v = g.order(g.tmpo(poff + i)); dst[i] = g.code(v);
+        const int v = g.tmpo(poff + i); dst[i] = g.cm(v) & 0x7f;
         if (dcov) { uint32_t c = g.cov(v); for (int u = g.ring(v); u != v; u = g.ring(u)) c += g.cov(u); dcov[i] = c; }
     }
     mem_sync();
@@ -410,7 +438,7 @@ __device__ void tile_emit(const GG& g, const LLT<BW>& w, const PoaJobSet& J, uin
     }
     if (lane == 0) {
         J.out_len[slot] = n; J.out_cw[slot] = st.cw_sum;
-        if (J.out_span) { J.out_span[2 * slot] = n > 0 ? (int32_t)g.anchor(g.order(g.tmpo(poff + span_b))) : 0; J.out_span[2 * slot + 1] = n > 0 ? (int32_t)g.anchor(g.order(g.tmpo(poff + span_e))) : -1; }
+        if (J.out_span) { J.out_span[2 * slot] = n > 0 ? (int32_t)g.anchor(g.tmpo(poff + span_b)) : 0; J.out_span[2 * slot + 1] = n > 0 ? (int32_t)g.anchor(g.tmpo(poff + span_e)) : -1; }
     }
     if (J.phase_cycles && lane == 0) atomicAdd(&PHS(J)[12], (unsigned long long)n);
     mem_sync();
@@ -481,7 +509,7 @@ __device__ __forceinline__ unsigned poa_row_finish(const int (&X)[CPL], const in
 }
 
 template <int CPL, int MODE>
-__device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, uint8_t* Dfull, const PSeq& S, int V, int gp_, int sm_, int sn_, int lane, int& bestv_out, int& bestpk_out, int& nslow_out)
+__device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, uint8_t* Dfull, const PSeq& S, int V, int nov, int gp_, int sm_, int sn_, int lane, int& bestv_out, int& bestpk_out, int& nslow_out)
 {
     constexpr int BW = 64 * CPL;
     int nslow = 0;
@@ -644,9 +672,15 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
             int Xd[CPL], Dslot[CPL], Xu[CPL], Uslot[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; ++c) { Xd[c] = 0; Xu[c] = 0; Dslot[c] = 0; Uslot[c] = 0; }
-            int slot = 0;
-            for (int eit = nopred ? NONE16 : __builtin_amdgcn_readfirstlane((int)g.in_first(g.order(r))); eit != NONE16; eit = __builtin_amdgcn_readfirstlane((int)g.e_next_in(eit)), ++slot) {
-                const int pr = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(eit)));
+            // in-edges in creation order: the inline pair, then the overflow entries of this rank (slot = position in that order, as the traceback decodes it)
+            const uint32_t ppv = nopred ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readfirstlane((int)g.pp(r));
+            const bool many_r = !nopred && (__builtin_amdgcn_readfirstlane((int)g.cm(r)) & 0x80);
+            int ovx = -1;
+            for (int slot = 0;; ++slot) {
+                int pr;
+                if (slot == 0) { pr = ppv & 0xffff; if (pr == NONE16) break; }
+                else if (slot == 1) { pr = ppv >> 16; if (pr == NONE16) break; }
+                else { if (!many_r) break; ovx = ov_next(g, nov, r, ovx + 1, lane); if (ovx < 0) break; pr = __builtin_amdgcn_readfirstlane((int)g.ov_tail(ovx)); }
                 const int plo = (int)(__builtin_amdgcn_readfirstlane((unsigned)g.ri(pr)) & 0xffff);
                 const int pc0 = jb - plo;
                 int hp[CPL + 1];
@@ -758,7 +792,7 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
 
 // align S to the graph and merge it.  returns 0 = dropped (no valid end cell), 1 = added, 2 = does not fit
 template <int CPL>
-__device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, uint8_t* Dfull, const PoaJobSet& J, const PSeq& S, TS& st, int lane, int& edge_out)
+__device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, uint8_t* Dfull, const PoaJobSet& J, const PSeq& S, TS& st, int lane, int& edge_out)
 {
     constexpr int BW = 64 * CPL;
     // wave-uniform by construction; tell the compiler so the row loops get scalar control flow
@@ -773,10 +807,10 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     //          64 near row (one or two predecessors, all within the LDS ring, band shifts 0..DLO_MAX),
     //          128 first row of a tight run of chain rows (its length replaces dlo0; see the last pass)
     const BandMap bm = band_map(S, st.L0, BW);
-    // One pass, two 64-rank chunks per iteration: the loads of both chunks are issued before either is consumed, so the dependent chain
-    // order -> in-edge -> tail -> rank / anchor (L2 / HBM latency each) is paid once for 128 ranks.  The band start of a predecessor is
-    // recomputed from its anchor (a load that travels with the rank lookup) instead of being read back from a first pass over all ranks.
-    // need[] (HBM-copy requests) and marks[] (phase D) are all zero here: the tile start clears them and their readers clear what they find.
+    // One STREAMING pass, two 64-rank chunks per iteration: the graph is stored in rank order, so a rank's record (tails of its first two in-edges, anchor,
+    // letter, flags) is one coalesced load per array; the only dependent loads are the anchors of the two predecessors (their band starts are recomputed
+    // from them).  far[] (a successor more than HR ranks behind: the row needs an HBM copy) is a graph property kept by the merge, so the rows of a tight
+    // run are known here and no second pass is needed.
     const bool seq_lds = (unsigned)L * 2u <= (unsigned)(HR * (BW + RPADL + RPADR) * 4) && (unsigned)L * 2u <= (unsigned)(TBR * BW) && (unsigned)((L + 63) / 64) * 12u <= (unsigned)(TBR * 8);
     const SeqU16 alnode = { POA_LDS(l16, LLT<BW>::HRING), &g.alnode(0), seq_lds }, nodeof = { POA_LDS(l16, LLT<BW>::DIRBLK), &g.nodeof(0), seq_lds };
     unsigned kinds[5] = {0, 0, 0, 0, 0};
@@ -784,45 +818,36 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
 #if POA_REPEAT == 1
     for (int rep_ = 0; rep_ < 2; ++rep_) {
 #endif
-    bool setneed = false;
     for (int rb = 0; rb < V; rb += 128) {
-        int vv[2], e0v[2], e1v[2], p0v[2], p1v[2], l0v[2], lp0[2], lp1[2], e2v[2], ofv[2], cdv[2];
+        uint32_t ppv[2], arv[2]; int cmv[2], ofv[2], frv[2], lp0[2], lp1[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; vv[u] = r < V ? (int)g.order(r) : 0; }
+        for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; const bool ok = r < V; ppv[u] = ok ? g.pp(r) : 0xFFFFFFFFu; arv[u] = ok ? g.ar(r) : 0u; cmv[u] = ok ? (int)g.cm(r) : 0; ofv[u] = ok ? (int)g.of(r) : 1; frv[u] = ok ? (int)g.far(r) : 0; }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; const bool ok = r < V; e0v[u] = ok ? (int)g.in_first(vv[u]) : NONE16; l0v[u] = ok ? (int)g.anchor(vv[u]) : 0; ofv[u] = ok ? (int)g.out_first(vv[u]) : 0; cdv[u] = ok ? (int)g.code(vv[u]) : 0; }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const bool h = e0v[u] != NONE16; p0v[u] = h ? (int)g.e_tail(e0v[u]) : 0; e1v[u] = h ? (int)g.e_next_in(e0v[u]) : NONE16; }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const bool h0 = e0v[u] != NONE16, h1 = e1v[u] != NONE16; lp0[u] = h0 ? (int)g.anchor(p0v[u]) : 0; p0v[u] = h0 ? (int)g.rank(p0v[u]) : 0; p1v[u] = h1 ? (int)g.e_tail(e1v[u]) : 0; e2v[u] = h1 ? (int)g.e_next_in(e1v[u]) : NONE16; }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const bool h1 = e1v[u] != NONE16; lp1[u] = h1 ? (int)g.anchor(p1v[u]) : 0; p1v[u] = h1 ? (int)g.rank(p1v[u]) : 0; }
+        for (int u = 0; u < 2; ++u) { const int a = ppv[u] & 0xffff, b = ppv[u] >> 16; lp0[u] = a != NONE16 ? (int)g.anchor(a) : 0; lp1[u] = b != NONE16 ? (int)g.anchor(b) : 0; }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int r = rb + u * 64 + lane; const bool ok = r < V;          // (no divergent exits: the run lengths below are a wave ballot)
-            const int l0 = band_lo(l0v[u], bm, BW); int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
+            const int p0 = ppv[u] & 0xffff, p1 = ppv[u] >> 16;
+            const int l0 = band_lo((int)(arv[u] & 0xffff), bm, BW); int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
             if (ok) {
-                if (e0v[u] == NONE16) fl |= 1;
+                if (p0 == NONE16) fl |= 1;
                 else {
-                    d0 = r - p0v[u]; dl0 = l0 - band_lo(lp0[u], bm, BW); if (d0 > HR) { g.need(p0v[u]) = 1; setneed = true; }
-                    if (e1v[u] != NONE16) {
-                        d1 = r - p1v[u]; dl1 = l0 - band_lo(lp1[u], bm, BW); if (d1 > HR) { g.need(p1v[u]) = 1; setneed = true; }
-                        if (e2v[u] != NONE16) { fl |= 2; for (int e = e2v[u]; e != NONE16; e = g.e_next_in(e)) { const int pr = g.rank(g.e_tail(e)); if (r - pr > HR) { g.need(pr) = 1; setneed = true; } } }
-                    }
+                    d0 = r - p0; dl0 = l0 - band_lo(lp0[u], bm, BW);
+                    if (p1 != NONE16) { d1 = r - p1; dl1 = l0 - band_lo(lp1[u], bm, BW); if (cmv[u] & 0x80) fl |= 2; }
                     if (d0 > 255 || d1 > 255 || dl0 < 0 || dl0 > 255 || dl1 < 0 || dl1 > 255) { fl |= 2; d0 = d1 = dl0 = dl1 = 0; }
                 }
-                if (ofv[u] == NONE16) fl |= 4;
+                if (!ofv[u]) fl |= 4;
+                if (frv[u]) fl |= 8;
                 if (!(fl & 3)) {
                     if (d0 == 1 && d1 == 0 && dl0 <= 1) fl |= 16 | (dl0 << 5);
                     else if (d0 <= HR && d1 <= HR && dl0 <= DLO_MAX && dl1 <= DLO_MAX) fl |= 64;
                 }
             }
-            // TIGHT runs of the forward pass: consecutive chain rows whose band moves by one column per row, that hold no end cell and lie in
-            // one block of direction rows.  Every row of a run carries the number of rows left in it (flag 128, count in the dlo0 byte, which
-            // chain rows do not use): the forward pass does such a run in a counted loop without decoding flags row by row.  Rows that turn
-            // out to need an HBM copy (flag 8) are taken out of their runs by the last pass.
+            // TIGHT runs of the forward pass: consecutive chain rows whose band moves by one column per row, that hold no end cell, need no HBM copy and lie
+            // in one block of direction rows.  Every row of a run carries the number of rows left in it (flag 128, count in the dlo0 byte, which chain rows
+            // do not use): the forward pass does such a run in a counted loop without decoding flags row by row.
             const bool endz = (mode == NGSID_POA_SEMI || (fl & 4)) && (unsigned)(L - l0) < (unsigned)BW;
-            const bool tight = ok && (fl & (16 | 32)) == (16 | 32) && (mode == NGSID_POA_LOCAL || !endz);
+            const bool tight = ok && (fl & (16 | 32 | 8)) == (16 | 32) && (mode == NGSID_POA_LOCAL || !endz);
             const unsigned long long tm = __ballot(tight);
             if (tight) {
                 const unsigned long long x = ~(tm >> lane);
@@ -832,48 +857,21 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             }
             if (ok) g.ri(r) = (unsigned long long)(unsigned)l0 | ((unsigned long long)(unsigned)d0 << 16) | ((unsigned long long)(unsigned)d1 << 24)
                                | ((unsigned long long)(unsigned)dl0 << 32) | ((unsigned long long)(unsigned)dl1 << 40)
-                               | ((unsigned long long)(unsigned)cdv[u] << 48) | ((unsigned long long)(unsigned)fl << 56);
+                               | ((unsigned long long)(unsigned)(cmv[u] & 0x7f) << 48) | ((unsigned long long)(unsigned)fl << 56);
+            if (ph_detail) {            // dev instrumentation: row kinds of the forward pass (counted per alignment, one atomic each)
+                const unsigned long long tmk = tm;
+                kinds[0] += __popcll(tmk); kinds[1] += __popcll(__ballot(tight && (lane == 0 || (lane & (TBR - 1)) == 0 || !((tmk >> (lane - 1)) & 1))));
+                kinds[2] += __popcll(__ballot(ok && !tight && (fl & 16))); kinds[3] += __popcll(__ballot(ok && !(fl & 16) && (fl & 64))); kinds[4] += __popcll(__ballot(ok && !(fl & (16 | 64))));
+            }
         }
     }
-    const bool anyneed = __ballot(setneed) != 0ull;
     for (int i = lane; i < HR * (RPADL + RPADR); i += 64) {       // guard cells of the ring rows
         const int row = i / (RPADL + RPADR), k = i % (RPADL + RPADR);
         w.hring()[row * (BW + RPADL + RPADR) + (k < RPADL ? k : BW + k)] = 0;          // "minus infinity" of the biased cell values
     }
-    // alnode[] / nodeof[] of this alignment: LDS when they fit (ring: 2 bytes x L, direction block: 2 bytes x L, chunk summaries in the row-info block)
     for (int i = lane; i < L; i += 64) { if (!seq_lds) g.alnode(i) = NONE16; w.sq()[i] = S.s[i]; }
     for (int i = lane; i < BW; i += 64) w.sq()[L + i] = 0xFF;            // pad: columns past the end never match
     if (lane == 0) w.sq()[-1] = 0xFF;
-    // last pass: HBM-copy flag (8) of the rows a far successor asked for.  Such a row leaves its tight run: it becomes a plain chain row again
-    // (band shift 1) and the rows of the run before it count up to it only.  Far successors are rare: most chunks have nothing to do.
-    if (anyneed || ph_detail) mem_sync();
-    if (anyneed || ph_detail)
-    for (int rb = 0; rb < V; rb += 64) {
-        const int r = rb + lane;
-        const bool nd = r < V && g.need(r);
-        const unsigned long long nm = __ballot(nd);
-        if (nd) g.need(r) = 0;
-        if (nm || ph_detail) {
-            unsigned long long ri = r < V ? g.ri(r) : 0ull;
-            const bool was_tight = ((unsigned)(ri >> 56) & 128u) != 0;
-            bool changed = false;
-            if (nd) {
-                if (was_tight) ri = (ri & ~((0xFFull << 32) | (128ull << 56))) | (1ull << 32);
-                ri |= 8ull << 56; changed = true;
-            } else if (was_tight) {
-                const unsigned long long up = nm >> lane;                     // bit k: rank r + k needs a copy
-                const int d = up ? __builtin_ctzll(up) : 64, cr = (int)((ri >> 32) & 0xff);
-                if (d < cr) { ri = (ri & ~(0xFFull << 32)) | ((unsigned long long)d << 32); changed = true; }
-            }
-            if (changed) g.ri(r) = ri;
-            if (ph_detail) {            // dev instrumentation: row kinds of the forward pass (counted per alignment, one atomic each)
-                const unsigned f2 = (unsigned)(ri >> 56); const bool tg = r < V && (f2 & 128);
-                const unsigned long long tmk = __ballot(tg);
-                kinds[0] += __popcll(tmk); kinds[1] += __popcll(__ballot(tg && (lane == 0 || (lane & (TBR - 1)) == 0 || !((tmk >> (lane - 1)) & 1) || ((nm >> (lane - 1)) & 1))));
-                kinds[2] += __popcll(__ballot(r < V && !tg && (f2 & 16))); kinds[3] += __popcll(__ballot(r < V && !(f2 & 16) && (f2 & 64))); kinds[4] += __popcll(__ballot(r < V && !(f2 & (16 | 64))));
-            }
-        }
-    }
 #if POA_REPEAT == 1
     mem_sync();
     }
@@ -887,9 +885,9 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
 #if POA_REPEAT == 2
     for (int rep_ = 0; rep_ < 2; ++rep_)
 #endif
-    if (local) poa_forward<CPL, NGSID_POA_LOCAL>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
-    else if (mode == NGSID_POA_SEMI) poa_forward<CPL, NGSID_POA_SEMI>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
-    else poa_forward<CPL, NGSID_POA_GLOBAL>(g, w, Hg, Dg, Dfull, S, V, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    if (local) poa_forward<CPL, NGSID_POA_LOCAL>(g, w, Hg, Dg, Dfull, S, V, st.nov, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    else if (mode == NGSID_POA_SEMI) poa_forward<CPL, NGSID_POA_SEMI>(g, w, Hg, Dg, Dfull, S, V, st.nov, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+    else poa_forward<CPL, NGSID_POA_GLOBAL>(g, w, Hg, Dg, Dfull, S, V, st.nov, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[5], (unsigned long long)V); atomicAdd(&PHS(J)[6], (unsigned long long)nslow); }
     mem_sync();                                       // direction rows must have landed before the traceback pulls them back
     PH(J, 1, tph);
@@ -1000,7 +998,8 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
             if (slot == SRC_SLOT) break;
             int pr;
             if (!((rhi >> 24) & 2) && slot <= 1) pr = r - (int)(slot == 0 ? ((rlo >> 16) & 0xff) : (rlo >> 24));
-            else { int e = g.in_first(g.order(r)); for (int t = 0; t < slot; ++t) e = g.e_next_in(e); pr = __builtin_amdgcn_readfirstlane((int)g.rank(g.e_tail(e))); }
+            else if (slot <= 1) pr = __builtin_amdgcn_readfirstlane(slot == 0 ? (int)g.p0(r) : (int)g.p1(r));
+            else { int e = -1; for (int t = 2; t <= slot; ++t) e = ov_next(g, st.nov, r, e + 1, lane); pr = __builtin_amdgcn_readfirstlane((int)g.ov_tail(e)); }
             r = pr;
         }
         if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[7], (unsigned long long)n_iter); atomicAdd(&PHS(J)[13], (unsigned long long)n_reload); atomicAdd(&PHS(J)[14], c_reload); }
@@ -1012,27 +1011,25 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
 #endif
     if (seq_lds) lds_sync(); else mem_sync();         // alnode[] is read by other lanes next
     PH(J, 2, tph);
-    // ---------- A: rank -> node, then the existing node per position: the aligned node if the letter matches, else a sibling (same column)
-    //             with that letter whose rank lies strictly between the previous aligned position's node and this one (oracle
-    //             g_add_alignment: keeps the order topological without a re-sort)
+    // ---------- A: the existing node per position: the aligned node if the letter matches, else a sibling (same column) with that letter whose rank lies
+    //             strictly between the previous aligned position's node and this one (oracle g_add_alignment / rg_add_alignment: keeps the order
+    //             topological without a re-sort).  alnode[] keeps the aligned RANK, nodeof[] receives the existing rank or NONE16 (= a new node).
     // Per 64-position chunk phase A leaves a summary in LDS (the DP ring is free now): the mask of positions that need a NEW node, the aligned
-    // node of the chunk's last aligned position and the node CHOSEN for its first aligned position (reused sibling or the aligned node).
-    // Phase C then only touches the chunks that create nodes and takes its carries (nearest aligned position before / after) from the summaries.
+    // rank of the chunk's last aligned position and the rank CHOSEN for its first aligned position (reused sibling or the aligned node).
     const unsigned ch_base = seq_lds ? LLT<BW>::RBLK : 0u;                  // (the ring and the direction block hold alnode[] / nodeof[] then)
     const lu64 ch_new = POA_LDS(lu64, ch_base);                             // [nch]
-    const l16 ch_last = POA_LDS(l16, ch_base + 8u * (unsigned)((L + 63) / 64));      // [nch] aligned node of the last aligned position, NONE16 = none
-    const l16 ch_first = ch_last + (L + 63) / 64;                          // [nch] node chosen for the first aligned position, NONE16 = none
+    const l16 ch_last = POA_LDS(l16, ch_base + 8u * (unsigned)((L + 63) / 64));      // [nch] aligned rank of the last aligned position, NONE16 = none
+    const l16 ch_first = ch_last + (L + 63) / 64;                          // [nch] rank chosen for the first aligned position, NONE16 = none
+    const int nch = (L + 63) / 64;
     int nnew = 0;
     {
-        int carry = -1;                                   // rank of the aligned node of the nearest aligned position before the chunk
+        int carry = -1;                                   // aligned rank of the nearest aligned position before the chunk
         for (int ib = 0; ib < L; ib += 128) {             // two chunks per iteration: both chunks' loads are in flight together
-            int arv[2], vv[2], cdv[2];
+            int arv[2], cdv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) { const int i = ib + u * 64 + lane; arv[u] = (i < L) ? alnode.get(i) : NONE16; }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) vv[u] = arv[u] != NONE16 ? (int)g.order(arv[u]) : NONE16;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) cdv[u] = vv[u] != NONE16 ? (int)g.code(vv[u]) : -1;
+            for (int u = 0; u < 2; ++u) cdv[u] = arv[u] != NONE16 ? (int)(g.cm(arv[u]) & 0x7f) : -1;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int i = ib + u * 64 + lane; bool isnew = false;
@@ -1042,20 +1039,20 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
                 const int psrc = lt ? 63 - __clzll(lt) : 0;
                 const int pv = __shfl(ar, psrc);
                 const int prev_rank = lt ? pv : carry;
-                int chosen = NONE16; const int v = vv[u];
+                int chosen = NONE16;
                 if (i < L) {
-                    const uint8_t ch = w.sq()[i]; int found = NONE16;
+                    const int ch = w.sq()[i]; int found = NONE16;
                     if (ar != NONE16) {
-                        if (cdv[u] == ch) found = v;
-                        else for (int x = g.ring(v); x != v; x = g.ring(x)) if (g.code(x) == ch) { const int ru = g.rank(x); if (ru > prev_rank && ru < ar) { found = x; break; } }
-                        chosen = found != NONE16 ? found : v;
+                        if (cdv[u] == ch) found = ar;
+                        else for (int x = g.ring(ar); x != ar; x = g.ring(x)) if ((int)(g.cm(x) & 0x7f) == ch && x > prev_rank && x < ar) { found = x; break; }
+                        chosen = found != NONE16 ? found : ar;
                     }
-                    alnode.set(i, v); nodeof.set(i, found); isnew = found == NONE16;
+                    nodeof.set(i, found); isnew = found == NONE16;
                 }
                 const unsigned long long mn = __ballot(isnew);
                 nnew += __popcll(mn);
                 if (ib + u * 64 < L) {
-                    const int fc = __shfl(chosen, ma ? __ffsll((long long)ma) - 1 : 0), lv = __shfl(v, ma ? 63 - __clzll(ma) : 0);
+                    const int fc = __shfl(chosen, ma ? __ffsll((long long)ma) - 1 : 0), lv = __shfl(ar, ma ? 63 - __clzll(ma) : 0);
                     if (lane == 0) { const int c = (ib >> 6) + u; ch_new[c] = mn; ch_first[c] = (uint16_t)(ma ? fc : NONE16); ch_last[c] = (uint16_t)(ma ? lv : NONE16); }
                 }
                 if (ma) { const int hl = 63 - __clzll(ma); carry = __shfl(ar, hl); }
@@ -1065,119 +1062,142 @@ __device__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, 
     if (ph_detail) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(alnode.get(i) + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&PHS(J)[10], (unsigned long long)nnew); atomicAdd(&PHS(J)[11], sm_); } }
     if (seq_lds) lds_sync(); else mem_sync();
     if (V + nnew > st.capV || st.E + L > st.capE) return 2;      // oracle g_add_alignment capacity rule
-    // ---------- C: create nodes (ids in sequence order).  anchor: nearest aligned position at or before i, else after, else a0.
-    //             A new node goes immediately before rf = the node chosen for the first aligned position >= i (end of the order if there is none).
-    //             The k-th new node is inserted before old rank ins (V = end; non-decreasing in k): it lands on rank ins + k, and marks[ins]
-    //             counts it so that phase D can shift the old nodes with one prefix sum.  Chunks without new nodes cost two LDS reads.
-    int ins_min = V;
-    if (nnew) {
-        const int nch = (L + 63) / 64;
-        int base = V, lastal = NONE16;
+    // ---------- new nodes of the chunks that have any (ids do not exist any more: a node IS its rank).  The k-th new node of the sequence goes immediately
+    //             before old rank ins = the rank chosen for the first aligned position at or after its own (V = the end; non-decreasing in k) and lands on
+    //             rank ins + k.  One routine, two uses: pass 0 only needs (ins, k) to build shift[]; pass 1, after the old records have moved, writes the records.
+    // shift[r] (r <= V) = new nodes inserted at or before old rank r: an old node moves from r to r + shift[r].  u8 in the LDS behind alnode[] when the counts
+    // fit a byte and the ring has the room, else u16 in the HBM scratch.
+    const bool sh_lds = seq_lds && nnew <= 255 && (unsigned)(2 * ((L + 7) & ~7) + V + 2) <= (unsigned)(HR * (BW + RPADL + RPADR) * 4);
+    const l8 sh_l = POA_LDS(l8, LLT<BW>::HRING + 2u * (unsigned)((L + 7) & ~7));
+    auto SH = [&](int x) __attribute__((always_inline)) -> int { return sh_lds ? (int)sh_l[x] : (int)g.shiftg(x); };
+    auto RM = [&](int x) __attribute__((always_inline)) -> int { return x + SH(x); };
+    auto new_nodes = [&](const int pass) __attribute__((always_inline)) {
+        int base = 0, lastal = NONE16;
         for (int c = 0; c < nch; ++c) {
             const unsigned long long mn = ch_new[c];
             if (mn) {
                 const int i = c * 64 + lane; const bool isnew = (mn >> lane) & 1ull;
-                const int a = (i < L) ? alnode.get(i) : NONE16; const int nf = (i < L) ? nodeof.get(i) : NONE16;
+                const int a = (i < L) ? alnode.get(i) : NONE16; const int nf = (i < L && !isnew) ? nodeof.get(i) : NONE16;
                 const int chosen = a != NONE16 ? (nf != NONE16 ? nf : a) : NONE16;
                 const unsigned long long ma = __ballot(a != NONE16);
                 const unsigned long long le = ma & (~0ull >> (63 - lane));
                 const int lv = __shfl(a, le ? 63 - __clzll(le) : 0);
-                const int la = le ? lv : lastal;
+                const int la = le ? lv : lastal;                   // nearest aligned position at or before i
                 const unsigned long long ge = ma & (~0ull << lane);
                 const int rv = __shfl(chosen, ge ? __ffsll((long long)ge) - 1 : 0);
-                int nxt = NONE16;                                  // node chosen for the first aligned position after the chunk
+                int nxt = NONE16;                                  // rank chosen for the first aligned position after the chunk
                 for (int c2 = c + 1; c2 < nch; ++c2) { const int f = ch_first[c2]; if (f != NONE16) { nxt = f; break; } }
                 const int rf = ge ? rv : nxt;
-                const int before = __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-                if (isnew) {
-                    const int y = base + before;
-                    const int anc = la != NONE16 ? g.anchor(la) : (rf != NONE16 ? g.anchor(rf) : (S.a1 < S.a0 ? 0 : S.a0));
-                    g.code(y) = w.sq()[i]; g.anchor(y) = (uint16_t)anc; g.in_first(y) = g.in_last(y) = g.out_first(y) = g.out_last(y) = NONE16; g.cov(y) = 0;
-                    if (a != NONE16) { g.ring(y) = g.ring(a); g.ring(a) = (uint16_t)y; } else g.ring(y) = (uint16_t)y;
+                const int k = base + __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                const int ins = rf != NONE16 ? rf : V;
+                if (pass == 0) {
+                    // the LAST new node of a run of equal insertion points writes the count; a later chunk with the same point overwrites it with a larger one
+                    const unsigned long long later = mn & ((lane == 63) ? 0ull : (~0ull << (lane + 1)));
+                    const int ins_next = __shfl(ins, later ? __ffsll((long long)later) - 1 : 0);
+                    if (isnew && (!later || ins_next != ins)) { if (sh_lds) sh_l[ins] = (uint8_t)(k + 1); else g.shiftg(ins) = (uint16_t)(k + 1); }
+                    if (!sh_lds) mem_sync();                        // (HBM fall-back: keep the stores of successive chunks to one address in order)
+                } else if (isnew) {
+                    const int y = ins + k;
+                    const int anc = la != NONE16 ? (int)g.anchor(RM(la)) : (rf != NONE16 ? (int)g.anchor(RM(rf)) : (S.a1 < S.a0 ? 0 : S.a0));
+                    int rg = y;
+                    if (a != NONE16) { const int v = RM(a); rg = g.ring(v); g.ring(v) = (uint16_t)y; }      // joins the ring right behind the node it is aligned to
+                    g.cm(y) = w.sq()[i]; g.ar(y) = (uint32_t)anc | ((uint32_t)rg << 16); g.pp(y) = 0xFFFFFFFFu; g.ww(y) = 0ull; g.cov(y) = 0u; g.of(y) = 0;
                     nodeof.set(i, y);
-                    const int ins = rf != NONE16 ? (int)g.rank(rf) : V;
-                    g.tmpo(ins + (y - V)) = (uint16_t)y; atomicAdd(&g.marks(ins), 1u);
-                    ins_min = min(ins_min, ins);
                 }
                 base += __popcll(mn);
             }
             const int lc = ch_last[c];
             if (lc != NONE16) lastal = lc;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) ins_min = min(ins_min, __shfl_xor(ins_min, d));
-        ins_min = __builtin_amdgcn_readfirstlane(ins_min);
-    }
-    mem_sync();
-    // ---------- D: ranks.  old node at rank p -> p + #{new nodes inserted before a rank <= p} (prefix sum of marks); new nodes were placed in C.
-    //             Ranks before the first insertion point keep their place; marks[] is left all zero for the next alignment.
+    };
     if (nnew) {
-        const int p0 = ins_min & ~127;
-        int carry = 0;
-        for (int pb = p0; pb < V; pb += 128) {
-            int mv[2], ov[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) { const int p = pb + u * 64 + lane; mv[u] = p < V ? (int)g.marks(p) : 0; ov[u] = p < V ? (int)g.order(p) : 0; }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int p = pb + u * 64 + lane;
-                const int incl = wave_incl_add_scan(mv[u]) + carry;
-                if (p < V) g.tmpo(p + incl) = (uint16_t)ov[u];
-                if (mv[u]) g.marks(p) = 0;
-                carry = __builtin_amdgcn_readlane(incl, 63);
+        // ---------- S: shift[] = running maximum of the counts the runs wrote; far[] of the whole new rank range is cleared (the move recomputes it)
+        for (int r = lane; r <= V; r += 64) { if (sh_lds) sh_l[r] = 0; else g.shiftg(r) = 0; }
+        for (int r = lane; r < V + nnew; r += 64) g.far(r) = 0;
+        if (sh_lds) lds_sync(); else mem_sync();
+        new_nodes(0);
+        if (sh_lds) lds_sync(); else mem_sync();
+        {
+            int carry = 0;
+            for (int rb = 0; rb <= V; rb += 64) {
+                const int r = rb + lane; const int v = r <= V ? SH(r) : 0;
+                const int m = max(wave_incl_max_scan(v), carry);
+                if (r <= V) { if (sh_lds) sh_l[r] = (uint8_t)m; else g.shiftg(r) = (uint16_t)m; }
+                carry = __builtin_amdgcn_readlane(m, 63);
             }
         }
-        if (lane == 0) g.marks(V) = 0;
-        mem_sync();
-        for (int rb = p0; rb < V + nnew; rb += 128) {
-            int tv[2];
+        mem_sync();                                       // (also: far[] cleared before the move sets it)
+        // ---------- D: the old records move up by shift[], highest ranks first (in place: a destination never lies below its source, distinct ranks have
+        //             distinct destinations, and both chunks of an iteration are loaded before either is stored); rank-valued fields are remapped; a
+        //             predecessor that ends up more than HR ranks before its successor gets its far flag back
+        for (int rb = (V - 1) & ~127; rb >= 0; rb -= 128) {
+            uint32_t ppv[2], arv[2], cvv[2]; unsigned long long wwv[2]; int cmv[2], ofv[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; tv[u] = r < V + nnew ? (int)g.tmpo(r) : 0; }
+            for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; if (r < V) { ppv[u] = g.pp(r); arv[u] = g.ar(r); cvv[u] = g.cov(r); wwv[u] = g.ww(r); cmv[u] = g.cm(r); ofv[u] = g.of(r); } else { ppv[u] = 0xFFFFFFFFu; arv[u] = 0; cvv[u] = 0; wwv[u] = 0; cmv[u] = 0; ofv[u] = 0; } }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const int r = rb + u * 64 + lane; if (r < V + nnew) { g.order(r) = (uint16_t)tv[u]; g.rank(tv[u]) = (uint16_t)r; } }
+            for (int u = 0; u < 2; ++u) {
+                const int r = rb + u * 64 + lane;
+                if (r < V) {
+                    const int nr = RM(r); int a = ppv[u] & 0xffff, b = ppv[u] >> 16; const int rg = RM((int)(arv[u] >> 16));
+                    if (a != NONE16) { a = RM(a); if (nr - a > HR) g.far(a) = 1; }
+                    if (b != NONE16) { b = RM(b); if (nr - b > HR) g.far(b) = 1; }
+                    g.pp(nr) = (uint32_t)a | ((uint32_t)b << 16); g.ar(nr) = (arv[u] & 0xffffu) | ((uint32_t)rg << 16); g.cov(nr) = cvv[u]; g.ww(nr) = wwv[u]; g.cm(nr) = (uint8_t)cmv[u]; g.of(nr) = (uint8_t)ofv[u];
+                }
+            }
         }
+        for (int x = lane; x < st.nov; x += 64) { const int h = RM((int)g.ov_head(x)), t = RM((int)g.ov_tail(x)); g.ov_head(x) = (uint16_t)h; g.ov_tail(x) = (uint16_t)t; if (h - t > HR) g.far(t) = 1; }
+        mem_sync();
+        // ---------- N: records of the new nodes
+        new_nodes(1);
+        // existing nodes the sequence goes through: their final ranks
+        for (int i = lane; i < L; i += 64) if (!((ch_new[i >> 6] >> (i & 63)) & 1ull)) nodeof.set(i, RM(nodeof.get(i)));
         mem_sync();
     }
-    // ---------- E: coverage and edges (edge ids in sequence order)
+    // ---------- E: coverage and edges along the sequence (final ranks).  Every node of the path is touched by ONE position (its in-edge record, its coverage);
+    //             the out-flag and the far flag of a node are written by the lane of the NEXT position (separate byte arrays).  A new edge takes the first
+    //             free inline slot of its head, else an overflow entry (sequence order)
     {
-        int ebase = st.E;
-        for (int ib = 0; ib < L; ib += 128) {             // two chunks per iteration (independent: every node of the path is touched by one position only)
-            int av[2], bv[2], e0v[2], h0v[2];
+        int ebase = st.E, nov = st.nov;
+        for (int ib = 0; ib < L; ib += 128) {             // two chunks per iteration (independent)
+            int av[2], bv[2]; uint32_t ppb[2], covv[2]; unsigned long long wwb[2]; int cmb[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) { const int i = ib + u * 64 + lane; bv[u] = i < L ? nodeof.get(i) : NONE16; av[u] = (i < L && i > 0) ? nodeof.get(i - 1) : NONE16; }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) e0v[u] = av[u] != NONE16 ? (int)g.out_first(av[u]) : NONE16;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) h0v[u] = e0v[u] != NONE16 ? (int)g.e_head(e0v[u]) : NONE16;
-            uint32_t covv[2]; int ewv[2];       // read-modify-write operands fetched with the rest (no two positions of an alignment share a node or an edge)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) { covv[u] = bv[u] != NONE16 ? g.cov(bv[u]) : 0u; ewv[u] = (e0v[u] != NONE16 && h0v[u] == bv[u]) ? g.e_w(e0v[u]) : 0; }
+            for (int u = 0; u < 2; ++u) { const bool h = bv[u] != NONE16; ppb[u] = h ? g.pp(bv[u]) : 0xFFFFFFFFu; wwb[u] = h ? g.ww(bv[u]) : 0ull; covv[u] = h ? g.cov(bv[u]) : 0u; cmb[u] = h ? (int)g.cm(bv[u]) : 0; }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int i = ib + u * 64 + lane; bool newedge = false; const int a = av[u], b = bv[u]; int wgt = 0;
+                const int i = ib + u * 64 + lane; bool newedge = false, needov = false; const int a = av[u], b = bv[u]; int wgt = 0;
                 if (i < L) {
                     g.cov(b) = covv[u] + S.cw;
                     if (i > 0) {
                         wgt = wtof(S, i - 1) + wtof(S, i);
-                        int e = e0v[u];
-                        if (e != NONE16 && h0v[u] == b) g.e_w(e) = ewv[u] + wgt;
+                        const int t0 = ppb[u] & 0xffff, t1 = ppb[u] >> 16;
+                        if (t0 == a) g.w0(b) = (int)(unsigned)wwb[u] + wgt;
+                        else if (t1 == a) g.w1(b) = (int)(unsigned)(wwb[u] >> 32) + wgt;
                         else {
-                            if (e != NONE16) for (e = g.e_next_out(e); e != NONE16; e = g.e_next_out(e)) if (g.e_head(e) == b) break;
-                            if (e != NONE16) g.e_w(e) += wgt; else newedge = true;
+                            int e = -1;
+                            if (cmb[u] & 0x80) for (int x = 0; x < nov; ++x) if ((int)g.ov_head(x) == b && (int)g.ov_tail(x) == a) { e = x; break; }
+                            if (e >= 0) g.ov_w(e) += wgt;
+                            else {
+                                newedge = true;
+                                if (t0 == NONE16) { g.p0(b) = (uint16_t)a; g.w0(b) = wgt; }
+                                else if (t1 == NONE16) { g.p1(b) = (uint16_t)a; g.w1(b) = wgt; }
+                                else needov = true;
+                                g.of(a) = 1; if (b - a > HR) g.far(a) = 1;
+                            }
                         }
                     }
                 }
-                const unsigned long long mn = __ballot(newedge);
-                if (newedge) {
-                    const int e = ebase + __popcll(mn & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-                    g.e_tail(e) = (uint16_t)a; g.e_head(e) = (uint16_t)b; g.e_w(e) = wgt; g.e_next_in(e) = NONE16; g.e_next_out(e) = NONE16;
-                    if (g.out_last(a) == NONE16) g.out_first(a) = (uint16_t)e; else g.e_next_out(g.out_last(a)) = (uint16_t)e; g.out_last(a) = (uint16_t)e;
-                    if (g.in_last(b) == NONE16) g.in_first(b) = (uint16_t)e; else g.e_next_in(g.in_last(b)) = (uint16_t)e; g.in_last(b) = (uint16_t)e;
+                const unsigned long long mo = __ballot(needov);
+                if (needov) {
+                    const int e = nov + __popcll(mo & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                    g.ov_head(e) = (uint16_t)b; g.ov_tail(e) = (uint16_t)a; g.ov_w(e) = wgt; g.cm(b) = (uint8_t)(cmb[u] | 0x80);
                 }
-                ebase += __popcll(mn);
+                if (mo) { nov += __popcll(mo); mem_sync(); }       // (a later chunk may look the list up)
+                ebase += __popcll(__ballot(newedge));
             }
         }
-        st.E = ebase;
+        st.E = ebase; st.nov = nov;
     }
     st.V = V + nnew; st.cw_sum += S.cw;
     mem_sync();
@@ -1197,7 +1217,8 @@ size_t poa_lds_bytes(int Vc, int Ec, int Lm, int BW)
 static size_t poa_graph_bytes(int Vc, int Ec, int Lm)
 {
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    return 9 * al(2 * ((size_t)Vc + 1)) + 26 * al(Vc) + 6 * al(2 * (size_t)Ec) + 16 + 3 * al(2 * (size_t)Lm);
+    const size_t n = (size_t)Vc + 1;
+    return 3 * al(4 * n) + 3 * al(8 * n) + 2 * al(2 * n) + 3 * al(n) + 2 * al(2 * (size_t)Ec) + al(4 * (size_t)Ec) + 2 * al(2 * (size_t)Lm);
 }
 
 template <int CPL>
@@ -1211,7 +1232,8 @@ __device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscra
         auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
         w.sinkbits = POA_LDS(LDSP unsigned int*, (unsigned)al((size_t)2 * Vc));
         g.base = gscratch + (size_t)blockIdx.x * gbytes;
-        g.s16 = (uint32_t)al(2 * ((size_t)Vc + 1)); g.s8 = (uint32_t)al(Vc); g.se = (uint32_t)al(2 * (size_t)Ec); g.sl = (uint32_t)al(2 * (size_t)Lm);
+        g.s32 = (uint32_t)al(4 * ((size_t)Vc + 1)); g.s64 = (uint32_t)al(8 * ((size_t)Vc + 1)); g.s16 = (uint32_t)al(2 * ((size_t)Vc + 1)); g.s8 = (uint32_t)al((size_t)Vc + 1);
+        g.se16 = (uint32_t)al(2 * (size_t)Ec); g.se32 = (uint32_t)al(4 * (size_t)Ec); g.sl = (uint32_t)al(2 * (size_t)Lm);
     }
     int32_t* Hg = J.Hglob + (size_t)blockIdx.x * Vc * BW;
     uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW * 3 / 2;      // packed direction blocks (4 bits per cell) ...
@@ -1227,7 +1249,7 @@ __device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscra
         int edge = 0;
         const uint32_t s0 = J.job_off[job], s1 = J.job_off[job + 1];
         const int bbi = J.job_bb ? J.job_bb[job] : -1;
-        TS st; st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.nout = 0; st.cw_sum = 0;
+        TS st; st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.nout = 0; st.cw_sum = 0; st.nov = 0;
         uint32_t ndrop = 0;
         {   // per-job capacity = oracle run_tile: cap_for(L0) but at least the longest member + 1; edges 1.5x
             int maxlen = bbi >= 0 ? J.bbs[bbi].len : 0, first = bbi >= 0 ? J.bbs[bbi].len : 0;
@@ -1250,7 +1272,7 @@ __device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscra
                 if (rcode == 1) { st.members += 1; break; }
                 if (rcode == 0 || attempt == 1) { ++ndrop; break; }
                 tile_emit(g, w, J, job, st, lane);
-                st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.cw_sum = 0;
+                st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.cw_sum = 0; st.nov = 0;
             }
         }
 #if POA_REPEAT == 4
