@@ -17,10 +17,10 @@ import torch
 # `reads` = reads PER GPU in the default weak-scaling mode (C4 / C5 are quoted on 8 GPUs: 10 M / 8 and 2 M / 8), and `total` = the size of the
 # ONE global set of --scaling strong.  C1 (sample_h1 through the CLI) is a test, not a bench workload.
 CONFIGS = {
-    "c2": dict(reads=100000, total=100000, species=1, length=750, mu=17.0, k=13, w=20, abundance_ratio=0.1, geometric=None, flags="--ont --abundance_ratio 0.1"),
-    "c3": dict(reads=1000000, total=1000000, species=5, length=750, mu=17.0, k=13, w=20, abundance_ratio=0.02, geometric=None, flags="--ont --abundance_ratio 0.02"),
-    "c4": dict(reads=1250000, total=10000000, species=50, length=750, mu=17.0, k=13, w=20, abundance_ratio=0.005, geometric=None, flags="--ont --abundance_ratio 0.005"),
-    "c5": dict(reads=250000, total=2000000, species=20, length=2000, mu=30.0, k=15, w=50, abundance_ratio=0.002, geometric=0.8, flags="--isoseq --abundance_ratio 0.002"),
+    "c2": dict(preset="--ont", reads=100000, total=100000, species=1, length=750, mu=17.0, k=13, w=20, abundance_ratio=0.1, geometric=None, flags="--ont --abundance_ratio 0.1"),
+    "c3": dict(preset="--ont", reads=1000000, total=1000000, species=5, length=750, mu=17.0, k=13, w=20, abundance_ratio=0.02, geometric=None, flags="--ont --abundance_ratio 0.02"),
+    "c4": dict(preset="--ont", reads=1250000, total=10000000, species=50, length=750, mu=17.0, k=13, w=20, abundance_ratio=0.005, geometric=None, flags="--ont --abundance_ratio 0.005"),
+    "c5": dict(preset="--isoseq", reads=250000, total=2000000, species=20, length=2000, mu=30.0, k=15, w=50, abundance_ratio=0.002, geometric=0.8, flags="--isoseq --abundance_ratio 0.002"),
 }
 
 
@@ -231,6 +231,7 @@ def main():
         ed.append(0 if c[3] in tset else min(min(edit_distance(c[3][a:len(c[3]) - b if b else None], t) for a in range(4) for b in range(4)) for t in truths))
     # ---- roofline of the dominant kernel (HIP-event times on the library's own stream)
     redo_tiles = kern.pop("poa_band_redo_tiles", (0, 0.0))[0]
+    poa_rows = kern.pop("poa_dp_rows", (0, 0.0))[0]; sg_cells = kern.pop("sg_dp_cells", (0, 0.0))[0]      # work counters of the timed steps (counted by the kernels themselves, ngsid_profile_read)
     dom = max(kern.items(), key=lambda kv: kv[1][1]) if kern else (None, (0, 0.0))
     f_aln = float(res["counters"][2]) / n
     L = args.length; M = int(round(0.21 * 0.75 * L)) if K_ <= 13 else int(round(0.054 * 0.75 * L))          # minimizers per read (118 at 750 bp k13/w20, 80 at 2 kb k15/w50)
@@ -249,34 +250,45 @@ def main():
         ach = alg_bytes_per_launch / avg_s / 1e9
         traffic = None
         traffic_src = None
-        try:    # HBM bytes per launch from the committed PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, tools/r03_profiles.sh): a counter
+        try:    # HBM bytes per launch from the committed PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, tools/r04_profiles.sh): a counter
                 # pass cannot run inside this process, so the figure is a measurement of the recorded commit on the recorded workload, not of this run
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")))
             if tj.get("workload_reads") == args.reads and tj.get("config", "c3") == args.config and dom[0] in tj and world == 1:
                 traffic = int(tj[dom[0]]["hbm_bytes_per_step"] * args.steps / max(cnt, 1))      # per launch, like `achieved`
-                traffic_src = {"file": "profiles/r03_hbm_traffic.json", "measured_at_commit": tj.get("commit"), "launches_per_step_then": tj[dom[0]].get("launches_per_step")}
+                traffic_src = {"file": "profiles/r04_hbm_traffic.json", "measured_at_commit": tj.get("commit"), "launches_per_step_then": tj[dom[0]].get("launches_per_step")}
         except Exception:
             traffic = None
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
-                "limited_by": "memory latency under load in the lane-parallel graph phases + VALU issue in the DP rows (not HBM bandwidth): see `issue` and DESIGN.md section 4",
+                "limited_by": "VALU instruction issue (the DP rows and the graph bookkeeping of one wave per tile), not HBM bandwidth: see `valu_issue` / `dp_kernels` and DESIGN.md section 4",
                 "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-                "note": "integer DP kernel, one wave per tile: the DP rows run at the VALU issue rate of six waves per SIMD (21 - 22 VALU per row in the tight loop), the graph phases between them wait for dependent L2 / HBM round trips (`issue` has the counters of the recorded commit) - not bound by HBM bandwidth, so the fraction of the HBM roofline is small by construction (DESIGN.md sections 4 and 10)"}
-        if dom[0] == "k_poa_tile":      # instruction-issue view of the same kernel: SQ counters of a committed PMC pass on THIS workload at the default tile depth (not measurable from inside this process)
+                "note": "integer DP kernel, one wave per tile: bound by VALU issue (`valu_issue`: DP rows counted in this run x instructions per row of the committed counter pass / this run's kernel time), so the fraction of the HBM roofline is small by construction (DESIGN.md sections 4 and 10)"}
+        # ---- what actually bounds the two DP kernels: VALU issue.  Work (DP rows / cells) is counted by the kernels in THIS run; the instructions per unit of
+        #      work come from the committed SQ-counter pass (POA: profiles/r04_pmc_poa_tile.json, with its commit) or the ISA (aligner): a counter pass cannot run
+        #      inside this process.  achieved = work x instructions per unit / the kernel's time in this run (HIP events); peak = CUs x 4 SIMDs x clock / 4 cycles.
+        prop = torch.cuda.get_device_properties(dev)
+        clk = float(getattr(prop, "clock_rate", 2400000)) * 1e3
+        peak_issue = prop.multi_processor_count * 4 * clk / 4.0
+        band_cols = args.band if args.band else (64 if L <= 1024 else 128)
+        views = {}
+        if "k_poa_tile" in kern and poa_rows:
+            ms_p = kern["k_poa_tile"][1]; v = {"dp_rows": int(poa_rows), "band_columns": band_cols, "kernel_ms": round(ms_p, 2), "gcups": round(poa_rows * band_cols / (ms_p / 1e3) / 1e9, 1)}
             try:
-                ij = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_poa_tile.json")))
+                ij = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_poa_tile.json")))
                 if ij.get("workload_reads") == args.reads and ij.get("config", "c3") == args.config:
-                    roof["issue"] = {k_: ij[k_] for k_ in ("valu_per_row", "salu_per_row", "rows", "pipe_busy", "wave_cycles_waiting_frac", "commit") if k_ in ij}
-                    roof["issue"]["file"] = "profiles/r03_pmc_poa_tile.json"
+                    wi = poa_rows * ij["valu_per_row"] / (ms_p / 1e3)
+                    v.update({"valu_per_row": ij["valu_per_row"], "salu_per_row": ij.get("salu_per_row"), "achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4),
+                              "instructions_per_row_source": {"file": "profiles/r04_pmc_poa_tile.json", "measured_at_commit": ij.get("commit"), "rows_then": ij.get("rows"), "pipe_busy_then": ij.get("pipe_busy")}})
             except Exception:
                 pass
-        if dom[0] == "k_sg_align":      # what actually bounds it: VALU issue.  17.7 VALU instructions per DP cell and lane (ISA count, k_align16.hip), 64 cells per wave instruction
-            prop = torch.cuda.get_device_properties(dev)
-            clk = float(getattr(prop, "clock_rate", 2400000)) * 1e3
-            peak_issue = prop.multi_processor_count * 4 * clk / 4.0
-            cells = units * L * L
-            wi = cells / 64.0 * 17.7 / (ms / 1e3)
-            roof["valu_issue"] = {"achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4),
-                                  "dp_cells_per_s": round(cells / (ms / 1e3), 0)}
+            views["k_poa_tile"] = v
+        if "k_sg_align" in kern and sg_cells:
+            ms_a = kern["k_sg_align"][1] + kern.get("k_sg_align_side", (0, 0.0))[1]
+            per_cell = 14.4            # VALU instructions per DP cell and lane, two pairs per wave (ISA count, csrc/k_align16p.hip; 17.7 in the one-pair kernel)
+            wi = sg_cells / 64.0 * per_cell / (ms_a / 1e3)
+            views["k_sg_align"] = {"dp_cells": int(sg_cells), "kernel_ms": round(ms_a, 2), "gcups": round(sg_cells / (ms_a / 1e3) / 1e9, 1), "valu_per_cell": per_cell, "achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2),
+                                   "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "instructions_per_cell_source": "ISA count of the step loop (378 VALU per step for two pairs of 12-14 rows per lane), DESIGN.md section 4"}
+        if dom[0] in views: roof["valu_issue"] = dict(views[dom[0]], kernel=dom[0])
+        roof["dp_kernels"] = views
     # ---- CPU baseline: the oracle (a scalar port of the same algorithms) on a bounded sample of the same workload: one core, and all host cores
     #      with one batch per core like the reference's `--t N` worker processes (merge rounds not included: they are O(representatives))
     cpu = None
@@ -357,7 +369,7 @@ def main():
             fq = os.path.join(tmp, "reads.fastq"); fastio.write_fastq(fq, perm, names, hrs)
             in_bytes = os.path.getsize(fq)
             outd = os.path.join(tmp, "out"); os.makedirs(outd)
-            cargs = _cli.build_parser().parse_args([("--isoseq" if K_ == 15 else "--ont"), "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", str(AB_)])
+            cargs = _cli.build_parser().parse_args([cfg["preset"], "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", str(AB_)])
             cargs.k, cargs.w = K_, W_
             tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl
             out_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs)
@@ -366,10 +378,10 @@ def main():
                        "stage_s": {k_: round(v, 3) for k_, v in r["timings"].items()}, "input_fastq_bytes": in_bytes, "output_bytes": out_bytes,
                        "files_on": "tmpfs (/dev/shm)" if base else "disk (tmp dir)", "consensus_equals_amplicons": got == sorted(truths),
                        "what": "python -m ngspeciesid_amd %s --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio %s: FASTQ parse, score, sort, sorted.fastq, "
-                               "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % ("--isoseq" if K_ == 15 else "--ont", args.cli_t, AB_)}
+                               "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % (cfg["preset"], args.cli_t, AB_)}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), 750 bp ONT", "value": round(reads_per_s, 1), "unit": "reads/s",
+    out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), %d bp %s" % (args.length, "CCS" if cfg["preset"] == "--isoseq" else "ONT"), "value": round(reads_per_s, 1), "unit": "reads/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
            "scaling": args.scaling if world > 1 or force_dist else "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic",
            "config": {"workload": (args.config.upper() + ": %d synthetic %d bp %s-profile reads " + ("in total, one `--t N` batch per GPU" if (args.scaling == "strong" and (world > 1 or force_dist)) else "per GPU") + " (mu=%.0f), %d species @15%% divergence%s, k=%d w=%d, cluster + spoa-style POA + racon-style polish x3, abundance_ratio %s, POA tile depth %d band %s")

@@ -156,7 +156,10 @@ typedef struct {
                               <= 1 024 bases, else 128).  A tile in which a traceback touches a clipped band edge is redone with twice the band (up to 256) */
     int32_t node_cap;      /* graph node capacity per tile as a multiple of 1/16 of the first read length (<=0 default) */
     int32_t trim;          /* 0 = none (spoa: the heaviest bundle is completed to a sink, so the consensus can carry the unsupported tail of a single
-                              read); 1 = coverage-trim the ends of every tile consensus (bases covered by less than half of the sequences merged) */
+                              read); 1 = coverage-trim the ends of every tile consensus (bases covered by less than half of the sequences merged) AND,
+                              on the upper levels of the hierarchy (members = weighted tile consensuses, the final tile included), drop interior bases
+                              whose column carries less than a third of the merged weight (round 3; a genuine insertion carried by under a third of the
+                              reads goes as well - with tile_depth <= 0 there is one level and the rule never applies).  DESIGN.md section 2 */
 } ngsid_poa_params_t;
 
 /* (a13,a14) replaces form_draft_consensus' per-cluster `spoa reads.fq -l 0 -r 0 -g -2` (consensus.py:83-92,249-278).
@@ -244,7 +247,7 @@ int32_t ngsid_host_infix_locate(const uint8_t* query, int32_t qlen, const uint8_
 
 /* Scheduling options of a context, for tests and tools: "cluster_block" (reads per speculative block, 0 = adaptive), "ed_band" (Ukkonen band of the
  * polisher's first aligner launch, 0 = off, -1 = automatic), "ed_win_all", "align32" (force the int32 clustering aligner), "align_noclass" (no
- * query-length classes), "align_paired" (0 = the one-pair-per-wave kernel for every length class; default 1: two pairs per wave for 513 - 896 query bases), "poa_tiles_per_cu", "minimizers_lean" (the long-read LDS layout of the minimizer kernel for every read), "poa_host_levels" (hierarchy levels driven by the host), "scratch_budget_mb" (cap of the aligners' traceback scratch: several contexts on one GPU), "release_scratch" (frees the context's grow-only scratch and the block cache now).  RESULTS NEVER
+ * query-length classes), "align_paired" (0 = the one-pair-per-wave kernel for every length class; default 1: two pairs per wave for every single-strip length class, i.e. queries of up to 896 bases, in batches of at least 4 096 pairs), "poa_tiles_per_cu", "minimizers_lean" (the long-read LDS layout of the minimizer kernel for every read), "poa_host_levels" (hierarchy levels driven by the host), "scratch_budget_mb" (cap of the aligners' traceback scratch: several contexts on one GPU), "release_scratch" (frees the context's grow-only scratch and the block cache now).  RESULTS NEVER
  * DEPEND ON THEM (tests/test_gpu_stress.py runs the parity suites under several settings); the library reads no environment variable for them.
  * Environment variables the library does read, none of which changes a result: NGSID_HOST_THREADS (thread count of the ngsid_host_* helpers,
  * default = hardware threads, at most 32), and three developer aids - NGSID_DEBUG_SYNC (synchronise and log after every launch),

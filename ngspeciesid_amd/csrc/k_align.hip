@@ -248,9 +248,27 @@ static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen
     return NGSID_OK;
 }
 
+// measurement (profiling on): DP cells of the call = sum of n x m over its pairs, one atomic per workgroup
+__global__ __launch_bounds__(256) void k_align_cells(AlignJob J, unsigned long long* __restrict__ stat)
+{
+    const uint64_t np = J.npairs_dev ? (uint64_t)*J.npairs_dev : J.npairs;
+    unsigned long long c = 0;
+    for (uint64_t x = (uint64_t)blockIdx.x * 256 + threadIdx.x; x < np; x += (uint64_t)gridDim.x * 256) {
+        const uint64_t p = J.pair_list ? J.pair_list[x] : x; const uint32_t qi = J.qidx[p], ti = J.tidx[p];
+        c += (unsigned long long)(J.qoff[qi + 1] - J.qoff[qi]) * (unsigned long long)(J.toff[ti + 1] - J.toff[ti]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(stat, part[0] + part[1] + part[2] + part[3]);
+}
+
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open, uint32_t min_qlen)
 {
     if (job.npairs == 0) return NGSID_OK;
+    if (ctx->prof && ctx->stat.p && !job.bp) { hipLaunchKernelGGL(k_align_cells, dim3((unsigned)std::min<uint64_t>(1024, (job.npairs + 255) / 256)), dim3(256), 0, ctx->stream, job, ctx->stat.p + 1); HIPCHK(ctx, hipGetLastError()); }
     if (job.npairs > 0xf0000000ull) NGSID_FAIL(ctx, NGSID_ERR_ARG, "more than 2^32 pairs in one aligner call");
     if (max_tlen > NGSID_MAX_READ_LEN || max_qlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in aligner", NGSID_MAX_READ_LEN);
     if (job.k > 64) NGSID_FAIL(ctx, NGSID_ERR_ARG, "window k > 64 unsupported");

@@ -64,7 +64,7 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
         int n0 = pp_sgpr((int)(J.qoff[qi0 + 1] - J.qoff[qi0])), m0 = pp_sgpr((int)(J.toff[ti0 + 1] - J.toff[ti0]));
         int n1 = pp_sgpr((int)(J.qoff[qi1 + 1] - J.qoff[qi1])), m1 = pp_sgpr((int)(J.toff[ti1 + 1] - J.toff[ti1]));
         if (!have1) { n1 = 0; m1 = 0; }                                   // single pair: the high halves stay inactive
-        // an empty target (the queries of these classes are never empty): the outputs of k_sg_align16 for that case, the half takes no part in the DP
+        // an empty target or an empty query (class 0 holds queries from 0 bases up): the outputs of k_sg_align16 for that case, the half takes no part in the DP
         auto degenerate = [&](uint64_t p, int n, int m) {
             if (lane == 0) {
                 const int cols = n + m; const int mid = J.match_id ? J.match_id[p] : J.k;

@@ -9,7 +9,7 @@ struct PoaJobSet {
     const uint32_t* nrun_dev;                 /* != null: the number of tiles to run is read from device memory (device-driven hierarchy: no host round trip between levels) */
     int m, n, g, Vcap, Ecap, Lmax, D, node_cap, trim_tiles;       // D = output slots per job
     int32_t* Hglob; uint8_t* dirglob; uint32_t* covglob;           // per resident workgroup scratch (filled by poa_run_jobs)
-    uint8_t* out; int32_t* out_len; int32_t* out_span /* (a0, a1) per slot, may be null */; uint64_t* out_cw; uint32_t* out_n; uint32_t* out_cov; uint32_t* dropped; uint32_t* slot_overflow; unsigned long long* phase_cycles; int phase_detail;   // optional dev instrumentation (NGSID_POA_PHASES=1: phase cycles; =2: also row kinds / checksums, which cost extra passes)
+    uint8_t* out; int32_t* out_len; int32_t* out_span /* (a0, a1) per slot, may be null */; uint64_t* out_cw; uint32_t* out_n; uint32_t* out_cov; uint32_t* dropped; uint32_t* slot_overflow; unsigned long long* phase_cycles; int phase_detail; unsigned long long* stat_rows /* != null (profiling on): DP rows are added here, one atomic per tile */;   // optional dev instrumentation (NGSID_POA_PHASES=1: phase cycles; =2: also row kinds / checksums, which cost extra passes)
 };
 
 // Tiles of a level: n sequences in tiles of D in order; a remainder of fewer than (D + 1) / 2 sequences does not get a tile of its own but joins the last full tile

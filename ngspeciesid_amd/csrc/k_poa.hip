@@ -20,6 +20,9 @@
 #include "k_poa.h"
 #include <algorithm>
 
+#ifndef POA_LT
+#define POA_LT 0          // experiment (not kept: slower, register pressure): band starts per anchor from an LDS table instead of three divisions per rank
+#endif
 #ifndef POA_REPEAT
 #define POA_REPEAT 0      // dev timing builds (tools/micro/build_repeat.sh): 1 / 2 / 3 / 4 = run the prepass / forward pass / traceback / emission twice (same results)
 #endif
@@ -403,16 +406,16 @@ __device__ __forceinline__ void tile_emit(const GG& g, const LLT<BW>& w, const P
     const int poff = V - n;
     mem_sync();
     PH(J, 15, tph2);
+    const bool trim = J.trim_tiles && dcov && n > 0;        // oracle EMIT: coverage-trim the tile consensus ends
+    const uint32_t thr = (uint32_t)(st.cw_sum / 2);
+    int tb = 0x7fffffff, te = -1;                            // first / last position whose column carries at least half of the merged weight
     for (int i = lane; i < n; i += 64) {
         const int v = g.tmpo(poff + i); dst[i] = g.cm(v) & 0x7f;
-        if (dcov) { uint32_t c = g.cov(v); for (int u = g.ring(v); u != v; u = g.ring(u)) c += g.cov(u); dcov[i] = c; }
+        if (dcov) { uint32_t c = g.cov(v); for (int u = g.ring(v); u != v; u = g.ring(u)) c += g.cov(u); dcov[i] = c; if (c >= thr) { tb = min(tb, i); te = max(te, i); } }
     }
-    mem_sync();
     int span_b = 0, span_e = n - 1;              // consensus positions whose nodes give the span (a0, a1) of the output in the first sequence's coordinates
-    if (J.trim_tiles && dcov && n > 0) {     // oracle EMIT: coverage-trim the tile consensus ends
-        const uint32_t thr = (uint32_t)(st.cw_sum / 2);
-        int b = 0x7fffffff, e = -1;
-        for (int i = lane; i < n; i += 64) if (dcov[i] >= thr) { b = min(b, i); e = max(e, i); }
+    if (trim) {
+        int b = tb, e = te;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { b = min(b, __shfl_xor(b, d)); e = max(e, __shfl_xor(e, d)); }
         if (b < e && b != 0x7fffffff) {
@@ -420,20 +423,24 @@ __device__ __forceinline__ void tile_emit(const GG& g, const LLT<BW>& w, const P
             // upper levels (trim_tiles & 2, members = weighted tile consensuses): between the kept ends every base whose column carries less than a THIRD of the
             // merged weight goes as well (oracle EMIT: the heaviest bundle maximises the SUM of the edge weights of a path, so a k-base insertion of the weight w
             // beats the direct edge W of the rest when (k + 1) w > W - a third for one base, a seventh for five).  Level-0 tiles keep spoa's / racon's behaviour.
-            // Ordered in-place compaction, 64 positions per round (an output index never exceeds the input index).
+            // Ordered in-place compaction, 64 positions per round: a round's stores land below the next round's loads (an output index never exceeds the input
+            // index), and a round's own loads have returned before its stores issue (they carry the loaded values): one drain in front of the loop suffices.
             const uint32_t thr3 = (J.trim_tiles & 2) ? (uint32_t)(st.cw_sum / 3) : 0u;
-            const int m2 = e - b + 1; int kept = 0;
-            for (int c0 = 0; c0 < m2; c0 += 64) {
-                const int x = c0 + lane; uint8_t ch = 0; uint32_t cv = 0;
-                if (x < m2) { ch = dst[b + x]; cv = dcov[b + x]; }
-                const bool keep = x < m2 && cv >= thr3;
-                const unsigned long long km = __ballot(keep);
+            const int m2 = e - b + 1;
+            if (thr3 == 0u && b == 0) n = m2;                 // nothing moves
+            else {
+                int kept = 0;
                 mem_sync();
-                if (keep) { const int o = kept + __popcll(km & ((1ull << lane) - 1ull)); dst[o] = ch; dcov[o] = cv; }
-                kept += __popcll(km);
-                mem_sync();
+                for (int c0 = 0; c0 < m2; c0 += 64) {
+                    const int x = c0 + lane; uint8_t ch = 0; uint32_t cv = 0;
+                    if (x < m2) { ch = dst[b + x]; cv = dcov[b + x]; }
+                    const bool keep = x < m2 && cv >= thr3;
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) { const int o = kept + __popcll(km & ((1ull << lane) - 1ull)); dst[o] = ch; dcov[o] = cv; }
+                    kept += __popcll(km);
+                }
+                n = kept;
             }
-            n = kept;
         }
     }
     if (lane == 0) {
@@ -818,6 +825,12 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
 #if POA_REPEAT == 1
     for (int rep_ = 0; rep_ < 2; ++rep_) {
 #endif
+    // band start per ANCHOR (anchors are coordinates in the first sequence: 0 .. L0-1): one division per anchor value in a table (the direction block is free
+    // until the forward pass stages its first row) instead of three per rank
+    const bool lt_lds = POA_LT && (unsigned)st.L0 * 2u <= (unsigned)(TBR * BW);
+    const l16 lt = POA_LDS(l16, LLT<BW>::DIRBLK);
+    if (lt_lds) { for (int a = lane; a < st.L0; a += 64) lt[a] = (uint16_t)band_lo(a, bm, BW); lds_sync(); }
+    auto BL = [&](int anchor) __attribute__((always_inline)) -> int { return lt_lds ? (int)lt[anchor] : band_lo(anchor, bm, BW); };
     for (int rb = 0; rb < V; rb += 128) {
         uint32_t ppv[2], arv[2]; int cmv[2], ofv[2], frv[2], lp0[2], lp1[2];
 #pragma unroll
@@ -828,12 +841,12 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
         for (int u = 0; u < 2; ++u) {
             const int r = rb + u * 64 + lane; const bool ok = r < V;          // (no divergent exits: the run lengths below are a wave ballot)
             const int p0 = ppv[u] & 0xffff, p1 = ppv[u] >> 16;
-            const int l0 = band_lo((int)(arv[u] & 0xffff), bm, BW); int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
+            const int l0 = BL((int)(arv[u] & 0xffff)); int fl = 0, d0 = 0, d1 = 0, dl0 = 0, dl1 = 0;
             if (ok) {
                 if (p0 == NONE16) fl |= 1;
                 else {
-                    d0 = r - p0; dl0 = l0 - band_lo(lp0[u], bm, BW);
-                    if (p1 != NONE16) { d1 = r - p1; dl1 = l0 - band_lo(lp1[u], bm, BW); if (cmv[u] & 0x80) fl |= 2; }
+                    d0 = r - p0; dl0 = l0 - BL(lp0[u]);
+                    if (p1 != NONE16) { d1 = r - p1; dl1 = l0 - BL(lp1[u]); if (cmv[u] & 0x80) fl |= 2; }
                     if (d0 > 255 || d1 > 255 || dl0 < 0 || dl0 > 255 || dl1 < 0 || dl1 > 255) { fl |= 2; d0 = d1 = dl0 = dl1 = 0; }
                 }
                 if (!ofv[u]) fl |= 4;
@@ -1061,6 +1074,7 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
     }
     if (ph_detail) { unsigned long long sm_ = 0; for (int i = lane; i < L; i += 64) sm_ += (unsigned long long)(alnode.get(i) + 1) * (unsigned)(i + 1); for (int d = 32; d >= 1; d >>= 1) sm_ += __shfl_xor(sm_, d); if (lane == 0) { atomicAdd(&PHS(J)[10], (unsigned long long)nnew); atomicAdd(&PHS(J)[11], sm_); } }
     if (seq_lds) lds_sync(); else mem_sync();
+    unsigned long long tpu = tph; PH(J, 21, tpu);
     if (V + nnew > st.capV || st.E + L > st.capE) return 2;      // oracle g_add_alignment capacity rule
     // ---------- new nodes of the chunks that have any (ids do not exist any more: a node IS its rank).  The k-th new node of the sequence goes immediately
     //             before old rank ins = the rank chosen for the first aligned position at or after its own (V = the end; non-decreasing in k) and lands on
@@ -1069,6 +1083,11 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
     // fit a byte and the ring has the room, else u16 in the HBM scratch.
     const bool sh_lds = seq_lds && nnew <= 255 && (unsigned)(2 * ((L + 7) & ~7) + V + 2) <= (unsigned)(HR * (BW + RPADL + RPADR) * 4);
     const l8 sh_l = POA_LDS(l8, LLT<BW>::HRING + 2u * (unsigned)((L + 7) & ~7));
+    // compact list of the new nodes (position, aligned rank, nearest aligned rank at or before, reference rank) behind nodeof[] in the direction block: the
+    // records of ALL new nodes are then written in one round (one dependent round trip for the anchors / ring links instead of one per 64-position chunk)
+    const int nn_cap = seq_lds ? (int)((unsigned)(TBR * BW) - 2u * (unsigned)((L + 7) & ~7)) / 8 : 0;
+    const bool nn_lds = nnew > 0 && nnew <= nn_cap;
+    const l16 nn_l = POA_LDS(l16, LLT<BW>::DIRBLK + 2u * (unsigned)((L + 7) & ~7));      // [4][nn_cap]
     auto SH = [&](int x) __attribute__((always_inline)) -> int { return sh_lds ? (int)sh_l[x] : (int)g.shiftg(x); };
     auto RM = [&](int x) __attribute__((always_inline)) -> int { return x + SH(x); };
     auto new_nodes = [&](const int pass) __attribute__((always_inline)) {
@@ -1095,6 +1114,7 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
                     const unsigned long long later = mn & ((lane == 63) ? 0ull : (~0ull << (lane + 1)));
                     const int ins_next = __shfl(ins, later ? __ffsll((long long)later) - 1 : 0);
                     if (isnew && (!later || ins_next != ins)) { if (sh_lds) sh_l[ins] = (uint8_t)(k + 1); else g.shiftg(ins) = (uint16_t)(k + 1); }
+                    if (isnew && nn_lds) { nn_l[k] = (uint16_t)i; nn_l[nn_cap + k] = (uint16_t)a; nn_l[2 * nn_cap + k] = (uint16_t)la; nn_l[3 * nn_cap + k] = (uint16_t)rf; }
                     if (!sh_lds) mem_sync();                        // (HBM fall-back: keep the stores of successive chunks to one address in order)
                 } else if (isnew) {
                     const int y = ins + k;
@@ -1147,11 +1167,26 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
         }
         for (int x = lane; x < st.nov; x += 64) { const int h = RM((int)g.ov_head(x)), t = RM((int)g.ov_tail(x)); g.ov_head(x) = (uint16_t)h; g.ov_tail(x) = (uint16_t)t; if (h - t > HR) g.far(t) = 1; }
         mem_sync();
+        PH(J, 22, tpu);
         // ---------- N: records of the new nodes
-        new_nodes(1);
+        if (nn_lds) {
+            for (int k0 = 0; k0 < nnew; k0 += 64) {
+                const int k = k0 + lane;
+                if (k < nnew) {
+                    const int i = nn_l[k], a = nn_l[nn_cap + k], la = nn_l[2 * nn_cap + k], rf = nn_l[3 * nn_cap + k];
+                    const int y = (rf != NONE16 ? rf : V) + k;
+                    const int anc = la != NONE16 ? (int)g.anchor(RM(la)) : (rf != NONE16 ? (int)g.anchor(RM(rf)) : (S.a1 < S.a0 ? 0 : S.a0));
+                    int rg = y;
+                    if (a != NONE16) { const int v = RM(a); rg = g.ring(v); g.ring(v) = (uint16_t)y; }      // joins the ring right behind the node it is aligned to
+                    g.cm(y) = w.sq()[i]; g.ar(y) = (uint32_t)anc | ((uint32_t)rg << 16); g.pp(y) = 0xFFFFFFFFu; g.ww(y) = 0ull; g.cov(y) = 0u; g.of(y) = 0;
+                    nodeof.set(i, y);
+                }
+            }
+        } else new_nodes(1);
         // existing nodes the sequence goes through: their final ranks
         for (int i = lane; i < L; i += 64) if (!((ch_new[i >> 6] >> (i & 63)) & 1ull)) nodeof.set(i, RM(nodeof.get(i)));
         mem_sync();
+        PH(J, 23, tpu);
     }
     // ---------- E: coverage and edges along the sequence (final ranks).  Every node of the path is touched by ONE position (its in-edge record, its coverage);
     //             the out-flag and the far flag of a node are written by the lane of the NEXT position (separate byte arrays).  A new edge takes the first
@@ -1250,7 +1285,7 @@ __device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscra
         const uint32_t s0 = J.job_off[job], s1 = J.job_off[job + 1];
         const int bbi = J.job_bb ? J.job_bb[job] : -1;
         TS st; st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.nout = 0; st.cw_sum = 0; st.nov = 0;
-        uint32_t ndrop = 0;
+        uint32_t ndrop = 0; unsigned long long nrows = 0;
         {   // per-job capacity = oracle run_tile: cap_for(L0) but at least the longest member + 1; edges 1.5x
             int maxlen = bbi >= 0 ? J.bbs[bbi].len : 0, first = bbi >= 0 ? J.bbs[bbi].len : 0;
             for (uint32_t si = s0; si < s1; ++si) { const int l = J.seqs[J.seq_idx ? J.seq_idx[si] : si].len; if (l > maxlen) maxlen = l; if (first == 0 && bbi < 0 && si == s0) first = l; }
@@ -1268,6 +1303,7 @@ __device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscra
                     if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, B, st, lane); }
                     else { if (S.len > st.capV) ++ndrop; else { tile_add_first(g, S, st, lane); st.members = 1; } break; }
                 }
+                nrows += (unsigned)st.V;
                 const int rcode = tile_align_add<CPL>(g, w, Hg, Dg, Dfull, J, S, st, lane, edge);
                 if (rcode == 1) { st.members += 1; break; }
                 if (rcode == 0 || attempt == 1) { ++ndrop; break; }
@@ -1279,7 +1315,7 @@ __device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscra
         { const int no_ = st.nout; tile_emit(g, w, J, job, st, lane); st.nout = no_; }
 #endif
         tile_emit(g, w, J, job, st, lane);
-        if (lane == 0) { J.out_n[job] = (uint32_t)st.nout | (edge ? 0x80000000u : 0u); if (ndrop && J.dropped) atomicAdd(J.dropped, ndrop); }      // bit 31: a traceback touched a clipped band edge
+        if (lane == 0) { J.out_n[job] = (uint32_t)st.nout | (edge ? 0x80000000u : 0u); if (ndrop && J.dropped) atomicAdd(J.dropped, ndrop); if (J.stat_rows) atomicAdd(J.stat_rows, nrows); }      // bit 31: a traceback touched a clipped band edge
         mem_sync();
     }
 }
@@ -1317,7 +1353,7 @@ int32_t poa_run_jobs(ngsid_ctx* ctx, PoaJobSet J, int band)
     if (ctx->poa_h.n < nwg * cells) HIPCHK(ctx, ctx->poa_h.alloc(nwg * cells));
     if (ctx->poa_d.n < nwg * cells * 3 / 2) HIPCHK(ctx, ctx->poa_d.alloc(nwg * cells * 3 / 2));
     if (ctx->poa_g.n < nwg * gbytes) HIPCHK(ctx, ctx->poa_g.alloc(nwg * gbytes));
-    J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = nullptr;
+    J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = nullptr; J.stat_rows = ctx->prof ? ctx->stat.p : nullptr;
     if (ctx->poa_ctr.n < 1) HIPCHK(ctx, ctx->poa_ctr.alloc(16));
     HIPCHK(ctx, hipMemsetAsync(ctx->poa_ctr.p, 0, sizeof(uint32_t), ctx->stream));
     ProfScope ps_(ctx, "k_poa_tile");
@@ -1376,7 +1412,7 @@ int32_t poa_launch(ngsid_ctx* ctx, const PoaPlan& P, PoaJobSet J, int BW, bool r
     const uint32_t nwg = redo ? P.nwg_redo : P.nwg_main;
     if (nwg == 0) return NGSID_OK;
     const size_t gbytes = poa_graph_bytes(J.Vcap, J.Ecap, J.Lmax);
-    J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = nullptr;
+    J.Hglob = ctx->poa_h.p; J.dirglob = ctx->poa_d.p; J.covglob = nullptr; J.stat_rows = ctx->prof ? ctx->stat.p : nullptr;
     ProfScope ps_(ctx, redo ? "k_poa_tile_redo" : "k_poa_tile");
     if (BW == 64) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile1, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, work_ctr); }
     else if (BW == 128) { HIPCHK(ctx, hipFuncSetAttribute((const void*)k_poa_tile2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_poa_tile2, dim3(nwg), dim3(64), lds, ctx->stream, J, ctx->poa_g.p, gbytes, work_ctr); }

@@ -456,6 +456,7 @@ extern "C" int32_t ngsid_profile_enable(ngsid_ctx* ctx, int32_t on)
 {
     if (!ctx) return NGSID_ERR_ARG;
     prof_collect(ctx); ctx->prof_acc.clear(); ctx->prof = on != 0;
+    if (on) { if (ctx->stat.n < 8) HIPCHK(ctx, ctx->stat.alloc(8)); HIPCHK(ctx, hipMemsetAsync(ctx->stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
     return NGSID_OK;
 }
 extern "C" int32_t ngsid_reads_upload(ngsid_ctx* ctx, const ngsid_reads_t* host, ngsid_reads_t* dev)
@@ -518,6 +519,10 @@ extern "C" int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap)
     for (auto& kv : ctx->prof_acc) { char line[256]; snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.second, kv.second.first); out += line; }
     ctx->prof_acc.clear();
     { char line[128]; snprintf(line, sizeof line, "poa_band_redo_tiles %llu 0.0\n", (unsigned long long)ctx->poa_redo_tiles); out += line; ctx->poa_redo_tiles = 0; }   // not a kernel: tiles redone with a wider band (band-edge check)
+    if (ctx->stat.p) {          // work counters (not kernels): DP rows of k_poa_tile (x band columns = cell updates), DP cells of the clustering aligner
+        unsigned long long h[8] = {0}; HIPCHK(ctx, hipMemcpy(h, ctx->stat.p, sizeof h, hipMemcpyDeviceToHost)); HIPCHK(ctx, hipMemset(ctx->stat.p, 0, sizeof h));
+        char line[160]; snprintf(line, sizeof line, "poa_dp_rows %llu 0.0\nsg_dp_cells %llu 0.0\n", h[0], h[1]); out += line;
+    }
     if (out.size() + 1 > cap) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "profile buffer too small");
     memcpy(buf, out.c_str(), out.size() + 1);
     return NGSID_OK;

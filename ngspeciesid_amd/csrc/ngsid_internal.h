@@ -87,6 +87,7 @@ struct ngsid_ctx {
     void* pin = nullptr; size_t pin_bytes = 0;     // pinned host staging (device -> host copies of offsets)
     std::map<std::string, long long> options;     // ngsid_ctx_option
     bool debug_sync = false;
+    DevBuf<unsigned long long> stat;     // work counters while profiling is on (bench.py): [0] DP rows of k_poa_tile, [1] DP cells of the clustering aligner
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
 };
@@ -146,7 +147,7 @@ int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qle
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
 int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t min_qlen = 0);
 int32_t ngsid_side_streams(ngsid_ctx* ctx);          // creates ctx->side / events on first use
-int32_t ngsid_paired_tb_words(ngsid_ctx* ctx, int cls, uint64_t npairs, uint32_t max_tlen, uint64_t* words);      // k_align16p.hip: two pairs per wave for the classes 2 and 3
+int32_t ngsid_paired_tb_words(ngsid_ctx* ctx, int cls, uint64_t npairs, uint32_t max_tlen, uint64_t* words);      // k_align16p.hip: two pairs per wave for every single-strip length class (queries of up to 896 bases)
 int32_t ngsid_launch_paired_class(ngsid_ctx* ctx, const AlignJob& job, int cls, uint32_t max_tlen, hipStream_t st, uint64_t* tb);
 int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job);      // query-length classes {<=256, <=512, <=768, <=896, rest}: lists in ctx->aln_cls, counts in ctx->aln_ctr[8..12]
 int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out);   // k_ed_align.hip (uses qseq..npairs, bp, bp_windows, window, span)

@@ -119,7 +119,7 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
                 ctx->poa_redo_tiles += redo.size();
             }
             for (uint32_t j = 0; j < njobs; ++j) h_out_n[j] &= 0x7fffffffu;
-            if (want_ph) { std::vector<unsigned long long> hs(24 * 256); HIPCHK(ctx, hipMemcpy(hs.data(), d_ph.p, 192 * 256, hipMemcpyDeviceToHost)); unsigned long long h[24] = {0}; for (int s_ = 0; s_ < 256; ++s_) for (int k_ = 0; k_ < 24; ++k_) h[k_] += hs[s_ * 24 + k_]; fprintf(stderr, "[ngsid poa phases, Mcycles] jobs %u prepass %.1f forward %.1f traceback %.1f update %.1f emit %.1f | rows %llu non-chain %llu | sums: bestv %llu bestpk %llu nnew %llu alnsum %llu outlen %llu | tb iters %llu reloads %llu reload Mcycles %.1f | emit backtrack %.1f | row kinds: tight %llu in %llu runs, chain %llu, near %llu, generic %llu\n", njobs, h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[7], h[13], h[14] / 1e6, h[15] / 1e6, h[16], h[17], h[18], h[19], h[20]); }
+            if (want_ph) { std::vector<unsigned long long> hs(24 * 256); HIPCHK(ctx, hipMemcpy(hs.data(), d_ph.p, 192 * 256, hipMemcpyDeviceToHost)); unsigned long long h[24] = {0}; for (int s_ = 0; s_ < 256; ++s_) for (int k_ = 0; k_ < 24; ++k_) h[k_] += hs[s_ * 24 + k_]; fprintf(stderr, "[ngsid poa phases, Mcycles] jobs %u prepass %.1f forward %.1f traceback %.1f update %.1f emit %.1f | rows %llu non-chain %llu | sums: bestv %llu bestpk %llu nnew %llu alnsum %llu outlen %llu | tb iters %llu reloads %llu reload Mcycles %.1f | emit backtrack %.1f | row kinds: tight %llu in %llu runs, chain %llu, near %llu, generic %llu | update: A %.1f S+D %.1f N %.1f\n", njobs, h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[5], h[6], h[8], h[9], h[10], h[11], h[12], h[7], h[13], h[14] / 1e6, h[15] / 1e6, h[16], h[17], h[18], h[19], h[20], h[21] / 1e6, h[22] / 1e6, h[23] / 1e6); }
             if (h_flags[2]) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA tile kernel loop guard tripped (code %u)", h_flags[2]);
             if (!h_flags[1]) break;
             if (slots >= (int)maxD) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: POA output slot overflow at full depth");

@@ -66,7 +66,10 @@ def orient_reads(rs: ReadSet, flip) -> ReadSet:
     else:
         k = rs.keep if isinstance(rs.keep, dict) else {}
         if k.get("seq") is None:
-            raise ValueError("orient_reads needs a host read set or a torch-backed device read set")
+            # a read set made by Api.upload_reads keeps its host copy and the Api it was uploaded through: orient the host copy, upload the result
+            if k.get("host") is not None and k.get("api") is not None:
+                return k["api"].upload_reads(orient_reads(k["host"], flip))
+            raise ValueError("orient_reads needs a host read set, a torch-backed device read set or one made by Api.upload_reads")
         seq_t, qual_t, off_t = k["seq"], k.get("qual"), k["off"]
     dev = seq_t.device
     comp = torch.from_numpy(_COMP).to(dev)

@@ -131,6 +131,12 @@ static inline int bcode(uint8_t c) {
     switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
 }
 typedef struct { int score, i_end, j_end; uint8_t* tb; int n, m; } sg_result;
+/* Tie-break ENVELOPE (tools/r04_tiebreak_envelope.py): which of several co-optimal alignments parasail 1.2.4 returns is unpinned, so the
+   oracle can be switched to the other plausible orders to count how many clustering decisions depend on the choice.  0 = this build's rules (the only mode the
+   HIP kernels implement and every test runs).  bit 0: H prefers diag > F > E (instead of diag > E > F); bit 1: E / F prefer OPENING on ties; bit 2: end cell
+   = LAST maximum (last column from the bottom first, then the last row from the right); bit 3: H prefers a gap on ties (E > F > diag; with bit 0: F > E > diag). */
+static int g_sg_tiebreak = 0;
+int32_t ongsid_debug_sg_tiebreak(int32_t mode) { const int old = g_sg_tiebreak; if (mode >= 0) g_sg_tiebreak = mode; return old; }
 
 static int sg_align(const uint8_t* q, int n, const uint8_t* t, int m, int match, int mismatch, int open, int ext, sg_result* R) {
     R->n = n; R->m = m; R->tb = NULL; R->score = 0; R->i_end = 0; R->j_end = 0;
@@ -145,12 +151,16 @@ static int sg_align(const uint8_t* q, int n, const uint8_t* t, int m, int match,
         int qa = bcode(q[i - 1]);
         for (int j = 1; j <= m; ++j) {
             int tbv;
-            int e_ext = e - ext, e_opn = hleft - open; int ebit = e_ext >= e_opn; e = ebit ? e_ext : e_opn;
-            int f_ext = F[j] - ext, f_opn = H[j] - open; int fbit = f_ext >= f_opn; int f = fbit ? f_ext : f_opn;
+            const int tbm = g_sg_tiebreak;
+            int e_ext = e - ext, e_opn = hleft - open; int ebit = (tbm & 2) ? (e_ext > e_opn) : (e_ext >= e_opn); e = ebit ? e_ext : e_opn;
+            int f_ext = F[j] - ext, f_opn = H[j] - open; int fbit = (tbm & 2) ? (f_ext > f_opn) : (f_ext >= f_opn); int f = fbit ? f_ext : f_opn;
             int ta = bcode(t[j - 1]);
             int s = (qa > 3 || ta > 3) ? 0 : (qa == ta ? match : mismatch);
             int d = hdiag + s, h, src;
-            if (d >= e && d >= f) { h = d; src = 0; } else if (e >= f) { h = e; src = 1; } else { h = f; src = 2; }
+            if (!(tbm & (1 | 8))) { if (d >= e && d >= f) { h = d; src = 0; } else if (e >= f) { h = e; src = 1; } else { h = f; src = 2; } }
+            else if (!(tbm & 8)) { if (d >= e && d >= f) { h = d; src = 0; } else if (f >= e) { h = f; src = 2; } else { h = e; src = 1; } }                 /* diag > F > E */
+            else if (!(tbm & 1)) { if (e >= f && e >= d) { h = e; src = 1; } else if (f >= d) { h = f; src = 2; } else { h = d; src = 0; } }                 /* E > F > diag */
+            else { if (f >= e && f >= d) { h = f; src = 2; } else if (e >= d) { h = e; src = 1; } else { h = d; src = 0; } }                                /* F > E > diag */
             tbv = src | (ebit << 2) | (fbit << 3);
             tb[(size_t)(i - 1) * m + (j - 1)] = (uint8_t)tbv;
             hdiag = H[j]; H[j] = h; F[j] = f; hleft = h;
@@ -158,8 +168,13 @@ static int sg_align(const uint8_t* q, int n, const uint8_t* t, int m, int match,
         lastcol[i] = H[m];
     }
     int best = NEGINF, bi = n, bj = 1;
-    for (int j = 1; j <= m; ++j) if (H[j] > best) { best = H[j]; bi = n; bj = j; }
-    for (int i = 1; i <= n; ++i) if (lastcol[i] > best) { best = lastcol[i]; bi = i; bj = m; }
+    if (!(g_sg_tiebreak & 4)) {
+        for (int j = 1; j <= m; ++j) if (H[j] > best) { best = H[j]; bi = n; bj = j; }
+        for (int i = 1; i <= n; ++i) if (lastcol[i] > best) { best = lastcol[i]; bi = i; bj = m; }
+    } else {
+        for (int i = n; i >= 1; --i) if (lastcol[i] > best) { best = lastcol[i]; bi = i; bj = m; }
+        for (int j = m; j >= 1; --j) if (H[j] > best) { best = H[j]; bi = n; bj = j; }
+    }
     R->score = best; R->i_end = bi; R->j_end = bj; R->tb = tb;
     free(H); free(F); free(lastcol);
     return 0;

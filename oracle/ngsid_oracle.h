@@ -68,6 +68,9 @@ int32_t ongsid_polish_trace(const ngsid_reads_t* backbones, const ngsid_reads_t*
    (ngsid_oracle_poa_rank.c, the representation of csrc/k_poa.hip); e < 0 only reads.  Returns the previous value. */
 int32_t ongsid_debug_poa_engine(int32_t e);
 
+/* tie-break envelope of the aligner (ngsid_oracle.c: g_sg_tiebreak); mode < 0 only reads.  Returns the previous mode. */
+int32_t ongsid_debug_sg_tiebreak(int32_t mode);
+
 /* debugging taps used by the golden tests (per-read mapping-stage triple of cluster.py:302) */
 int32_t ongsid_debug_enable_trace(int32_t* best_m, int32_t* nshared, double* ratio, uint64_t n);
 

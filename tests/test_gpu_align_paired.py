@@ -36,6 +36,7 @@ def _make(seed, npairs, nt=24, lo_len=500, min_q=513):
         if len(q) < min_q: q = np.concatenate([q, LET[rng.integers(0, 4, min_q - len(q))]])
         if rng.random() < 0.05: q = q.copy(); q[rng.integers(0, len(q), 3)] = ord("N")   # wildcards
         if rng.random() < 0.05: q = q.copy(); q[: len(q) // 3] |= 0x20                    # lower case (raw-character identity differs from the score's)
+        if min_q <= 1 and rng.random() < 0.003: q = np.zeros(0, dtype=np.uint8)          # an empty QUERY (class 0): the degenerate branch, query side
         qs.append(q); qi.append(p); ti.append(t if rng.random() > 0.002 else nt)
     Q = ReadSet(np.concatenate(qs), None, np.concatenate(([0], np.cumsum([len(x) for x in qs]))).astype(np.uint64))
     T = ReadSet(np.concatenate(targets), None, np.concatenate(([0], np.cumsum([len(x) for x in targets]))).astype(np.uint64))
@@ -84,3 +85,26 @@ def test_paired_kernel_odd_bins_and_single_class(gpu_api):
             _opt(gpu_api, b"align_paired", 1)
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+def test_paired_kernel_break_points_and_spans(gpu_api):
+    """the per-window break points and the aligned span (AlignJob.bp / .span: what the polisher's layers are cut from) of the paired kernel against the
+    one-pair kernel: a polishing call with the affine read -> backbone aligner (aln_mode 0) over > 4 096 reads returns the same sequences and read
+    counts either way (the two outputs were not compared directly)"""
+    from ngspeciesid_amd import synth
+    from ngspeciesid_amd._capi import polish_params
+    sp = synth.make_species(2, 700, 0.15, seed=5)
+    rd = synth.make_reads(sp, 5000, mu=15.0, seed=6)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    spc = rd["species"].numpy(); order = np.argsort(spc, kind="stable").astype(np.uint32); n0 = int((spc == 0).sum())
+    bb = ReadSet.from_strings([rs.get(int(order[0]))[0], rs.get(int(order[n0]))[0]])
+    res = {}
+    try:
+        for v in (1, 0):
+            _opt(gpu_api, b"align_paired", v)
+            res[v] = gpu_api.polish(bb, rs, [0, n0, rs.n], polish_params(iters=2, k=13, w=20, tile_depth=6, band=0, trim=2, aln_mode=0, stop_when_stable=0), read_order=order)
+    finally:
+        _opt(gpu_api, b"align_paired", 1)
+    assert res[1][0] == res[0][0] and np.array_equal(res[1][1], res[0][1])
+    assert sorted(res[1][0]) == sorted(s.tobytes().decode() for s in sp)
+

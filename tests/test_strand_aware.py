@@ -87,6 +87,9 @@ def test_strand_aware_option_hip_equals_oracle(gpu_api, oracle):
     drs = ReadSet.from_torch(torch.from_numpy(sub.seq).to(dev), torch.from_numpy(sub.qual).to(dev), torch.from_numpy(sub.off.astype(np.int64)).to(dev))
     d = _run(gpu_api, drs, score, strand_aware=True)
     assert np.array_equal(d["rep_of"], on["rep_of"]) and [c[3] for c in d["centers"]] == [c[3] for c in on["centers"]]
+    # a read set uploaded through the C-ABI (ngsid_reads_upload: no torch tensors behind it): oriented from its host copy, same result
+    u = _run(gpu_api, gpu_api.upload_reads(sub), score, strand_aware=True)
+    assert np.array_equal(u["rep_of"], on["rep_of"]) and np.array_equal(u["flip"], on["flip"]) and [c[3] for c in u["centers"]] == [c[3] for c in on["centers"]]
 
 
 @pytest.mark.gpu

@@ -14,10 +14,14 @@ for line in open("gpurun_out/r4q/phases.txt"):
     if m:
         for k,v in zip(("prepass","forward","traceback","update","emit"),m.groups()[:5]): ph[k]+=float(v)
         rows+=int(m.group(6))
+    m=re.search(r"update: A ([\d.]+) S\+D ([\d.]+) N ([\d.]+)",line)
+    if m:
+        for k,v in zip(("uA","uSD","uN"),m.groups()): ph[k]+=float(v)
     m=re.search(r"row kinds: tight (\d+) in (\d+) runs, chain (\d+), near (\d+), generic (\d+)",line)
     if m:
         for k,v in zip(("tight","runs","chain","near","generic"),m.groups()): ph["k_"+k]+=int(v)
 tot=sum(ph[k] for k in ("prepass","forward","traceback","update","emit"))
+print("update split (share of all phases):",{k:round(ph[k]/tot,3) for k in ("uA","uSD","uN")})
 print("rows",rows,{k:round(ph[k]/tot,3) for k in ("prepass","forward","traceback","update","emit")}, {k:int(v) for k,v in ph.items() if k.startswith("k_")})
 fs=glob.glob("gpurun_out/r4q/pmc/**/*counter_collection.csv",recursive=True)
 sq=collections.defaultdict(float)
