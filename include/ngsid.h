@@ -174,6 +174,13 @@ int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const ui
 int32_t ngsid_poa_consensus_cov(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                                 const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint32_t* cov, uint64_t cons_cap, uint64_t* needed);
 
+/* (8e step 3: the N-GPU merge of per-shard partial consensuses, parallelize.py:107-217 has no counterpart - the reference never splits a cluster's
+ * consensus) same as ngsid_poa_consensus, but sequence i of `reads` stands for weight[i] reads (host array over the reads of the set, 0 counts as 1):
+ * qualities are ignored and every base of the sequence weighs weight[i] (capped at 2^20 per base, like the tile consensuses of the upper levels). */
+int32_t ngsid_poa_consensus_weighted(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                     const ngsid_poa_params_t* prm, const uint32_t* weight,
+                                     uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed);
+
 typedef struct {
     int32_t iters;            /* --racon_iter (NGSpeciesID:212) */
     int32_t window;           /* racon -w 500 */

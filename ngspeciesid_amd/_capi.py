@@ -264,6 +264,20 @@ class Api:
         if rc: self._err(rc)
         return [cons[int(coff[g]):int(coff[g + 1])].tobytes().decode() for g in range(ng)]
 
+    def poa_consensus_weighted(self, rs: ReadSet, grp_off, prm: PoaParams, weight, cap=None, read_order=None):
+        """ngsid_poa_consensus_weighted: sequence i stands for weight[i] reads (the merge of per-shard partial consensuses)"""
+        grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
+        ro = None if read_order is None else np.ascontiguousarray(read_order, dtype=np.uint32)
+        wv = np.ascontiguousarray(weight, dtype=np.uint32); assert len(wv) == rs.n
+        ng = len(grp_off) - 1
+        if cap is None:
+            lens = np.diff(rs.off.astype(np.int64)) if rs.mem == MEM_HOST else None
+            cap = int(4 * (lens.max() if lens is not None and len(lens) else 16384) * max(ng, 1) + 1024)
+        coff = np.zeros(ng + 1, dtype=np.uint64); cons = np.zeros(cap, dtype=np.uint8); needed = C.c_uint64(0)
+        rc = self._call("poa_consensus_weighted", C.byref(rs.c), _p(ro), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(wv), _p(coff), _p(cons), C.c_uint64(cap), C.byref(needed))
+        if rc: self._err(rc)
+        return [cons[int(coff[g]):int(coff[g + 1])].tobytes().decode() for g in range(ng)]
+
     def poa_consensus_cov(self, rs: ReadSet, grp_off, prm: PoaParams, cap=None, read_order=None):
         """-> [(consensus string, uint32 coverage array)] per group"""
         grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)

@@ -24,11 +24,14 @@ struct Level {                      // device buffers of one hierarchy level (ke
     DevBuf<PSeq> seqs; DevBuf<uint8_t> out; DevBuf<int32_t> out_len; DevBuf<uint64_t> out_cw; DevBuf<uint32_t> out_n, out_cov;
 };
 
-__global__ void k_make_pseq_reads(const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint64_t n, int mode, PSeq* out)
+__global__ void k_make_pseq_reads(const uint8_t* seq, const uint8_t* qual, const uint64_t* off, uint64_t n, int mode, const uint32_t* weight, PSeq* out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     PSeq S; S.s = seq + off[i]; S.q = qual ? qual + off[i] : nullptr; S.len = (int32_t)(off[i + 1] - off[i]); S.uw = 1; S.cw = 1; S.mode = mode; S.a0 = 0; S.a1 = -1;
+    if (weight) {        // a sequence that stands for weight[i] reads (ngsid_poa_consensus_weighted): unit weights of that size, like the tile consensuses of the upper levels
+        const uint32_t wv = weight[i]; S.q = nullptr; S.cw = wv; S.uw = (int32_t)(wv > (1u << 20) ? (1u << 20) : (wv < 1u ? 1u : wv));
+    }
     out[i] = S;
 }
 
@@ -516,7 +519,16 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
 
 // ---------------------------------------------------------------------------------------------- (a13,a14)
 static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
-                                  const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov);
+                                  const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov, const uint32_t* weight = nullptr);
+
+// (8e step 3) the merge of per-shard partial consensuses: sequence i stands for weight[i] reads (host array, one entry per read of `reads`; 0 counts as 1).
+// Qualities are ignored: every base of sequence i weighs weight[i] (capped at 2^20 per base like the tile consensuses of the hierarchy's upper levels).
+extern "C" int32_t ngsid_poa_consensus_weighted(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                                const ngsid_poa_params_t* prm, const uint32_t* weight, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed)
+{
+    if (ctx && !weight) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null weight array");
+    return poa_consensus_impl(ctx, reads, read_order, grp_off, n_groups, prm, cons_off, cons, cons_cap, needed, nullptr, weight);
+}
 
 extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                                        const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed)
@@ -533,7 +545,7 @@ extern "C" int32_t ngsid_poa_consensus_cov(ngsid_ctx* ctx, const ngsid_reads_t* 
 }
 
 static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
-                                  const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov)
+                                  const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov, const uint32_t* weight)
 {
     if (!ctx) return NGSID_ERR_ARG;
     if (!reads || !grp_off || !prm || !cons_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
@@ -544,7 +556,8 @@ static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, co
     if (read_order) for (uint64_t x = 0; x < grp_off[n_groups]; ++x) if (read_order[x] >= RD.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "read_order[%llu] out of range", (unsigned long long)x);
     htc.mark("checks");
     DevBuf<PSeq> d_seqs; HIPCHK(ctx, d_seqs.alloc(RD.n));
-    if (RD.n) hipLaunchKernelGGL(k_make_pseq_reads, dim3((unsigned)((RD.n + 255) / 256)), dim3(256), 0, ctx->stream, RD.seq, RD.qual, RD.off, RD.n, prm->mode, d_seqs.p);
+    DevBuf<uint32_t> d_weight; if (weight && RD.n) { HIPCHK(ctx, d_weight.alloc(RD.n)); HIPCHK(ctx, hipMemcpyAsync(d_weight.p, weight, 4 * RD.n, hipMemcpyHostToDevice, ctx->stream)); }
+    if (RD.n) hipLaunchKernelGGL(k_make_pseq_reads, dim3((unsigned)((RD.n + 255) / 256)), dim3(256), 0, ctx->stream, RD.seq, RD.qual, RD.off, RD.n, prm->mode, weight ? d_weight.p : (const uint32_t*)nullptr, d_seqs.p);
     HIPCHK(ctx, hipGetLastError());
     std::vector<Unit> units(n_groups);
     for (uint64_t g = 0; g < n_groups; ++g) {

@@ -142,22 +142,23 @@ def run_virtual_ranks(world, fn):
 
 
 def _weighted_merge_all(api, partials, counts, band):
-    """For every selected cluster: POA of its per-shard partial consensuses; the quality string carries the weight (reads represented,
-    scaled to 1..93).  partials[c] / counts[c] = one entry per shard.  All clusters go through ONE library call (one group each)."""
+    """For every selected cluster: POA of its per-shard partial consensuses, each weighted by the NUMBER OF READS it stands for (ngsid_poa_consensus_weighted;
+    until round 3 the count was squeezed into a quality character, 1 .. 93: a shard holding under 1 % of a cluster's reads - the common case for the rare
+    species of a skewed sample - then weighed 1/93 instead of its share).  partials[c] / counts[c] = one entry per shard.  All clusters go through ONE
+    library call (one group each)."""
     out = [""] * len(partials)
-    seqs, quals, grp, which = [], [], [0], []
+    seqs, weights, grp, which = [], [], [0], []
     for c, (ps, cs) in enumerate(zip(partials, counts)):
-        items = [(s, n) for s, n in zip(ps, cs) if s and n > 0]
+        items = [(s, int(n)) for s, n in zip(ps, cs) if s and n > 0]
         if not items:
             continue
         if len(items) == 1:
             out[c] = items[0][0]; continue
-        mx = max(n for _, n in items)
         for s, n in items:
-            seqs.append(s); quals.append(chr(33 + max(1, min(93, int(round(93.0 * n / mx))))) * len(s))
+            seqs.append(s); weights.append(n)
         grp.append(len(seqs)); which.append(c)
     if which:
-        res = api.poa_consensus(ReadSet.from_strings(seqs, quals), grp, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=band))
+        res = api.poa_consensus_weighted(ReadSet.from_strings(seqs), grp, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=band), np.asarray(weights, dtype=np.uint32))
         for c, r in zip(which, res):
             out[c] = r
     return out

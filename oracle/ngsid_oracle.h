@@ -57,6 +57,8 @@ int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_or
                              uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed);
 int32_t ongsid_poa_consensus_cov(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                                  const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint32_t* cov, uint64_t cons_cap, uint64_t* needed);
+int32_t ongsid_poa_consensus_weighted(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                      const ngsid_poa_params_t* prm, const uint32_t* weight, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed);
 int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                       const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                       uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used);

@@ -372,6 +372,15 @@ static int default_band(const ngsid_reads_t* reads) { uint64_t mx = 0; for (uint
 
 static int32_t poa_consensus_impl(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                                   const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov_out);
+static const uint32_t* g_seq_weight = NULL;      /* ongsid_poa_consensus_weighted: per-read weights of the call in progress */
+int32_t ongsid_poa_consensus_weighted(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                      const ngsid_poa_params_t* prm, const uint32_t* weight, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed) {
+    if (!weight) return NGSID_ERR_ARG;
+    g_seq_weight = weight;
+    const int32_t rc = poa_consensus_impl(reads, read_order, grp_off, n_groups, prm, cons_off, cons, cons_cap, needed, NULL);
+    g_seq_weight = NULL;
+    return rc;
+}
 int32_t ongsid_poa_consensus(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                              const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed) {
     return poa_consensus_impl(reads, read_order, grp_off, n_groups, prm, cons_off, cons, cons_cap, needed, NULL);
@@ -392,6 +401,7 @@ static int32_t poa_consensus_impl(const ngsid_reads_t* reads, const uint32_t* re
             uint64_t r = read_order ? read_order[grp_off[g] + (uint64_t)i] : grp_off[g] + (uint64_t)i;
             seqs[i].s = reads->seq + reads->off[r]; seqs[i].q = reads->qual ? reads->qual + reads->off[r] : NULL; seqs[i].len = (int)(reads->off[r + 1] - reads->off[r]);
             seqs[i].uw = 1; seqs[i].cw = 1; seqs[i].mode = prm->mode; seqs[i].a0 = 0; seqs[i].a1 = -1;
+            if (g_seq_weight) { const uint32_t wv = g_seq_weight[r]; seqs[i].q = NULL; seqs[i].cw = wv; seqs[i].uw = (int)(wv > (1u << 20) ? (1u << 20) : (wv < 1u ? 1u : wv)); }
         }
         uint8_t* c = NULL; uint32_t* cv = NULL; int len = run_hierarchy(seqs, ns, NULL, &P, prm->tile_depth, prm->mode, &c, cov_out ? &cv : NULL, cov_out != NULL);
         if (total + (uint64_t)len <= cons_cap) { memcpy(cons + total, c, (size_t)len); if (cov_out) for (int x = 0; x < len; ++x) cov_out[total + (uint64_t)x] = cv ? cv[x] : 0; } else overflow = 1;

@@ -117,3 +117,42 @@ def test_virtual_rank_failure_does_not_hang(oracle):
         return comm.all_gather_obj(dict(x=np.arange(3)))
     with pytest.raises(ValueError):
         distributed.run_virtual_ranks(3, fn)
+
+
+def test_skewed_shards_weigh_their_share(oracle, monkeypatch):
+    """one shard holds 0.5 % of a cluster's reads (the common case for rare species of a skewed sample).  The per-shard partial
+    consensuses are merged with the NUMBER OF READS each stands for as weight (ngsid_poa_consensus_weighted; the 1 .. 93 quality-character clamp of
+    round 3 gave such a shard 1/93 instead of its share): the weights handed to the library are the read counts, and the sharded result equals the
+    single-process result and the amplicons."""
+    from ngspeciesid_amd import distributed, synth, pipeline
+    from ngspeciesid_amd._capi import ReadSet
+    from ngspeciesid_amd.hostutil import subset_reads
+    from ngspeciesid_amd.ptable import select_p_table
+    sp = synth.make_species(2, 600, 0.15, seed=41)
+    rd = synth.make_reads(sp, 1600, mu=15.0, seed=43)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    score, err, keep = oracle.score_reads(rs, 13, 7.0)
+    idx = np.nonzero(keep)[0]; idx = idx[np.argsort(-score[idx], kind="stable")]
+    spc = rd["species"].numpy()[idx]
+    a_reads = idx[spc == 0]; b_reads = idx[spc == 1]
+    na = len(a_reads); tiny = max(3, na // 200)                       # 0.5 % of species A ...
+    half = (na - tiny) // 2
+    shards = [np.sort(np.concatenate([a_reads[:half], b_reads[: len(b_reads) // 3]])), np.sort(np.concatenate([a_reads[half:na - tiny], b_reads[len(b_reads) // 3: 2 * len(b_reads) // 3]])),
+              np.sort(np.concatenate([a_reads[na - tiny:], b_reads[2 * len(b_reads) // 3:]]))]          # ... sits in the third shard, next to a third of species B
+    order = {int(r): x for x, r in enumerate(idx)}
+    shards = [np.array(sorted(s.tolist(), key=lambda r: order[int(r)])) for s in shards]             # every shard in score order (the greedy order)
+    seen = []
+    real = oracle.poa_consensus_weighted
+    monkeypatch.setattr(oracle, "poa_consensus_weighted", lambda rset, grp, prm, weight, **kw: (seen.append(np.asarray(weight).tolist()), real(rset, grp, prm, weight, **kw))[1], raising=False)
+    kw = dict(k=13, w=20, p_shared=select_p_table(13, 20), abundance_ratio=0.05, racon_iter=1, tile_depth=6)
+    def fn(comm):
+        s = shards[comm.rank]
+        return distributed.sharded_hot_path(oracle, subset_reads(rs, s), score[s], acc_rank_local=np.array([order[int(r)] for r in s], dtype=np.uint32), comm=comm, **kw)
+    res = distributed.run_virtual_ranks(3, fn)
+    cent = [sorted((c[0], c[3]) for c in r["centers"]) for r in res]
+    assert all(c == cent[0] for c in cent[1:]) and len(cent[0]) == 2
+    assert any(min(wl) <= tiny and max(wl) >= 100 * min(wl) for wl in seen), "no merge saw the skewed weights: %s" % seen[:4]       # real counts, not 1 .. 93
+    truths = sorted(t.tobytes().decode() for t in sp)
+    assert sorted(c[1] for c in cent[0]) == truths
+    one = pipeline.run_hot_path(oracle, subset_reads(rs, idx), score[idx], acc_rank=np.arange(len(idx), dtype=np.uint32), **kw)
+    assert sorted(c[3] for c in one["centers"]) == sorted(c[1] for c in cent[0])

@@ -44,7 +44,9 @@ def _check_consensus(sp, res, max_ed):
     from util_seq import edit_distance
     truths = [s.tobytes().decode() for s in sp]
     assert len(res["centers"]) == len(truths)
+    tset = set(truths)
     for c in res["centers"]:
+        if c[3] in tset: continue                              # exact hit (the rule at these sizes; 20 truths x 9 end trims of a 2 kb edit distance take a minute)
         ed = min(min(edit_distance(c[3][a:len(c[3]) - b if b else None], t) for a in range(3) for b in range(3)) for t in truths)
         assert ed <= max_ed, "consensus of cluster %d is %d edits away from every amplicon" % (c[1], ed)
 
