@@ -233,6 +233,9 @@ int32_t ngsid_merge_representatives(ngsid_ctx* ctx, const ngsid_reads_t* reps, c
  * ngsid_host_normalize_bases: in place, a..z -> A..Z, then anything outside ACGTN -> N; *changed = bytes altered.
  * ngsid_host_write_records: kind 0 = FASTQ records "@name sfx \n seq \n+\n qual \n", kind 1 = TSV lines "pre \t name \n" for reads idx[0..n); sfx / pre are
  *   CSR strings per OUTPUT record (sfx_off NULL = none; per READ, i.e. indexed by idx[j], when sfx_by_read != 0); first_token != 0 cuts the name at the first blank (consensus.py:213). */
+/* ngsid_host_thread_cap: upper bound of the worker threads the helpers below start when called from the CALLING thread (0 = none; default: the CPUs the process
+ * may use - hardware threads, affinity mask, container quota - at most 32).  Returns the previous bound.  The CLI's background writers take 4 each. */
+int32_t ngsid_host_thread_cap(int32_t n);
 int32_t ngsid_host_fastq_index(const uint8_t* buf, uint64_t len, uint64_t* rec, uint32_t* name_len, uint32_t* seq_len, uint64_t cap_records, uint64_t* n_records);
 int32_t ngsid_host_gather(const uint8_t* src, const uint64_t* src_off, const uint32_t* len, uint64_t n, uint8_t* dst, const uint64_t* dst_off);
 int32_t ngsid_host_normalize_bases(uint8_t* seq, uint64_t len, uint64_t* changed);

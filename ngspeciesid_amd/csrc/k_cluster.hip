@@ -555,11 +555,16 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
 
     // ---- per-read preprocessing (a1-a3)
     DevBuf<uint64_t>& mzcode = ctx->pol_mzcode; DevBuf<uint32_t>& mzpos = ctx->pol_mzpos;      // the two big ones (12 bytes per base) are grow-only scratch of the context
-    DevBuf<uint32_t> mzcnt, hlen, d_acc; DevBuf<double> herr0, herr, rawerr, d_known; DevBuf<uint8_t> eidx; DevBuf<int> flag;
-    HIPCHK(ctx, mzcode.reserve(RD.total + 1)); HIPCHK(ctx, mzpos.reserve(RD.total + 1)); HIPCHK(ctx, mzcnt.alloc(N)); HIPCHK(ctx, hlen.alloc(N));
+    DevBuf<uint32_t>& mzcnt = ctx->mzc_cnt; DevBuf<uint32_t>& hlen = ctx->mzc_hlen; DevBuf<uint32_t> d_acc; DevBuf<double> herr0, herr, rawerr, d_known; DevBuf<uint8_t> eidx; DevBuf<int> flag;
+    ctx->mzc.valid = false;
+    HIPCHK(ctx, mzcode.reserve(RD.total + 1)); HIPCHK(ctx, mzpos.reserve(RD.total + 1)); HIPCHK(ctx, mzcnt.reserve(N)); HIPCHK(ctx, hlen.reserve(N));
     HIPCHK(ctx, herr0.alloc(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N)); HIPCHK(ctx, eidx.alloc(N)); HIPCHK(ctx, flag.alloc(2)); HIPCHK(ctx, d_acc.alloc(N));
     HIPCHK(ctx, hipMemsetAsync(flag.p, 0, 2 * sizeof(int), ctx->stream));
     rc = ngsid_launch_minimizers(ctx, RD, k, w, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr0.p, rawerr.p, flag.p); if (rc) return rc;
+    if (k <= 21 && N >= 1024) {       // key of the minimizer cache (the polisher's strand detection may be handed the same reads next); small sets are not worth the fingerprint
+        unsigned long long fp = 0; rc = ngsid_reads_fingerprint(ctx, RD, &fp); if (rc) return rc;
+        ctx->mzc.n = N; ctx->mzc.total = RD.total; ctx->mzc.k = k; ctx->mzc.w = w; ctx->mzc.fp = fp; ctx->mzc.valid = true;
+    }
     if (known_err) { HIPCHK(ctx, d_known.alloc(N)); HIPCHK(ctx, hipMemcpyAsync(d_known.p, known_err, 8 * N, hipMemcpyHostToDevice, ctx->stream)); }
     hipLaunchKernelGGL(k_eidx, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, herr0.p, known_err ? d_known.p : nullptr, N, herr.p, eidx.p);
     HIPCHK(ctx, hipGetLastError());

@@ -346,3 +346,37 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     if (KW == 2) return mz_rename_wide(ctx, R, d_codes, d_hi.p, d_cnt);
     return NGSID_OK;
 }
+
+// ---- fingerprint of a device-resident read set (key of the context's minimizer cache, ngsid_internal.h: MzCache)
+__global__ __launch_bounds__(256) void k_reads_fingerprint(const uint8_t* __restrict__ seq, uint64_t total, const uint64_t* __restrict__ off, uint64_t n, unsigned long long* __restrict__ out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nth = (uint64_t)gridDim.x * 256;
+    unsigned long long h = 0;
+    const uint64_t nw = total / 8;                                     // (hipMalloc'd / torch buffers are at least 8-byte aligned; a misaligned base takes the byte loop)
+    if (((uintptr_t)seq & 7) == 0) {
+        const unsigned long long* w8 = (const unsigned long long*)seq;
+        for (uint64_t i = tid; i < nw; i += nth) { unsigned long long x = w8[i] + (i + 1) * 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; h += x; }
+        for (uint64_t i = nw * 8 + tid; i < total; i += nth) h += ((unsigned long long)seq[i] + 1) * (i * 0x94D049BB133111EBull + 7);
+    } else {
+        for (uint64_t i = tid; i < total; i += nth) h += ((unsigned long long)seq[i] + 1) * (i * 0x94D049BB133111EBull + 7);
+    }
+    for (uint64_t i = tid; i <= n; i += nth) { unsigned long long x = off[i] + (i + 1) * 0xD6E8FEB86659FD93ull; x ^= x >> 31; x *= 0x9E3779B97F4A7C15ull; h += x; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) h += __shfl_xor(h, d);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+int32_t ngsid_reads_fingerprint(ngsid_ctx* ctx, const DevReads& R, unsigned long long* fp)
+{
+    if (ctx->mzc_fp.n < 1) HIPCHK(ctx, ctx->mzc_fp.alloc(1));
+    HIPCHK(ctx, hipMemsetAsync(ctx->mzc_fp.p, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_reads_fingerprint, dim3(2048), dim3(256), 0, ctx->stream, R.seq, R.total, R.off, R.n, ctx->mzc_fp.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(fp, ctx->mzc_fp.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NGSID_OK;
+}
+

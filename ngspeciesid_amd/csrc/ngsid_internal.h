@@ -87,6 +87,11 @@ struct ngsid_ctx {
     void* pin = nullptr; size_t pin_bytes = 0;     // pinned host staging (device -> host copies of offsets)
     std::map<std::string, long long> options;     // ngsid_ctx_option
     bool debug_sync = false;
+    // minimizers of the last clustering / polishing call (codes and positions in pol_mzcode / pol_mzpos, counts and HPC lengths here), keyed by the read set's
+    // size, (k, w) and a 64-bit fingerprint of its bases and offsets: the polisher's strand detection reuses them when it is handed the reads the clustering
+    // call just saw (k <= 21: one-word codes, comparable between calls) instead of running k_hpc_minimizers a second time
+    struct MzCache { bool valid = false; uint64_t n = 0, total = 0; int k = 0, w = 0; unsigned long long fp = 0; } mzc;
+    DevBuf<uint32_t> mzc_cnt, mzc_hlen; DevBuf<unsigned long long> mzc_fp;
     DevBuf<unsigned long long> stat;     // work counters while profiling is on (bench.py): [0] DP rows of k_poa_tile, [1] DP cells of the clustering aligner
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
@@ -124,6 +129,7 @@ struct DevReads {
     DevBuf<uint8_t> own_seq, own_qual; DevBuf<uint64_t> own_off;
 };
 int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* out, bool need_qual);
+int32_t ngsid_reads_fingerprint(ngsid_ctx* ctx, const DevReads& R, unsigned long long* fp);      // k_minimizers.hip: position-mixed 64-bit sum over the bases and the offsets (one pass, ~0.2 ms per GB)
 
 // ---- kernels' host launchers (defined in the .hip files) ----
 // per read: HPC length, minimizer count, HPC error rate, raw mean error; minimizers written sparsely at [off[r], off[r]+cnt)

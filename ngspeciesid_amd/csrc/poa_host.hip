@@ -750,13 +750,24 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
     }
     ht.mark("group map");
     // ---- strand detection (replaces minimap2's strand call): shared HPC minimizers with the initial backbone, fw vs rc
-    DevBuf<uint64_t>& mzcode = ctx->pol_mzcode; DevBuf<uint32_t>& mzpos = ctx->pol_mzpos; DevBuf<uint32_t> mzcnt, hlen, d_rgroup; DevBuf<double> herr, rawerr; DevBuf<int> flag; DevBuf<uint8_t> d_orient;
-    HIPCHK(ctx, mzcode.reserve(RD.total + 1)); HIPCHK(ctx, mzpos.reserve(RD.total + 1)); HIPCHK(ctx, mzcnt.alloc(N)); HIPCHK(ctx, hlen.alloc(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N));
+    DevBuf<uint64_t>& mzcode = ctx->pol_mzcode; DevBuf<uint32_t>& mzpos = ctx->pol_mzpos; DevBuf<uint32_t>& mzcnt = ctx->mzc_cnt; DevBuf<uint32_t>& hlen = ctx->mzc_hlen; DevBuf<uint32_t> d_rgroup; DevBuf<double> herr, rawerr; DevBuf<int> flag; DevBuf<uint8_t> d_orient;
+    HIPCHK(ctx, mzcode.reserve(RD.total + 1)); HIPCHK(ctx, mzpos.reserve(RD.total + 1)); HIPCHK(ctx, mzcnt.reserve(N)); HIPCHK(ctx, hlen.reserve(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N));
     HIPCHK(ctx, flag.alloc(1)); HIPCHK(ctx, d_rgroup.alloc(N)); HIPCHK(ctx, d_orient.alloc(N));
     HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_rgroup.p, h_rgroup.data(), 4 * N, hipMemcpyHostToDevice, ctx->stream));
     const int sk = std::min(prm->k, 21), sw = std::max(prm->w, sk);       // strand detection only needs SOME minimizer scheme: one-word codes, comparable between the two launches
-    rc = ngsid_launch_minimizers(ctx, RD, sk, sw, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr.p, rawerr.p, flag.p); if (rc) return rc;
+    {   // the clustering call that preceded this one left the minimizers of the same reads in the context (same bases, offsets, k, w): reuse them
+        bool hit = false;
+        if (ctx->mzc.valid && ctx->mzc.n == N && ctx->mzc.total == RD.total && ctx->mzc.k == sk && ctx->mzc.w == sw) {
+            unsigned long long fp = 0; rc = ngsid_reads_fingerprint(ctx, RD, &fp); if (rc) return rc;
+            hit = fp == ctx->mzc.fp;
+        }
+        if (!hit) {
+            ctx->mzc.valid = false;
+            rc = ngsid_launch_minimizers(ctx, RD, sk, sw, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr.p, rawerr.p, flag.p); if (rc) return rc;
+            if (N >= 1024) { unsigned long long fp = 0; rc = ngsid_reads_fingerprint(ctx, RD, &fp); if (rc) return rc; ctx->mzc.n = N; ctx->mzc.total = RD.total; ctx->mzc.k = sk; ctx->mzc.w = sw; ctx->mzc.fp = fp; ctx->mzc.valid = true; }
+        }
+    }
     {
         // backbone fw + rc minimizers through the same kernel, then sorted on the host (a handful of short lists)
         std::vector<std::string> two; for (uint32_t g = 0; g < G; ++g) two.push_back(B[g]); for (uint32_t g = 0; g < G; ++g) two.push_back(revcomp(B[g]));

@@ -63,7 +63,13 @@ class BackgroundWriters:
         self.pool = ThreadPoolExecutor(max_workers=workers); self.futures = []
 
     def submit(self, fn, *a, **kw):
-        self.futures.append(self.pool.submit(fn, *a, **kw))
+        def job():
+            # a writer takes at most 8 helper threads (two writers at a time fill a 16-CPU quota; the big writes run while the GPU does the long consensus launches)
+            import ctypes as C
+            try: runtime.load_library().ngsid_host_thread_cap(C.c_int32(int(os.environ.get("NGSID_CLI_WRITER_THREADS", "8"))))
+            except Exception: pass
+            return fn(*a, **kw)
+        self.futures.append(self.pool.submit(job))
 
     def join(self):
         futures, self.futures = self.futures, []
@@ -131,7 +137,10 @@ def score_and_sort(args, api, T=None):
     order = idx[np.argsort(-score[idx], kind="stable")]                   # read_array.sort(key=score, reverse=True) is stable
     sfx = fastio.repr_doubles(score[order], prefix="_")                   # "_" + repr(score), as "{0}".format(score) prints a float
     T["sort"] = time() - t0; t0 = time()
-    _write(args, fastio.write_fastq, out_path, order, names, rs, suffixes=sfx)       # 1.5 GB at C3: written while the reads are clustered
+    # sorted.fastq (1.5 GB at C3) is written by a worker thread while the reads are clustered (ngsid_host_write_records: every helper thread writes its records
+    # with pwrite() at their own offset).  Dev switch NGSID_CLI_DEFER_SORTED_WRITE=1 starts the write after the clustering call instead (the serial writer of
+    # round 3 cost that call 0.1 s of host interference; measured both ways in round 4)
+    getattr(args, "_deferred", []).append((fastio.write_fastq, (out_path, order, names, rs), dict(suffixes=sfx))) if hasattr(args, "_deferred") else _write(args, fastio.write_fastq, out_path, order, names, rs, suffixes=sfx)
     T["write_sorted_fastq"] = time() - t0; t0 = time()
     logging.debug(f"{len(order)} reads passed quality critera (avg phred Q val over {args.quality_threshold} and length > 2*k) and will be clustered.")
     er = np.sort(err[idx])
@@ -142,10 +151,18 @@ def score_and_sort(args, api, T=None):
             lf.write("Median read error rate:{0}\n".format(float(er[int(len(er) / 2)])))
             lf.write("Mean read error rate:{0}\n".format(float(sum(er.tolist()) / len(er))))
         lf.write("\n")
-    sub = subset_reads(rs, order)
     nm = names.compact(order)                       # names of the kept reads in their own small buffer (the file buffer can go)
+    # the accession ranks of ALL sorted reads (the clustering's third sort key) are computed by a worker thread while the reads are gathered, normalised and
+    # uploaded (numpy's sort releases the GIL); cluster() takes them when it clusters every read, which is the usual call
+    from concurrent.futures import ThreadPoolExecutor
+    sfx_csr = sfx if isinstance(sfx, tuple) else fastio._csr(sfx)
+    pool = ThreadPoolExecutor(max_workers=1)
+    fut = pool.submit(_string_ranks, nm, sfx_csr, np.arange(len(order), dtype=np.int64)); pool.shutdown(wait=False)
+    sub = subset_reads(rs, order)
     T["gather_sorted"] = time() - t0
-    return SortedReads(nm, sub, sfx, score[order], err[order])
+    sr = SortedReads(nm, sub, sfx_csr, score[order], err[order])
+    sr.rank_all = fut
+    return sr
 
 
 def normalized_reads(sr: SortedReads):
@@ -161,7 +178,7 @@ def normalized_reads(sr: SortedReads):
     return sr.rs
 
 
-def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None):
+def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None, T=None):
     """clusters the reads sel (indices into the sorted set, ascending = processing order).
     -> rep_of [n] (sorted index of the final representative, self for reads outside sel), herr [n], pos [n] (position in the cluster's read list),
        counters, acc_id [n] (dense rank of the accession 'name_score', -1 outside sel; None when all accessions are distinct)"""
@@ -181,7 +198,11 @@ def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None):
                          symmetric=bool(getattr(args, "symmetric_map_align_thresholds", False)), p_shared=select_p_table(args.k, args.w))
     if np.isnan(select_p_table(args.k, args.w)).all():
         raise KeyError("no rows in the shared-minimizer table for k=%d, w=%d (NGSpeciesID:72-77)" % (args.k, args.w))
-    rank = _string_ranks(sr.names, sr.sfx, sel)
+    T = T if T is not None else {}
+    t1 = time()
+    fut = getattr(sr, "rank_all", None)
+    rank = fut.result() if (fut is not None and len(sel) == n) else _string_ranks(sr.names, sr.sfx, sel)      # (a subset needs its own dense ranks: equal strings, equal rank)
+    T["cluster_wait_for_accession_ranks"] = time() - t1
     lens = lens_all[sel]; score = sr.score[sel]
     counters = np.zeros(4, dtype=np.uint64)
     if args.nr_cores > 1:
@@ -193,13 +214,21 @@ def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None):
         rep_l, herr_l, joins = parallelize.tree_cluster(fn, lens, score, args.nr_cores, getattr(args, "batch_type", "total_nt"))
         pos_l = parallelize.list_positions(len(sel), joins)
     else:
+        t1 = time()
         rep_l, herr_l, st, cnt = api.cluster_greedy(work, prm, acc_rank=rank)
+        T["cluster_library_call"] = time() - t1; t1 = time()
         counters[:] = cnt
         rep_l = rep_l.astype(np.int64)
-        herr_l = np.where(rep_l == np.arange(len(sel)), herr_l, np.nan)
-        # single pass: the list of a cluster is its representative followed by the joining reads in processing order
-        o = np.lexsort((np.arange(len(sel)), rep_l)); first = np.ones(len(sel), dtype=bool); first[1:] = rep_l[o][1:] != rep_l[o][:-1]
+        is_rep = rep_l == np.arange(len(sel))
+        herr_l = np.where(is_rep, herr_l, np.nan)
+        # single pass: the list of a cluster is its representative followed by the joining reads in processing order.  Stable sort by cluster: with fewer than
+        # 65 536 clusters the dense 16-bit key makes it numpy's radix sort (the int64 sort took 80 ms per million reads)
+        dense = np.cumsum(is_rep) - 1; nrep = int(dense[-1]) + 1 if len(dense) else 0
+        key = dense[rep_l]
+        o = np.argsort(key.astype(np.uint16) if nrep < 65536 else key, kind="stable")
+        ks = key[o]; first = np.ones(len(sel), dtype=bool); first[1:] = ks[1:] != ks[:-1]
         start = np.maximum.accumulate(np.where(first, np.arange(len(sel)), 0)); pos_l = np.empty(len(sel), dtype=np.int64); pos_l[o] = np.arange(len(sel)) - start
+        T["cluster_list_positions"] = time() - t1
     rep_of[sel] = sel[rep_l]; herr[sel] = herr_l; pos[sel] = pos_l
     logging.debug("Passed mapping criteria:{0}".format(int(counters[0])))
     logging.debug("Passed alignment criteria in this process:{0}".format(int(counters[1])))
@@ -210,17 +239,32 @@ def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None):
     return rep_of, herr, pos, counters, acc_id
 
 
-def cluster_table(sr, sel, rep_of, pos):
+def cluster_table(sr, sel, rep_of, pos, single_pass=False):
     """clusters of the clustered reads: (reps in OUTPUT order [(size, score) descending, read index ascending], sizes, member index lists as CSR in the
-    reference's list order, and in file order (score descending, stable))"""
-    reps, inv, sizes = np.unique(rep_of[sel], return_inverse=True, return_counts=True)
+    reference's list order, and in file order (score descending, stable)).  Representatives are read indices, so sizes come from a bincount and the list order
+    from a scatter (pos = position in the cluster's list, a permutation of 0 .. size-1 per cluster): no sort over the million reads."""
+    n = sr.n
+    r = rep_of[sel]
+    sizes_all = np.bincount(r, minlength=n)
+    reps = np.flatnonzero(sizes_all); sizes = sizes_all[reps]
+    idmap = np.empty(n, dtype=np.int64); idmap[reps] = np.arange(len(reps)); inv = idmap[r]
     out_order = np.lexsort((reps, -sr.score[reps], -sizes))               # sorted(clusters.items(), key=(len, score), reverse=True): ties keep dict order = read order
     out_rank = np.empty(len(reps), dtype=np.int64); out_rank[out_order] = np.arange(len(reps))
     cl = out_rank[inv]                                                     # output id of every clustered read
-    list_order = sel[np.lexsort((pos[sel], cl))]                          # cluster by cluster, the reference's list order (spoa input order)
-    file_order = sel[np.lexsort((pos[sel], -sr.score[sel], cl))]          # sorted(all_read_acc, key=score, reverse=True) is stable w.r.t. the list order
     goff = np.zeros(len(reps) + 1, dtype=np.int64); goff[1:] = np.cumsum(sizes[out_order])
-    return reps[out_order], sizes[out_order], goff, list_order, file_order, np.sort(cl)
+    list_order = np.full(len(sel), -1, dtype=np.int64)
+    tgt = goff[cl] + pos[sel]
+    ok = len(sel) == 0 or (int(tgt.min()) >= 0 and int(tgt.max()) < len(sel))
+    if ok: list_order[tgt] = sel
+    if not ok or (list_order < 0).any():                                  # (not a permutation per cluster: never seen; the sort is the definition)
+        list_order = sel[np.lexsort((pos[sel], cl))]                      # cluster by cluster, the reference's list order (spoa input order)
+    if single_pass:
+        # one clustering pass over score-sorted reads: a cluster's list is its representative (the smallest index) followed by the members in processing
+        # order = ascending index = descending score with ties in list order: the file order IS the list order
+        file_order = list_order
+    else:
+        file_order = sel[np.lexsort((pos[sel], -sr.score[sel], cl))]      # sorted(all_read_acc, key=score, reverse=True) is stable w.r.t. the list order
+    return reps[out_order], sizes[out_order], goff, list_order, file_order, np.repeat(np.arange(len(reps), dtype=np.int64), sizes[out_order])
 
 
 def write_cluster_files(args, sr, reps, sizes, herr, file_order, cl_sorted):
@@ -397,6 +441,7 @@ def _main(args, api):
     T = {}
     t0 = time()
     args.outfile = os.path.join(args.outfolder, "sorted.fastq")
+    if os.environ.get("NGSID_CLI_DEFER_SORTED_WRITE", "0") == "1": args._deferred = []        # dev switch (A/B of the write schedule, round 4): with the parallel record writer the write is short enough to run beside the clustering call
     sr = score_and_sort(args, api, T)
     work = normalized_reads(sr)
     T["normalize"] = time() - t0 - sum(T.values()); t0 = time()
@@ -413,7 +458,11 @@ def _main(args, api):
         sel = sel[np.asarray(sorted(random.sample(range(len(sel)), args.sample_size)), dtype=np.int64)]
     abundance_cutoff = int(args.abundance_ratio * len(sel))
     logging.info(f"Starting Clustering: {len(sel)} reads")
-    rep_of, herr, pos, counters, acc_id = cluster(sr, work, sel, args, api, work_dev)
+    try:
+        rep_of, herr, pos, counters, acc_id = cluster(sr, work, sel, args, api, work_dev, T)
+    finally:                                        # sorted.fastq is written whatever the clustering call did (the reference has it on disk before it clusters)
+        deferred, args._deferred = getattr(args, "_deferred", []), []
+        for fn_, a_, kw_ in deferred: _write(args, fn_, *a_, **kw_)
     T["cluster"] = time() - t0; t0 = time()
     logging.debug(f"Time elapsed clustering: {T['cluster']}")
     if getattr(args, "strand_aware", False) and len(sel) == sr.n:
@@ -431,7 +480,7 @@ def _main(args, api):
         T["strand_merge"] = time() - t0; t0 = time()
     elif getattr(args, "strand_aware", False):
         logging.warning("--strand_aware needs all reads clustered (no --m / --s / --sample_size selection): ignored")
-    reps, sizes, goff, list_order, file_order, cl_sorted = cluster_table(sr, sel, rep_of, pos)
+    reps, sizes, goff, list_order, file_order, cl_sorted = cluster_table(sr, sel, rep_of, pos, single_pass=(args.nr_cores <= 1 and not getattr(args, "strand_aware", False)))
     nontrivial = write_cluster_files(args, sr, reps, sizes, herr, file_order, cl_sorted)
     T["write_clusters"] = time() - t0; t0 = time()
     logging.debug(f"Nr clusters larger than 1: {nontrivial}")

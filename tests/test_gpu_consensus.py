@@ -200,3 +200,28 @@ def test_device_driven_levels_equal_host_driven_levels(gpu_api, oracle):
             assert x == [sp[g].tobytes().decode() for g in big]
     finally:
         host.close()
+
+
+def test_minimizer_cache_is_keyed_by_content(gpu_api, oracle):
+    """round 4: the polisher's strand detection reuses the minimizers the clustering call left in the context when it is handed the same reads (same size, (k, w)
+    and 64-bit fingerprint of bases + offsets).  A read set of the SAME shape whose bases differ (a fifth of the reads reverse-complemented in place: their strand
+    flips) must miss the cache; both calls equal the oracle."""
+    from ngspeciesid_amd import pipeline
+    from ngspeciesid_amd._capi import cluster_params
+    from ngspeciesid_amd.ptable import select_p_table
+    sp, rd, rs = make_set(1600, L=600, mu=15.0, seed=12, rc_fraction=0.5)
+    bb = ReadSet.from_strings([sp[0].tobytes().decode()])
+    prm = polish_params(iters=1, k=13, w=20, tile_depth=6, band=0, trim=2, stop_when_stable=0)
+    gpu_api.cluster_greedy(rs, cluster_params(k=13, w=20, p_shared=select_p_table(13, 20)))              # leaves the key of `rs` in the context
+    a = gpu_api.polish(bb, rs, [0, rs.n], prm); ea = oracle.polish(bb, rs, [0, rs.n], prm)               # hit
+    assert a[0] == ea[0] and np.array_equal(a[1], ea[1]) and a[0][0] == sp[0].tobytes().decode()
+    seq = rs.seq.copy(); qual = rs.qual.copy(); off = rs.off.astype(np.int64)
+    comp = np.zeros(256, dtype=np.uint8)
+    for x, y in zip(b"ACGTN", b"TGCAN"): comp[x] = y
+    for i in range(0, rs.n, 5):
+        s0, s1 = int(off[i]), int(off[i + 1]); seq[s0:s1] = comp[seq[s0:s1][::-1]]; qual[s0:s1] = qual[s0:s1][::-1]
+    rs2 = ReadSet(seq, qual, rs.off)
+    b = gpu_api.polish(bb, rs2, [0, rs2.n], prm); eb = oracle.polish(bb, rs2, [0, rs2.n], prm)           # same shape, other content: miss
+    assert b[0] == eb[0] and np.array_equal(b[1], eb[1]) and b[0][0] == sp[0].tobytes().decode()
+    c = gpu_api.polish(bb, rs, [0, rs.n], prm)                                                            # the key is rs2's now: miss again, same answer as before
+    assert c[0] == a[0] and np.array_equal(c[1], a[1])
