@@ -101,12 +101,13 @@ def test_mixed_strand_reads_are_merged_and_polished(gpu_api, mu):
 
 
 
-@pytest.mark.parametrize("name,total", [("c4", 2400000), ("c5", 1000000)])
+@pytest.mark.parametrize("name,total", [("c4", 2400000), ("c5", 2000000)])
 def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total):
     """what makes C4 / C5 the 8-GPU configurations, composed - eight `--t 8` batches of ONE global set (C4: 8 x 300 k x 750 bp,
-    50 species, abundance_ratio 0.005; C5 at HALF size: 8 x 125 k x 2 kb CCS, 20 species with geometric abundance 0.8^i, k15/w50, abundance_ratio
-    0.002, the rarest species at ~360 reads per shard - eight full 250 k x 2 kb shards need more working memory than ONE 288 GB GPU has, and a
-    context keeps its grow-only scratch) through distributed.sharded_hot_path: representatives all-gathered and merged by
+    50 species, abundance_ratio 0.005; C5 at its FULL size since round 4: 8 x 250 k x 2 kb CCS = the 2 M reads of BASELINE.json, 20 species with geometric
+    abundance 0.8^i, k15/w50, abundance_ratio 0.002 - it fits one 288 GB GPU with the per-context budgets below; C4 at full size (8 x 1.25 M) does not: the
+    level buffers of eight contexts plus the single-process pass over 10 M reads exceed the memory, tools/micro/run_composed_full.py c4 10000000 ends in a
+    clean NGSID_ERR_HIP out-of-memory) through distributed.sharded_hot_path: representatives all-gathered and merged by
     ngsid_merge_representatives, cross-shard abundance cutoff by all-reduce, eight weighted partial consensuses per cluster (draft and polished).
     The eight ranks are eight threads of this process, each with its own ngsid context on the one GPU (distributed.LocalComm: same payloads,
     exchanged in memory - eight PROCESSES on one MI355X stall in torch's generator kernels before any library call; torch.distributed itself is
