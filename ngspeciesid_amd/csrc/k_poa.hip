@@ -797,6 +797,29 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
     bestv_out = bestv; bestpk_out = bestpk; nslow_out = nslow;
 }
 
+#ifndef POA_FWD_CALL
+#define POA_FWD_CALL 0      // experiment: the forward pass as a real (non-inlined) function with a register allocation of its own
+#endif
+#if POA_FWD_CALL
+struct FwdOut { int bestv, bestpk, nslow; };
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v); }
+template <int CPL, int MODE>
+__device__ __attribute__((noinline)) FwdOut poa_forward_call(unsigned long long gbase, uint32_t s32, uint32_t s64, uint32_t s16, uint32_t s8, uint32_t se16, uint32_t se32, uint32_t sl,
+                                                              unsigned long long hg, unsigned long long dg, unsigned long long dfull, int slen, int V, int nov, int gp, int sm, int sn, int lane)
+{
+    // arguments arrive in VGPRs: make the wave-uniform ones scalar again (once per alignment)
+    GG g; g.base = (uint8_t*)uni64(gbase);
+    g.s32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s32); g.s64 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s64); g.s16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s16); g.s8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s8);
+    g.se16 = (uint32_t)__builtin_amdgcn_readfirstlane((int)se16); g.se32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)se32); g.sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);
+    LLT<64 * CPL> w; w.sinkbits = nullptr;
+    PSeq S; S.s = nullptr; S.q = nullptr; S.len = __builtin_amdgcn_readfirstlane(slen); S.uw = 0; S.cw = 0; S.mode = MODE; S.a0 = 0; S.a1 = -1;
+    FwdOut o;
+    poa_forward<CPL, MODE>(g, w, (int32_t*)uni64(hg), (uint8_t*)uni64(dg), (uint8_t*)uni64(dfull), S, __builtin_amdgcn_readfirstlane(V), __builtin_amdgcn_readfirstlane(nov),
+                           __builtin_amdgcn_readfirstlane(gp), __builtin_amdgcn_readfirstlane(sm), __builtin_amdgcn_readfirstlane(sn), lane, o.bestv, o.bestpk, o.nslow);
+    return o;
+}
+#endif
+
 // align S to the graph and merge it.  returns 0 = dropped (no valid end cell), 1 = added, 2 = does not fit
 template <int CPL>
 __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& w, int32_t* Hg, uint8_t* Dg, uint8_t* Dfull, const PoaJobSet& J, const PSeq& S, TS& st, int lane, int& edge_out)
@@ -898,9 +921,17 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
 #if POA_REPEAT == 2
     for (int rep_ = 0; rep_ < 2; ++rep_)
 #endif
+#if POA_FWD_CALL
+    { FwdOut fo;
+      if (local) fo = poa_forward_call<CPL, NGSID_POA_LOCAL>((unsigned long long)g.base, g.s32, g.s64, g.s16, g.s8, g.se16, g.se32, g.sl, (unsigned long long)Hg, (unsigned long long)Dg, (unsigned long long)Dfull, L, V, st.nov, gp, J.m, J.n, lane);
+      else if (mode == NGSID_POA_SEMI) fo = poa_forward_call<CPL, NGSID_POA_SEMI>((unsigned long long)g.base, g.s32, g.s64, g.s16, g.s8, g.se16, g.se32, g.sl, (unsigned long long)Hg, (unsigned long long)Dg, (unsigned long long)Dfull, L, V, st.nov, gp, J.m, J.n, lane);
+      else fo = poa_forward_call<CPL, NGSID_POA_GLOBAL>((unsigned long long)g.base, g.s32, g.s64, g.s16, g.s8, g.se16, g.se32, g.sl, (unsigned long long)Hg, (unsigned long long)Dg, (unsigned long long)Dfull, L, V, st.nov, gp, J.m, J.n, lane);
+      bestv = fo.bestv; bestpk = fo.bestpk; nslow = fo.nslow; }
+#else
     if (local) poa_forward<CPL, NGSID_POA_LOCAL>(g, w, Hg, Dg, Dfull, S, V, st.nov, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     else if (mode == NGSID_POA_SEMI) poa_forward<CPL, NGSID_POA_SEMI>(g, w, Hg, Dg, Dfull, S, V, st.nov, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     else poa_forward<CPL, NGSID_POA_GLOBAL>(g, w, Hg, Dg, Dfull, S, V, st.nov, gp, J.m, J.n, lane, bestv, bestpk, nslow);
+#endif
     if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[5], (unsigned long long)V); atomicAdd(&PHS(J)[6], (unsigned long long)nslow); }
     mem_sync();                                       // direction rows must have landed before the traceback pulls them back
     PH(J, 1, tph);

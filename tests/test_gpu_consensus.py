@@ -151,7 +151,7 @@ def test_short_tail_window_parity(gpu_api, oracle, L):
         seqs.append(rd["seq"].numpy()); quals.append(rd["qual"].numpy()); off += list(off[-1] + rd["off"].numpy()[1:])
     rs = ReadSet(np.concatenate(seqs), np.concatenate(quals), np.array(off, dtype=np.uint64))
     bbs = [s.tobytes().decode() for s in sp]
-    for tail in ((3, 7, 30, 49, 50, 120) if L < 1500 else (7, 49, 50)):      # force every tail-window shape, merged (< 50) and not (the oracle takes seconds per call at 1 549 bases)
+    for tail in ((3, 7, 30, 49, 50, 120) if L < 1000 else (7, 49, 50)):      # force every tail-window shape, merged (< 50) and not (the oracle takes seconds per call at 1 549 bases)
         b2 = [b[:(len(b) // 500) * 500 + tail] if len(b) > 500 + tail else b for b in bbs]
         prm = polish_params(iters=2, k=13, w=20, tile_depth=8, band=0, trim=2)
         a, ua = gpu_api.polish(ReadSet.from_strings(b2), rs, [0, 300, 600], prm); b, ub = oracle.polish(ReadSet.from_strings(b2), rs, [0, 300, 600], prm)
