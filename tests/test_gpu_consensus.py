@@ -225,3 +225,26 @@ def test_minimizer_cache_is_keyed_by_content(gpu_api, oracle):
     assert b[0] == eb[0] and np.array_equal(b[1], eb[1]) and b[0][0] == sp[0].tobytes().decode()
     c = gpu_api.polish(bb, rs, [0, rs.n], prm)                                                            # the key is rs2's now: miss again, same answer as before
     assert c[0] == a[0] and np.array_equal(c[1], a[1])
+
+
+def test_polish_trace_and_weighted_consensus_equal_the_oracle(gpu_api, oracle):
+    """round 4 entry points through the C-ABI: ngsid_polish_trace (the sequence after EVERY iteration; its last iteration is what ngsid_polish returns, with and
+    without the early stop) and ngsid_poa_consensus_weighted (sequence i stands for weight[i] reads) == the oracle's bytes"""
+    sp, rd, rs = make_set(400, L=620, mu=13.0, seed=14, nsp=2)
+    spc = rd["species"].numpy(); order = np.argsort(spc, kind="stable").astype(np.uint32); n0 = int((spc == 0).sum())
+    bb = ReadSet.from_strings([rs.get(int(order[0]))[0], rs.get(int(order[n0]))[0]])          # raw reads as backbones: every iteration changes them
+    for stop in (0, 1):
+        prm = polish_params(iters=3, k=13, w=20, tile_depth=6, band=0, trim=2, stop_when_stable=stop)
+        a, ua = gpu_api.polish_trace(bb, rs, [0, n0, rs.n], prm, read_order=order)
+        b, ub = oracle.polish_trace(bb, rs, [0, n0, rs.n], prm, read_order=order)
+        assert a == b and np.array_equal(ua, ub)
+        last, used = gpu_api.polish(bb, rs, [0, n0, rs.n], prm, read_order=order)
+        assert last == a[-1] and np.array_equal(used, ua[-1]) and len(a) == 3
+    assert a[0] != a[-1] or a[0] == [s.tobytes().decode() for s in sp]
+    # weighted merge: three "partial consensuses" per group with very different weights (a heavy exact one, a light noisy one, a tiny one)
+    seqs = [sp[0].tobytes().decode(), rs.get(int(order[1]))[0], rs.get(int(order[2]))[0], sp[1].tobytes().decode(), rs.get(int(order[n0 + 1]))[0], rs.get(int(order[n0 + 2]))[0]]
+    wts = np.array([90000, 700, 3, 5, 40000, 39999], dtype=np.uint32)
+    pr = poa_params(mode=POA_LOCAL, tile_depth=0, band=0)
+    w1 = gpu_api.poa_consensus_weighted(ReadSet.from_strings(seqs), [0, 3, 6], pr, wts)
+    w2 = oracle.poa_consensus_weighted(ReadSet.from_strings(seqs), [0, 3, 6], pr, wts)
+    assert w1 == w2 and w1[0] == seqs[0]
