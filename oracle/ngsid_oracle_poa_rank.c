@@ -66,7 +66,8 @@ static inline int rg_band_lo(const rgraph* G, const pseq* S, int r, int BW) {
     long span = (long)a1 - a0 + 1; if (span < 1) span = 1;
     long c = ((long)(G->anchor[r] - a0) * (long)S->len) / span;
     long lo = c - BW / 2; long mx = (long)S->len + 1 - BW; if (mx < 0) mx = 0;
-    if (lo < 0) lo = 0; if (lo > mx) lo = mx;
+    if (lo < 0) lo = 0;
+    if (lo > mx) lo = mx;
     return (int)lo;
 }
 
