@@ -79,7 +79,7 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
         HIPCHK(ctx, hipMemcpyAsync(d_job_off.p, job_off.data(), 4 * job_off.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_seq_idx.p, seq_idx.data(), 4 * seq_idx.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_job_bb.p, job_bb.data(), 4 * job_bb.size(), hipMemcpyHostToDevice, ctx->stream));
-        int slots = slots_cap ? slots_cap : (int)std::min<uint32_t>(maxD, 4);
+        int slots = slots_cap ? slots_cap : (int)std::min<uint32_t>(maxD, (uint32_t)std::max<long long>(1, ngsid_opt(ctx, "poa_out_slots", 4)));
         static thread_local PinVec<uint32_t> h_out_n; static thread_local PinVec<int32_t> h_out_len, h_out_span; static thread_local PinVec<uint64_t> h_out_cw;
         const bool need_cov = hp.want_cov || hp.trim_tiles;
         for (;;) {      // retry with more output slots if a tile had to split more often than `slots`
@@ -409,7 +409,7 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
     const int band0 = hp.band <= 64 ? 64 : (hp.band <= 128 ? 128 : 256);
     if (capV > 0xFFF0 || 3 * capV / 2 > 0xFFF0 || (long long)hp.m * Lmax >= 65536 || hp.m < 0 || hp.g >= 0) return NGSID_OK;      // the host loop reports what is wrong (or fits where this margin does not)
     for (int bw = band0; bw <= 256; bw *= 2) if (poa_lds_bytes((int)capV, (int)(3 * capV / 2), Lmax, bw) > 160 * 1024) return NGSID_OK;
-    const int slots = (int)std::min<uint32_t>(maxD, 4);
+    const int slots = (int)std::min<uint32_t>(maxD, (uint32_t)std::max<long long>(1, ngsid_opt(ctx, "poa_out_slots", 4)));      // output slots per tile of the first attempt (a tile that closes its graph more often falls back to the host-driven loop, which retries with more)
     int levels_est = 1; { uint64_t n = maxn; const uint64_t Dd = hp.D > 0 ? (uint64_t)hp.D : maxn; while (n > 1 && levels_est < C_MAXLV - 4) { n = (n + Dd - 1) / std::max<uint64_t>(Dd, 2); ++levels_est; } }
     levels_est = std::min(levels_est + 1, C_MAXLV - 2);
     uint32_t cap[2]; cap[0] = njobs0;

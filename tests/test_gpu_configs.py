@@ -102,12 +102,12 @@ def test_mixed_strand_reads_are_merged_and_polished(gpu_api, mu):
 
 
 @pytest.mark.parametrize("name,total", [("c4", 2400000), ("c5", 2000000)])
-def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total):
+def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total, compare_single_process=True, out_slots=0):
     """what makes C4 / C5 the 8-GPU configurations, composed - eight `--t 8` batches of ONE global set (C4: 8 x 300 k x 750 bp,
     50 species, abundance_ratio 0.005; C5 at its FULL size since round 4: 8 x 250 k x 2 kb CCS = the 2 M reads of BASELINE.json, 20 species with geometric
     abundance 0.8^i, k15/w50, abundance_ratio 0.002 - it fits one 288 GB GPU with the per-context budgets below; C4 at full size (8 x 1.25 M) does not: the
-    level buffers of eight contexts plus the single-process pass over 10 M reads exceed the memory, tools/micro/run_composed_full.py c4 10000000 ends in a
-    clean NGSID_ERR_HIP out-of-memory) through distributed.sharded_hot_path: representatives all-gathered and merged by
+    eight contexts' working sets (12 bytes of minimizer scratch per base, level buffers, aligner traceback) exceed the memory even with two output slots per tile and
+    without the single-process comparison pass: tools/micro/run_composed_full.py c4 10000000 ends in a clean NGSID_ERR_HIP out-of-memory in the polisher) through distributed.sharded_hot_path: representatives all-gathered and merged by
     ngsid_merge_representatives, cross-shard abundance cutoff by all-reduce, eight weighted partial consensuses per cluster (draft and polished).
     The eight ranks are eight threads of this process, each with its own ngsid context on the one GPU (distributed.LocalComm: same payloads,
     exchanged in memory - eight PROCESSES on one MI355X stall in torch's generator kernels before any library call; torch.distributed itself is
@@ -143,6 +143,7 @@ def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total):
     # and aligner waves - scheduling only, the results do not depend on it)
     import ctypes as C
     small = {"scratch_budget_mb": 3072, "poa_tiles_per_cu": 6}
+    if out_slots: small["poa_out_slots"] = out_slots          # (tools/micro/run_composed_full.py: C4 at its full 10 M reads)
     apis = [gpu_api] + [runtime.new_api(0, small) for _ in range(world - 1)]
     for k_, v_ in small.items(): gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, k_.encode(), C.c_int64(v_))
     try:
@@ -158,7 +159,7 @@ def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total):
         dt = time.perf_counter() - t0
     finally:
         for a_ in apis[1:]: a_.close()
-        gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"scratch_budget_mb", C.c_int64(32768)); gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"poa_tiles_per_cu", C.c_int64(0))
+        gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"scratch_budget_mb", C.c_int64(32768)); gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"poa_tiles_per_cu", C.c_int64(0)); gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"poa_out_slots", C.c_int64(4))
     # identical centres on every rank
     cent = [[(c[0], c[1], c[2], c[3]) for c in r["centers"]] for r in res]
     assert all(c == cent[0] for c in cent[1:])
@@ -175,11 +176,12 @@ def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total):
     big = np.isin(final, np.unique(final)[np.argsort(-np.bincount(np.unique(final, return_inverse=True)[1]))[:nsp]])
     purity = float((spc[final[big]] == spc[big]).mean())
     assert purity > 0.9999 and big.mean() > 0.99, (purity, big.mean())          # (the membership itself is pinned above; a handful of noisy reads join another species' cluster in the reference's --t 8 schedule too)
-    # sharded consensus == the single-process path on the whole set
-    grs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
-    one = pipeline.run_hot_path(gpu_api, grs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), **kw)
-    assert sorted(c[3] for c in one["centers"]) == sorted(c[3] for c in cent[0])
+    # sharded consensus == the single-process path on the whole set (skipped by the full-size C4 tool run: one context cannot hold 10 M reads' level buffers)
+    if compare_single_process:
+        grs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
+        one = pipeline.run_hot_path(gpu_api, grs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), **kw)
+        assert sorted(c[3] for c in one["centers"]) == sorted(c[3] for c in cent[0])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(dict(config=name, total_reads=int(len(glens)), shards=world, species=nsp, wall_s_eight_shards_sharing_one_gpu=round(dt, 2), stage_s_rank0={k_: round(v, 3) for k_, v in res[0]["T"].items()},
-                   centres=len(cent[0]), purity_of_the_large_clusters=purity, membership_equals_t8=True, consensus_equals_amplicons=True, equals_single_process=True),
+                   centres=len(cent[0]), purity_of_the_large_clusters=purity, membership_equals_t8=True, consensus_equals_amplicons=True, equals_single_process=(True if compare_single_process else None)),
               open(os.path.join(ROOT, "gpurun_out", "composed_%s_8_shards_one_gpu.json" % name), "w"), indent=1)
