@@ -245,6 +245,12 @@ int32_t ngsid_host_normalize_bases(uint8_t* seq, uint64_t len, uint64_t* changed
  *   (get_sorted_fastq_for_cluster.py:176). */
 int32_t ngsid_host_count_foreign_bases(const uint8_t* seq, uint64_t len, uint64_t* count);
 int32_t ngsid_host_repr_doubles(const double* v, uint64_t n, int32_t prefix, uint8_t* buf, uint64_t cap, uint64_t* off, uint64_t* needed);
+/* ngsid_host_argsort_desc: order[0..n) = the STABLE argsort of v in descending order (read_array.sort(key=score, reverse=True),
+ *   get_sorted_fastq_for_cluster.py:174: equal scores keep their input order; -0.0 == 0.0; NaNs last).
+ * ngsid_host_list_positions: pos[i] = number of j < i with rep[j] == rep[i] (rep = the representative's read index, < n): a read's position in its cluster's
+ *   list when one clustering pass appends the joining reads in processing order behind the representative (cluster.py:338-345). */
+int32_t ngsid_host_argsort_desc(const double* v, uint64_t n, uint64_t* order);
+int32_t ngsid_host_list_positions(const int64_t* rep, uint64_t n, int64_t* pos);
 int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
                                  const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
                                  const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read, const uint8_t* seq, const uint8_t* qual, const uint64_t* off);

@@ -130,6 +130,52 @@ extern "C" int32_t ngsid_host_normalize_bases(uint8_t* seq, uint64_t len, uint64
     return NGSID_OK;
 }
 
+// pos[i] = number of j < i with rep[j] == rep[i]: the position of read i in its cluster's read list when the list is the representative followed by the
+// joining reads in processing order (cluster.py:338-345 on one pass over score-sorted reads).  rep values are read indices < n.  One serial pass.
+extern "C" int32_t ngsid_host_list_positions(const int64_t* rep, uint64_t n, int64_t* pos)
+{
+    if ((!rep || !pos) && n) return NGSID_ERR_ARG;
+    std::vector<uint32_t> cnt(n, 0);
+    for (uint64_t i = 0; i < n; ++i) { const int64_t r = rep[i]; if (r < 0 || (uint64_t)r >= n) return NGSID_ERR_ARG; pos[i] = (int64_t)cnt[(size_t)r]++; }
+    return NGSID_OK;
+}
+
+// order = the stable argsort of v in DESCENDING order (list.sort(key=score, reverse=True) of get_sorted_fastq_for_cluster.py:174: equal scores keep their
+// input order; -0.0 == 0.0; NaNs last, in input order).  LSD radix sort on the order-reversing bit pattern, 11-bit digits, digits that are equal for all keys
+// skipped, per-thread histograms (stable: thread t owns a contiguous range of the current order).
+extern "C" int32_t ngsid_host_argsort_desc(const double* v, uint64_t n, uint64_t* order)
+{
+    if ((!v || !order) && n) return NGSID_ERR_ARG;
+    if (n == 0) return NGSID_OK;
+    std::vector<uint64_t> key(n), key2(n), ord2(n);
+    const int T = n_threads(n * 16);
+    std::vector<uint64_t> orv(T, 0), andv(T, ~0ull);
+    parallel_ranges(n, T, [&](uint64_t a, uint64_t b, int t) { uint64_t o = 0, an = ~0ull;
+        for (uint64_t i = a; i < b; ++i) {
+            double x = v[i]; uint64_t u;
+            if (x != x) u = ~0ull;                                        // NaN: after everything else
+            else { x = -x + 0.0; memcpy(&u, &x, 8); u = (u >> 63) ? ~u : (u | 0x8000000000000000ull); if (u == ~0ull) u = ~0ull - 1; }   // ascending order of -x
+            key[i] = u; order[i] = i; o |= u; an &= u; }
+        orv[t] = o; andv[t] = an; });
+    uint64_t o = 0, an = ~0ull; for (int t = 0; t < T; ++t) { o |= orv[t]; an &= andv[t]; }
+    const uint64_t differ = o ^ an;                                       // bits in which at least two keys differ
+    uint64_t* k0 = key.data(); uint64_t* k1 = key2.data(); uint64_t* o0 = order; uint64_t* o1 = ord2.data();
+    constexpr int B = 11, R = 1 << B;
+    std::vector<uint64_t> hist((size_t)T * R);
+    for (int sh = 0; sh < 64; sh += B) {
+        if (((differ >> sh) & (R - 1)) == 0) continue;
+        std::fill(hist.begin(), hist.end(), 0);
+        parallel_ranges(n, T, [&](uint64_t a, uint64_t b, int t) { uint64_t* h = hist.data() + (size_t)t * R; for (uint64_t i = a; i < b; ++i) ++h[(k0[i] >> sh) & (R - 1)]; });
+        uint64_t run = 0;
+        for (int d = 0; d < R; ++d) for (int t = 0; t < T; ++t) { uint64_t& h = hist[(size_t)t * R + d]; const uint64_t c = h; h = run; run += c; }
+        parallel_ranges(n, T, [&](uint64_t a, uint64_t b, int t) { uint64_t* h = hist.data() + (size_t)t * R;
+            for (uint64_t i = a; i < b; ++i) { const uint64_t dst = h[(k0[i] >> sh) & (R - 1)]++; k1[dst] = k0[i]; o1[dst] = o0[i]; } });
+        std::swap(k0, k1); std::swap(o0, o1);
+    }
+    if (o0 != order) memcpy(order, o0, 8 * n);
+    return NGSID_OK;
+}
+
 // Record writer.  Output record j (j < n) is built from read idx[j]:
 //   kind 0 (FASTQ):  '@' name sfx_j '\n' seq '\n' '+' '\n' qual '\n'
 //   kind 1 (TSV):    pre_j '\t' name '\n'                                  (final_clusters.tsv: pre_j = the cluster's output id)

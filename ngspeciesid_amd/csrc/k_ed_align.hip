@@ -139,6 +139,9 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
                         const u64 npv = Mh | ~(Xv | Ph);
                         Pv[b] = npv; Mv[b] = Ph & Xv;
                         ngsid_v4u w; w.x = (unsigned)diag; w.y = (unsigned)(diag >> 32); w.z = (unsigned)npv; w.w = (unsigned)(npv >> 32);
+#if defined(ED_EXP_STORE_EVERY)
+                        if ((j % ED_EXP_STORE_EVERY) == 0)           // timing experiment (wrong results): what the traceback-word stores cost
+#endif
                         col[(u64)(WIN ? blk - fb : blk) * mstride * 64] = w;
                         hin = hout63;
                     }
@@ -167,6 +170,9 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
         auto tb_blk = [&](int ii, int col0) { int tb_ = (ii - 1) >> 6; if (WIN) { const int lo_row = col0 + dmin - bandK - 1; tb_ -= lo_row > 0 ? (lo_row >> 6) : 0; } return tb_; };
         auto tb_load = [&](int tb_, int col0) { return __builtin_nontemporal_load(mytb + (((u64)tb_ * mstride + (u64)col0) * 64 + lane)); };
         int jj = i > 0 ? j : 0;
+#if defined(ED_EXP_NO_TB)
+        jj = 0;                                                       // timing experiment (wrong results): no traceback
+#endif
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) jj = max(jj, __shfl_xor(jj, d));
         jj = __builtin_amdgcn_readfirstlane(jj);

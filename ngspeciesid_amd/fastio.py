@@ -103,6 +103,26 @@ def repr_doubles(values, prefix=""):
     return buf[:int(off[-1])].copy() if len(v) else np.zeros(1, np.uint8), off
 
 
+def argsort_desc(values) -> np.ndarray:
+    """stable argsort in descending order (the order of sorted.fastq: get_sorted_fastq_for_cluster.py:174) - ngsid_host_argsort_desc"""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    order = np.empty(len(v), dtype=np.uint64)
+    rc = runtime.load_library().ngsid_host_argsort_desc(_p(v), C.c_uint64(len(v)), _p(order))
+    if rc != 0:
+        raise RuntimeError("ngsid_host_argsort_desc failed (%d)" % rc)
+    return order.astype(np.int64)
+
+
+def list_positions(rep) -> np.ndarray:
+    """pos[i] = number of earlier reads with the same representative - ngsid_host_list_positions"""
+    r = np.ascontiguousarray(rep, dtype=np.int64)
+    pos = np.empty(len(r), dtype=np.int64)
+    rc = runtime.load_library().ngsid_host_list_positions(_p(r), C.c_uint64(len(r)), _p(pos))
+    if rc != 0:
+        raise ValueError("ngsid_host_list_positions: a representative index is out of range")
+    return pos
+
+
 def _csr(strs):
     bs = [s if isinstance(s, bytes) else s.encode() for s in strs]
     off = np.zeros(len(bs) + 1, dtype=np.uint64)

@@ -121,3 +121,31 @@ def test_crlf_fastq_reads_like_text_mode(tmp_path):
     p2 = tmp_path / "crlf_end.fastq"; p2.write_bytes((txt + "\r\n").encode())
     names, rs, plain = fastio.read_fastq(str(p2))
     assert plain and rs.get(2) == ("A", "I")
+
+
+def test_argsort_desc_is_the_stable_descending_sort():
+    """ngsid_host_argsort_desc == sorted(range(n), key=score, reverse=True) (get_sorted_fastq_for_cluster.py:174): ties keep the input order"""
+    rng = np.random.default_rng(5)
+    cases = [np.zeros(0), np.array([3.5]), rng.random(100000) * 300.0, np.round(rng.random(200000) * 40.0, 1),                 # many ties
+             np.concatenate([rng.standard_normal(5000) * 1e-300, [0.0, -0.0, 0.0, np.inf, -np.inf, 1e308, -1e308, 5e-324, -5e-324]]),
+             np.full(70000, 7.25), np.array([1.0, np.nan, 2.0, np.nan, 2.0, -1.0])]
+    for v in cases:
+        got = fastio.argsort_desc(v)
+        want = np.array(sorted(range(len(v)), key=lambda i: (v[i] != v[i], -v[i] if v[i] == v[i] else 0.0)), dtype=np.int64)   # NaNs last, else descending, stable
+        assert np.array_equal(got, want)
+        if not np.isnan(v).any():
+            assert np.array_equal(got, np.argsort(-v, kind="stable"))
+
+
+def test_list_positions_counts_earlier_reads_of_the_cluster():
+    rng = np.random.default_rng(6)
+    n = 50000
+    rep = np.minimum(np.arange(n), rng.integers(0, 40, n)).astype(np.int64)
+    rep[rep > 0] = np.where(rng.random((rep > 0).sum()) < 0.1, np.arange(n)[rep > 0], rep[rep > 0])           # some singletons
+    pos = fastio.list_positions(rep)
+    seen = {}
+    for i, r in enumerate(rep.tolist()):
+        assert pos[i] == seen.get(r, 0); seen[r] = seen.get(r, 0) + 1
+    assert len(fastio.list_positions(np.zeros(0, dtype=np.int64))) == 0
+    with pytest.raises(ValueError):
+        fastio.list_positions(np.array([0, 5], dtype=np.int64))
