@@ -28,7 +28,8 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
     LDSP u64* planes = (LDSP u64*)smem;                     // [block][3][lane]
     ngsid_v4u* mytb = tb + (u64)blockIdx.x * tb_per_wave;
     int8_t* myh = hcar + (u64)blockIdx.x * mstride * 64;
-    const u64 npairs = J.npairs_dev ? (u64)*J.npairs_dev : J.npairs;       // optional indirection: a query-length class of a larger batch
+    const u64 npairs1 = J.npairs_dev ? (u64)*J.npairs_dev : J.npairs;      // optional indirection: a query-length class of a larger batch ...
+    const u64 npairs = npairs1 + (J.npairs_dev2 ? (u64)*J.npairs_dev2 : 0);  // ... and a second class behind it
     const u64 nbundles = (npairs + 63) / 64;
     for (;;) {
         uint32_t kq = 0; if (lane == 0) kq = atomicAdd(work_ctr, 1u);
@@ -36,7 +37,7 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
         if (kq >= nbundles) break;
         const u64 pk = (u64)kq * 64 + lane;
         const bool have = pk < npairs;
-        const u64 p = have ? (J.pair_list ? (u64)J.pair_list[pk] : pk) : 0;
+        const u64 p = have ? (J.pair_list ? (pk < npairs1 ? (u64)J.pair_list[pk] : (u64)J.pair_list2[pk - npairs1]) : pk) : 0;
         const uint8_t* q = nullptr; const uint8_t* t = nullptr; int n = 0, m = 0;
         if (have) { const uint32_t qi = J.qidx[p], ti = J.tidx[p]; q = J.qseq + J.qoff[qi]; n = (int)(J.qoff[qi + 1] - J.qoff[qi]); t = J.tseq + J.toff[ti]; m = (int)(J.toff[ti + 1] - J.toff[ti]); }
         int nmax = n, mmax = m;
@@ -88,10 +89,23 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
 #pragma unroll
             for (int b = 0; b < BMAX; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
             const bool more = !WIN && g0 + BMAX < B;        // a further group follows: keep the horizontal deltas of this group's last row
-            // ---- forward: column by column, blocks top to bottom
+            // ---- forward: column by column, blocks top to bottom.  The target letters of 64 columns are three bit planes in REGISTERS (letter bit 0, bit 1, "is A/C/G/T"),
+            // refilled every 64 columns: the column loop itself contains no global load, so no column waits (s_waitcnt vmcnt) for the traceback-word stores of
+            // the columns before it.  The horizontal delta handed from block to block travels as two 0/1 words (hp: +1, hm: -1): no per-lane branches in a block step.
+            u64 TPlo = 0, TPhi = 0, TPok = 0;
             for (int j = 0; j < mmax; ++j) {
-                const int tc = j < m ? ngsid_bcode(t[j]) : 4;
-                const u64 Tlo = (tc & 1) ? ~0ull : 0ull, Thi = (tc & 2) ? ~0ull : 0ull, Tok = tc < 4 ? ~0ull : 0ull;
+                const int jb = j & 63;
+                if (jb == 0) {
+                    u64 lo = 0, hi = 0, ok = 0;
+#pragma unroll 16
+                    for (int c = 0; c < 64; ++c) {
+                        const int jc = j + c;
+                        const int cd = jc < m ? ngsid_bcode(t[jc]) : 4;
+                        lo |= (u64)(cd & 1) << c; hi |= (u64)((cd >> 1) & 1) << c; ok |= (u64)(cd < 4) << c;
+                    }
+                    TPlo = lo; TPhi = hi; TPok = ok;
+                }
+                const u64 Tlo = 0ull - ((TPlo >> jb) & 1ull), Thi = 0ull - ((TPhi >> jb) & 1ull), Tok = 0ull - ((TPok >> jb) & 1ull);
                 int fb = 0, lb = Bg - 1;
                 if (band) {
                     const int lo_row = j + dmin - bandK - 1;
@@ -111,43 +125,42 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
                         if (nb < B) build_planes(nb, nb % BMAX);
                     }
                 }
-                int hin = g0 ? (int)myh[(u64)j * 64 + lane] : (fb > 0 ? 1 : 0);      // top row of the matrix is all zeros (target prefix free)
+                unsigned hp, hm;                                                     // horizontal delta entering the next block: +1 / -1 / 0 as (hp, hm) = (1,0) / (0,1) / (0,0)
+                if (g0) { const int h0 = (int)myh[(u64)j * 64 + lane]; hp = h0 > 0; hm = h0 < 0; }
+                else { hp = fb > 0 ? 1u : 0u; hm = 0u; }                             // top row of the matrix is all zeros (target prefix free)
                 ngsid_v4u* col = mytb + ((u64)j * 64 + lane);
                 const int slot0 = WIN ? fbw % BMAX : 0;
+                const bool inm = j < m;
 #pragma unroll
                 for (int b = 0; b < BMAX; ++b) {
                     const int blk = WIN ? fbw + b : g0 + b;                          // block held by register slot b
-                    if ((WIN ? blk : b) >= fb && (WIN ? blk : b) <= lb) {
+                    if (WIN ? blk <= lb : (b >= fb && b <= lb)) {                    // WIN: slot 0 holds the first block of the band (fbw == fb)
                         const int ps = WIN ? (slot0 + b >= BMAX ? slot0 + b - BMAX : slot0 + b) : b;
                         const u64 lo = planes[(ps * 3 + 0) * 64 + lane], hi = planes[(ps * 3 + 1) * 64 + lane], ok = planes[(ps * 3 + 2) * 64 + lane];
-                        const u64 Eq = ~(lo ^ Tlo) & ~(hi ^ Thi) & ok & Tok;
+                        const u64 Eq = ~((lo ^ Tlo) | (hi ^ Thi)) & ok & Tok;
                         const u64 pv = Pv[b], mv = Mv[b];
                         const u64 Xv = Eq | mv;
-                        const u64 Eqh = Eq | (hin < 0 ? 1ull : 0ull);
+                        const u64 Eqh = Eq | (u64)hm;
                         const u64 Xh = (((Eqh & pv) + pv) ^ pv) | Eqh;
                         u64 Ph = mv | ~(Xh | pv), Mh = pv & Xh;
                         // moves (oracle: diagonal if D[i-1][j-1] + neq == D[i][j]): a match always qualifies; a mismatch iff the diagonal delta
                         // h(i,j) + v(i,j-1) is +1, i.e. (h,v) = (+1,0) or (0,+1)
                         const u64 diag = Eq | (Ph & ~(pv | mv)) | (~(Ph | Mh) & pv);
-                        const int hout63 = (int)((Ph >> 63) & 1) - (int)((Mh >> 63) & 1);
-                        if (blk == bl && j < m) {
+                        if (blk == bl && inm) {
                             score += (int)((Ph >> lastbit) & 1) - (int)((Mh >> lastbit) & 1);
                             if (score < best) { best = score; bestj = j + 1; }
                         }
-                        Ph <<= 1; Mh <<= 1;
-                        if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+                        const unsigned php = (unsigned)(Ph >> 63), phm = (unsigned)(Mh >> 63);
+                        Ph = (Ph << 1) | (u64)hp; Mh = (Mh << 1) | (u64)hm;
                         const u64 npv = Mh | ~(Xv | Ph);
                         Pv[b] = npv; Mv[b] = Ph & Xv;
                         ngsid_v4u w; w.x = (unsigned)diag; w.y = (unsigned)(diag >> 32); w.z = (unsigned)npv; w.w = (unsigned)(npv >> 32);
-#if defined(ED_EXP_STORE_EVERY)
-                        if ((j % ED_EXP_STORE_EVERY) == 0)           // timing experiment (wrong results): what the traceback-word stores cost
-#endif
-                        col[(u64)(WIN ? blk - fb : blk) * mstride * 64] = w;
-                        hin = hout63;
+                        col[(u64)(WIN ? b : blk) * mstride * 64] = w;
+                        hp = php; hm = phm;
                     }
                 }
-                if (more) myh[(u64)j * 64 + lane] = (int8_t)hin;
-                if (band) { sb += hin; lbprev = lb; }
+                if (more) myh[(u64)j * 64 + lane] = (int8_t)((int)hp - (int)hm);
+                if (band) { sb += (int)hp - (int)hm; lbprev = lb; }
             }
             if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
         }
@@ -239,13 +252,13 @@ static int32_t ed_reserve(ngsid_ctx* ctx, u64& want, u64 per_wave)
 }
 
 template <int BMAX, bool WIN = false>
-static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out, uint32_t ctr_slot = 14, int bandK = 0)
+static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out, uint32_t ctr_slot = 14, int bandK = 0, uint32_t fail_slot = 15, uint32_t* fail_list = nullptr)
 {
     const u64 nbundles = (job.npairs + 63) / 64;
     const uint32_t mstride = (max_tlen + 63u) & ~63u;                     // rounded so that backbones growing by a few bases between iterations reuse the scratch
     const u64 nblocks = WIN ? (u64)BMAX : std::max<u64>(1, ((u64)max_qlen + 63) / 64);     // WIN: band-relative storage, BMAX blocks per column
     const u64 per_wave = nblocks * mstride * 64;                           // 16-byte units
-    const size_t lds = (size_t)BMAX * 3 * 64 * 8;
+    const size_t lds = (size_t)BMAX * 3 * 64 * 8 + (size_t)ngsid_opt(ctx, "ed_lds_pad_kb", 0) * 1024;      // (dev option: extra LDS per wave = fewer resident waves, for occupancy measurements)
     int occ = 0;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ed_align<BMAX, WIN>, 64, lds));
     if (occ < 1) occ = 1;
@@ -257,15 +270,23 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen,
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
     HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), ctx->stream));
     { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX, WIN>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + ctr_slot, dist_out, ctx->ed_h.p,
-                                                            bandK, ctx->ed_fail.p, ctx->aln_ctr.p + 15); }
+                                                            bandK, fail_list ? fail_list : ctx->ed_fail.p, ctx->aln_ctr.p + fail_slot); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }
 
-// pairs whose distance exceeded the band of the first launch (list ctx->ed_fail, count aln_ctr[15]): unbanded
-static int32_t launch_ed_fallback(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out)
+// pairs whose distance exceeded the band of the first launch (list ctx->ed_fail, count aln_ctr[15]): unbanded.  With retryK > 0 (class launches with a band of at most
+// 150) they first run in the sliding-window instance with that wider band - half the blocks per column of the unbanded instance, and a handful of pairs costs the
+// latency of ONE pair - and only what exceeds it too (list ctx->ed_fail2, count aln_ctr[7]) runs unbanded.
+static int32_t launch_ed_fallback(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out, int retryK = 0)
 {
-    AlignJob j = job; j.pair_list = ctx->ed_fail.p; j.npairs_dev = ctx->aln_ctr.p + 15;
+    AlignJob j = job; j.pair_list = ctx->ed_fail.p; j.npairs_dev = ctx->aln_ctr.p + 15; j.pair_list2 = nullptr; j.npairs_dev2 = nullptr;
+    if (retryK > 0) {
+        HIPCHK(ctx, ctx->ed_fail2.reserve(job.npairs));
+        int32_t rc = launch_ed<8, true>(ctx, j, max_qlen, max_tlen, dist_out, 6, retryK, 7, ctx->ed_fail2.p);
+        if (rc) return rc;
+        j.pair_list = ctx->ed_fail2.p; j.npairs_dev = ctx->aln_ctr.p + 7;
+    }
     return launch_ed<16>(ctx, j, max_qlen, max_tlen, dist_out, 13, 0);
 }
 
@@ -302,11 +323,18 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
         // 513-768 bases: the 8-block window instance as well (12 KB of LDS per wave instead of 18 KB: three waves per SIMD instead of two, -8 %);
         // NGSID_ED_WIN_ALL=0 selects the 12-block instance with all blocks resident
         const bool win_all = ngsid_opt(ctx, "ed_win_all", 1) != 0;
-        if (max_qlen > 512 && (rc = (win_all && bandK > 0 && bandK <= 150) ? launch_ed<8, true>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK)
-                                                          : launch_ed<12>(ctx, cls(2, 768), std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK))) return rc;
-        if (max_qlen > 768 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4, bandK))) return rc;
+        // The sliding-window instance takes queries of any length, so the 769-896 class (the few reads of a 750-base amplicon set that came out long) rides in the same
+        // launch as a second index list instead of paying the latency of one pair in a launch of its own (2 ms per polishing iteration at C3).
+        const bool win2 = win_all && bandK > 0 && bandK <= 150;
+        if (max_qlen > 512) {
+            AlignJob j2 = cls(2, 768);
+            if (win2 && max_qlen > 768) { j2.pair_list2 = ctx->aln_cls.p + (size_t)3 * n; j2.npairs_dev2 = ctx->aln_ctr.p + 8 + 3; }
+            if ((rc = win2 ? launch_ed<8, true>(ctx, j2, std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 3, bandK)
+                           : launch_ed<12>(ctx, j2, std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK))) return rc;
+        }
+        if (max_qlen > 768 && !win2 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4, bandK))) return rc;
         if (max_qlen > 896 && (rc = win16 ? launch_ed<16, true>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK) : win ? launch_ed<8, true>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK) : launch_ed<16>(ctx, cls(4, 0), max_qlen, max_tlen, dist_out, 5, bandK))) return rc;
-        return bandK > 0 ? launch_ed_fallback(ctx, job, max_qlen, max_tlen, dist_out) : NGSID_OK;
+        return bandK > 0 ? launch_ed_fallback(ctx, job, max_qlen, max_tlen, dist_out, win2 ? 180 : 0) : NGSID_OK;
     }
     if (bandK > 0) HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + 15, 0, sizeof(uint32_t), ctx->stream));
     int32_t rc;

@@ -77,6 +77,7 @@ struct ngsid_ctx {
     DevBuf<ngsid_v4u_t> ed_tb; // traceback vectors of the edit-distance aligner
     DevBuf<int8_t> ed_h;       // its horizontal deltas between block groups
     DevBuf<uint32_t> ed_fail;  // pairs beyond the band of the first launch
+    DevBuf<uint32_t> ed_fail2; // ... and beyond the wider band of the retry launch
     DevBuf<uint32_t> poa_ctr; // POA tile work-queue counter
     uint64_t poa_redo_tiles = 0;   // tiles redone with a wider band since the context was created (band-edge check)
     struct PoaLevelBufs { DevBuf<uint8_t> out, seqs /* PSeq[] */; DevBuf<int32_t> out_len, out_span, job_bb; DevBuf<uint64_t> out_cw; DevBuf<uint32_t> out_n, out_cov, job_off, seq_idx, flags, job_list, job_unit, job_pos; };
@@ -148,6 +149,8 @@ struct AlignJob {            // device pointers
     const uint32_t* pair_list; const uint32_t* npairs_dev;
     // optional alignment columns (int32 kernel only): ops + ops_off[p] receives one byte per column in traceback (reverse) order, 0 '=' 1 'X' 2 'I' 3 'D'
     uint8_t* ops; const uint64_t* ops_off;
+    // optional SECOND index list behind the first (k_ed_align only: two query-length classes in one launch): item k >= *npairs_dev is pair_list2[k - *npairs_dev]
+    const uint32_t* pair_list2; const uint32_t* npairs_dev2;
 };
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20, uint32_t min_qlen = 0);   // min_qlen: lower bound of the query lengths (lets empty length classes be skipped)
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
