@@ -251,6 +251,11 @@ int32_t ngsid_host_repr_doubles(const double* v, uint64_t n, int32_t prefix, uin
  *   list when one clustering pass appends the joining reads in processing order behind the representative (cluster.py:338-345). */
 int32_t ngsid_host_argsort_desc(const double* v, uint64_t n, uint64_t* order);
 int32_t ngsid_host_list_positions(const int64_t* rep, uint64_t n, int64_t* pos);
+/* ngsid_host_group_by_rep: clusters of a representative map (rep[i] = read index of read i's representative, rep[rep[i]] == rep[i]): reps[0..*n_reps) = the
+ *   representatives in ascending order, counts[c] / grp_off[c] = size / start of cluster c, order = the reads sorted by cluster, ascending index inside a cluster
+ *   (the read lists form_draft_consensus feeds to spoa: representative first, members in processing order; consensus.py:257-266).  reps / counts: room for n
+ *   entries, grp_off: n + 1. */
+int32_t ngsid_host_group_by_rep(const int64_t* rep, uint64_t n, int64_t* reps, uint64_t* n_reps, uint32_t* order, uint64_t* grp_off, int64_t* counts);
 int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
                                  const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
                                  const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read, const uint8_t* seq, const uint8_t* qual, const uint64_t* off);

@@ -123,6 +123,18 @@ def list_positions(rep) -> np.ndarray:
     return pos
 
 
+def group_by_rep(rep_of):
+    """-> (reps, order, grp_off, counts) of a representative map - ngsid_host_group_by_rep"""
+    r = np.ascontiguousarray(rep_of, dtype=np.int64); n = len(r)
+    reps = np.empty(n, dtype=np.int64); counts = np.empty(n, dtype=np.int64); order = np.empty(n, dtype=np.uint32); goff = np.empty(n + 1, dtype=np.uint64)
+    nr = C.c_uint64(0)
+    rc = runtime.load_library().ngsid_host_group_by_rep(_p(r), C.c_uint64(n), _p(reps), C.byref(nr), _p(order), _p(goff), _p(counts))
+    if rc != 0:
+        raise ValueError("ngsid_host_group_by_rep: not a representative map (an index out of range, or a representative that does not represent itself)")
+    R = int(nr.value)
+    return reps[:R].copy(), order, goff[:R + 1].copy(), counts[:R].copy()
+
+
 def _csr(strs):
     bs = [s if isinstance(s, bytes) else s.encode() for s in strs]
     off = np.zeros(len(bs) + 1, dtype=np.uint64)

@@ -31,17 +31,8 @@ def clusters_from_rep(rep_of: np.ndarray):
     """-> (reps, order, grp_off): clusters keyed by representative read; order lists each cluster's reads with the
     representative first and the members in processing order (cluster.py:338-345: the representative was processed
     before any read that joined it, and reads are processed in index order)."""
-    rep_of = np.asarray(rep_of)
-    n = len(rep_of)
-    is_rep = rep_of == np.arange(n, dtype=rep_of.dtype)
-    reps = np.nonzero(is_rep)[0]                                     # ascending read index = np.unique(rep_of)
-    dense = np.cumsum(is_rep) - 1                                    # representative read -> dense cluster id
-    key = dense[rep_of]
-    # stable sort by cluster; with < 65536 clusters the 16-bit key makes it numpy's radix sort (several times faster at 1 M reads)
-    order = np.argsort(key.astype(np.uint16) if len(reps) < 65536 else key, kind="stable").astype(np.uint32)
-    counts = np.bincount(key, minlength=len(reps))
-    grp_off = np.concatenate(([0], np.cumsum(counts))).astype(np.uint64)
-    return reps.astype(np.int64), order, grp_off, counts
+    from . import fastio
+    return fastio.group_by_rep(rep_of)                               # three counting passes in the host library (NumPy: compare, cumsum, gather, radix argsort, bincount - 7 ms per 10^6 reads)
 
 
 def select_centers(reps, counts, score, abundance_cutoff):
