@@ -329,7 +329,11 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
         if (max_qlen > 512) {
             AlignJob j2 = cls(2, 768);
             if (win2 && max_qlen > 768) { j2.pair_list2 = ctx->aln_cls.p + (size_t)3 * n; j2.npairs_dev2 = ctx->aln_ctr.p + 8 + 3; }
-            if ((rc = win2 ? launch_ed<8, true>(ctx, j2, std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 3, bandK)
+            // a band of up to ~100 fits a window of SIX blocks (9 KB of LDS and 12 state registers less per wave: four waves per SIMD instead of three); a bundle
+            // whose length spread needs more (span check in the kernel) goes to the retry launch
+            const bool win6 = win2 && bandK <= 100 && ngsid_opt(ctx, "ed_win6", 1) != 0;
+            if ((rc = win6 ? launch_ed<6, true>(ctx, j2, std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 3, bandK)
+                    : win2 ? launch_ed<8, true>(ctx, j2, std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 3, bandK)
                            : launch_ed<12>(ctx, j2, std::min<uint32_t>(max_qlen, 768), max_tlen, dist_out, 3, bandK))) return rc;
         }
         if (max_qlen > 768 && !win2 && (rc = launch_ed<16>(ctx, cls(3, 896), std::min<uint32_t>(max_qlen, 896), max_tlen, dist_out, 4, bandK))) return rc;

@@ -493,7 +493,7 @@ extern "C" int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev)
 extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return NGSID_ERR_ARG;
-    static const char* known[] = {"cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb"};
+    static const char* known[] = {"cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
     for (const char* k : known) if (!strcmp(k, name)) { ctx->options[name] = (long long)value; return NGSID_OK; }
     if (!strcmp(name, "release_scratch")) {        // gives the context's grow-only scratch (aligner traceback, POA tiles and levels, polisher arrays) and the cached blocks back to the driver
         (void)hipStreamSynchronize(ctx->stream);
