@@ -1,4 +1,4 @@
-// dev tool: issue cost of the 64-bit integer VALU forms the bit-vector aligner uses, on gfx950.  One workgroup of W waves per CU-sized grid; every wave runs
+// dev tool (measured round 4: a lone wave issues one VALU instruction per ~8 cycles, 64-bit shifts / adds cost the same as 32-bit ops, v_alignbit 9.5): issue cost of the 64-bit integer VALU forms the bit-vector aligner uses, on gfx950.  One workgroup of W waves per CU-sized grid; every wave runs
 // N x 8 independent instructions of one kind and reports wall-clock cycles / instruction (s_memtime).     hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,8 +20,6 @@ template <int OP> __global__ __launch_bounds__(1024) void k(u64* out, int n, u64
         if (OP == 6) { asm volatile("v_add_co_u32 %0, vcc, %0, %8\nv_addc_co_u32 %1, vcc, %1, %8, vcc\nv_add_co_u32 %2, vcc, %2, %8\nv_addc_co_u32 %3, vcc, %3, %8, vcc\nv_add_co_u32 %4, vcc, %4, %8\nv_addc_co_u32 %5, vcc, %5, %8, vcc\nv_add_co_u32 %6, vcc, %6, %8\nv_addc_co_u32 %7, vcc, %7, %8, vcc" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(sh) : "vcc"); }
         if (OP == 7) { asm volatile("v_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1\nv_xor_b32 %0, %0, %1" : "+v"(x0) : "v"(sh)); }      // dependent chain
         if (OP == 8) { asm volatile("v_lshl_add_u64 %0, %0, 0, %1\nv_lshl_add_u64 %0, %0, 0, %1\nv_lshl_add_u64 %0, %0, 0, %1\nv_lshl_add_u64 %0, %0, 0, %1\nv_lshl_add_u64 %0, %0, 0, %1\nv_lshl_add_u64 %0, %0, 0, %1\nv_lshl_add_u64 %0, %0, 0, %1\nv_lshl_add_u64 %0, %0, 0, %1" : "+v"(a0) : "v"(b)); }   // dependent chain
-        if (OP == 9) { asm volatile("s_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1\ns_add_u32 s40, s40, 1\ns_add_u32 s41, s41, 1\ns_add_u32 s42, s42, 1\ns_add_u32 s43, s43, 1" ::: "s40", "s41", "s42", "s43"); }
-        if (OP == 10) { asm volatile("v_xor_b32 %0, %0, %4\ns_add_u32 s40, s40, 1\nv_xor_b32 %1, %1, %4\ns_add_u32 s41, s41, 1\nv_xor_b32 %2, %2, %4\ns_add_u32 s42, s42, 1\nv_xor_b32 %3, %3, %4\ns_add_u32 s43, s43, 1" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(sh) : "s40", "s41", "s42", "s43"); }    // VALU / SALU alternating in ONE wave
     }
     const u64 t1 = __builtin_readcyclecounter();
     u64 r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
@@ -44,7 +42,7 @@ int main()
 {
     for (int w : {4, 8, 16}) {
         run<3>("v_xor_b32 (independent)", w); run<7>("v_xor_b32 (dependent)", w); run<0>("v_lshlrev_b64 x,1", w); run<2>("v_lshrrev_b64 x,v", w); run<1>("v_lshl_add_u64", w); run<8>("v_lshl_add_u64 (dependent)", w);
-        run<6>("v_add_co + v_addc_co", w); run<4>("v_alignbit_b32", w); run<5>("v_bfi_b32", w); run<9>("s_add_u32", w); run<10>("v_xor / s_add alternating", w);
+        run<6>("v_add_co + v_addc_co", w); run<4>("v_alignbit_b32", w); run<5>("v_bfi_b32", w);
     }
     return 0;
 }
