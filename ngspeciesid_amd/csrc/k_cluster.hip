@@ -676,13 +676,22 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             }
             { ProfScope ps_(ctx, "k_decide_map"); hipLaunchKernelGGL(k_decide_map, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R); }
             HIPCHK(ctx, hipGetLastError());
+            const uint32_t w0 = (lo - b0) >> 6, w1 = (b1 - b0 + 63) >> 6;
+            int eflag = 0;
             for (;;) {      // alignment rounds: resolve from cache or request pairs, align, cache, repeat
                 HIPCHK(ctx, hipMemsetAsync(d_scal.p, 0, 4, ctx->stream));
                 { ProfScope ps_(ctx, "k_aln_next"); hipLaunchKernelGGL(k_aln_next, dim3((b1 - lo + 15) / 16), dim3(1024), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R,
                                    req_q.p, req_t.p, req_slot.p, req_open.p, req_mid.p, d_scal.p); }
                 HIPCHK(ctx, hipGetLastError());
+                // the new-representative mask of the block is computed and fetched in the SAME round trip as the request count: when no pair is requested every item
+                // of [lo, b1) is decided and the mask is the one the next step needs (most rounds of a noisy tail; one host round trip less per round); when pairs are
+                // requested it is recomputed after the alignments
                 uint32_t nreq = 0;
+                hipLaunchKernelGGL(k_newrep_mask, dim3(((w1 - w0) * 64 + 255) / 256), dim3(256), 0, ctx->stream, dec.p, d_items.p, b0 + w0 * 64, lo, b1, b0, d_mask.p);
+                HIPCHK(ctx, hipGetLastError());
                 HIPCHK(ctx, hipMemcpyAsync(&nreq, d_scal.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(h_mask.data() + w0, d_mask.p + w0, 8ull * (w1 - w0), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(&eflag, flag.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
                 if (!nreq) break;
                 AlignJob J{};
@@ -693,14 +702,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
                 hipLaunchKernelGGL(k_cache_insert, dim3((nreq + 255) / 256), dim3(256), 0, ctx->stream, D, req_q.p, req_slot.p, req_region.p, nreq);
                 HIPCHK(ctx, hipGetLastError());
             }
-            // ---- the items that decided "new representative", in block order (bit mask of the block, scanned on the host)
-            const uint32_t w0 = (lo - b0) >> 6, w1 = (b1 - b0 + 63) >> 6;
-            hipLaunchKernelGGL(k_newrep_mask, dim3(((w1 - w0) * 64 + 255) / 256), dim3(256), 0, ctx->stream, dec.p, d_items.p, b0 + w0 * 64, lo, b1, b0, d_mask.p);
-            HIPCHK(ctx, hipGetLastError());
-            int eflag = 0;
-            HIPCHK(ctx, hipMemcpyAsync(h_mask.data() + w0, d_mask.p + w0, 8ull * (w1 - w0), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(&eflag, flag.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            // ---- the items that decided "new representative", in block order (bit mask of the block, fetched with the last request count above, scanned on the host)
             if (eflag) NGSID_FAIL(ctx, NGSID_ERR_NO_PTABLE, "no p_shared entry for an (e1,e2) pair met during mapping (KeyError in cluster.py:367)");
             uint32_t C[TMAX + 1]; uint32_t nC = 0;
             for (uint32_t wd = w0; wd < w1 && nC <= TMAX; ++wd) {
