@@ -63,10 +63,12 @@ class BackgroundWriters:
         self.pool = ThreadPoolExecutor(max_workers=workers); self.futures = []
 
     def submit(self, fn, *a, **kw):
+        threads = kw.pop("_threads", None)
         def job():
-            # a writer takes at most 8 helper threads (two writers at a time fill a 16-CPU quota; the big writes run while the GPU does the long consensus launches)
+            # a writer takes at most 8 helper threads (two writers at a time fill a 16-CPU quota; the big writes run while the GPU does the long consensus launches);
+            # the writer of sorted.fastq runs beside the clustering call, whose driver thread needs its core back after every launch: 4
             import ctypes as C
-            try: runtime.load_library().ngsid_host_thread_cap(C.c_int32(int(os.environ.get("NGSID_CLI_WRITER_THREADS", "8"))))
+            try: runtime.load_library().ngsid_host_thread_cap(C.c_int32(int(threads or os.environ.get("NGSID_CLI_WRITER_THREADS", "8"))))
             except Exception: pass
             return fn(*a, **kw)
         self.futures.append(self.pool.submit(job))
@@ -86,6 +88,7 @@ class BackgroundWriters:
 def _write(args, fn, *a, **kw):
     bg = getattr(args, "_writers", None)
     if bg is None:
+        kw.pop("_threads", None)
         fn(*a, **kw)
     else:
         bg.submit(fn, *a, **kw)
@@ -140,7 +143,7 @@ def score_and_sort(args, api, T=None):
     # sorted.fastq (1.5 GB at C3) is written by a worker thread while the reads are clustered (ngsid_host_write_records: every helper thread writes its records
     # with pwrite() at their own offset).  Dev switch NGSID_CLI_DEFER_SORTED_WRITE=1 starts the write after the clustering call instead (the serial writer of
     # round 3 cost that call 0.1 s of host interference; measured both ways in round 4)
-    getattr(args, "_deferred", []).append((fastio.write_fastq, (out_path, order, names, rs), dict(suffixes=sfx))) if hasattr(args, "_deferred") else _write(args, fastio.write_fastq, out_path, order, names, rs, suffixes=sfx)
+    getattr(args, "_deferred", []).append((fastio.write_fastq, (out_path, order, names, rs), dict(suffixes=sfx))) if hasattr(args, "_deferred") else _write(args, fastio.write_fastq, out_path, order, names, rs, suffixes=sfx, _threads=int(os.environ.get("NGSID_CLI_SORTED_WRITER_THREADS", "4")))
     T["write_sorted_fastq"] = time() - t0; t0 = time()
     logging.debug(f"{len(order)} reads passed quality critera (avg phred Q val over {args.quality_threshold} and length > 2*k) and will be clustered.")
     er = np.sort(err[idx])
@@ -296,6 +299,16 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
         if mx >= 0:
             b = min(b, a + mx)
         groups.append(list_order[a:b])
+    # The pooled read file of a centre that absorbs no other cluster is that cluster's read list (consensus.py:208-215), known NOW: its writer starts before the draft
+    # consensus instead of after the reverse-complement merge, so the 1.5 GB of reads_to_consensus_*.fastq at C3 have the draft AND the polishing stage to reach the disk.
+    # A centre that does absorb others (rare) has its file rewritten after the merge, when these writers are done.  (Not with duplicate accessions: the pooled file of
+    # the reference de-duplicates by header, handled in _merge_and_polish.)
+    args._pooled_early = {}
+    if acc_id is None and getattr(args, "_writers", None) is not None and os.environ.get("NGSID_CLI_EARLY_POOLED", "1") == "1":
+        for c in range(nsel):
+            path = os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(int(reps[c])))
+            _write(args, _write_pooled, path, groups[c], sr)
+            args._pooled_early[int(reps[c])] = (c,)
     sub_off = np.concatenate(([0], np.cumsum([len(g) for g in groups]))).astype(np.uint64)
     long_reads = bool(np.diff(sr.rs.off.astype(np.int64))[np.concatenate(groups)].max() > 1000)
     node_cap = 22 if long_reads else 0
@@ -353,6 +366,16 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
     logging.debug(f"{len(merged)} consensus formed.")
     pooled = []
     seen_clusters = set(); polish_lists = []          # the polisher takes a read under one centre only (pipeline.pooled_read_lists): first centre wins
+    early = getattr(args, "_pooled_early", {})        # pooled files whose writers were started before the draft: {c_id: cluster tuple the file holds}
+    if early and any(early.get(int(c_id)) != tuple(cs) for _, c_id, _, cs in merged):
+        # some centre absorbed other clusters: wait for the early writers, then rewrite the merged files below and drop the files of the absorbed centres
+        args._writers.join()
+        keep = {int(m[1]) for m in merged}
+        for cid in list(early):
+            if cid not in keep:
+                try: os.remove(os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(cid)))
+                except OSError: pass
+                del early[cid]
     for nr, c_id, center, cs in merged:
         with open(os.path.join(args.outfolder, "consensus_reference_{0}.fasta".format(c_id)), "w") as f:
             f.write(">{0}\n{1}\n".format("consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr), center))
@@ -375,7 +398,9 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
             logging.warning("centre %d: %d cluster(s) were merged into an earlier centre as well; their reads polish that one only", c_id, len(parts) - len(fresh))
         seen_clusters.update(cs)
         polish_lists.append(np.concatenate(fresh) if fresh else np.zeros(0, dtype=ids.dtype))
-        _write(args, _write_pooled, os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(c_id)), ids, sr)     # while the polisher runs
+        if early.get(int(c_id)) != tuple(cs):
+            _write(args, _write_pooled, os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(c_id)), ids, sr)     # while the polisher runs
+            if early: early[int(c_id)] = tuple(cs)
     T["rc_merge_write_pooled_reads"] = T.get("rc_merge_write_pooled_reads", 0.0) + time() - t0; t0 = time()
     if getattr(args, "racon", False) and args.racon_iter >= 0:
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in polish_lists]))).astype(np.uint64)
