@@ -289,6 +289,33 @@ def main():
                                    "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "instructions_per_cell_source": "ISA count of the step loop (378 VALU per step for two pairs of 12-14 rows per lane), DESIGN.md section 4"}
         if dom[0] in views: roof["valu_issue"] = dict(views[dom[0]], kernel=dom[0])
         roof["dp_kernels"] = views
+    # ---- the drop-in surface (runs before the CPU baseline leg): FASTQ file in -> the reference's output files out (python -m ngspeciesid_amd ...), same reads, same flags as C3
+    cli_leg = None
+    if not args.no_cli and world == 1:
+        import shutil, tempfile, argparse as _ap
+        from ngspeciesid_amd import fastio, fastpath, cli as _cli
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        tmp = tempfile.mkdtemp(prefix="ngsid_bench_", dir=base)
+        try:
+            hseq = rd["seq"].cpu().numpy(); hqual = rd["qual"].cpu().numpy(); hoff = rd["off"].cpu().numpy().astype(np.uint64); hsp = rd["species"].cpu().numpy()
+            hrs = ReadSet(hseq, hqual, hoff)
+            perm = np.random.default_rng(3).permutation(n)                      # the file is NOT in score order
+            names = fastio.Names.from_list(["r%d_sp%d" % (i, hsp[i]) for i in range(n)])
+            fq = os.path.join(tmp, "reads.fastq"); fastio.write_fastq(fq, perm, names, hrs)
+            in_bytes = os.path.getsize(fq)
+            outd = os.path.join(tmp, "out"); os.makedirs(outd)
+            cargs = _cli.build_parser().parse_args([cfg["preset"], "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", str(AB_)])
+            cargs.k, cargs.w = K_, W_
+            tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl
+            out_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs)
+            got = sorted(m[2] for m in r["centers"])
+            cli_leg = {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "ratio_to_hot_path": round((n / dcl) / reads_per_s, 3), "t": args.cli_t,
+                       "stage_s": {k_: round(v, 3) for k_, v in r["timings"].items()}, "input_fastq_bytes": in_bytes, "output_bytes": out_bytes,
+                       "files_on": "tmpfs (/dev/shm)" if base else "disk (tmp dir)", "consensus_equals_amplicons": got == sorted(truths),
+                       "what": "python -m ngspeciesid_amd %s --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio %s: FASTQ parse, score, sort, sorted.fastq, "
+                               "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % (cfg["preset"], args.cli_t, AB_)}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     # ---- CPU baseline: the oracle (a scalar port of the same algorithms) on a bounded sample of the same workload: one core, and all host cores
     #      with one batch per core like the reference's `--t N` worker processes (merge rounds not included: they are O(representatives))
     cpu = None
@@ -354,33 +381,6 @@ def main():
                "sample": "%d reads strided from the same batch (same params, tile_depth %d): %d per worker process, one process per usable core (affinity mask / cgroup quota; start-up of the interpreters included in the wall time) running oracle/libngsid_oracle.so "
                          "(scalar C port of this build's algorithms; the reference's own tools - parasail, spoa, racon - are SIMD codes and are not in the image, see BASELINE.md)"
                          % (ns, args.tile_depth, per_core)}
-    # ---- the drop-in surface: FASTQ file in -> the reference's output files out (python -m ngspeciesid_amd ...), same reads, same flags as C3
-    cli_leg = None
-    if not args.no_cli and world == 1:
-        import shutil, tempfile, argparse as _ap
-        from ngspeciesid_amd import fastio, fastpath, cli as _cli
-        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-        tmp = tempfile.mkdtemp(prefix="ngsid_bench_", dir=base)
-        try:
-            hseq = rd["seq"].cpu().numpy(); hqual = rd["qual"].cpu().numpy(); hoff = rd["off"].cpu().numpy().astype(np.uint64); hsp = rd["species"].cpu().numpy()
-            hrs = ReadSet(hseq, hqual, hoff)
-            perm = np.random.default_rng(3).permutation(n)                      # the file is NOT in score order
-            names = fastio.Names.from_list(["r%d_sp%d" % (i, hsp[i]) for i in range(n)])
-            fq = os.path.join(tmp, "reads.fastq"); fastio.write_fastq(fq, perm, names, hrs)
-            in_bytes = os.path.getsize(fq)
-            outd = os.path.join(tmp, "out"); os.makedirs(outd)
-            cargs = _cli.build_parser().parse_args([cfg["preset"], "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", str(AB_)])
-            cargs.k, cargs.w = K_, W_
-            tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl
-            out_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs)
-            got = sorted(m[2] for m in r["centers"])
-            cli_leg = {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "ratio_to_hot_path": round((n / dcl) / reads_per_s, 3), "t": args.cli_t,
-                       "stage_s": {k_: round(v, 3) for k_, v in r["timings"].items()}, "input_fastq_bytes": in_bytes, "output_bytes": out_bytes,
-                       "files_on": "tmpfs (/dev/shm)" if base else "disk (tmp dir)", "consensus_equals_amplicons": got == sorted(truths),
-                       "what": "python -m ngspeciesid_amd %s --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio %s: FASTQ parse, score, sort, sorted.fastq, "
-                               "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % (cfg["preset"], args.cli_t, AB_)}
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
     out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), %d bp %s" % (args.length, "CCS" if cfg["preset"] == "--isoseq" else "ONT"), "value": round(reads_per_s, 1), "unit": "reads/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
            "scaling": args.scaling if world > 1 or force_dist else "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic",
