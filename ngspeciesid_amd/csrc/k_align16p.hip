@@ -81,10 +81,14 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
         if (deg0) { n0 = 0; m0 = 0; }
         if (deg1) { n1 = 0; m1 = 0; }
         if (deg0 && (deg1 || !have1)) continue;
-        for (int x = lane; x < m0; x += 64) tgt0[x] = pp_perm_letter(t0[x]);
-        for (int x = lane; x < n0; x += 64) qry0[x] = pp_perm_letter(q0[x]);
-        for (int x = lane; x < m1; x += 64) tgt1[x] = pp_perm_letter(t1[x]);
-        for (int x = lane; x < n1; x += 64) qry1[x] = pp_perm_letter(q1[x]);
+        // letters outside ACGT (bits 0x7C of the permuted byte) score 0 against everything: two mask operations per cell that an item without such letters - nearly
+        // every item - does not need (NOWILD instances of the step loop below; same results by construction)
+        unsigned wild = 0;
+        for (int x = lane; x < m0; x += 64) { const uint8_t v = pp_perm_letter(t0[x]); tgt0[x] = v; wild |= v; }
+        for (int x = lane; x < n0; x += 64) { const uint8_t v = pp_perm_letter(q0[x]); qry0[x] = v; wild |= v; }
+        for (int x = lane; x < m1; x += 64) { const uint8_t v = pp_perm_letter(t1[x]); tgt1[x] = v; wild |= v; }
+        for (int x = lane; x < n1; x += 64) { const uint8_t v = pp_perm_letter(q1[x]); qry1[x] = v; wild |= v; }
+        const bool nowild = __ballot((wild & 0x7Cu) != 0) == 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
 
@@ -105,19 +109,22 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
             hl2[r] = 0; e2[r] = PP(NEG16, NEG16);
         }
 
-        auto forward = [&](auto OPc) {
-            constexpr int OWN_P = decltype(OPc)::value;
+        auto forward = [&](auto OPc, auto NWc) {
+            constexpr int OWN_P = decltype(OPc)::value; constexpr bool NOWILD = decltype(NWc)::value;
             int hdiag2 = 0;                                               // H[i0-1][j-1], both pairs
             int send_h = 0, send_f = PP(NEG16, NEG16);                    // bottom row of this lane for the next one
-            for (int tau = 0; tau < steps; ++tau) {
+            // The steps in which EVERY lane stands inside both targets (tau - lane in [0, min(m0, m1)) for all 64 lanes: 63 <= tau < min(m0, m1), 84 % of the steps of a 750-base
+            // pair) need none of the range masks: their own instance of the step (STEADY) drops the mask selects of the state (one per row, three per step) and the range tests.
+            auto step = [&](int tau, auto STc) {
+                constexpr bool STEADY = decltype(STc)::value;
                 const int j = tau - lane;
                 int hup = __builtin_amdgcn_update_dpp(0, send_h, 0x138, 0xf, 0xf, false), fup = __builtin_amdgcn_update_dpp(0, send_f, 0x138, 0xf, 0xf, false);
                 if (lane == 0) { hup = 0; fup = PP(NEG16, NEG16); }
-                const bool a0 = j >= 0 && j < m0, a1 = j >= 0 && j < m1;
-                const int l0 = tgt0[a0 ? j : 0], l1 = tgt1[a1 ? j : 0];
+                const bool a0 = STEADY || (j >= 0 && j < m0), a1 = STEADY || (j >= 0 && j < m1);      // STEADY: every lane stands inside both targets
+                const int l0 = tgt0[STEADY ? j : (a0 ? j : 0)], l1 = tgt1[STEADY ? j : (a1 ? j : 0)];
                 const int tc2 = PP(l0 & 3, l1 & 3);
-                const int nwt2 = PP((a0 && !(l0 & 0x7C)) ? 0xffff : 0, (a1 && !(l1 & 0x7C)) ? 0xffff : 0);
-                const int am2 = PP(a0 ? 0xffff : 0, a1 ? 0xffff : 0);
+                int nwt2 = 0; if constexpr (!NOWILD) nwt2 = PP((a0 && !(l0 & 0x7C)) ? 0xffff : 0, (a1 && !(l1 & 0x7C)) ? 0xffff : 0);
+                const int am2 = STEADY ? -1 : PP(a0 ? 0xffff : 0, a1 ? 0xffff : 0);
                 int hu2 = hup, f2 = fup, hd2 = hdiag2;
                 int acc[NA], cap2 = 0;
 #pragma unroll
@@ -127,7 +134,8 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
                     const int e_ext = pp_sub_i16_s(e2[r], EXT2), e_opn = pp_sub_i16_s(hl2[r], OPEN2); const int E = pp_max_i16(e_ext, e_opn);
                     const int f_ext = pp_sub_i16_s(f2, EXT2), f_opn = pp_sub_i16_s(hu2, OPEN2); const int F = pp_max_i16(f_ext, f_opn);
                     const int z = pp_min_u16_s(qc2[r] ^ tc2, ONE2);                                // 1 = letters differ
-                    const int sc = pp_mad_i16_sv(z, NDIFF2, MATCH2) & nwq2[r] & nwt2;              // match / mismatch / 0 for wildcards
+                    int sc = pp_mad_i16_sv(z, NDIFF2, MATCH2);                                     // match / mismatch ...
+                    if constexpr (!NOWILD) sc = sc & nwq2[r] & nwt2;                                // ... / 0 for wildcards (and for columns outside the target, whose cells nothing reads)
                     const int d = pp_add_i16(hd2, sc);
                     const int mx = pp_max_i16(E, F); const int h = pp_max_i16(d, mx);
                     // COMPLEMENT flags (1 = "not equal"): bit0 h!=d, bit1 mx!=E (F>E), bit2 E!=e_ext (opened), bit3 F!=f_ext (opened)
@@ -137,7 +145,7 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
                     c |= pp_min_u16_s(pp_sub_u16(F, f_ext), ONE2) << 3;
                     acc[r >> 2] = (acc[r >> 2] << 4) | c;                                           // four nibbles per half and accumulator
                     hd2 = hl2[r];
-                    hl2[r] = pp_sel(am2, h, hl2[r]);
+                    hl2[r] = STEADY ? h : pp_sel(am2, h, hl2[r]);
                     e2[r] = E;                 // not masked (see k_align16.hip: before a lane's first column E only relaxes to -open, after its last it is not used)
                     hu2 = h; f2 = F;
                     if (r == OWN_P) cap2 = h;
@@ -148,20 +156,26 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
                 for (int a = 0; a < NA; ++a) { w0 |= (unsigned long long)((unsigned)acc[a] & 0xffffu) << (16 * a); w1 |= (unsigned long long)((unsigned)acc[a] >> 16) << (16 * a); }
                 mytb0[(uint64_t)tau * 64 + lane] = w0;
                 mytb1[(uint64_t)tau * 64 + lane] = w1;
-                hdiag2 = pp_sel(am2, hup, hdiag2);
-                send_h = pp_sel(am2, hu2, send_h); send_f = pp_sel(am2, f2, send_f);
+                if (STEADY) { hdiag2 = hup; send_h = hu2; send_f = f2; }
+                else { hdiag2 = pp_sel(am2, hup, hdiag2); send_h = pp_sel(am2, hu2, send_h); send_f = pp_sel(am2, f2, send_f); }
                 {   // last query row: first maximum over the columns
                     const int v0 = PLO(cap2), v1 = PHI(cap2);
                     const bool b0_ = a0 && lane == own_lane0 && v0 > bestRowV0; bestRowV0 = b0_ ? v0 : bestRowV0; bestRowJ0 = b0_ ? j : bestRowJ0;
                     const bool b1_ = a1 && lane == own_lane1 && v1 > bestRowV1; bestRowV1 = b1_ ? v1 : bestRowV1; bestRowJ1 = b1_ ? j : bestRowJ1;
                 }
-            }
+            };
+            const int mmin = m0 < m1 ? m0 : m1;
+            const int st_lo = 63 < steps ? 63 : steps, st_hi = mmin > st_lo ? (mmin < steps ? mmin : steps) : st_lo;
+            int tau = 0;
+            for (; tau < st_lo; ++tau) step(tau, std::false_type{});
+            for (; tau < st_hi; ++tau) step(tau, std::true_type{});
+            for (; tau < steps; ++tau) step(tau, std::false_type{});
         };
         switch (own_p) {
-#define PCASE(k) case k: forward(std::integral_constant<int, (R > k ? k : 0)>{}); break;
+#define PCASE(k) case k: if (nowild) forward(std::integral_constant<int, (R > k ? k : 0)>{}, std::true_type{}); else forward(std::integral_constant<int, (R > k ? k : 0)>{}, std::false_type{}); break;
             PCASE(0) PCASE(1) PCASE(2) PCASE(3) PCASE(4) PCASE(5) PCASE(6) PCASE(7) PCASE(8) PCASE(9) PCASE(10) PCASE(11) PCASE(12) PCASE(13) PCASE(14)
 #undef PCASE
-            default: forward(std::integral_constant<int, (R > 15 ? 15 : 0)>{}); break;
+            default: if (nowild) forward(std::integral_constant<int, (R > 15 ? 15 : 0)>{}, std::true_type{}); else forward(std::integral_constant<int, (R > 15 ? 15 : 0)>{}, std::false_type{}); break;
         }
         // last target column of each pair: the state holds H[i][m-1] for every row
         int bestColV0 = -(1 << 29), bestColI0 = 0x7fffffff, bestColV1 = -(1 << 29), bestColI1 = 0x7fffffff;
