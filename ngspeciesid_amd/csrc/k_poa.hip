@@ -553,20 +553,20 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
             for (int c = 0; c < CPL; ++c) asm volatile("" : "+v"(qn[c]));      // consumed here: the loop header then carries no pending LDS read, so the
                                                                               // loop waits for its own prefetch only (lgkmcnt(2)), never for the row stores
             int cvn = (__builtin_amdgcn_readlane(chi, r & 63) >> 16) & 0xff;
-            do {
+            // one row of the run: qa = this row's letters (already in registers), qb receives the next row's.  Two rows per loop iteration (round 4): the letter
+            // registers swap roles instead of being copied (q = qn) and the row's candidate needs no copy in front of the scan at the loop's back edge
+            auto tight_row = [&](int (&qa)[CPL], int (&qb)[CPL]) {
                 const int cv = cvn;
                 cvn = (__builtin_amdgcn_readlane(chi, (r + 1) & 63) >> 16) & 0xff;     // next row's letter (an unused lane read at the end of a chunk)
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) q[c] = qn[c];
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) qn[c] = sq0[l0 + 1 + c];      // letters of the next row: their LDS latency hides behind this row (sq is padded)
+                for (int c = 0; c < CPL; ++c) qb[c] = sq0[l0 + 1 + c];      // letters of the next row: their LDS latency hides behind this row (sq is padded)
                 const int rt = __builtin_amdgcn_update_dpp(0, hprev[0], 0x130, 0xf, 0xf, true);             // lane+1's first column
                 int X[CPL], Dd[CPL];
                 int floor0 = 0;
                 if (LOCAL) { int l0g = l0 * gp_; asm volatile("" : "+s"(l0g)); floor0 = PBIAS - l0g - lane_jg; }
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
-                    const int sc = q[c] == cv ? sm : sn;
+                    const int sc = qa[c] == cv ? sm : sn;
                     const int xu = (c + 1 < CPL ? hprev[c + 1] : rt) + gp; int xd = hprev[c] + sc, ds = 0;
                     if (semi) { const int sv = sc + PBIAS; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT << 2; } }
                     X[c] = max(xd, xu); Dd[c] = xu > xd ? 1 : ds;
@@ -579,7 +579,9 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                     for (int c = 0; c < CPL; ++c) bkey[c] = max(bkey[c], ((unsigned)(hprev[c] - (floor0 - c * gp)) << 16) | rk);
                 }
                 ++r; ++l0;
-            } while (--n);
+            };
+            for (; n >= 2; n -= 2) { tight_row(qn, q); tight_row(q, qn); }
+            if (n) tight_row(qn, q);
             rfl = 0;                                                           // nothing pending for the rows just done
         } else if (rfl & 16) {
             // ---- run of chain rows: registers + one DPP per row, LDS only for letters / ring / staged directions
