@@ -283,10 +283,16 @@ def main():
             views["k_poa_tile"] = v
         if "k_sg_align" in kern and sg_cells:
             ms_a = kern["k_sg_align"][1] + kern.get("k_sg_align_side", (0, 0.0))[1]
-            per_cell = 14.4            # VALU instructions per DP cell and lane, two pairs per wave (ISA count, csrc/k_align16p.hip; 17.7 in the one-pair kernel)
+            per_cell, src = 14.4, "ISA count of the step loop of round 3 (378 VALU per step for two pairs of 12-14 rows per lane), DESIGN.md section 4"
+            try:            # round 4: VALU instructions per DP cell from the SQ-counter pass of the bench workload (all k_sg_align* dispatches of one step / the cells the kernels counted in it)
+                aj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sg_align.json")))
+                if aj.get("workload_reads") == args.reads and aj.get("config", "c3") == args.config:
+                    per_cell = float(aj["valu_per_cell"]); src = {"file": "profiles/r04_pmc_sg_align.json", "measured_at_commit": aj.get("commit"), "cells_then": aj.get("cells"), "pipe_busy_then": aj.get("pipe_busy")}
+            except Exception:
+                pass
             wi = sg_cells / 64.0 * per_cell / (ms_a / 1e3)
             views["k_sg_align"] = {"dp_cells": int(sg_cells), "kernel_ms": round(ms_a, 2), "gcups": round(sg_cells / (ms_a / 1e3) / 1e9, 1), "valu_per_cell": per_cell, "achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2),
-                                   "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "instructions_per_cell_source": "ISA count of the step loop (378 VALU per step for two pairs of 12-14 rows per lane), DESIGN.md section 4"}
+                                   "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "instructions_per_cell_source": src}
         if dom[0] in views: roof["valu_issue"] = dict(views[dom[0]], kernel=dom[0])
         roof["dp_kernels"] = views
     # ---- the drop-in surface (runs before the CPU baseline leg): FASTQ file in -> the reference's output files out (python -m ngspeciesid_amd ...), same reads, same flags as C3

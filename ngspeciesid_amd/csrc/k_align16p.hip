@@ -18,6 +18,10 @@ PKOP2(pp_sub_i16, "v_pk_sub_i16")
 PKOP2(pp_add_i16, "v_pk_add_i16")
 PKOP2(pp_max_i16, "v_pk_max_i16")
 PKOP2(pp_sub_u16, "v_pk_sub_u16")
+__device__ __forceinline__ int pp_lshr16(int a, int k2_s) { int d; asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(d) : "s"(k2_s), "v"(a)); return d; }  // per-half logical shift right; k2_s = the amount in BOTH halves of an SGPR (an inline constant would shift the high half by 0)
+// (inline asm: from the C expression the compiler builds and / or3 chains of the same length as the min / shift / or form they replace; the masks live in SGPRs)
+__device__ __forceinline__ int pp_bfi(int mask_s, int a, int b) { int d; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask_s), "v"(a), "v"(b)); return d; }        // (a & mask) | (b & ~mask)
+__device__ __forceinline__ int pp_and_or(int a, int mask_s, int b) { int d; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(mask_s), "v"(b)); return d; }  // (a & mask) | b
 #define PKOP2S(name, mnem) __device__ __forceinline__ int name(int a, int b) { int d; asm(mnem " %0, %1, %2" : "=v"(d) : "v"(a), "s"(b)); return d; }
 PKOP2S(pp_sub_i16_s, "v_pk_sub_i16")
 PKOP2S(pp_min_u16_s, "v_pk_min_u16")
@@ -95,6 +99,8 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
         const int OPEN2 = pp_sgpr(PP(J.open[p0], J.open[p1])), EXT2 = pp_sgpr(PP(J.ext, J.ext));
         const int MATCH2 = PP(J.match, J.match), NDIFF2 = pp_sgpr(PP(J.mismatch - J.match, J.mismatch - J.match));
         const int ONE2 = pp_sgpr(0x00010001);
+        const int MK1 = pp_sgpr(0x20002000), MK2 = pp_sgpr(0x40004000), MK3 = pp_sgpr((int)0x80008000u), MKN = pp_sgpr((int)0xF000F000u);      // flag-nibble masks of the step
+        const int SH2 = pp_sgpr(0x00020002), SH3 = pp_sgpr(0x00030003), SH4 = pp_sgpr(0x00040004);                                              // packed shift amounts
         const int mmax = m0 > m1 ? m0 : m1;
         const int steps = mmax + 63;
         const int own_lane0 = n0 > 0 ? (n0 - 1) / R : -1, own_lane1 = n1 > 0 ? (n1 - 1) / R : -1;
@@ -139,11 +145,14 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
                     const int d = pp_add_i16(hd2, sc);
                     const int mx = pp_max_i16(E, F); const int h = pp_max_i16(d, mx);
                     // COMPLEMENT flags (1 = "not equal"): bit0 h!=d, bit1 mx!=E (F>E), bit2 E!=e_ext (opened), bit3 F!=f_ext (opened)
-                    int c = pp_min_u16_s(pp_sub_u16(h, d), ONE2);
-                    c |= pp_min_u16_s(pp_sub_u16(mx, E), ONE2) << 1;
-                    c |= pp_min_u16_s(pp_sub_u16(E, e_ext), ONE2) << 2;
-                    c |= pp_min_u16_s(pp_sub_u16(F, f_ext), ONE2) << 3;
-                    acc[r >> 2] = (acc[r >> 2] << 4) | c;                                           // four nibbles per half and accumulator
+                    // each flag is the SIGN of a packed difference (smaller - larger: negative iff they differ); the four signs are moved to bits 12..15 of their half by
+                    // per-half shifts and merged with bit-field inserts (6 operations instead of 4 min + 3 shift + ors), and the nibble enters its accumulator at the TOP:
+                    // the k-th of the cnt rows of an accumulator ends in nibble (4 - cnt + k) of its half (round 4)
+                    const int s0 = pp_sub_i16(d, h), s1 = pp_sub_i16(E, mx), s2 = pp_sub_i16(e_ext, E), s3 = pp_sub_i16(f_ext, F);
+                    int c = pp_bfi(MK1, pp_lshr16(s1, SH2), pp_lshr16(s0, SH3));
+                    c = pp_bfi(MK2, pp_lshr16(s2, ONE2), c);
+                    c = pp_bfi(MK3, s3, c);
+                    acc[r >> 2] = pp_and_or(c, MKN, pp_lshr16(acc[r >> 2], SH4));                   // four nibbles per half and accumulator
                     hd2 = hl2[r];
                     hl2[r] = STEADY ? h : pp_sel(am2, h, hl2[r]);
                     e2[r] = E;                 // not masked (see k_align16.hip: before a lane's first column E only relaxes to -open, after its last it is not used)
@@ -253,7 +262,7 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
                     if ((l >> 3) == blk_g && tau <= blk_hi && tau >= blk_hi - 63) {
                         const uint64_t word = tbblk[(blk_hi - tau) * 8 + (l & 7)];
                         const int a = r >> 2; const int cnt_a = (R - 4 * a) < 4 ? (R - 4 * a) : 4;
-                        const int sh = 16 * a + 4 * (cnt_a - 1 - (r & 3));
+                        const int sh = 16 * a + 4 * (4 - cnt_a + (r & 3));
                         vk = (int)((~(word >> sh)) & 15);        // stored complemented -> bit0 diag, bit1 E>=F, bit2 E extends, bit3 F extends
                         inb = true;
                     }

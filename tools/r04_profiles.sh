@@ -67,5 +67,28 @@ if sq and rows:
        "_how":"rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-extra-step, summed over every k_poa_tile1 dispatch of the step; rows = DP rows of the same step from NGSID_POA_PHASES=1 (r04_poa_phases.txt); pipe_busy = VALU instructions x 4 cycles / (1 024 SIMDs x busy cycles per shader engine)"}
     json.dump(j,open("gpurun_out/r4/r04_pmc_poa_tile.json","w"),indent=1); print(json.dumps({k:v for k,v in j.items() if k not in ("raw","_how")}))
 PY
+python - <<PY
+# the clustering aligner from the same SQ pass: VALU instructions of every k_sg_align* dispatch of the step / the DP cells the kernels counted in the bench line (per step)
+import csv,glob,collections,json,os
+commit=os.environ.get("NGSID_COMMIT","unknown")
+fs=glob.glob("gpurun_out/r4/pmc_sq/**/*counter_collection.csv",recursive=True)
+sq=collections.defaultdict(float)
+if fs:
+    for r in csv.DictReader(open(fs[0])):
+        if "k_sg_align" in r["Kernel_Name"]: sq[r["Counter_Name"]]+=float(r["Counter_Value"])
+try:
+    d=json.loads(open("gpurun_out/r4/r04_bench_1m.json").read().strip().splitlines()[-1]); v=d["roofline"]["dp_kernels"]["k_sg_align"]; cells=v["dp_cells"]/d["steps"]
+except Exception: cells=0
+kt=glob.glob("gpurun_out/r4/pmc_sq/**/*kernel_trace.csv",recursive=True); dur=0
+if kt:
+    for r in csv.DictReader(open(kt[0])):
+        if "k_sg_align" in r["Kernel_Name"]: dur+=int(r["End_Timestamp"])-int(r["Start_Timestamp"])
+if sq and cells:
+    j={"workload_reads":1000000,"config":"c3","commit":commit,"cells":int(cells),"valu_per_cell":round(sq["SQ_INSTS_VALU"]*64/cells,2),"salu_per_cell":round(sq["SQ_INSTS_SALU"]*64/cells,2),
+       "wave_cycles_waiting_frac":round(sq["SQ_WAIT_ANY"]/max(sq["SQ_WAVE_CYCLES"],1),3),"kernel_ns_under_the_counter_pass":dur,
+       "pipe_busy":round(sq["SQ_INSTS_VALU"]*4/(1024*(sq["SQ_BUSY_CYCLES"]/32.0)),3) if sq.get("SQ_BUSY_CYCLES") else None,"raw":{k:int(v) for k,v in sq.items()},
+       "_how":"same counter pass as r04_pmc_poa_tile.json, summed over every k_sg_align* dispatch (clustering + the reverse-complement merge) of one bench step; cells = DP cells (query x target bases) the kernels counted per step in the bench line; valu_per_cell = wave VALU instructions x 64 lanes / cells"}
+    json.dump(j,open("gpurun_out/r4/r04_pmc_sg_align.json","w"),indent=1); print(json.dumps({k:v for k,v in j.items() if k not in ("raw","_how")}))
+PY
 python -c "
 import json; d=json.loads(open('gpurun_out/r4/r04_bench_1m.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['config']['stage_s_per_step'], d['config']['kernel_ms_per_step'], d['roofline'], d['config'].get('cli',{}).get('reads_per_s'), d['cpu_baseline']['value'])"
