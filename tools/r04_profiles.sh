@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4; mkdir -p $O
 BARGS="--no-cpu-baseline --no-cli"
 # 1. the bench line (defaults: C3, 1 GPU)
-python $R/bench.py > $O/r04_bench_1m.json 2> $O/r04_bench_1m.err
+timeout 900 python $R/bench.py > $O/r04_bench_1m.json 2> $O/r04_bench_1m.err
 # 2. kernel trace + stats of the same command
 rm -rf $O/prof_stats; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o r04 -- python $R/bench.py --steps 2 --warmup 1 $BARGS > $O/prof_stats.log 2>&1
 cp $(find $O/prof_stats -name "*kernel_stats.csv" | head -1) $O/r04_rocprofv3_kernel_stats_1m.csv 2>/dev/null
@@ -16,7 +16,7 @@ done
 # 4. SQ counters of the POA kernel ON THE BENCH WORKLOAD at the default tile depth (one step)
 rm -rf $O/pmc_sq; timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-trace --output-format csv -d $O/pmc_sq -o pmc -- python $R/bench.py --steps 1 --warmup 0 $BARGS --no-extra-step > $O/pmc_sq.log 2>&1
 # 5. DP rows of the same step (phase counters of the host-driven loop: same tiles, same rows)
-NGSID_POA_PHASES=1 python $R/bench.py --steps 1 --warmup 0 $BARGS --no-extra-step > $O/phases.json 2> $O/r04_poa_phases.txt
+NGSID_POA_PHASES=1 timeout 600 python $R/bench.py --steps 1 --warmup 0 $BARGS --no-extra-step > $O/phases.json 2> $O/r04_poa_phases.txt
 cd $R
 python - <<PY
 import csv,glob,collections,json,os,re
