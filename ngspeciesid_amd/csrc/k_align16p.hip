@@ -119,13 +119,14 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
             constexpr int OWN_P = decltype(OPc)::value; constexpr bool NOWILD = decltype(NWc)::value;
             int hdiag2 = 0;                                               // H[i0-1][j-1], both pairs
             int send_h = 0, send_f = PP(NEG16, NEG16);                    // bottom row of this lane for the next one
+            int keyRow0 = (int)0x80000000u, keyRow1 = (int)0x80000000u; const int jinv0 = 0xFFFF + lane;      // steady steps: packed (last-row value, -column) maxima
             // The steps in which EVERY lane stands inside both targets (tau - lane in [0, min(m0, m1)) for all 64 lanes: 63 <= tau < min(m0, m1), 84 % of the steps of a 750-base
             // pair) need none of the range masks: their own instance of the step (STEADY) drops the mask selects of the state (one per row, three per step) and the range tests.
             auto step = [&](int tau, auto STc) {
                 constexpr bool STEADY = decltype(STc)::value;
                 const int j = tau - lane;
-                int hup = __builtin_amdgcn_update_dpp(0, send_h, 0x138, 0xf, 0xf, false), fup = __builtin_amdgcn_update_dpp(0, send_f, 0x138, 0xf, 0xf, false);
-                if (lane == 0) { hup = 0; fup = PP(NEG16, NEG16); }
+                // lane 0 has no source lane: the shift leaves it the `old` operand - 0 for H (row -1 of the matrix), minus infinity for F (no select needed)
+                const int hup = __builtin_amdgcn_update_dpp(0, send_h, 0x138, 0xf, 0xf, false), fup = __builtin_amdgcn_update_dpp(PP(NEG16, NEG16), send_f, 0x138, 0xf, 0xf, false);
                 const bool a0 = STEADY || (j >= 0 && j < m0), a1 = STEADY || (j >= 0 && j < m1);      // STEADY: every lane stands inside both targets
                 const int l0 = tgt0[STEADY ? j : (a0 ? j : 0)], l1 = tgt1[STEADY ? j : (a1 ? j : 0)];
                 const int tc2 = PP(l0 & 3, l1 & 3);
@@ -167,7 +168,13 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
                 mytb1[(uint64_t)tau * 64 + lane] = w1;
                 if (STEADY) { hdiag2 = hup; send_h = hu2; send_f = f2; }
                 else { hdiag2 = pp_sel(am2, hup, hdiag2); send_h = pp_sel(am2, hu2, send_h); send_f = pp_sel(am2, f2, send_f); }
-                {   // last query row: first maximum over the columns
+                if (STEADY) {
+                    // last query row, first maximum over the columns, as ONE signed maximum per pair of (value << 16 | 0xFFFF - column): equal values keep the larger low
+                    // half = the smaller column.  Every lane runs it, only the lane that owns the last row is read (merged into bestRow* after the steady steps).
+                    const int jinv = jinv0 - tau;
+                    keyRow0 = max(keyRow0, (int)(((unsigned)cap2 << 16) | (unsigned)jinv));
+                    keyRow1 = max(keyRow1, (int)(((unsigned)cap2 & 0xFFFF0000u) | (unsigned)jinv));
+                } else {   // last query row: first maximum over the columns
                     const int v0 = PLO(cap2), v1 = PHI(cap2);
                     const bool b0_ = a0 && lane == own_lane0 && v0 > bestRowV0; bestRowV0 = b0_ ? v0 : bestRowV0; bestRowJ0 = b0_ ? j : bestRowJ0;
                     const bool b1_ = a1 && lane == own_lane1 && v1 > bestRowV1; bestRowV1 = b1_ ? v1 : bestRowV1; bestRowJ1 = b1_ ? j : bestRowJ1;
@@ -181,6 +188,11 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
             // is consumed by the second step in place, instead of being copied back into the loop's registers after every step (~38 v_mov per step of ~340 instructions)
             for (; tau + 1 < st_hi; tau += 2) { step(tau, std::true_type{}); step(tau + 1, std::true_type{}); }
             for (; tau < st_hi; ++tau) step(tau, std::true_type{});
+            if (st_hi > st_lo) {      // the steady steps' maxima join the running ones (their columns lie between those of the ramp-up and of the ramp-down steps)
+                const int v0 = keyRow0 >> 16, v1 = keyRow1 >> 16;
+                if (lane == own_lane0 && v0 > bestRowV0) { bestRowV0 = v0; bestRowJ0 = 0xFFFF - (keyRow0 & 0xFFFF); }
+                if (lane == own_lane1 && v1 > bestRowV1) { bestRowV1 = v1; bestRowJ1 = 0xFFFF - (keyRow1 & 0xFFFF); }
+            }
             for (; tau < steps; ++tau) step(tau, std::false_type{});
         };
         switch (own_p) {
