@@ -155,6 +155,9 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
                         const u64 npv = Mh | ~(Xv | Ph);
                         Pv[b] = npv; Mv[b] = Ph & Xv;
                         ngsid_v4u w; w.x = (unsigned)diag; w.y = (unsigned)(diag >> 32); w.z = (unsigned)npv; w.w = (unsigned)(npv >> 32);
+#if defined(ED_EXP_STORE_EVERY)
+                        if ((j % ED_EXP_STORE_EVERY) == 0)           // timing build (wrong results): what the traceback-word stores cost
+#endif
                         col[(u64)(WIN ? b : blk) * mstride * 64] = w;
                         hp = php; hm = phm;
                     }
