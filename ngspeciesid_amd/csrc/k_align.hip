@@ -158,7 +158,9 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
             int cw = -1, w_qf = 0, w_ql = 0, w_tf = 0, w_tl = 0;
             int32_t* bpp = J.bp ? J.bp + p * (uint64_t)J.bp_windows * 4 : nullptr;
             int blk_s = -1, blk_g = -1, blk_hi = -1;       // loaded block: strip, 8-lane group, highest step
-            while (i >= 0 && j >= 0) {
+            // (every round of the walk takes at least one step or reloads a block once per 64 steps: the bound is never reached; it turns a corrupted traceback word into a wrong
+            // result the parity tests catch instead of a wave that never ends)
+            for (int guard = 4 * (n + m) + 512; i >= 0 && j >= 0 && guard > 0; --guard) {
                 const int sidx = i / STRIP; const int il = i - sidx * STRIP; const int l = il / RPL; const int r = il - l * RPL;
                 const int tau = j + l; const int grp = l >> 3;
                 if (sidx != blk_s || grp != blk_g || tau > blk_hi || tau < blk_hi - 63) {

@@ -221,7 +221,9 @@ void k_sg_align16(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_w
             int blk_s = -1, blk_g = -1, blk_hi = -1;
             // polishing window of the current column, tracked incrementally (no divisions in the loop): [ws, ws + window), index wsn
             int wsn = bpp ? j / Jt->window : 0, ws = bpp ? wsn * Jt->window : 0;
-            while (i >= 0 && j >= 0) {
+            // (every round of the walk takes at least one step or reloads a block once per 64 steps: the bound is never reached; it turns a corrupted traceback word into a wrong
+            // result the parity tests catch instead of a wave that never ends)
+            for (int guard = 4 * (n + m) + 512; i >= 0 && j >= 0 && guard > 0; --guard) {
                 if (bpp) while (j < ws) { ws -= Jt->window; --wsn; }
                 {   // make sure the block of traceback words around the current cell is in LDS (64 steps x one group of 8 lanes)
                     const int sidx = i / STRIP; const int il = i - sidx * STRIP; const int l = il / RPL; const int rr = il - l * RPL;

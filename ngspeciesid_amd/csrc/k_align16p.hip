@@ -248,7 +248,9 @@ void k_sg_align16p(AlignJob J, const uint32_t* __restrict__ sorted, const uint32
             int32_t* bpp = Jt->bp ? Jt->bp + p * (uint64_t)Jt->bp_windows * 4 : nullptr;
             int blk_g = -1, blk_hi = -1;
             int wsn = bpp ? j / Jt->window : 0, ws = bpp ? wsn * Jt->window : 0;
-            while (i >= 0 && j >= 0) {
+            // (every round of the walk takes at least one step or reloads a block once per 64 steps: the bound is never reached; it turns a corrupted traceback word into a wrong
+            // result the parity tests catch instead of a wave that never ends)
+            for (int guard = 4 * (n + m) + 512; i >= 0 && j >= 0 && guard > 0; --guard) {
                 if (bpp) while (j < ws) { ws -= Jt->window; --wsn; }
                 {   // the block of traceback words around the current cell in LDS (64 steps x one group of 8 lanes)
                     const int l = i / R; const int tau = j + l; const int grp = l >> 3;
