@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--length", type=int, default=None)
     ap.add_argument("--mu", type=float, default=None)
     ap.add_argument("--tile-depth", type=int, default=6, help="reads per POA tile (library / CLI default 6)")
-    ap.add_argument("--band", type=int, default=0, help="POA band width in columns of the first attempt (64 / 128 / 256); 0 = library default (64 for reads up to 1 024 bases)")
+    ap.add_argument("--band", type=int, default=0, help="POA band width in columns of the first attempt (64 / 128 / 256); 0 = library default (64 for reads up to 3 000 bases)")
     ap.add_argument("--node-cap", type=int, default=0, help="POA graph capacity in 1/16 of the first sequence length (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=1500, help="reads per worker process of the cpu_baseline leg")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the cpu_baseline leg (0 = all host cores)")
@@ -268,7 +268,7 @@ def main():
         prop = torch.cuda.get_device_properties(dev)
         clk = float(getattr(prop, "clock_rate", 2400000)) * 1e3
         peak_issue = prop.multi_processor_count * 4 * clk / 4.0
-        band_cols = args.band if args.band else (64 if L <= 1024 else 128)
+        band_cols = args.band if args.band else (64 if L <= 3000 else 128)          # NGSID_POA_BAND64_MAXLEN (include/ngsid.h)
         views = {}
         if "k_poa_tile" in kern and poa_rows:
             ms_p = kern["k_poa_tile"][1]; v = {"dp_rows": int(poa_rows), "band_columns": band_cols, "kernel_ms": round(ms_p, 2), "gcups": round(poa_rows * band_cols / (ms_p / 1e3) / 1e9, 1)}
@@ -391,7 +391,7 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
            "scaling": args.scaling if world > 1 or force_dist else "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic",
            "config": {"workload": (args.config.upper() + ": %d synthetic %d bp %s-profile reads " + ("in total, one `--t N` batch per GPU" if (args.scaling == "strong" and (world > 1 or force_dist)) else "per GPU") + " (mu=%.0f), %d species @15%% divergence%s, k=%d w=%d, cluster + spoa-style POA + racon-style polish x3, abundance_ratio %s, POA tile depth %d band %s")
-                      % (args.reads, args.length, "CCS" if args.mu >= 25 else "ONT", args.mu, args.species, (" with geometric abundance %.1f^i" % cfg["geometric"]) if cfg["geometric"] else "", K_, W_, AB_, args.tile_depth, ("%d" % args.band) if args.band else "64 (library default, widened per tile by the band-edge check)"),
+                      % (args.reads, args.length, "CCS" if args.mu >= 25 else "ONT", args.mu, args.species, (" with geometric abundance %.1f^i" % cfg["geometric"]) if cfg["geometric"] else "", K_, W_, AB_, args.tile_depth, ("%d" % args.band) if args.band else "%d (library default, widened per tile by the band-edge check)" % (64 if args.length <= 3000 else 128)),
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
                       "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()},
                       "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),

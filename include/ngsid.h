@@ -39,6 +39,7 @@ extern "C" {
 #define NGSID_MAX_K          32      /* k <= 21: 3-bit order-preserving k-mer codes (0=end,A,C,G,N,T) in a uint64; 22..32: two-word codes inside the
                                         library, handed on as dense order-preserving ranks per call (the reference's table has rows for k = 10..30) */
 #define NGSID_MAX_READ_LEN   16384   /* bases per read handled by the LDS-staged kernels */
+#define NGSID_POA_BAND64_MAXLEN 3000 /* default POA band (ngsid_poa_params_t.band <= 0): 64 columns when every read of the call has at most this many bases, else 128 (round 4: was 1 024; measured on 2 kb reads at 0.1 / 5 / 10 % error the 64-column first attempt + the redo of the tiles that touch the band edge is 26 - 31 % faster, at 5 kb ONT it is a wash) */
 
 typedef struct ngsid_ctx ngsid_ctx;
 
@@ -153,7 +154,7 @@ typedef struct {
     int32_t match, mismatch, gap;   /* spoa -m/-n/-g ; linear gaps (g >= e in consensus.py:87) */
     int32_t tile_depth;    /* reads per exact-order POA tile; <=0 = one tile per group (exact spoa order) */
     int32_t band;          /* DP band width in columns (64/128/256) of the first attempt; <=0 = library default (64 when every read of the call has
-                              <= 1 024 bases, else 128).  A tile in which a traceback touches a clipped band edge is redone with twice the band (up to 256) */
+                              <= NGSID_POA_BAND64_MAXLEN (3 000) bases, else 128).  A tile in which a traceback touches a clipped band edge is redone with twice the band (up to 256) */
     int32_t node_cap;      /* graph node capacity per tile as a multiple of 1/16 of the first read length (<=0 default) */
     int32_t trim;          /* 0 = none (spoa: the heaviest bundle is completed to a sink, so the consensus can carry the unsupported tail of a single
                               read); 1 = coverage-trim the ends of every tile consensus (bases covered by less than half of the sequences merged) AND,

@@ -564,7 +564,7 @@ static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, co
         if (read_order) units[g].seqs.assign(read_order + grp_off[g], read_order + grp_off[g + 1]);
         else { units[g].seqs.resize(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs[r - grp_off[g]] = (uint32_t)r; }
     }
-    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= 1024 ? 64 : 128), prm->node_cap, prm->tile_depth, prm->mode, cov != nullptr, prm->trim > 0 ? 1 : 0};
+    HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, prm->mode, cov != nullptr, prm->trim > 0 ? 1 : 0};
     std::vector<int> nobb;
     htc.mark("units");
     rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;
@@ -939,7 +939,7 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         DevBuf<PSeq> d_bbs; HIPCHK(ctx, d_bbs.alloc(bbs.size()));
         if (!bbs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_bbs.p, bbs.data(), sizeof(PSeq) * bbs.size(), hipMemcpyHostToDevice, ctx->stream));
         bool any_tgs = prm->trim >= 2; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
-        HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= 1024 ? 64 : 128), prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, prm->trim >= 2 ? 1 : 0};
+        HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, prm->trim >= 2 ? 1 : 0};
         ht.mark("unit lists");
         rc = run_hierarchy(ctx, (const PSeq*)d_lay_raw.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
         ht.mark("hierarchy");

@@ -368,7 +368,7 @@ static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P
 
 /* library default band (band <= 0): 64 columns when every read of the call is at most 1 024 bases, else 128; the band-edge check of
    run_tile widens it per tile where a path asks for more, so the choice only decides how much work the first attempt does */
-static int default_band(const ngsid_reads_t* reads) { uint64_t mx = 0; for (uint64_t i = 0; i < reads->n; ++i) { const uint64_t l = reads->off[i + 1] - reads->off[i]; if (l > mx) mx = l; } return mx <= 1024 ? 64 : 128; }
+static int default_band(const ngsid_reads_t* reads) { uint64_t mx = 0; for (uint64_t i = 0; i < reads->n; ++i) { const uint64_t l = reads->off[i + 1] - reads->off[i]; if (l > mx) mx = l; } return mx <= NGSID_POA_BAND64_MAXLEN ? 64 : 128; }
 
 static int32_t poa_consensus_impl(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                                   const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov_out);
