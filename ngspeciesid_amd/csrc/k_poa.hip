@@ -592,25 +592,28 @@ __device__ __forceinline__ void poa_forward(const GG& g, const LLT<64 * CPL>& w,
                 for (int c = 0; c < CPL; ++c) q[c] = sq0[l0 + c];          // sq is padded: no bounds branches
                 // Band start moved by one: diag = same register, up = next column; else diag = previous column, up = same.
                 // Lane 0 / 63 get 0 from the DPP (no source lane), which is the out-of-band value; column 0 never has a diagonal.
-                int up[CPL], dg[CPL];
+                // the two candidates are formed inside each band-shift case, so that the lane shift folds into the add (v_add_u32_dpp, as in the tight loop) and the cases
+                // need no register copies to meet (round 4)
+                int sc[CPL], xu[CPL], xdv[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) sc[c] = q[c] == cv ? sm : sn;
                 if (rfl & 32) {
                     const int rt = __builtin_amdgcn_update_dpp(0, hprev[0], 0x130, 0xf, 0xf, true);         // lane+1's first column
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) { up[c] = c + 1 < CPL ? hprev[c + 1] : rt; dg[c] = hprev[c]; }
+                    for (int c = 0; c < CPL; ++c) { xu[c] = (c + 1 < CPL ? hprev[c + 1] : rt) + gp; xdv[c] = hprev[c] + sc[c]; }
                 } else {
                     const int lf = __builtin_amdgcn_update_dpp(0, hprev[CPL - 1], 0x138, 0xf, 0xf, true);   // lane-1's last column
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c) { up[c] = hprev[c]; dg[c] = c ? hprev[c - 1] : lf; }
+                    for (int c = 0; c < CPL; ++c) { xu[c] = hprev[c] + gp; xdv[c] = (c ? hprev[c - 1] : lf) + sc[c]; }
                 }
                 int X[CPL], Dd[CPL];
                 int floor0 = 0;
                 if (LOCAL) { int l0g = l0 * gp_; asm volatile("" : "+s"(l0g)); floor0 = PBIAS - l0g - lane_jg; }      // scalar product (no per-lane v_mul_lo_u32)
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
-                    const int sc = q[c] == cv ? sm : sn;
-                    const int xu = up[c] + gp; int xd = dg[c] + sc, ds = 0;
-                    if (semi) { const int sv = sc + PBIAS; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT << 2; } }   // free start in the graph
-                    X[c] = max(xd, xu); Dd[c] = xu > xd ? 1 : ds;
+                    int xd = xdv[c], ds = 0;
+                    if (semi) { const int sv = sc[c] + PBIAS; if (l0 + lane * CPL + c >= 1 && sv > xd) { xd = sv; ds = SRC_SLOT << 2; } }   // free start in the graph
+                    X[c] = max(xd, xu[c]); Dd[c] = xu[c] > xd ? 1 : ds;
                 }
                 const unsigned dpack = poa_row_finish<CPL, LOCAL>(X, Dd, floor0, gp, hprev);
                 poa_row_tail_store<CPL>(ring0 + (r & (HR - 1)) * RS, stage0 + (r & (TBR - 1)) * BW, hprev, dpack);
