@@ -68,6 +68,10 @@ class BackgroundWriters:
             # a writer takes at most 8 helper threads (two writers at a time fill a 16-CPU quota; the big writes run while the GPU does the long consensus launches);
             # the writer of sorted.fastq runs beside the clustering call, whose driver thread needs its core back after every launch: 4
             import ctypes as C
+            if os.environ.get("NGSID_CLI_WRITER_NICE"):
+                import threading
+                try: os.setpriority(os.PRIO_PROCESS, threading.get_native_id(), int(os.environ["NGSID_CLI_WRITER_NICE"]))      # dev switch: the helper threads inherit it
+                except Exception: pass
             try: runtime.load_library().ngsid_host_thread_cap(C.c_int32(int(threads or os.environ.get("NGSID_CLI_WRITER_THREADS", "8"))))
             except Exception: pass
             return fn(*a, **kw)
