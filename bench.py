@@ -55,6 +55,7 @@ def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device, abundance=Non
         nseq[d0:d0 + len(src)] = rd["seq"][src]; nqual[d0:d0 + len(src)] = rd["qual"][src]
     out = dict(seq=nseq, qual=nqual, off=noff, species=rd["species"][perm_t], score=score[perm], orig=perm)
     torch.cuda.synchronize(device)       # same for the gather into score order
+    del rd, rs, src, idx; torch.cuda.empty_cache()        # the unsorted copy (+ torch's cached generator temporaries: 3 x the read set at 10 M reads) goes back to the driver
     return sp, out
 
 
@@ -231,6 +232,7 @@ def main():
         ed.append(0 if c[3] in tset else min(min(edit_distance(c[3][a:len(c[3]) - b if b else None], t) for a in range(4) for b in range(4)) for t in truths))
     # ---- roofline of the dominant kernel (HIP-event times on the library's own stream)
     redo_tiles = kern.pop("poa_band_redo_tiles", (0, 0.0))[0]
+    hbm_peak = kern.pop("hbm_peak_bytes", (0, 0.0))[0]; hbm_live = kern.pop("hbm_live_bytes", (0, 0.0))[0]      # device memory handed out by the library's allocator (process wide): high-water mark of the timed steps / still held after them
     poa_rows = kern.pop("poa_dp_rows", (0, 0.0))[0]; sg_cells = kern.pop("sg_dp_cells", (0, 0.0))[0]      # work counters of the timed steps (counted by the kernels themselves, ngsid_profile_read)
     dom = max(kern.items(), key=lambda kv: kv[1][1]) if kern else (None, (0, 0.0))
     f_aln = float(res["counters"][2]) / n
@@ -395,6 +397,7 @@ def main():
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
                       "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()},
                       "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),
+                      "hbm_gb": {"peak_in_timed_steps": round(hbm_peak / 1e9, 2), "held_after": round(hbm_live / 1e9, 2), "what": "bytes handed out by the library's device allocator, whole process (read set included)"},
                       "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok, "sharded_consensus_equals_single_process": single_same}},
            "roofline": roof, "cpu_baseline": cpu}
     if cli_leg is not None: out["config"]["cli"] = cli_leg

@@ -30,7 +30,7 @@ static bool g_cl_tables[16] = {false};
 struct ClDev {
     const uint8_t* seq; const uint8_t* qual; const uint64_t* off; uint64_t n;
     const uint32_t* hlen; const uint32_t* mzcnt; const double* herr; const double* rawerr; const uint8_t* eidx; const uint32_t* accrank;
-    const uint64_t* mzcode; const uint32_t* mzpos;
+    const uint64_t* mzcode; const uint32_t* mzpos; const uint64_t* mzoff;      // compact CSR: the minimizers of read r start at mzoff[r] (round 5; round 1-4: at the read's base offset)
     const uint32_t* rep_read; const uint64_t* pool; const uint64_t* pool_off;
     const int32_t* maxgap;      // 225 ints, -2 = missing table entry
     int k, min_shared, symmetric; double min_fraction, mapped_threshold, aligned_threshold;
@@ -67,7 +67,7 @@ void k_count_hits(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, u
     const uint32_t read = items[it];
     if (D.hlen[read] < (uint32_t)D.k) return;
     const uint32_t M = D.mzcnt[read];
-    const uint64_t base = D.off[read];
+    const uint64_t base = D.mzoff[read];
     unsigned long long* row = (unsigned long long*)(cnt + (uint64_t)(it - row0) * stride);
     for (uint32_t a = lane; a < M; a += 64) {
         const uint64_t code = D.mzcode[base + a]; const uint32_t pos = D.mzpos[base + a];
@@ -111,7 +111,7 @@ __device__ __forceinline__ bool next_candidate(const ClDev& D, const uint64_t* r
 // mapped iff p_err^g >= min_prob_no_hits <=> g <= maxgap.
 __device__ __forceinline__ long long mapped_span(const ClDev& D, uint32_t read, uint32_t slot, int maxgap, int lane)
 {
-    const uint32_t M = D.mzcnt[read]; const uint64_t base = D.off[read];
+    const uint32_t M = D.mzcnt[read]; const uint64_t base = D.mzoff[read];
     const uint64_t* rc = D.pool + D.pool_off[slot]; const uint32_t rn = (uint32_t)(D.pool_off[slot + 1] - D.pool_off[slot]);
     long long total = 0;
     int last_idx = -1, last_pos = 0;
@@ -274,7 +274,7 @@ void k_count_hits_rep(ClDev D, const uint32_t* __restrict__ items, uint32_t it_l
     const uint64_t* __restrict__ rc = D.pool + D.pool_off[slot];
     const uint32_t n = (uint32_t)(D.pool_off[slot + 1] - D.pool_off[slot]);
     const uint32_t M = D.mzcnt[read];
-    const uint64_t base = D.off[read];
+    const uint64_t base = D.mzoff[read];
     unsigned long long* cell = (unsigned long long*)(cnt + (uint64_t)(it - row0) * stride + slot);
     unsigned long long acc = 0;
     for (uint32_t a = lane; a < M; a += 64) {
@@ -396,7 +396,7 @@ void k_count_hits_reps(ClDev D, const uint32_t* __restrict__ items, uint32_t it_
     const uint64_t* __restrict__ rc = D.pool + D.pool_off[slot];
     const uint32_t n = (uint32_t)(D.pool_off[slot + 1] - D.pool_off[slot]);
     const uint32_t M = D.mzcnt[read];
-    const uint64_t base = D.off[read];
+    const uint64_t base = D.mzoff[read];
     unsigned long long acc = 0;
     for (uint32_t a = lane; a < M; a += 64) {
         const uint64_t code = D.mzcode[base + a];
@@ -554,13 +554,19 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     if (!g_cl_tables[ctx->device & 15]) { HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_round2_t), NGSID_ROUND2_T, sizeof(double) * 15)); g_cl_tables[ctx->device & 15] = true; }
 
     // ---- per-read preprocessing (a1-a3)
-    DevBuf<uint64_t>& mzcode = ctx->pol_mzcode; DevBuf<uint32_t>& mzpos = ctx->pol_mzpos;      // the two big ones (12 bytes per base) are grow-only scratch of the context
+    DevBuf<uint64_t>& mzcode = ctx->pol_mzcode; DevBuf<uint32_t>& mzpos = ctx->pol_mzpos;      // compact CSR of the context (12 bytes per minimizer, grow-only), offsets in ctx->mz_off / ctx->h_mzoff
     DevBuf<uint32_t>& mzcnt = ctx->mzc_cnt; DevBuf<uint32_t>& hlen = ctx->mzc_hlen; DevBuf<uint32_t> d_acc; DevBuf<double> herr0, herr, rawerr, d_known; DevBuf<uint8_t> eidx; DevBuf<int> flag;
     ctx->mzc.valid = false;
-    HIPCHK(ctx, mzcode.reserve(RD.total + 1)); HIPCHK(ctx, mzpos.reserve(RD.total + 1)); HIPCHK(ctx, mzcnt.reserve(N)); HIPCHK(ctx, hlen.reserve(N));
+    HIPCHK(ctx, mzcnt.reserve(N)); HIPCHK(ctx, hlen.reserve(N));
     HIPCHK(ctx, herr0.alloc(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N)); HIPCHK(ctx, eidx.alloc(N)); HIPCHK(ctx, flag.alloc(2)); HIPCHK(ctx, d_acc.alloc(N));
     HIPCHK(ctx, hipMemsetAsync(flag.p, 0, 2 * sizeof(int), ctx->stream));
-    rc = ngsid_launch_minimizers(ctx, RD, k, w, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr0.p, rawerr.p, flag.p); if (rc) return rc;
+    static thread_local PinVec<uint32_t> h_hlen, h_mzcnt;      // host mirrors are kept across calls (fresh multi-megabyte vectors page-fault on every call)
+    h_hlen.resize(N); h_mzcnt.resize(N);
+    {
+        long long bad = -1;
+        rc = ngsid_minimizers_csr(ctx, RD, k, w, ngsid_ctx_mz(ctx), mzcnt.p, hlen.p, herr0.p, rawerr.p, h_mzcnt.data(), h_hlen.data(), &bad); if (rc) return rc;
+        if (bad >= 0) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "read %lld: base outside ACGTN", bad);
+    }
     if (k <= 21 && N >= 1024) {       // key of the minimizer cache (the polisher's strand detection may be handed the same reads next); small sets are not worth the fingerprint
         unsigned long long fp = 0; rc = ngsid_reads_fingerprint(ctx, RD, &fp); if (rc) return rc;
         ctx->mzc.n = N; ctx->mzc.total = RD.total; ctx->mzc.k = k; ctx->mzc.w = w; ctx->mzc.fp = fp; ctx->mzc.valid = true;
@@ -570,13 +576,6 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     HIPCHK(ctx, hipGetLastError());
     if (acc_rank) HIPCHK(ctx, hipMemcpyAsync(d_acc.p, acc_rank, 4 * N, hipMemcpyHostToDevice, ctx->stream));
     else { std::vector<uint32_t> id(N); for (uint64_t i = 0; i < N; ++i) id[i] = (uint32_t)i; HIPCHK(ctx, hipMemcpyAsync(d_acc.p, id.data(), 4 * N, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
-    static thread_local PinVec<uint32_t> h_hlen, h_mzcnt;      // host mirrors are kept across calls (fresh multi-megabyte vectors page-fault on every call)
-    h_hlen.resize(N); h_mzcnt.resize(N); int h_flag[2] = {0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(h_hlen.data(), hlen.p, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h_mzcnt.data(), mzcnt.p, 4 * N, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h_flag, flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h_flag[0]) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "read %d: base outside ACGTN", h_flag[0] - 1);
 
     // ---- max tolerated run of non-shared minimizers per (e1,e2): largest g with p_err^g >= min_prob_no_hits,
     //      p_err^g by left-to-right repeated multiplication exactly like reduce(mul,[p]*g,1)  (cluster.py:97-105)
@@ -623,7 +622,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
         for (uint64_t i = 0; i < N; ++i) if (h_seeded[i] && h_hlen[i] >= (uint32_t)k) seeds.push_back((uint32_t)i);
         for (size_t s0 = 0; s0 < seeds.size(); s0 += 512) {
             const uint32_t nch = (uint32_t)std::min<size_t>(512, seeds.size() - s0);
-            rc = build_reps(ctx, S, seeds.data() + s0, nch, mzcode.p, RD.h_off.data(), h_mzcnt.data()); if (rc) return rc;
+            rc = build_reps(ctx, S, seeds.data() + s0, nch, mzcode.p, ctx->h_mzoff.data(), h_mzcnt.data()); if (rc) return rc;
             h_po.resize(nch + 1);
             HIPCHK(ctx, hipMemcpyAsync(h_po.data(), S.pool_off.p + S.R, 8ull * (nch + 1), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -633,7 +632,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
 
     ClDev D{};
     D.seq = RD.seq; D.qual = RD.qual; D.off = RD.off; D.n = N; D.hlen = hlen.p; D.mzcnt = mzcnt.p; D.herr = herr.p; D.rawerr = rawerr.p; D.eidx = eidx.p; D.accrank = d_acc.p;
-    D.mzcode = mzcode.p; D.mzpos = mzpos.p; D.maxgap = d_maxgap.p; D.k = k; D.min_shared = prm->min_shared; D.symmetric = prm->symmetric;
+    D.mzcode = mzcode.p; D.mzpos = mzpos.p; D.mzoff = ctx->mz_off.p; D.maxgap = d_maxgap.p; D.k = k; D.min_shared = prm->min_shared; D.symmetric = prm->symmetric;
     D.min_fraction = prm->min_fraction; D.mapped_threshold = prm->mapped_threshold; D.aligned_threshold = prm->aligned_threshold;
     D.dec = dec.p; D.kind = kind.p; D.alnflag = alnflag.p; D.top = top.p; D.cur_hi = cur_hi.p; D.cur_lo = cur_lo.p;
     D.cache_slot = cache_slot.p; D.cache_region = cache_region.p; D.cache_ptr = cache_ptr.p; D.errflag = flag.p + 1;
@@ -718,7 +717,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             const uint32_t next_c = nC > T ? C[T] : 0xffffffffu;
             uint32_t creads[TMAX];
             for (uint32_t t = 0; t < T; ++t) creads[t] = h_items[C[t]];
-            rc = build_reps(ctx, S, creads, T, mzcode.p, RD.h_off.data(), h_mzcnt.data()); if (rc) return rc;
+            rc = build_reps(ctx, S, creads, T, mzcode.p, ctx->h_mzoff.data(), h_mzcnt.data()); if (rc) return rc;
             refresh();
             if (C[0] + 1 < b1) {
                 PosBatch PB; for (uint32_t t = 0; t < 64; ++t) PB.pos[t] = t < T ? C[t] : 0xffffffffu;

@@ -244,13 +244,8 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
 
 // ---------------------------------------------------------------------------------------------- rename pass for k > 21
 namespace {
-__global__ void k_mz_compact(const uint64_t* __restrict__ off, const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ coff, uint64_t n,
-                             const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, uint64_t* __restrict__ klo, uint64_t* __restrict__ khi, uint32_t* __restrict__ idx)
-{
-    const uint64_t r = blockIdx.x; if (r >= n) return;
-    const uint64_t b = off[r], o = coff[r]; const uint32_t c = cnt[r];
-    for (uint32_t x = threadIdx.x; x < c; x += blockDim.x) { klo[o + x] = lo[b + x]; khi[o + x] = hi[b + x]; idx[o + x] = (uint32_t)(o + x); }
-}
+__global__ void k_iota32(uint32_t* __restrict__ idx, uint64_t n)
+{ const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) idx[i] = (uint32_t)i; }
 __global__ void k_gather64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint64_t n, uint64_t* __restrict__ dst)
 { const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[idx[i]]; }
 __global__ void k_mz_flags(const uint64_t* __restrict__ shi, const uint64_t* __restrict__ lo_c, const uint32_t* __restrict__ perm, uint64_t n, uint32_t* __restrict__ fl)
@@ -260,61 +255,51 @@ __global__ void k_mz_flags(const uint64_t* __restrict__ shi, const uint64_t* __r
 }
 __global__ void k_mz_scatter(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ perm, uint64_t n, uint64_t* __restrict__ out_c)
 { const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out_c[perm[i]] = (uint64_t)rank[i]; }
-__global__ void k_mz_expand(const uint64_t* __restrict__ off, const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ coff, uint64_t n, const uint64_t* __restrict__ cc, uint64_t* __restrict__ codes)
+// sparse (at the reads' base offsets, relative to `sbase`) -> compact CSR; one 64-lane workgroup per read
+__global__ void k_mz_gather(const uint64_t* __restrict__ roff, const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ moff, uint64_t n, uint64_t sbase,
+                            const uint64_t* __restrict__ scodes, const uint64_t* __restrict__ shi, const uint32_t* __restrict__ spos,
+                            uint64_t* __restrict__ codes, uint64_t* __restrict__ hi, uint32_t* __restrict__ pos)
 {
     const uint64_t r = blockIdx.x; if (r >= n) return;
-    const uint64_t b = off[r], o = coff[r]; const uint32_t c = cnt[r];
-    for (uint32_t x = threadIdx.x; x < c; x += blockDim.x) codes[b + x] = cc[o + x];
+    const uint64_t src = roff[r] - sbase, dst = moff[r]; const uint32_t c = cnt[r];
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) { codes[dst + i] = scodes[src + i]; pos[dst + i] = spos[src + i]; if (hi) hi[dst + i] = shi[src + i]; }
 }
 }  // namespace
 
-// (hi, lo) pairs at the reads' base offsets -> dense, order-preserving ranks written over d_codes (equal k-mers equal code)
-static int32_t mz_rename_wide(ngsid_ctx* ctx, const DevReads& R, uint64_t* d_codes, const uint64_t* d_hi, const uint32_t* d_cnt)
+// compact (lo, hi) code pairs -> dense, order-preserving ranks written over d_lo (equal k-mers equal code)
+static int32_t mz_rename_wide(ngsid_ctx* ctx, uint64_t* d_lo, const uint64_t* d_hi, uint64_t M)
 {
-    const uint64_t n = R.n;
-    DevBuf<uint64_t> coff; HIPCHK(ctx, coff.alloc(n + 1));
-    DevBuf<unsigned char> tmp; size_t tb = 0;
-    // exclusive scan of the counts (as uint64) -> compact offsets; total on the host
-    std::vector<uint32_t> hc(n); HIPCHK(ctx, hipMemcpyAsync(hc.data(), d_cnt, 4 * n, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<uint64_t> ho(n + 1, 0); for (uint64_t i = 0; i < n; ++i) ho[i + 1] = ho[i] + hc[i];
-    const uint64_t M = ho[n];
     if (M == 0) return NGSID_OK;
     if (M > 0xfffffff0ull) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "more than 2^32 minimizers in one call with k > 21");
-    HIPCHK(ctx, hipMemcpyAsync(coff.p, ho.data(), 8 * (n + 1), hipMemcpyHostToDevice, ctx->stream));
-    DevBuf<uint64_t> klo, khi, k2, shi; DevBuf<uint32_t> idx, p1, p2, fl, rk;
-    HIPCHK(ctx, klo.alloc(M)); HIPCHK(ctx, khi.alloc(M)); HIPCHK(ctx, k2.alloc(M)); HIPCHK(ctx, shi.alloc(M)); HIPCHK(ctx, idx.alloc(M)); HIPCHK(ctx, p1.alloc(M)); HIPCHK(ctx, p2.alloc(M)); HIPCHK(ctx, fl.alloc(M)); HIPCHK(ctx, rk.alloc(M));
-    hipLaunchKernelGGL(k_mz_compact, dim3((unsigned)n), dim3(64), 0, ctx->stream, R.off, d_cnt, coff.p, n, d_codes, d_hi, klo.p, khi.p, idx.p);
-    // LSD: stable sort by lo, then stable sort by hi
-    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, klo.p, k2.p, idx.p, p1.p, (int)M, 0, 63, ctx->stream));
-    HIPCHK(ctx, tmp.alloc(tb));
-    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, klo.p, k2.p, idx.p, p1.p, (int)M, 0, 63, ctx->stream));
+    DevBuf<unsigned char> tmp; size_t tb = 0;
+    DevBuf<uint64_t> k2, shi; DevBuf<uint32_t> idx, p1, p2, fl, rk;
+    HIPCHK(ctx, k2.alloc(M)); HIPCHK(ctx, shi.alloc(M)); HIPCHK(ctx, idx.alloc(M)); HIPCHK(ctx, p1.alloc(M)); HIPCHK(ctx, p2.alloc(M)); HIPCHK(ctx, fl.alloc(M)); HIPCHK(ctx, rk.alloc(M));
     const unsigned gb = (unsigned)((M + 255) / 256);
-    hipLaunchKernelGGL(k_gather64, dim3(gb), dim3(256), 0, ctx->stream, khi.p, p1.p, M, k2.p);                       // hi in lo-sorted order
+    hipLaunchKernelGGL(k_iota32, dim3(gb), dim3(256), 0, ctx->stream, idx.p, M);
+    // LSD: stable sort by lo, then stable sort by hi
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_lo, k2.p, idx.p, p1.p, (int)M, 0, 63, ctx->stream));
+    HIPCHK(ctx, tmp.alloc(tb));
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, d_lo, k2.p, idx.p, p1.p, (int)M, 0, 63, ctx->stream));
+    hipLaunchKernelGGL(k_gather64, dim3(gb), dim3(256), 0, ctx->stream, d_hi, p1.p, M, k2.p);                        // hi in lo-sorted order
     size_t tb2 = 0; HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, k2.p, shi.p, p1.p, p2.p, (int)M, 0, 64, ctx->stream));
     if (tb2 > tb) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, tmp.alloc(tb2)); tb = tb2; }
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp.p, tb2, k2.p, shi.p, p1.p, p2.p, (int)M, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(k_mz_flags, dim3(gb), dim3(256), 0, ctx->stream, shi.p, klo.p, p2.p, M, fl.p);
+    hipLaunchKernelGGL(k_mz_flags, dim3(gb), dim3(256), 0, ctx->stream, shi.p, d_lo, p2.p, M, fl.p);
     size_t tb3 = 0; HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tb3, fl.p, rk.p, (int)M, ctx->stream));
     if (tb3 > tb) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, tmp.alloc(tb3)); tb = tb3; }
     HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp.p, tb3, fl.p, rk.p, (int)M, ctx->stream));
     hipLaunchKernelGGL(k_mz_scatter, dim3(gb), dim3(256), 0, ctx->stream, rk.p, p2.p, M, k2.p);                      // k2[compact index] = rank
-    hipLaunchKernelGGL(k_mz_expand, dim3((unsigned)n), dim3(64), 0, ctx->stream, R.off, d_cnt, coff.p, n, k2.p, d_codes);
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(d_lo, k2.p, 8 * M, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return NGSID_OK;
 }
 
-int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
-                                uint64_t* d_codes, uint32_t* d_pos, uint32_t* d_cnt, uint32_t* d_hlen, double* d_herr, double* d_rawerr, int* d_flag)
+// one launch over the reads of R (a view: R.off may point into a longer offset array); every output pointer is indexed by the view's read number, the
+// sparse arrays d_codes / d_hi / d_pos by the reads' ABSOLUTE base offsets (the caller shifts them when its scratch starts at another base)
+static int32_t mz_launch(ngsid_ctx* ctx, const DevReads& R, int k, int w,
+                         uint64_t* d_codes, uint64_t* d_hi, uint32_t* d_pos, uint32_t* d_cnt, uint32_t* d_hlen, double* d_herr, double* d_rawerr, int* d_flag)
 {
-    if (k < 1 || k > NGSID_MAX_K || w < k || w > 255) NGSID_FAIL(ctx, NGSID_ERR_ARG, "k must be in [1,%d] and k <= w <= 255 (k=%d w=%d)", NGSID_MAX_K, k, w);
-    if (R.maxlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "read of %u bases exceeds NGSID_MAX_READ_LEN=%d", R.maxlen, NGSID_MAX_READ_LEN);
-    if (!g_tables_loaded[ctx->device & 15]) {
-        for (int qc = 0; qc < 127; ++qc)          // the run-quality choice of the kernel compares max(q, 33) instead of table entries: valid iff the table has this shape
-            if (qc < 33 ? NGSID_PHRED_P[qc] != NGSID_PHRED_P[qc + 1] : !(NGSID_PHRED_P[qc] > NGSID_PHRED_P[qc + 1])) NGSID_FAIL(ctx, NGSID_ERR_ARG, "internal: phred table is not constant below '!' and strictly decreasing above");
-        HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_phred_p), NGSID_PHRED_P, sizeof(double) * 128));
-        g_tables_loaded[ctx->device & 15] = true;
-    }
     if (R.n == 0) return NGSID_OK;
     const int W = w - k + 1;
     const int KW = k <= 21 ? 1 : 2;
@@ -330,8 +315,6 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
     const size_t lds = lpw * wpb;
     if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "minimizer kernel needs %zu bytes of LDS", lds);
     const unsigned blocks = (unsigned)((R.n + wpb - 1) / wpb);
-    DevBuf<uint64_t> d_hi;
-    if (KW == 2) HIPCHK(ctx, d_hi.alloc(R.total + 1));
     {
         ProfScope ps_(ctx, "k_hpc_minimizers");
         auto go = [&](auto kern, uint64_t* hi_p) -> hipError_t {
@@ -340,10 +323,74 @@ int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
             return hipSuccess;
         };
         if (KW == 1) HIPCHK(ctx, mode == 2 ? go(k_hpc_minimizers<1, 2>, nullptr) : mode == 1 ? go(k_hpc_minimizers<1, 1>, nullptr) : go(k_hpc_minimizers<1, 0>, nullptr));
-        else HIPCHK(ctx, mode == 1 ? go(k_hpc_minimizers<2, 1>, d_hi.p) : go(k_hpc_minimizers<2, 0>, d_hi.p));
+        else HIPCHK(ctx, mode == 1 ? go(k_hpc_minimizers<2, 1>, d_hi) : go(k_hpc_minimizers<2, 0>, d_hi));
     }
     HIPCHK(ctx, hipGetLastError());
-    if (KW == 2) return mz_rename_wide(ctx, R, d_codes, d_hi.p, d_cnt);
+    return NGSID_OK;
+}
+
+// Reads per launch: the kernel writes a read's minimizers at the read's base offset (no allocation pass, no atomics), i.e. into 12 (k > 21: 20) bytes per BASE.
+// Round 5: that sparse image only ever exists for one chunk of at most MZ_CHUNK_BASES bases (3 GB of scratch); a gather per chunk appends the chunk to the compact
+// CSR the consumers read (ctx->pol_mzcode / pol_mzpos through ctx->mz_off).  The counts come to the host chunk by chunk (the clustering driver needs them there
+// anyway), the compact offsets are their running sum.
+#define MZ_CHUNK_BASES ((uint64_t)256 << 20)
+
+int32_t ngsid_minimizers_csr(ngsid_ctx* ctx, const DevReads& R, int k, int w, const MzOut& out, uint32_t* d_cnt, uint32_t* d_hlen, double* d_herr, double* d_rawerr,
+                             uint32_t* h_cnt, uint32_t* h_hlen, long long* bad_read)
+{
+    DevBuf<uint64_t>& o_code = *out.code; DevBuf<uint32_t>& o_pos = *out.pos; DevBuf<uint64_t>& o_off = *out.off; PinVec<uint64_t>& o_hoff = *out.h_off;
+    if (k < 1 || k > NGSID_MAX_K || w < k || w > 255) NGSID_FAIL(ctx, NGSID_ERR_ARG, "k must be in [1,%d] and k <= w <= 255 (k=%d w=%d)", NGSID_MAX_K, k, w);
+    if (R.maxlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "read of %u bases exceeds NGSID_MAX_READ_LEN=%d", R.maxlen, NGSID_MAX_READ_LEN);
+    if (!g_tables_loaded[ctx->device & 15]) {
+        for (int qc = 0; qc < 127; ++qc)          // the run-quality choice of the kernel compares max(q, 33) instead of table entries: valid iff the table has this shape
+            if (qc < 33 ? NGSID_PHRED_P[qc] != NGSID_PHRED_P[qc + 1] : !(NGSID_PHRED_P[qc] > NGSID_PHRED_P[qc + 1])) NGSID_FAIL(ctx, NGSID_ERR_ARG, "internal: phred table is not constant below '!' and strictly decreasing above");
+        HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_phred_p), NGSID_PHRED_P, sizeof(double) * 128));
+        g_tables_loaded[ctx->device & 15] = true;
+    }
+    if (bad_read) *bad_read = -1;
+    const uint64_t n = R.n;
+    o_hoff.resize(n + 1); o_hoff[0] = 0;
+    HIPCHK(ctx, o_off.reserve(n + 1));
+    if (n == 0) { HIPCHK(ctx, hipMemsetAsync(o_off.p, 0, 8, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return NGSID_OK; }
+    const bool wide = k > 21;
+    DevBuf<int> d_flag; HIPCHK(ctx, d_flag.alloc(1));
+    DevBuf<uint64_t> s_hi, c_hi;                 // k > 21: second code word, sparse per chunk and compact over the call (until the rename pass)
+    uint64_t done = 0, total = 0;                                  // reads finished, minimizers so far
+    uint64_t cap_have = std::min<uint64_t>(o_code.p ? o_code.cap : 0, o_pos.p ? o_pos.cap : 0);
+    if (wide) cap_have = 0;
+    while (done < n) {
+        uint64_t r1 = done + 1; const uint64_t b0 = R.h_off[done];
+        while (r1 < n && R.h_off[r1 + 1] - b0 <= MZ_CHUNK_BASES) ++r1;
+        const uint64_t nr = r1 - done, cb = R.h_off[r1] - b0;
+        HIPCHK(ctx, ctx->mz_scode.reserve(cb + 1)); HIPCHK(ctx, ctx->mz_spos.reserve(cb + 1)); if (wide) HIPCHK(ctx, s_hi.reserve(cb + 1));
+        DevReads V; V.seq = R.seq; V.qual = R.qual; V.off = R.off + done; V.n = nr; V.total = cb; V.maxlen = R.maxlen; V.minlen = R.minlen;
+        HIPCHK(ctx, hipMemsetAsync(d_flag.p, 0, sizeof(int), ctx->stream));
+        int32_t rc = mz_launch(ctx, V, k, w, ctx->mz_scode.p - b0, wide ? s_hi.p - b0 : nullptr, ctx->mz_spos.p - b0, d_cnt + done, d_hlen + done, d_herr + done, d_rawerr + done, d_flag.p);
+        if (rc) return rc;
+        int hf = 0;
+        HIPCHK(ctx, hipMemcpyAsync(h_cnt + done, d_cnt + done, 4 * nr, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(h_hlen + done, d_hlen + done, 4 * nr, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(&hf, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (hf && bad_read && *bad_read < 0) *bad_read = (long long)done + (hf - 1);
+        uint64_t* ho = o_hoff.data();
+        for (uint64_t r = done; r < r1; ++r) ho[r + 1] = ho[r] + h_cnt[r];
+        total = ho[r1];
+        if (total + 1 > cap_have) {         // grow the compact arrays, keeping what the earlier chunks wrote; sized for the rest of the call at this chunk's density (+ 12 %)
+            const double dens = (double)(total - ho[done]) / (double)std::max<uint64_t>(cb, 1);
+            const uint64_t want = total + (uint64_t)(dens * 1.125 * (double)(R.total - R.h_off[r1])) + 1024;
+            o_code.n = o_pos.n = ho[done]; if (wide) c_hi.n = ho[done];
+            HIPCHK(ctx, o_code.grow(want, ctx->stream)); HIPCHK(ctx, o_pos.grow(want, ctx->stream)); if (wide) HIPCHK(ctx, c_hi.grow(want, ctx->stream));
+            cap_have = want;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(o_off.p + done, ho + done, 8 * (nr + 1), hipMemcpyHostToDevice, ctx->stream));      // (pinned: h_mzoff stays valid and unchanged below r1)
+        hipLaunchKernelGGL(k_mz_gather, dim3((unsigned)nr), dim3(64), 0, ctx->stream, R.off + done, d_cnt + done, o_off.p + done, nr, b0,
+                           ctx->mz_scode.p, wide ? s_hi.p : nullptr, ctx->mz_spos.p, o_code.p, wide ? c_hi.p : nullptr, o_pos.p);
+        HIPCHK(ctx, hipGetLastError());
+        done = r1;
+    }
+    o_code.n = std::max<size_t>(o_code.n, total); o_pos.n = std::max<size_t>(o_pos.n, total);
+    if (wide) return mz_rename_wide(ctx, o_code.p, c_hi.p, total);
     return NGSID_OK;
 }
 

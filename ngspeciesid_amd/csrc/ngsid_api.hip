@@ -12,7 +12,7 @@ extern "C" const char* ngsid_last_error(ngsid_ctx* ctx) { return ctx ? ctx->err 
 
 // ---------------------------------------------------------------------------------------------- device memory cache
 namespace {
-struct DevPool { std::mutex mu; std::multimap<unsigned long long, void*> free_; size_t cached = 0; int contexts = 0;
+struct DevPool { std::mutex mu; std::multimap<unsigned long long, void*> free_; size_t cached = 0; int contexts = 0; size_t live = 0, peak = 0;
                  struct Upload { size_t bs; void* q; size_t bq; void* off; size_t bo; }; std::map<void*, Upload> uploads;      // read sets handed out by ngsid_reads_upload
 };
 DevPool g_pool;
@@ -26,13 +26,14 @@ hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got)
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
         auto it = g_pool.free_.find(pool_key(dev, cls));
-        if (it != g_pool.free_.end()) { *p = it->second; g_pool.free_.erase(it); g_pool.cached -= cls; *got = cls; return hipSuccess; }
+        if (it != g_pool.free_.end()) { *p = it->second; g_pool.free_.erase(it); g_pool.cached -= cls; *got = cls; g_pool.live += cls; g_pool.peak = std::max(g_pool.peak, g_pool.live); return hipSuccess; }
     }
     hipError_t e = hipMalloc(p, cls);
     if (e != hipSuccess) {          // out of memory: give the cached blocks back and retry once
         (void)hipGetLastError(); ngsid_pool_release_all(); e = hipMalloc(p, cls);
     }
     *got = e == hipSuccess ? cls : 0;
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.live += cls; g_pool.peak = std::max(g_pool.peak, g_pool.live); }
     return e;
 }
 void ngsid_pool_free(void* p, size_t bytes)
@@ -44,10 +45,13 @@ void ngsid_pool_free(void* p, size_t bytes)
     int dev = 0; (void)hipGetDevice(&dev);
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
+        g_pool.live -= std::min(g_pool.live, bytes);
         if (bytes && g_pool.cached + bytes <= POOL_LIMIT) { g_pool.free_.emplace(pool_key(dev, bytes), p); g_pool.cached += bytes; return; }
     }
     (void)hipFree(p);
 }
+size_t ngsid_pool_cached_bytes() { std::lock_guard<std::mutex> lk(g_pool.mu); return g_pool.cached; }
+void ngsid_pool_stats(size_t* live, size_t* peak, bool reset_peak) { std::lock_guard<std::mutex> lk(g_pool.mu); if (live) *live = g_pool.live; if (peak) *peak = g_pool.peak; if (reset_peak) g_pool.peak = g_pool.live; }
 void ngsid_pool_release_all()
 {
     std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -281,16 +285,6 @@ extern "C" int32_t ngsid_ed_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* que
 }
 
 // ---------------------------------------------------------------------------------------------- (a1-a3)
-__global__ void k_csr_gather(const uint64_t* __restrict__ roff, const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ moff,
-                             const uint64_t* __restrict__ scodes, const uint32_t* __restrict__ spos, uint64_t n,
-                             uint64_t* __restrict__ codes, uint32_t* __restrict__ pos)
-{
-    const uint64_t r = blockIdx.x;
-    if (r >= n) return;
-    const uint64_t src = roff[r], dst = moff[r]; const uint32_t c = cnt[r];
-    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) { codes[dst + i] = scodes[src + i]; pos[dst + i] = spos[src + i]; }
-}
-
 extern "C" int32_t ngsid_hpc_minimizers(ngsid_ctx* ctx, const ngsid_reads_t* reads, int32_t k, int32_t w,
                                         uint64_t* mz_off, uint64_t* codes, uint32_t* pos, uint64_t cap, uint64_t* needed,
                                         uint32_t* hpc_len, double* hpc_err)
@@ -299,22 +293,14 @@ extern "C" int32_t ngsid_hpc_minimizers(ngsid_ctx* ctx, const ngsid_reads_t* rea
     if (!reads || !mz_off) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
     DevReads R; int32_t rc = ngsid_upload_reads(ctx, reads, &R, false); if (rc) return rc;
     const uint64_t n = R.n;
-    DevBuf<uint64_t> scodes; DevBuf<uint32_t> spos, dcnt, dhl; DevBuf<double> dherr, draw; DevBuf<int> dflag;
-    HIPCHK(ctx, scodes.alloc(R.total + 1)); HIPCHK(ctx, spos.alloc(R.total + 1)); HIPCHK(ctx, dcnt.alloc(n)); HIPCHK(ctx, dhl.alloc(n));
-    HIPCHK(ctx, dherr.alloc(n)); HIPCHK(ctx, draw.alloc(n)); HIPCHK(ctx, dflag.alloc(1));
-    HIPCHK(ctx, hipMemsetAsync(dflag.p, 0, sizeof(int), ctx->stream));
-    rc = ngsid_launch_minimizers(ctx, R, k, w, scodes.p, spos.p, dcnt.p, dhl.p, dherr.p, draw.p, dflag.p); if (rc) return rc;
-    std::vector<uint32_t> hcnt(n), hhl(n); std::vector<double> hherr(n); int hflag = 0;
-    if (n) {
-        HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), dcnt.p, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(hhl.data(), dhl.p, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(hherr.data(), dherr.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIPCHK(ctx, hipMemcpyAsync(&hflag, dflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DevBuf<uint64_t> ccode, coff; DevBuf<uint32_t> cpos, dcnt, dhl; DevBuf<double> dherr, draw; PinVec<uint64_t> hmoff; PinVec<uint32_t> hcnt(n), hhl(n);
+    HIPCHK(ctx, dcnt.alloc(n)); HIPCHK(ctx, dhl.alloc(n)); HIPCHK(ctx, dherr.alloc(n)); HIPCHK(ctx, draw.alloc(n));
+    long long bad = -1;
+    rc = ngsid_minimizers_csr(ctx, R, k, w, MzOut{&ccode, &cpos, &coff, &hmoff}, dcnt.p, dhl.p, dherr.p, draw.p, hcnt.data(), hhl.data(), &bad); if (rc) return rc;      // (chunked: the sparse image of the kernel never exceeds 3 GB)
+    if (bad >= 0) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "read %lld: base outside ACGTN", bad);
+    std::vector<double> hherr(n);
+    if (n) HIPCHK(ctx, hipMemcpyAsync(hherr.data(), dherr.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (hflag) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "read %d: base outside ACGTN", hflag - 1);
-    std::vector<uint64_t> hmoff(n + 1); hmoff[0] = 0;
-    for (uint64_t i = 0; i < n; ++i) hmoff[i + 1] = hmoff[i] + hcnt[i];
     const uint64_t total = hmoff[n];
     if (needed) *needed = total;
     if (hpc_len) memcpy(hpc_len, hhl.data(), 4 * n);
@@ -324,19 +310,9 @@ extern "C" int32_t ngsid_hpc_minimizers(ngsid_ctx* ctx, const ngsid_reads_t* rea
         if (!dev_out) memcpy(mz_off, hmoff.data(), 8 * (n + 1));
         NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "minimizer buffer too small: need %llu entries", (unsigned long long)total);
     }
-    DevBuf<uint64_t> dmoff, ocodes; DevBuf<uint32_t> opos;
-    HIPCHK(ctx, dmoff.alloc(n + 1));
-    HIPCHK(ctx, hipMemcpyAsync(dmoff.p, hmoff.data(), 8 * (n + 1), hipMemcpyHostToDevice, ctx->stream));
-    uint64_t* tc = codes; uint32_t* tp = pos;
-    if (!dev_out) { HIPCHK(ctx, ocodes.alloc(total + 1)); HIPCHK(ctx, opos.alloc(total + 1)); tc = ocodes.p; tp = opos.p; }
-    if (n) hipLaunchKernelGGL(k_csr_gather, dim3((unsigned)n), dim3(64), 0, ctx->stream, R.off, dcnt.p, dmoff.p, scodes.p, spos.p, n, tc, tp);
-    HIPCHK(ctx, hipGetLastError());
-    if (dev_out) {
-        HIPCHK(ctx, hipMemcpyAsync(mz_off, dmoff.p, 8 * (n + 1), hipMemcpyDeviceToDevice, ctx->stream));
-    } else {
-        memcpy(mz_off, hmoff.data(), 8 * (n + 1));
-        if (total) { HIPCHK(ctx, hipMemcpyAsync(codes, tc, 8 * total, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(pos, tp, 4 * total, hipMemcpyDeviceToHost, ctx->stream)); }
-    }
+    const hipMemcpyKind kind = dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (dev_out) HIPCHK(ctx, hipMemcpyAsync(mz_off, coff.p, 8 * (n + 1), kind, ctx->stream)); else memcpy(mz_off, hmoff.data(), 8 * (n + 1));
+    if (total) { HIPCHK(ctx, hipMemcpyAsync(codes, ccode.p, 8 * total, kind, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(pos, cpos.p, 4 * total, kind, ctx->stream)); }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return NGSID_OK;
 }
@@ -493,14 +469,14 @@ extern "C" int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev)
 extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return NGSID_ERR_ARG;
-    static const char* known[] = {"cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
+    static const char* known[] = {"poa_level_budget_mb", "cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
     for (const char* k : known) if (!strcmp(k, name)) { ctx->options[name] = (long long)value; return NGSID_OK; }
     if (!strcmp(name, "release_scratch")) {        // gives the context's grow-only scratch (aligner traceback, POA tiles and levels, polisher arrays) and the cached blocks back to the driver
         (void)hipStreamSynchronize(ctx->stream);
         ctx->tb.release(); ctx->bnd.release(); ctx->aln_cls.release(); ctx->aln_psorted.release(); ctx->aln_pbin.release(); ctx->ed_tb.release(); ctx->ed_h.release(); ctx->ed_fail.release(); ctx->ed_fail2.release();
         ctx->poa_h.release(); ctx->poa_d.release(); ctx->poa_g.release(); ctx->poa_cov.release();
         for (auto& L : ctx->poa_lv) { L.out.release(); L.seqs.release(); L.out_len.release(); L.out_span.release(); L.job_bb.release(); L.out_cw.release(); L.out_n.release(); L.out_cov.release(); L.job_off.release(); L.seq_idx.release(); L.flags.release(); L.job_list.release(); L.job_unit.release(); L.job_pos.release(); }
-        ctx->mzc.valid = false; ctx->mzc_cnt.release(); ctx->mzc_hlen.release();
+        ctx->mzc.valid = false; ctx->mzc_cnt.release(); ctx->mzc_hlen.release(); ctx->mz_off.release(); ctx->mz_scode.release(); ctx->mz_spos.release();
         ctx->pol_mzcode.release(); ctx->pol_mzpos.release(); ctx->pol_oseq.release(); ctx->pol_oqual.release(); ctx->pol_valid.release(); ctx->pol_bp.release(); ctx->pol_lay.release();
         ngsid_pool_release_all();
         return NGSID_OK;
@@ -519,7 +495,11 @@ extern "C" int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap)
     std::string out;
     for (auto& kv : ctx->prof_acc) { char line[256]; snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.second, kv.second.first); out += line; }
     ctx->prof_acc.clear();
-    { char line[128]; snprintf(line, sizeof line, "poa_band_redo_tiles %llu 0.0\n", (unsigned long long)ctx->poa_redo_tiles); out += line; ctx->poa_redo_tiles = 0; }   // not a kernel: tiles redone with a wider band (band-edge check)
+    { char line[128]; snprintf(line, sizeof line, "poa_band_redo_tiles %llu 0.0\n", (unsigned long long)ctx->poa_redo_tiles); out += line; ctx->poa_redo_tiles = 0; }
+    {   // not kernels: device memory handed out by the library's allocator (process wide: every context, read sets of ngsid_reads_upload included) - live now / high-water mark since the last read
+        size_t live = 0, peak = 0; ngsid_pool_stats(&live, &peak, true);
+        char line[160]; snprintf(line, sizeof line, "hbm_live_bytes %llu 0.0\nhbm_peak_bytes %llu 0.0\n", (unsigned long long)live, (unsigned long long)peak); out += line;
+    }   // not a kernel: tiles redone with a wider band (band-edge check)
     if (ctx->stat.p) {          // work counters (not kernels): DP rows of k_poa_tile (x band columns = cell updates), DP cells of the clustering aligner
         unsigned long long h[8] = {0}; HIPCHK(ctx, hipMemcpy(h, ctx->stat.p, sizeof h, hipMemcpyDeviceToHost)); HIPCHK(ctx, hipMemset(ctx->stat.p, 0, sizeof h));
         char line[160]; snprintf(line, sizeof line, "poa_dp_rows %llu 0.0\nsg_dp_cells %llu 0.0\n", h[0], h[1]); out += line;

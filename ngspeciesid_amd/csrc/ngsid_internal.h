@@ -20,6 +20,8 @@
 hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got);
 void ngsid_pool_free(void* p, size_t bytes);
 void ngsid_pool_release_all();
+size_t ngsid_pool_cached_bytes();      // bytes the cache holds for reuse (they count as used in hipMemGetInfo)
+void ngsid_pool_stats(size_t* live, size_t* peak, bool reset_peak);      // bytes handed out through ngsid_pool_alloc and not returned: now / high-water mark (process wide)
 
 // RAII device buffer (returned to the cache at scope exit; all work is synchronised before return)
 template <typename T> struct DevBuf {
@@ -93,6 +95,10 @@ struct ngsid_ctx {
     // call just saw (k <= 21: one-word codes, comparable between calls) instead of running k_hpc_minimizers a second time
     struct MzCache { bool valid = false; uint64_t n = 0, total = 0; int k = 0, w = 0; unsigned long long fp = 0; } mzc;
     DevBuf<uint32_t> mzc_cnt, mzc_hlen; DevBuf<unsigned long long> mzc_fp;
+    // round 5: the minimizers of a read set are kept as a COMPACT CSR (pol_mzcode / pol_mzpos indexed through mz_off[read], host mirror h_mzoff) - the kernel still
+    // writes them sparsely at the reads' base offsets, but into a bounded scratch (mz_scode / mz_spos: one chunk of reads at a time, ngsid_minimizers_csr), so the
+    // 12 bytes per BASE of round 1-4 (90 GB at the 10 M reads of C4) are 12 bytes per MINIMIZER (14 GB) + a fixed 3 GB
+    DevBuf<uint64_t> mz_off, mz_scode; DevBuf<uint32_t> mz_spos; PinVec<uint64_t> h_mzoff;
     DevBuf<unsigned long long> stat;     // work counters while profiling is on (bench.py): [0] DP rows of k_poa_tile, [1] DP cells of the clustering aligner
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
@@ -133,10 +139,14 @@ int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* ou
 int32_t ngsid_reads_fingerprint(ngsid_ctx* ctx, const DevReads& R, unsigned long long* fp);      // k_minimizers.hip: position-mixed 64-bit sum over the bases and the offsets (one pass, ~0.2 ms per GB)
 
 // ---- kernels' host launchers (defined in the .hip files) ----
-// per read: HPC length, minimizer count, HPC error rate, raw mean error; minimizers written sparsely at [off[r], off[r]+cnt)
-int32_t ngsid_launch_minimizers(ngsid_ctx* ctx, const DevReads& R, int k, int w,
-                                uint64_t* d_codes, uint32_t* d_pos, uint32_t* d_cnt, uint32_t* d_hlen, double* d_herr, double* d_rawerr,
-                                int* d_flag);
+// per read: HPC length, minimizer count, HPC error rate, raw mean error + the minimizers (code, position in the HPC string)
+// as a compact CSR (`out`; the context's own store is ngsid_ctx_mz(ctx) = pol_mzcode / pol_mzpos / mz_off / h_mzoff), computed chunk by chunk through a bounded sparse scratch.
+// d_cnt / d_hlen / d_herr / d_rawerr: device arrays of R.n entries; h_cnt / h_hlen: host mirrors (R.n entries each, filled); *bad_read = index of a read with a base
+// outside ACGTN or -1.  The counts are on the host when it returns; the last gather may still be in flight on the stream.
+struct MzOut { DevBuf<uint64_t>* code; DevBuf<uint32_t>* pos; DevBuf<uint64_t>* off; PinVec<uint64_t>* h_off; };      // where the CSR goes (grow-only buffers; contents replaced)
+static inline MzOut ngsid_ctx_mz(ngsid_ctx* ctx) { return MzOut{&ctx->pol_mzcode, &ctx->pol_mzpos, &ctx->mz_off, &ctx->h_mzoff}; }
+int32_t ngsid_minimizers_csr(ngsid_ctx* ctx, const DevReads& R, int k, int w, const MzOut& out, uint32_t* d_cnt, uint32_t* d_hlen, double* d_herr, double* d_rawerr,
+                             uint32_t* h_cnt, uint32_t* h_hlen, long long* bad_read);
 
 struct AlignJob {            // device pointers
     const uint8_t* qseq; const uint64_t* qoff; const uint8_t* tseq; const uint64_t* toff;

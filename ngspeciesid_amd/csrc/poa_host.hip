@@ -506,13 +506,58 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
     return NGSID_OK;
 }
 
-int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
-                      std::vector<Unit>& units, const HierParams& hp)
+static int32_t run_hierarchy_batch(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
+                                   std::vector<Unit>& units, const HierParams& hp)
 {
     bool done = false;
     int32_t rc = run_hierarchy_dev(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hp, &done);
     if (rc || done) return rc;
     return run_hierarchy_host(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hp);
+}
+
+// Round 5: the level buffers of a hierarchy are sized by its level-0 tiles (output slots x graph capacity bytes per tile, + 4 bytes per base of
+// coverage when tiles are trimmed: 17.6 KB per tile of a 500-base polishing window), i.e. by the number of READS of the call - 107 GB for the two windows of 10 M
+// 750-base reads.  Units (clusters / windows) are independent hierarchies, so the call is cut into batches of whole units under a byte budget the context derives
+// from the HBM that is free NOW (a third of it, at most 48 GB, at least 1 GB; "poa_level_budget_mb" sets it for tests).  Results cannot depend on the batching: a
+// unit's hierarchy never sees another unit, and the launch geometry a batch plans for (graph capacity, slots) only decides whether the device-driven levels or
+// the host-driven loop run it (tests run one batch per unit against one batch for all).  A single unit larger than the budget still runs alone: the footprint is
+// bounded by max(budget, largest unit), not by the call.
+int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
+                      std::vector<Unit>& units, const HierParams& hp)
+{
+    size_t budget = 0;
+    { const long long mb = ngsid_opt(ctx, "poa_level_budget_mb", 0);
+      if (mb > 0) budget = (size_t)mb << 20;
+      else {
+          size_t freeb = 0, totalb = 0; if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) freeb = (size_t)16 << 30;
+          size_t own = 0; for (auto& L : ctx->poa_lv) own += L.out.abytes + L.out_cov.abytes + L.seqs.abytes;       // grow-only buffers of this context that the call will reuse
+          budget = std::min<size_t>(std::max<size_t>((freeb + own + ngsid_pool_cached_bytes()) / 3, (size_t)1 << 30), (size_t)48 << 30);
+      } }
+    // bytes per level-0 tile: both ping-pong level buffers (the second holds ~slots / D of the first + 25 %), as run_hierarchy_dev sizes them
+    int maxbb = 0; for (const Unit& U : units) if (!U.done && U.bb >= 0) maxbb = std::max(maxbb, bb_len[U.bb]);
+    const int Lb = std::max<int>((int)maxlen0, maxbb), Lb2 = Lb + Lb / 4 + 16;
+    long long capV = (long long)Lb2 * (hp.node_cap > 0 ? hp.node_cap : 28) / 16; capV = std::max<long long>(capV, Lb2 + 64);
+    const long long slots = std::max<long long>(1, ngsid_opt(ctx, "poa_out_slots", 4));
+    const bool need_cov = hp.want_cov || hp.trim_tiles;
+    const double per_tile = (double)slots * ((double)capV * (need_cov ? 5.0 : 1.0) + 64.0) * (hp.D > 0 ? 1.0 + 1.25 * (double)slots / (double)hp.D : 1.0) + 32.0;
+    // batches of consecutive units
+    std::vector<std::pair<size_t, size_t>> batches; size_t b0 = 0; double acc = 0;
+    for (size_t u = 0; u < units.size(); ++u) {
+        const uint32_t ncur = units[u].done ? 0u : (uint32_t)units[u].seqs.size();
+        const double need = ncur ? per_tile * (double)poa_ntiles(ncur, hp.D > 0 ? (uint32_t)hp.D : ncur) : 0.0;
+        if (u > b0 && acc + need > (double)budget) { batches.push_back({b0, u}); b0 = u; acc = 0; }
+        acc += need;
+    }
+    batches.push_back({b0, units.size()});
+    if (batches.size() == 1) return run_hierarchy_batch(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hp);
+    for (auto& bt : batches) {
+        std::vector<Unit> sub; sub.reserve(bt.second - bt.first);
+        for (size_t u = bt.first; u < bt.second; ++u) sub.push_back(std::move(units[u]));
+        const int32_t rc = run_hierarchy_batch(ctx, d_level0, maxlen0, d_bbs, bb_len, sub, hp);
+        for (size_t u = bt.first; u < bt.second; ++u) units[u] = std::move(sub[u - bt.first]);
+        if (rc) return rc;
+    }
+    return NGSID_OK;
 }
 
 }  // namespace
@@ -585,7 +630,7 @@ static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, co
 namespace {
 
 __global__ __launch_bounds__(256)
-void k_strand(const uint64_t* __restrict__ off, const uint32_t* __restrict__ mzcnt, const uint32_t* __restrict__ hlen, const uint64_t* __restrict__ mzcode, int k,
+void k_strand(const uint64_t* __restrict__ mzoff /* compact CSR offsets of the reads' minimizers */, const uint32_t* __restrict__ mzcnt, const uint32_t* __restrict__ hlen, const uint64_t* __restrict__ mzcode, int k,
               const uint32_t* __restrict__ rgroup, const uint64_t* __restrict__ bcodes, const uint64_t* __restrict__ boff /* 2G+1: fw lists then rc lists */, uint32_t G,
               uint64_t n, uint8_t* __restrict__ orient)
 {
@@ -599,7 +644,7 @@ void k_strand(const uint64_t* __restrict__ off, const uint32_t* __restrict__ mzc
     const uint64_t* cr = bcodes + boff[G + g]; const uint32_t nr = (uint32_t)(boff[G + g + 1] - boff[G + g]);
     int a = 0, b = 0;
     for (uint32_t x = lane; x < M; x += 64) {
-        const uint64_t code = mzcode[off[r] + x];
+        const uint64_t code = mzcode[mzoff[r] + x];
         uint32_t lo = 0, hi = nf; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cf[mid] < code) lo = mid + 1; else hi = mid; }
         a += (lo < nf && cf[lo] == code);
         lo = 0; hi = nr; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (cr[mid] < code) lo = mid + 1; else hi = mid; }
@@ -750,10 +795,9 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
     }
     ht.mark("group map");
     // ---- strand detection (replaces minimap2's strand call): shared HPC minimizers with the initial backbone, fw vs rc
-    DevBuf<uint64_t>& mzcode = ctx->pol_mzcode; DevBuf<uint32_t>& mzpos = ctx->pol_mzpos; DevBuf<uint32_t>& mzcnt = ctx->mzc_cnt; DevBuf<uint32_t>& hlen = ctx->mzc_hlen; DevBuf<uint32_t> d_rgroup; DevBuf<double> herr, rawerr; DevBuf<int> flag; DevBuf<uint8_t> d_orient;
-    HIPCHK(ctx, mzcode.reserve(RD.total + 1)); HIPCHK(ctx, mzpos.reserve(RD.total + 1)); HIPCHK(ctx, mzcnt.reserve(N)); HIPCHK(ctx, hlen.reserve(N)); HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N));
-    HIPCHK(ctx, flag.alloc(1)); HIPCHK(ctx, d_rgroup.alloc(N)); HIPCHK(ctx, d_orient.alloc(N));
-    HIPCHK(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+    DevBuf<uint64_t>& mzcode = ctx->pol_mzcode; DevBuf<uint32_t>& mzcnt = ctx->mzc_cnt; DevBuf<uint32_t>& hlen = ctx->mzc_hlen; DevBuf<uint32_t> d_rgroup; DevBuf<double> herr, rawerr; DevBuf<uint8_t> d_orient; DevBuf<int> flag;
+    HIPCHK(ctx, mzcnt.reserve(N)); HIPCHK(ctx, hlen.reserve(N)); HIPCHK(ctx, flag.alloc(1));
+    HIPCHK(ctx, d_rgroup.alloc(N)); HIPCHK(ctx, d_orient.alloc(N));
     HIPCHK(ctx, hipMemcpyAsync(d_rgroup.p, h_rgroup.data(), 4 * N, hipMemcpyHostToDevice, ctx->stream));
     const int sk = std::min(prm->k, 21), sw = std::max(prm->w, sk);       // strand detection only needs SOME minimizer scheme: one-word codes, comparable between the two launches
     {   // the clustering call that preceded this one left the minimizers of the same reads in the context (same bases, offsets, k, w): reuse them
@@ -764,38 +808,38 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         }
         if (!hit) {
             ctx->mzc.valid = false;
-            rc = ngsid_launch_minimizers(ctx, RD, sk, sw, mzcode.p, mzpos.p, mzcnt.p, hlen.p, herr.p, rawerr.p, flag.p); if (rc) return rc;
+            HIPCHK(ctx, herr.alloc(N)); HIPCHK(ctx, rawerr.alloc(N));
+            static thread_local PinVec<uint32_t> h_c, h_l; h_c.resize(N); h_l.resize(N); long long bad = -1;
+            rc = ngsid_minimizers_csr(ctx, RD, sk, sw, ngsid_ctx_mz(ctx), mzcnt.p, hlen.p, herr.p, rawerr.p, h_c.data(), h_l.data(), &bad); if (rc) return rc;
+            if (bad >= 0) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "base outside ACGTN in a read (read %lld)", bad);       // (the cache stays invalid: ADVICE r4)
             if (N >= 1024) { unsigned long long fp = 0; rc = ngsid_reads_fingerprint(ctx, RD, &fp); if (rc) return rc; ctx->mzc.n = N; ctx->mzc.total = RD.total; ctx->mzc.k = sk; ctx->mzc.w = sw; ctx->mzc.fp = fp; ctx->mzc.valid = true; }
         }
     }
     {
-        // backbone fw + rc minimizers through the same kernel, then sorted on the host (a handful of short lists)
+        // backbone fw + rc minimizers through the same kernel (a CSR of their own), then sorted on the host (a handful of short lists)
         std::vector<std::string> two; for (uint32_t g = 0; g < G; ++g) two.push_back(B[g]); for (uint32_t g = 0; g < G; ++g) two.push_back(revcomp(B[g]));
         std::vector<uint64_t> toff(2 * G + 1, 0); std::string cat; for (size_t i = 0; i < two.size(); ++i) { cat += two[i]; toff[i + 1] = cat.size(); }
         ngsid_reads_t br{(const uint8_t*)cat.data(), nullptr, toff.data(), 2ull * G, NGSID_MEM_HOST, 0};
         DevReads BR; rc = ngsid_upload_reads(ctx, &br, &BR, false); if (rc) return rc;
-        DevBuf<uint64_t> bc; DevBuf<uint32_t> bp_, bcnt, bhl; DevBuf<double> be, bw; DevBuf<int> bflag;
-        HIPCHK(ctx, bc.alloc(BR.total + 1)); HIPCHK(ctx, bp_.alloc(BR.total + 1)); HIPCHK(ctx, bcnt.alloc(2 * G)); HIPCHK(ctx, bhl.alloc(2 * G)); HIPCHK(ctx, be.alloc(2 * G)); HIPCHK(ctx, bw.alloc(2 * G)); HIPCHK(ctx, bflag.alloc(1));
-        HIPCHK(ctx, hipMemsetAsync(bflag.p, 0, sizeof(int), ctx->stream));
-        rc = ngsid_launch_minimizers(ctx, BR, sk, sw, bc.p, bp_.p, bcnt.p, bhl.p, be.p, bw.p, bflag.p); if (rc) return rc;
-        std::vector<uint64_t> hc(BR.total + 1); std::vector<uint32_t> hcnt(2 * G), hhl(2 * G); int hf = 0, rf = 0;
-        HIPCHK(ctx, hipMemcpyAsync(hc.data(), bc.p, 8 * (BR.total + 1), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(hcnt.data(), bcnt.p, 4 * 2 * G, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(hhl.data(), bhl.p, 4 * 2 * G, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(&hf, bflag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(&rf, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        DevBuf<uint64_t> bc, boff_; DevBuf<uint32_t> bp_, bcnt, bhl; DevBuf<double> be, bw; static thread_local PinVec<uint64_t> hmo; static thread_local PinVec<uint32_t> hcnt, hhl; hcnt.resize(2 * G); hhl.resize(2 * G);
+        HIPCHK(ctx, bcnt.alloc(2 * G)); HIPCHK(ctx, bhl.alloc(2 * G)); HIPCHK(ctx, be.alloc(2 * G)); HIPCHK(ctx, bw.alloc(2 * G));
+        long long bad = -1;
+        rc = ngsid_minimizers_csr(ctx, BR, sk, sw, MzOut{&bc, &bp_, &boff_, &hmo}, bcnt.p, bhl.p, be.p, bw.p, hcnt.data(), hhl.data(), &bad); if (rc) return rc;
+        if (bad >= 0) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "base outside ACGTN in a backbone");
+        const uint64_t btot = hmo[2 * G];
+        std::vector<uint64_t> hc(btot + 1);
+        if (btot) HIPCHK(ctx, hipMemcpyAsync(hc.data(), bc.p, 8 * btot, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (hf || rf) NGSID_FAIL(ctx, NGSID_ERR_ALPHABET, "base outside ACGTN in %s", hf ? "a backbone" : "a read");
         std::vector<uint64_t> lists, loff(2 * G + 1, 0);
         for (uint32_t i = 0; i < 2 * G; ++i) {
             const uint32_t c = hhl[i] >= (uint32_t)sk ? hcnt[i] : 0;
-            std::vector<uint64_t> v(hc.begin() + toff[i], hc.begin() + toff[i] + c); std::sort(v.begin(), v.end());
+            std::vector<uint64_t> v(hc.begin() + hmo[i], hc.begin() + hmo[i] + c); std::sort(v.begin(), v.end());
             lists.insert(lists.end(), v.begin(), v.end()); loff[i + 1] = lists.size();
         }
         DevBuf<uint64_t> d_lists, d_loff; HIPCHK(ctx, d_lists.alloc(lists.size() + 1)); HIPCHK(ctx, d_loff.alloc(loff.size()));
         if (!lists.empty()) HIPCHK(ctx, hipMemcpyAsync(d_lists.p, lists.data(), 8 * lists.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_loff.p, loff.data(), 8 * loff.size(), hipMemcpyHostToDevice, ctx->stream));
-        { ProfScope ps_(ctx, "k_strand"); hipLaunchKernelGGL(k_strand, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, RD.off, mzcnt.p, hlen.p, mzcode.p, sk, d_rgroup.p, d_lists.p, d_loff.p, G, N, d_orient.p); }
+        { ProfScope ps_(ctx, "k_strand"); hipLaunchKernelGGL(k_strand, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream, ctx->mz_off.p, mzcnt.p, hlen.p, mzcode.p, sk, d_rgroup.p, d_lists.p, d_loff.p, G, N, d_orient.p); }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }

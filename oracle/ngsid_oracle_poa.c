@@ -256,6 +256,29 @@ static int g_consensus(const graph* G, uint8_t* out, uint32_t* cov_out, int* anc
     return n;
 }
 
+
+/* dev aid (ODBG_CONS=1): where the consensus of a WINDOW graph leaves the backbone - the non-backbone nodes on the heaviest path, their weights and the
+   weight of the backbone edge they bypass */
+static void g_debug_consensus(const graph* G, int bblen) {
+    const int V = G->V; int* pred = malloc(sizeof(int) * (size_t)V); int64_t* sc = malloc(sizeof(int64_t) * (size_t)V); int64_t* pw = malloc(sizeof(int64_t) * (size_t)V);
+    for (int v = 0; v < V; ++v) { pred[v] = -1; sc[v] = -1; pw[v] = 0; }
+    int mx = -1;
+    for (int r = 0; r < V; ++r) { int v = G->order[r];
+        for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e]) { int t = G->e_tail[e]; if (sc[v] < G->e_w[e] || (sc[v] == G->e_w[e] && sc[pred[v]] <= sc[t])) { sc[v] = G->e_w[e]; pred[v] = t; pw[v] = G->e_w[e]; } }
+        if (pred[v] != -1) sc[v] += sc[pred[v]];
+        if (mx < 0 || sc[mx] < sc[v]) mx = v; }
+    fprintf(stderr, "[cons] window of %d backbone bases, %d nodes, %llu layers; best-score node %d (backbone? %d) anchor %d code %c out-edges %s\n", bblen, V, (unsigned long long)G->cw_sum, mx, mx < bblen, G->anchor[mx], G->code[mx], G->out_first[mx] >= 0 ? "yes -> branch completion" : "none");
+    for (int v = mx; v != -1; v = pred[v]) if (v >= bblen) {
+        fprintf(stderr, "   off-backbone node %d '%c' anchor %d cov %u ring:", v, G->code[v], G->anchor[v], G->cov[v]);
+        for (int u = G->ring[v]; u != v; u = G->ring[u]) fprintf(stderr, " %d'%c'(cov %u)", u, G->code[u], G->cov[u]);
+        fprintf(stderr, " | in:"); for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e]) fprintf(stderr, " %d'%c'->w%lld", G->e_tail[e], G->code[G->e_tail[e]], (long long)G->e_w[e]);
+        fprintf(stderr, " | out:"); for (int e = G->out_first[v]; e >= 0; e = G->e_next_out[e]) fprintf(stderr, " ->%d'%c' w%lld", G->e_head[e], G->code[G->e_head[e]], (long long)G->e_w[e]);
+        if (pred[v] >= 0) { fprintf(stderr, " | pred %d out:", pred[v]); for (int e = G->out_first[pred[v]]; e >= 0; e = G->e_next_out[e]) fprintf(stderr, " ->%d'%c' w%lld", G->e_head[e], G->code[G->e_head[e]], (long long)G->e_w[e]); }
+        fprintf(stderr, "\n");
+    }
+    free(pred); free(sc); free(pw);
+}
+
 /* ---------------------------------------------------------------- tile engine: sequences in order -> one or more (consensus, cw) */
 /* which tile engine run_tile uses: 0 = the node-indexed graph below (the definition), 1 = the rank-ordered restatement (ngsid_oracle_poa_rank.c).
    Both give the same bytes (tests/test_consensus_oracle.py::test_rank_engine_equals_node_engine). */
@@ -271,7 +294,7 @@ static int run_tile_band(const pseq* seqs, int ns, const pseq* backbone, const p
     graph G; g_init(&G, capV > maxlen + 1 ? capV : maxlen + 1);
     ppair* path = malloc(sizeof(ppair) * (size_t)(maxlen + G.capV + 4));
     int members = 0;
-#define EMIT() do { if (G.V > 0 && members > 0) { pout* o = &outs[nout++]; o->s = malloc((size_t)G.V + 1); o->cov = (want_cov || P->trim_tiles) ? malloc(sizeof(uint32_t) * ((size_t)G.V + 1)) : NULL; int* anc_ = malloc(sizeof(int) * ((size_t)G.V + 1)); \
+#define EMIT() do { if (G.V > 0 && members > 0) { if (backbone && getenv("ODBG_CONS")) g_debug_consensus(&G, backbone->len); pout* o = &outs[nout++]; o->s = malloc((size_t)G.V + 1); o->cov = (want_cov || P->trim_tiles) ? malloc(sizeof(uint32_t) * ((size_t)G.V + 1)) : NULL; int* anc_ = malloc(sizeof(int) * ((size_t)G.V + 1)); \
         o->len = g_consensus(&G, o->s, o->cov, anc_); o->cw = G.cw_sum; int b_ = 0, e_ = o->len - 1; \
         if (P->trim_tiles && o->len > 0) { /* coverage-trim the tile consensus ends: keeps unsupported backbone ends from propagating up the hierarchy */ \
             uint32_t thr = (uint32_t)(G.cw_sum / 2); for (; b_ < o->len; ++b_) if (o->cov[b_] >= thr) break; for (; e_ >= 0; --e_) if (o->cov[e_] >= thr) break; \
@@ -294,6 +317,7 @@ static int run_tile_band(const pseq* seqs, int ns, const pseq* backbone, const p
         int np = 0;
         int ok = poa_align(&G, S, P->m, P->n, P->g, band, path, &np, edge);
         if (!ok) continue;                                   /* no valid end cell inside the band: sequence dropped */
+        if (backbone && getenv("ODBG_CONS") && np > 0 && (path[0].node < 0 || path[np - 1].node < 0)) { static int shown = 0; if (shown++ < 40) { fprintf(stderr, "   [layer %d] mode %d span [%d, %d] len %d head %.8s tail %.8s | path starts:", i, S->mode, S->a0, S->a1, S->len, (const char*)S->s, (const char*)S->s + (S->len > 8 ? S->len - 8 : 0)); for (int x = 0; x < 6 && x < np; ++x) fprintf(stderr, " (n%d,p%d)", path[x].node, path[x].pos); fprintf(stderr, " ends:"); for (int x = np > 4 ? np - 4 : 0; x < np; ++x) fprintf(stderr, " (n%d,p%d)", path[x].node, path[x].pos); fprintf(stderr, "\n"); } }
         if (!g_add_alignment(&G, S, path, np)) {
             /* does not fit: close this graph, start a new one with this sequence */
             EMIT(); g_reset(&G); members = 0;

@@ -165,6 +165,7 @@ def test_device_driven_levels_equal_host_driven_levels(gpu_api, oracle):
     empty groups, more groups than one scan block), polishing with early stop, depth 6 / 8 / 3 / one-tile, band redo."""
     from ngspeciesid_amd import runtime
     host = runtime.new_api(options={"poa_host_levels": 1})
+    small = runtime.new_api(options={"poa_level_budget_mb": 1})       # round 5: units are batched under a byte budget (here: nearly one batch per unit) - same bytes
     try:
         rng = np.random.default_rng(3)
         sizes = [1, 2, 0, 7, 400, 13, 6, 36, 37, 0, 216, 5] + [int(x) for x in rng.integers(1, 30, 1200)]
@@ -183,6 +184,9 @@ def test_device_driven_levels_equal_host_driven_levels(gpu_api, oracle):
             a = gpu_api.poa_consensus_cov(rs, goff, prm); b = host.poa_consensus_cov(rs, goff, prm)           # [(consensus, coverage)] per group
             assert [x[0] for x in a] == [y[0] for y in b]
             assert all(np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+            if prm.tile_depth in (6, 3):
+                c = small.poa_consensus_cov(rs, goff, prm)
+                assert [x[0] for x in a] == [y[0] for y in c] and all(np.array_equal(x[1], y[1]) for x, y in zip(a, c))
         first = [0, 1, 3, 4]                                   # groups checked against the oracle as well (the whole set would take the scalar oracle minutes)
         sub_off = np.concatenate(([0], np.cumsum([sizes[g] for g in first]))).astype(np.uint64)
         order = np.concatenate([np.arange(int(goff[g]), int(goff[g + 1])) for g in first]).astype(np.uint32)
@@ -197,9 +201,11 @@ def test_device_driven_levels_equal_host_driven_levels(gpu_api, oracle):
             pp = polish_params(iters=3, k=13, w=20, tile_depth=6, band=0, trim=2, stop_when_stable=stop)
             x, ux = gpu_api.polish(bb, rs, p_off, pp, read_order=p_order); y, uy = host.polish(bb, rs, p_off, pp, read_order=p_order)
             assert x == y and np.array_equal(ux, uy)
+            z, uz = small.polish(bb, rs, p_off, pp, read_order=p_order)
+            assert x == z and np.array_equal(ux, uz)
             assert x == [sp[g].tobytes().decode() for g in big]
     finally:
-        host.close()
+        host.close(); small.close()
 
 
 def test_minimizer_cache_is_keyed_by_content(gpu_api, oracle):
