@@ -167,13 +167,17 @@ def main():
         res = step()
     trace("warm-up done")
     import ctypes as C
-    api.lib.ngsid_profile_enable(api.ctx, C.c_int32(1))
+    api.lib.ngsid_profile_enable(api.ctx, C.c_int32(0 if os.environ.get("NGSID_BENCH_NOPROF") else 1))      # (dev aid: NGSID_BENCH_NOPROF=1 times the steps without the per-launch HIP events)
     T = {}
     barrier(); t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step(T)
     barrier(); dt = time.perf_counter() - t0
     trace("timed region done: %.2f s, stages %s" % (dt, {k_: round(v, 2) for k_, v in T.items()}))
+    if os.environ.get("NGSID_BENCH_TRACE"):
+        for f_ in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.stat"):
+            try: trace("%s: %s" % (f_, open(f_).read().replace("\n", " ")))
+            except Exception: pass
     buf = C.create_string_buffer(1 << 16)
     api.lib.ngsid_profile_read(api.ctx, buf, C.c_uint64(len(buf)))
     api.lib.ngsid_profile_enable(api.ctx, C.c_int32(0))
@@ -232,6 +236,7 @@ def main():
         ed.append(0 if c[3] in tset else min(min(edit_distance(c[3][a:len(c[3]) - b if b else None], t) for a in range(4) for b in range(4)) for t in truths))
     # ---- roofline of the dominant kernel (HIP-event times on the library's own stream)
     redo_tiles = kern.pop("poa_band_redo_tiles", (0, 0.0))[0]
+    mem_parts = {k_[4:]: round(kern.pop(k_)[0] / 1e9, 2) for k_ in [x for x in kern if x.startswith("mem_")]}      # grow-only scratch of the context by purpose (GB)
     hbm_peak = kern.pop("hbm_peak_bytes", (0, 0.0))[0]; hbm_live = kern.pop("hbm_live_bytes", (0, 0.0))[0]      # device memory handed out by the library's allocator (process wide): high-water mark of the timed steps / still held after them
     poa_rows = kern.pop("poa_dp_rows", (0, 0.0))[0]; sg_cells = kern.pop("sg_dp_cells", (0, 0.0))[0]      # work counters of the timed steps (counted by the kernels themselves, ngsid_profile_read)
     dom = max(kern.items(), key=lambda kv: kv[1][1]) if kern else (None, (0, 0.0))
@@ -397,7 +402,7 @@ def main():
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
                       "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()},
                       "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),
-                      "hbm_gb": {"peak_in_timed_steps": round(hbm_peak / 1e9, 2), "held_after": round(hbm_live / 1e9, 2), "what": "bytes handed out by the library's device allocator, whole process (read set included)"},
+                      "hbm_gb": {"peak_in_timed_steps": round(hbm_peak / 1e9, 2), "held_after": round(hbm_live / 1e9, 2), "what": "bytes handed out by the library's device allocator, whole process (read set included)", "context_scratch_by_purpose": mem_parts},
                       "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok, "sharded_consensus_equals_single_process": single_same}},
            "roofline": roof, "cpu_baseline": cpu}
     if cli_leg is not None: out["config"]["cli"] = cli_leg

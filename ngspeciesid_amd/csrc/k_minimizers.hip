@@ -353,6 +353,7 @@ int32_t ngsid_minimizers_csr(ngsid_ctx* ctx, const DevReads& R, int k, int w, co
     HIPCHK(ctx, o_off.reserve(n + 1));
     if (n == 0) { HIPCHK(ctx, hipMemsetAsync(o_off.p, 0, 8, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return NGSID_OK; }
     const bool wide = k > 21;
+    const uint64_t chunk_bases = std::max<uint64_t>(MZ_CHUNK_BASES / (uint64_t)ngsid_pool_contexts(), (uint64_t)32 << 20);      // (several contexts on one GPU: a share each)
     DevBuf<int> d_flag; HIPCHK(ctx, d_flag.alloc(1));
     DevBuf<uint64_t> s_hi, c_hi;                 // k > 21: second code word, sparse per chunk and compact over the call (until the rename pass)
     uint64_t done = 0, total = 0;                                  // reads finished, minimizers so far
@@ -360,7 +361,7 @@ int32_t ngsid_minimizers_csr(ngsid_ctx* ctx, const DevReads& R, int k, int w, co
     if (wide) cap_have = 0;
     while (done < n) {
         uint64_t r1 = done + 1; const uint64_t b0 = R.h_off[done];
-        while (r1 < n && R.h_off[r1 + 1] - b0 <= MZ_CHUNK_BASES) ++r1;
+        while (r1 < n && R.h_off[r1 + 1] - b0 <= chunk_bases) ++r1;
         const uint64_t nr = r1 - done, cb = R.h_off[r1] - b0;
         HIPCHK(ctx, ctx->mz_scode.reserve(cb + 1)); HIPCHK(ctx, ctx->mz_spos.reserve(cb + 1)); if (wide) HIPCHK(ctx, s_hi.reserve(cb + 1));
         DevReads V; V.seq = R.seq; V.qual = R.qual; V.off = R.off + done; V.n = nr; V.total = cb; V.maxlen = R.maxlen; V.minlen = R.minlen;

@@ -17,6 +17,7 @@ struct DevPool { std::mutex mu; std::multimap<unsigned long long, void*> free_; 
 };
 DevPool g_pool;
 const size_t POOL_LIMIT = (size_t)48 << 30;          // bytes kept for reuse; beyond it blocks go back to the driver
+const size_t POOL_HEADROOM = (size_t)3 << 30;        // device memory the library leaves to the runtime (ngsid_pool_alloc)
 inline size_t pool_class(size_t b) { if (b < 4096) return 4096; int sh = 63 - __builtin_clzll((unsigned long long)b) - 3; size_t m = ((size_t)1 << sh) - 1; return (b + m) & ~m; }
 inline unsigned long long pool_key(int dev, size_t cls) { return ((unsigned long long)dev << 56) | (unsigned long long)cls; }
 }
@@ -28,9 +29,15 @@ hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got)
         auto it = g_pool.free_.find(pool_key(dev, cls));
         if (it != g_pool.free_.end()) { *p = it->second; g_pool.free_.erase(it); g_pool.cached -= cls; *got = cls; g_pool.live += cls; g_pool.peak = std::max(g_pool.peak, g_pool.live); return hipSuccess; }
     }
-    hipError_t e = hipMalloc(p, cls);
-    if (e != hipSuccess) {          // out of memory: give the cached blocks back and retry once
-        (void)hipGetLastError(); ngsid_pool_release_all(); e = hipMalloc(p, cls);
+    // Headroom: the HIP / HSA runtime allocates device memory of its own while kernels run (scratch for register spills, queues, signals) and ABORTS the process
+    // when it cannot ("HSA_STATUS_ERROR_OUT_OF_RESOURCES ... Available Free mem : 100 MB": eight contexts on one GPU, round 5).  The library therefore never takes the
+    // last POOL_HEADROOM bytes: cached blocks go back to the driver first, then the request fails with hipErrorOutOfMemory - an error code instead of an abort.
+    hipError_t e = hipErrorOutOfMemory;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        size_t freeb = 0, totalb = 0;
+        const bool known = hipMemGetInfo(&freeb, &totalb) == hipSuccess;
+        if (!known || freeb >= cls + POOL_HEADROOM) { e = hipMalloc(p, cls); if (e == hipSuccess) break; (void)hipGetLastError(); }
+        if (attempt == 0) ngsid_pool_release_all();          // out of memory (or too close to it): give the cached blocks back and retry once
     }
     *got = e == hipSuccess ? cls : 0;
     if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.live += cls; g_pool.peak = std::max(g_pool.peak, g_pool.live); }
@@ -51,6 +58,7 @@ void ngsid_pool_free(void* p, size_t bytes)
     (void)hipFree(p);
 }
 size_t ngsid_pool_cached_bytes() { std::lock_guard<std::mutex> lk(g_pool.mu); return g_pool.cached; }
+int ngsid_pool_contexts() { std::lock_guard<std::mutex> lk(g_pool.mu); return g_pool.contexts > 0 ? g_pool.contexts : 1; }
 void ngsid_pool_stats(size_t* live, size_t* peak, bool reset_peak) { std::lock_guard<std::mutex> lk(g_pool.mu); if (live) *live = g_pool.live; if (peak) *peak = g_pool.peak; if (reset_peak) g_pool.peak = g_pool.live; }
 void ngsid_pool_release_all()
 {
@@ -127,8 +135,11 @@ int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* ou
         // through pinned staging on the context's stream: a blocking copy into fresh pageable memory cost 26 ms for 8 MB here
         const size_t nb = sizeof(uint64_t) * (in->n + 1);
         if (ctx->pin_bytes < nb) { if (ctx->pin) (void)hipHostFree(ctx->pin); ctx->pin = nullptr; ctx->pin_bytes = 0; HIPCHK(ctx, hipHostMalloc(&ctx->pin, nb + nb / 8, hipHostMallocDefault)); ctx->pin_bytes = nb + nb / 8; }
+        const auto ts0 = std::chrono::steady_clock::now();
         HIPCHK(ctx, hipMemcpyAsync(ctx->pin, in->off, nb, hipMemcpyDeviceToHost, ctx->stream));
+        const auto ts1 = std::chrono::steady_clock::now();
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (hu.on) fprintf(stderr, "[ngsid host] upload_reads: d2h submit %.2f ms, wait %.2f ms\n", std::chrono::duration<double, std::milli>(ts1 - ts0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts1).count());
         hu.mark("d2h");
         memcpy(out->h_off.data(), ctx->pin, nb);
         hu.mark("memcpy");
@@ -499,6 +510,18 @@ extern "C" int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap)
     {   // not kernels: device memory handed out by the library's allocator (process wide: every context, read sets of ngsid_reads_upload included) - live now / high-water mark since the last read
         size_t live = 0, peak = 0; ngsid_pool_stats(&live, &peak, true);
         char line[160]; snprintf(line, sizeof line, "hbm_live_bytes %llu 0.0\nhbm_peak_bytes %llu 0.0\n", (unsigned long long)live, (unsigned long long)peak); out += line;
+        // ... and what THIS context holds in its grow-only scratch buffers (bytes), by purpose
+        size_t lv = 0; for (auto& L : ctx->poa_lv) lv += L.out.abytes + L.seqs.abytes + L.out_len.abytes + L.out_span.abytes + L.job_bb.abytes + L.out_cw.abytes + L.out_n.abytes + L.out_cov.abytes + L.job_off.abytes + L.seq_idx.abytes + L.job_list.abytes + L.job_unit.abytes + L.job_pos.abytes;
+        const struct { const char* nm; size_t b; } parts[] = {
+            {"mem_cluster_aligner_traceback", ctx->tb.abytes + ctx->bnd.abytes + ctx->aln_cls.abytes + ctx->aln_psorted.abytes + ctx->aln_pbin.abytes + ctx->aln_pint.abytes},
+            {"mem_polish_aligner_traceback", ctx->ed_tb.abytes + ctx->ed_h.abytes + ctx->ed_fail.abytes + ctx->ed_fail2.abytes},
+            {"mem_poa_resident_tiles", ctx->poa_h.abytes + ctx->poa_d.abytes + ctx->poa_g.abytes + ctx->poa_cov.abytes},
+            {"mem_poa_level_buffers", lv},
+            {"mem_minimizers_compact", ctx->pol_mzcode.abytes + ctx->pol_mzpos.abytes + ctx->mz_off.abytes + ctx->mzc_cnt.abytes + ctx->mzc_hlen.abytes},
+            {"mem_minimizers_sparse_chunk", ctx->mz_scode.abytes + ctx->mz_spos.abytes},
+            {"mem_oriented_reads", ctx->pol_oseq.abytes + ctx->pol_oqual.abytes},
+            {"mem_polish_layers", ctx->pol_valid.abytes + ctx->pol_bp.abytes + ctx->pol_lay.abytes}};
+        for (const auto& pt : parts) { snprintf(line, sizeof line, "%s %llu 0.0\n", pt.nm, (unsigned long long)pt.b); out += line; }
     }   // not a kernel: tiles redone with a wider band (band-edge check)
     if (ctx->stat.p) {          // work counters (not kernels): DP rows of k_poa_tile (x band columns = cell updates), DP cells of the clustering aligner
         unsigned long long h[8] = {0}; HIPCHK(ctx, hipMemcpy(h, ctx->stat.p, sizeof h, hipMemcpyDeviceToHost)); HIPCHK(ctx, hipMemset(ctx->stat.p, 0, sizeof h));

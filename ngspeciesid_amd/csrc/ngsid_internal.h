@@ -20,6 +20,7 @@
 hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got);
 void ngsid_pool_free(void* p, size_t bytes);
 void ngsid_pool_release_all();
+int ngsid_pool_contexts();            // live contexts of this process (they share the device: budgets derived from free memory are divided by it)
 size_t ngsid_pool_cached_bytes();      // bytes the cache holds for reuse (they count as used in hipMemGetInfo)
 void ngsid_pool_stats(size_t* live, size_t* peak, bool reset_peak);      // bytes handed out through ngsid_pool_alloc and not returned: now / high-water mark (process wide)
 

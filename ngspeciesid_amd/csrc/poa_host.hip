@@ -518,7 +518,7 @@ static int32_t run_hierarchy_batch(ngsid_ctx* ctx, const PSeq* d_level0, uint32_
 // Round 5: the level buffers of a hierarchy are sized by its level-0 tiles (output slots x graph capacity bytes per tile, + 4 bytes per base of
 // coverage when tiles are trimmed: 17.6 KB per tile of a 500-base polishing window), i.e. by the number of READS of the call - 107 GB for the two windows of 10 M
 // 750-base reads.  Units (clusters / windows) are independent hierarchies, so the call is cut into batches of whole units under a byte budget the context derives
-// from the HBM that is free NOW (a third of it, at most 48 GB, at least 1 GB; "poa_level_budget_mb" sets it for tests).  Results cannot depend on the batching: a
+// from the HBM that is free NOW (a third of it, divided by the live contexts of the process, at most 48 GB, at least 1 GB; "poa_level_budget_mb" sets it for tests).  Results cannot depend on the batching: a
 // unit's hierarchy never sees another unit, and the launch geometry a batch plans for (graph capacity, slots) only decides whether the device-driven levels or
 // the host-driven loop run it (tests run one batch per unit against one batch for all).  A single unit larger than the budget still runs alone: the footprint is
 // bounded by max(budget, largest unit), not by the call.
@@ -531,7 +531,7 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
       else {
           size_t freeb = 0, totalb = 0; if (hipMemGetInfo(&freeb, &totalb) != hipSuccess) freeb = (size_t)16 << 30;
           size_t own = 0; for (auto& L : ctx->poa_lv) own += L.out.abytes + L.out_cov.abytes + L.seqs.abytes;       // grow-only buffers of this context that the call will reuse
-          budget = std::min<size_t>(std::max<size_t>((freeb + own + ngsid_pool_cached_bytes()) / 3, (size_t)1 << 30), (size_t)48 << 30);
+          budget = std::min<size_t>(std::max<size_t>((freeb + own + ngsid_pool_cached_bytes()) / (3 * (size_t)ngsid_pool_contexts()), (size_t)1 << 30), (size_t)48 << 30);      // (contexts of one process share the device: eight virtual ranks each take a 24th)
       } }
     // bytes per level-0 tile: both ping-pong level buffers (the second holds ~slots / D of the first + 25 %), as run_hierarchy_dev sizes them
     int maxbb = 0; for (const Unit& U : units) if (!U.done && U.bb >= 0) maxbb = std::max(maxbb, bb_len[U.bb]);

@@ -72,6 +72,9 @@ int32_t ongsid_debug_poa_engine(int32_t e);
 
 /* tie-break envelope of the aligner (ngsid_oracle.c: g_sg_tiebreak); mode < 0 only reads.  Returns the previous mode. */
 int32_t ongsid_debug_sg_tiebreak(int32_t mode);
+/* round 5, reference-order experiments of the polisher (oracle only): bit 0 = overlap-span clipping of the read -> backbone alignment (what minimap2's q_begin / q_end do before
+   racon's edlib call), bit 1 = sub-graph alignment of layers that do not span their window (racon src/window.cpp); returns the previous value, r < 0 only reads */
+int32_t ongsid_debug_polish_rules(int32_t r);
 
 /* debugging taps used by the golden tests (per-read mapping-stage triple of cluster.py:302) */
 int32_t ongsid_debug_enable_trace(int32_t* best_m, int32_t* nshared, double* ratio, uint64_t n);

@@ -92,14 +92,34 @@ static inline int band_lo(const graph* G, const pseq* S, int v, int BW) {
     return (int)lo;
 }
 
+/* POA_SUBGRAPH (oracle only, ongsid_debug_polish_rules bit 1): racon's alignment of a layer that does not span its window - global (NW) alignment to the SUB-graph
+   between the backbone positions [a0, a1] of the layer (racon src/window.cpp: graph->subgraph(positions.first, positions.second); spoa Graph::subgraph /
+   extract_subgraph_nodes: every node reached backwards - in-edges and aligned siblings - from backbone node a1, backbone nodes below a0 left out; the first sequence of
+   a window graph is the backbone, so backbone position == node id).  Nodes whose predecessors all lie outside become sources, nodes without a successor inside sinks. */
+#define POA_SUBGRAPH 3
+static uint8_t* subgraph_mask(const graph* G, int a0, int a1) {
+    uint8_t* in = calloc((size_t)G->V + 1, 1); int* st = malloc(sizeof(int) * ((size_t)G->V * 4 + (size_t)G->E + 16)); int ns = 0;
+    if (a1 < 0 || a1 >= G->L0) a1 = G->L0 - 1; if (a0 < 0) a0 = 0;
+    st[ns++] = a1;
+    while (ns) { const int v = st[--ns]; if (in[v] || v < a0) continue; in[v] = 1;
+        for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e]) if (!in[G->e_tail[e]]) st[ns++] = G->e_tail[e];
+        for (int u = G->ring[v]; u != v; u = G->ring[u]) if (!in[u]) st[ns++] = u; }
+    free(st); return in;
+}
 static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW, ppair* path /* cap len+V */, int* npath, int* edge /* |= 1 when the traceback visits a clipped band-edge cell */) {
-    const int V = G->V, L = S->len, mode = S->mode;
+    const int V = G->V, L = S->len, sub = S->mode == POA_SUBGRAPH, mode = sub ? NGSID_POA_GLOBAL : S->mode;
+    uint8_t* insub = sub ? subgraph_mask(G, S->a0, S->a1) : NULL;
     int* H = malloc(sizeof(int) * (size_t)V * (size_t)BW); uint8_t* dir = malloc((size_t)V * (size_t)BW); int* lo = malloc(sizeof(int) * (size_t)V);
     for (int r = 0; r < V; ++r) lo[r] = band_lo(G, S, G->order[r], BW);
     int best = PNEG, br = -1, bc = -1;
     for (int r = 0; r < V; ++r) {
         const int v = G->order[r]; const int l0 = lo[r]; int* Hr = H + (size_t)r * BW; uint8_t* Dr = dir + (size_t)r * BW;
-        const int nopred = G->in_first[v] < 0;
+        int nopred = G->in_first[v] < 0, nosucc = G->out_first[v] < 0;
+        if (sub) {
+            if (!insub[v]) { for (int c = 0; c < BW; ++c) { Hr[c] = PNEG; Dr[c] = 3; } continue; }
+            nopred = 1; for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e]) if (insub[G->e_tail[e]]) { nopred = 0; break; }
+            nosucc = 1; for (int e = G->out_first[v]; e >= 0; e = G->e_next_out[e]) if (insub[G->e_head[e]]) { nosucc = 0; break; }
+        }
         const int use_src = nopred || mode == NGSID_POA_SEMI;
         for (int c = 0; c < BW; ++c) {
             const int j = l0 + c;
@@ -110,6 +130,7 @@ static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW,
                 const int sc = (G->code[v] == S->s[j - 1]) ? m : n;
                 for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e], ++slot) {
                     const int pr = G->rank[G->e_tail[e]]; const int pc = j - 1 - lo[pr];
+                    if (sub && !insub[G->e_tail[e]]) continue;
                     if (pr >= r) { fprintf(stderr, "ngsid oracle: topological order violated (pred rank %d >= %d)\n", pr, r); abort(); }
                     if (pc < 0 || pc >= BW) continue;
                     const int hv = H[(size_t)pr * BW + pc]; if (hv <= PNEG) continue;
@@ -121,6 +142,7 @@ static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW,
             slot = 0;
             for (int e = G->in_first[v]; e >= 0; e = G->e_next_in[e], ++slot) {
                 const int pr = G->rank[G->e_tail[e]]; const int pc = j - lo[pr];
+                if (sub && !insub[G->e_tail[e]]) continue;
                 if (pc < 0 || pc >= BW) continue;
                 const int hv = H[(size_t)pr * BW + pc]; if (hv <= PNEG) continue;
                 if (hv + g > bestv) { bestv = hv + g; bd = 1 | (slot << 2); }
@@ -132,7 +154,7 @@ static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW,
             Hr[c] = bestv; Dr[c] = (uint8_t)bd;
             if (bestv > PNEG) {
                 if (mode == NGSID_POA_LOCAL) { if (bestv > best) { best = bestv; br = r; bc = c; } }
-                else if (j == L && (mode == NGSID_POA_SEMI || G->out_first[v] < 0)) { if (bestv > best) { best = bestv; br = r; bc = c; } }
+                else if (j == L && (mode == NGSID_POA_SEMI || nosucc)) { if (bestv > best) { best = bestv; br = r; bc = c; } }
             }
         }
     }
@@ -161,7 +183,7 @@ static int poa_align(const graph* G, const pseq* S, int m, int n, int g, int BW,
         free(rev);
     }
     *npath = np;
-    free(H); free(dir); free(lo);
+    free(H); free(dir); free(lo); free(insub);
     return ok;
 }
 
@@ -279,6 +301,7 @@ static void g_debug_consensus(const graph* G, int bblen) {
     free(pred); free(sc); free(pw);
 }
 
+static int g_polish_rules = 0;      /* ongsid_debug_polish_rules, below */
 /* ---------------------------------------------------------------- tile engine: sequences in order -> one or more (consensus, cw) */
 /* which tile engine run_tile uses: 0 = the node-indexed graph below (the definition), 1 = the rank-ordered restatement (ngsid_oracle_poa_rank.c).
    Both give the same bytes (tests/test_consensus_oracle.py::test_rank_engine_equals_node_engine). */
@@ -318,6 +341,11 @@ static int run_tile_band(const pseq* seqs, int ns, const pseq* backbone, const p
         int ok = poa_align(&G, S, P->m, P->n, P->g, band, path, &np, edge);
         if (!ok) continue;                                   /* no valid end cell inside the band: sequence dropped */
         if (backbone && getenv("ODBG_CONS") && np > 0 && (path[0].node < 0 || path[np - 1].node < 0)) { static int shown = 0; if (shown++ < 40) { fprintf(stderr, "   [layer %d] mode %d span [%d, %d] len %d head %.8s tail %.8s | path starts:", i, S->mode, S->a0, S->a1, S->len, (const char*)S->s, (const char*)S->s + (S->len > 8 ? S->len - 8 : 0)); for (int x = 0; x < 6 && x < np; ++x) fprintf(stderr, " (n%d,p%d)", path[x].node, path[x].pos); fprintf(stderr, " ends:"); for (int x = np > 4 ? np - 4 : 0; x < np; ++x) fprintf(stderr, " (n%d,p%d)", path[x].node, path[x].pos); fprintf(stderr, "\n"); } }
+        pseq S2;
+        if (backbone && (g_polish_rules & 4) && np > 0) {      /* PROBE (bit 2): bases of a window layer that the alignment leaves in front of the graph's first / behind its last aligned node are dropped instead of becoming new source / sink nodes */
+            int h = 0, t = 0; while (h < np && path[h].node < 0) ++h; while (t < np - h && path[np - 1 - t].node < 0) ++t;
+            if (h + t > 0 && h + t < S->len) { S2 = *S; S2.s += h; if (S2.q) S2.q += h; S2.len -= h + t; for (int x = h; x < np - t; ++x) { path[x - h] = path[x]; if (path[x - h].pos >= 0) path[x - h].pos -= h; } np -= h + t; S = &S2; }
+        }
         if (!g_add_alignment(&G, S, path, np)) {
             /* does not fit: close this graph, start a new one with this sequence */
             EMIT(); g_reset(&G); members = 0;
@@ -453,6 +481,13 @@ static void lv_push(layervec* L, pseq s) { if (L->n == L->cap) { L->cap = L->cap
 static int polish_nwin(int Bl, int W) { const int raw = Bl <= W ? 1 : (Bl + W - 1) / W; const int tail = Bl - (raw - 1) * W; return (raw >= 2 && tail < W / 10) ? raw - 1 : raw; }
 static int polish_wlen(int Bl, int W, int w) { return w == polish_nwin(Bl, W) - 1 ? Bl - w * W : W; }
 
+/* Oracle-only switches for the REFERENCE-ORDER experiments of round 5 (tools/r05_reference_order.py; the kernels implement rules = 0):
+     bit 0  overlap-span clipping: minimap2 hands racon q_begin..q_end / t_begin..t_end of its chain (PAF without CIGAR: first anchor to last anchor, i.e. both ends inside an
+            exact k-mer match, k = 15 for -x map-ont) and racon's edlib call aligns ONLY that span (racon src/overlap.cpp find_breaking_points).  Here: of the whole-read
+            edit alignment only the columns from the first to the last run of at least 15 consecutive equal columns are kept - read ends that do not align stay out;
+     bit 1  a layer that does not span its window is aligned globally to the sub-graph of its span (POA_SUBGRAPH above) instead of end-free to the whole graph;
+     bit 2  PROBE, not a racon rule: unaligned head / tail bases of a window layer create no nodes (run_tile_band) - isolates the effect of source / sink nodes at the window edges. */
+int32_t ongsid_debug_polish_rules(int32_t r) { const int old = g_polish_rules; if (r >= 0) g_polish_rules = r; return old; }
 typedef struct { uint8_t** seq; int* len; uint64_t* used; } ptrace;      /* [it * G + g] */
 static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                            const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used, ptrace* tr);
@@ -532,7 +567,14 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                                            : ongsid_i_sg_ops(rs[i], n, B, Blen, prm->aln_match, prm->aln_mismatch, prm->aln_open, prm->aln_ext, ops);
                 int qi = 0, ti = 0, qb = -1, tb = -1, qe = -1, te = -1;
                 int* wf = malloc(sizeof(int) * 4 * ((size_t)nwin + 1)); for (int x = 0; x < 4 * nwin; ++x) wf[x] = -1;
+                int x0 = 0, x1 = c - 1;
+                if (g_polish_rules & 1) {        /* overlap span: first .. last run of >= 15 equal columns */
+                    int run = 0, first = -1, last = -1;
+                    for (int x = 0; x < c; ++x) { if (ops[x] == 0) { if (++run >= 15) { if (first < 0) first = x - 14; last = x; } } else run = 0; }
+                    if (first < 0) { x0 = c; x1 = c - 1; } else { x0 = first; x1 = last; }
+                }
                 for (int x = 0; x < c; ++x) {
+                    if (x < x0 || x > x1) { if (ops[x] <= 1) { ++qi; ++ti; } else if (ops[x] == 2) ++qi; else ++ti; continue; }
                     if (ops[x] <= 1) {
                         if (qb < 0) { qb = qi; tb = ti; } qe = qi; te = ti;
                         int wdx = ti / W; if (wdx > nwin - 1) wdx = nwin - 1; if (wf[wdx * 4] < 0) { wf[wdx * 4] = qi; wf[wdx * 4 + 2] = ti; } wf[wdx * 4 + 1] = qi; wf[wdx * 4 + 3] = ti;
@@ -552,7 +594,7 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                             int ws = wdx * W, wlen = polish_wlen(Blen, W, wdx);
                             int begin = tf - ws, end = tl - ws; int offset = (int)(0.01 * (double)wlen);
                             pseq S; S.s = rs[i] + qf; S.q = rq[i] ? rq[i] + qf : NULL; S.len = len; S.uw = 1; S.cw = 1; S.a0 = begin; S.a1 = end;
-                            S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : NGSID_POA_SEMI;
+                            S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : ((g_polish_rules & 2) ? POA_SUBGRAPH : NGSID_POA_SEMI);
                             lv_push(&LV[wdx], S); contributed = 1;
                         }
                     }

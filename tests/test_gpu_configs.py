@@ -101,14 +101,14 @@ def test_mixed_strand_reads_are_merged_and_polished(gpu_api, mu):
 
 
 
-@pytest.mark.parametrize("name,total", [("c4", 2400000), ("c5", 2000000)])
+@pytest.mark.parametrize("name,total", [("c4", 10000000), ("c5", 2000000)])
 def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total, compare_single_process=True, out_slots=0):
-    """what makes C4 / C5 the 8-GPU configurations, composed - eight `--t 8` batches of ONE global set (C4: 8 x 300 k x 750 bp,
-    50 species, abundance_ratio 0.005; C5 at its FULL size since round 4: 8 x 250 k x 2 kb CCS = the 2 M reads of BASELINE.json, 20 species with geometric
-    abundance 0.8^i, k15/w50, abundance_ratio 0.002 - it fits one 288 GB GPU with the per-context budgets below; C4 at full size (8 x 1.25 M) does not: the
-    eight contexts' working sets (12 bytes of minimizer scratch per base, level buffers, aligner traceback) exceed the memory even with two output slots per tile and
-    without the single-process comparison pass: tools/micro/run_composed_full.py c4 10000000 ends in a clean NGSID_ERR_HIP out-of-memory in the polisher) through distributed.sharded_hot_path: representatives all-gathered and merged by
-    ngsid_merge_representatives, cross-shard abundance cutoff by all-reduce, eight weighted partial consensuses per cluster (draft and polished).
+    """what makes C4 / C5 the 8-GPU configurations, composed AT THEIR STATED SIZES - eight `--t 8` batches of ONE global set (C4: 8 x 1.25 M x 750 bp =
+    the 10 M reads of BASELINE.json, 50 species, abundance_ratio 0.005; C5: 8 x 250 k x 2 kb CCS = 2 M reads, 20 species with geometric abundance 0.8^i, k15/w50,
+    abundance_ratio 0.002) through distributed.sharded_hot_path: representatives all-gathered and merged by ngsid_merge_representatives, cross-shard abundance cutoff by
+    all-reduce, eight weighted partial consensuses per cluster (draft and polished).  Round 5 made C4 fit: the minimizers are a compact CSR (12 bytes per minimizer instead of
+    per base), the POA hierarchies run in batches of whole units under a byte budget derived from the free memory and the number of contexts, and the allocator keeps 3 GB of
+    headroom for the runtime (eight contexts used to drive the device to "Available Free mem : 100 MB" and an HSA abort).
     The eight ranks are eight threads of this process, each with its own ngsid context on the one GPU (distributed.LocalComm: same payloads,
     exchanged in memory - eight PROCESSES on one MI355X stall in torch's generator kernels before any library call; torch.distributed itself is
     covered by the 2- / 4-process test above and the gloo tests on CPU).
@@ -122,6 +122,9 @@ def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total, compare_si
     from ngspeciesid_amd.ptable import select_p_table
     import gc
     import ctypes as C0
+    _t0 = time.perf_counter()
+    def trace(m):
+        if os.environ.get("NGSID_TEST_TRACE"): sys.stderr.write("[composed %.1fs free %.1f GB] %s\n" % (time.perf_counter() - _t0, torch.cuda.mem_get_info()[0] / 1e9, m)); sys.stderr.flush()
     gc.collect(); torch.cuda.empty_cache()            # eight contexts' working sets have to fit beside what earlier tests left cached in this process
     gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"release_scratch", C0.c_int64(1))
     cfg = bench.CONFIGS[name]; world = 8
@@ -155,8 +158,10 @@ def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total, compare_si
             r["T"] = T
             return r
         t0 = time.perf_counter()
+        trace("shards ready, starting the virtual ranks")
         res = distributed.run_virtual_ranks(world, rank_fn)
         dt = time.perf_counter() - t0
+        trace("virtual ranks done")
     finally:
         for a_ in apis[1:]: a_.close()
         gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"scratch_budget_mb", C.c_int64(32768)); gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"poa_tiles_per_cu", C.c_int64(0)); gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"poa_out_slots", C.c_int64(4))
@@ -170,13 +175,16 @@ def test_c4_c5_composed_eight_shards_on_one_gpu(gpu_api, name, total, compare_si
     final = np.concatenate([np.asarray([starts[o] + l for o, l in zip(r["final_owner"], r["final_lidx"])], dtype=np.int64) for r in res])
     hrs = ReadSet(rd["seq"].cpu().numpy(), rd["qual"].cpu().numpy(), rd["off"].cpu().numpy().astype(np.uint64))
     fn = make_cluster_fn(gpu_api, hrs, np.asarray(rd["orig"], dtype=np.uint32), cluster_params(k=K, w=W, p_shared=ptab))
+    del shards; gc.collect(); torch.cuda.empty_cache()
+    trace("replaying --t 8 on one context")
     rep_ref, _, _ = parallelize.tree_cluster(fn, glens, np.asarray(rd["score"]), world)
+    trace("replay done")
     assert np.array_equal(final, rep_ref), "sharded membership differs from --t 8 at %d reads" % int((final != rep_ref).sum())
     spc = rd["species"].cpu().numpy()
     big = np.isin(final, np.unique(final)[np.argsort(-np.bincount(np.unique(final, return_inverse=True)[1]))[:nsp]])
     purity = float((spc[final[big]] == spc[big]).mean())
     assert purity > 0.9999 and big.mean() > 0.99, (purity, big.mean())          # (the membership itself is pinned above; a handful of noisy reads join another species' cluster in the reference's --t 8 schedule too)
-    # sharded consensus == the single-process path on the whole set (skipped by the full-size C4 tool run: one context cannot hold 10 M reads' level buffers)
+    # sharded consensus == the single-process path on the whole set (round 5: one context holds the 10 M reads of C4 - 134 GB peak)
     if compare_single_process:
         grs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
         one = pipeline.run_hot_path(gpu_api, grs, rd["score"], acc_rank=np.asarray(rd["orig"], dtype=np.uint32), **kw)

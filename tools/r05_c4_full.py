@@ -48,6 +48,7 @@ out = dict(config=name, reads=int(rs.n), bases=int(rd["off"][-1].item()), specie
            library_hbm_peak_gb=round(kern.get("hbm_peak_bytes", (0, 0))[0] / 1e9, 2), library_hbm_held_after_gb=round(kern.get("hbm_live_bytes", (0, 0))[0] / 1e9, 2),
            device_free_before_gb=round(free0 / 1e9, 1), device_free_after_gb=round(free1 / 1e9, 1), device_total_gb=round(tot0 / 1e9, 1),
            read_set_gb=round(2 * int(rd["off"][-1].item()) / 1e9, 2),
+           context_scratch_gb_by_purpose={k_[4:]: round(v[0] / 1e9, 2) for k_, v in kern.items() if k_.startswith("mem_")},
            kernel_ms={k_: round(v[1], 1) for k_, v in kern.items() if v[1] > 0}, poa_tiles_redone=kern.get("poa_band_redo_tiles", (0, 0))[0])
 os.makedirs(os.path.join(ROOT, "gpurun_out", "r5"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r5", "r05_full_%s_%d.json" % (name, n)), "w"), indent=1)
