@@ -209,7 +209,7 @@ extern "C" int32_t ngsid_host_write_records(const char* path, int32_t append, in
     if (kind == 0 && n && (!seq || !qual || !off)) return NGSID_ERR_ARG;
     // Two passes: record sizes -> file offsets (prefix sum), then every worker thread assembles its records piece by piece and writes each piece with pwrite() at
     // its own offset (round 4: one fwrite() per 65 536-record chunk was a serial 1.5 GB copy into the page cache, 0.45 s of the CLI's 1.4 s at C3)
-    const int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0644); if (fd < 0) return NGSID_ERR_ARG;
+    const int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666); if (fd < 0) return NGSID_ERR_ARG;       // (0666 & ~umask, like fopen; append mode takes its base offset once: the caller must be the only writer of the file)
     const off_t base = append ? lseek(fd, 0, SEEK_END) : 0;
     if (base < 0) { close(fd); return NGSID_ERR_ARG; }
     std::vector<uint64_t> roff(n + 1, 0);
@@ -252,6 +252,7 @@ extern "C" int32_t ngsid_host_write_records(const char* path, int32_t append, in
             } });
     }
     int32_t rc = failed.load() ? NGSID_ERR_ARG : NGSID_OK;
+    if (rc != NGSID_OK) (void)!ftruncate(fd, base);           // a failed write leaves the file as it was found, not a sparse image at its full length
     if (close(fd) != 0) rc = NGSID_ERR_ARG;
     return rc;
 }

@@ -13,6 +13,10 @@
 #include <type_traits>
 
 #define NEG16 (-20000)
+// The traceback flags of this kernel are SIGN bits of packed 16-bit differences (d - h, E - mx, e_ext - E, f_ext - F): exact only while no difference wraps.  The
+// largest magnitude is a cell at the "minus infinity" NEG16 (less one extension) against the largest score a pair of this kernel can reach - the bounds of
+// ngsid_align16_applicable (match <= 4, ext <= 4, open <= 16) with queries of at most 896 bases (the single-strip classes): ADVICE r4.
+static_assert(-(NEG16) + 4 /* ext */ + 16 /* open */ + 4 /* match */ * 896 /* query rows */ < 32768, "packed sign-bit flags of k_sg_align16p would wrap");
 #define PKOP2(name, mnem) __device__ __forceinline__ int name(int a, int b) { int d; asm(mnem " %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 PKOP2(pp_sub_i16, "v_pk_sub_i16")
 PKOP2(pp_add_i16, "v_pk_add_i16")

@@ -741,7 +741,8 @@ extern "C" int32_t ngsid_polish_trace(ngsid_ctx* ctx, const ngsid_reads_t* backb
     if (!prm || !it_off || prm->iters < 1) NGSID_FAIL(ctx, NGSID_ERR_ARG, "ngsid_polish_trace: null argument or iters < 1");
     PolishTrace tr; std::vector<uint64_t> ooff(n_groups + 1, 0); uint64_t need1 = 0;
     const int32_t rc = polish_impl(ctx, backbones, reads, read_order, grp_off, n_groups, prm, ooff.data(), nullptr, 0, &need1, nullptr, &tr);
-    if (rc != NGSID_OK && rc != NGSID_ERR_CAPACITY) return rc;           // (the final sequences are the trace's last iteration: no buffer was handed to the inner call)
+    if (rc != NGSID_OK) return rc;                                        // (with a trace the inner call copies nothing out and checks no capacity: ADVICE r4)
+    if (tr.seq.size() != (size_t)prm->iters * n_groups || tr.used.size() != tr.seq.size()) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: polish trace holds %zu entries for %d x %llu", tr.seq.size(), (int)prm->iters, (unsigned long long)n_groups);
     uint64_t total = 0; bool ovf = false; it_off[0] = 0;
     for (size_t x = 0; x < tr.seq.size(); ++x) {
         if (it_out && total + tr.seq[x].size() <= it_cap) memcpy(it_out + total, tr.seq[x].data(), tr.seq[x].size()); else if (tr.seq[x].size()) ovf = true;
@@ -778,7 +779,7 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
     }
     if (N == 0 || G == 0) {
         uint64_t total = 0; out_off[0] = 0; bool ovf = false;
-        for (uint32_t g = 0; g < G; ++g) { if (total + B[g].size() <= out_cap && out) memcpy(out + total, B[g].data(), B[g].size()); else if (B[g].size()) ovf = true; total += B[g].size(); out_off[g + 1] = total; if (n_used) n_used[g] = 0; }
+        for (uint32_t g = 0; g < G; ++g) { if (trace) {} else if (total + B[g].size() <= out_cap && out) memcpy(out + total, B[g].data(), B[g].size()); else if (B[g].size()) ovf = true; total += B[g].size(); out_off[g + 1] = total; if (n_used) n_used[g] = 0; }
         if (trace) for (int it = 0; it < prm->iters; ++it) for (uint32_t g = 0; g < G; ++g) { trace->seq.push_back(B[g]); trace->used.push_back(0); }
         if (needed) *needed = total; if (ovf) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "output buffer too small"); return NGSID_OK;
     }
@@ -1008,7 +1009,8 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
     if (trace) while (trace->seq.size() < (size_t)prm->iters * G) { const size_t x = trace->seq.size() - G; trace->seq.push_back(trace->seq[x]); trace->used.push_back(trace->used[x]); }      // every group stable: the remaining iterations return the same strings
     uint64_t total = 0; bool ovf = false; out_off[0] = 0;
     for (uint32_t g = 0; g < G; ++g) {
-        if (total + B[g].size() <= out_cap && out) memcpy(out + total, B[g].data(), B[g].size()); else if (B[g].size()) ovf = true;
+        if (trace) { /* ngsid_polish_trace: the final sequences are the trace's last iteration, no buffer was handed in */ }
+        else if (total + B[g].size() <= out_cap && out) memcpy(out + total, B[g].data(), B[g].size()); else if (B[g].size()) ovf = true;
         total += B[g].size(); out_off[g + 1] = total; if (n_used) n_used[g] = used[g];
     }
     if (needed) *needed = total;

@@ -53,7 +53,9 @@ def read_fastq(path):
     """-> (Names, ReadSet (host CSR), plain): plain = the file was a 4-line FASTQ handled by the array path."""
     lib = runtime.load_library()
     import os
-    # the file is MAPPED, not copied (1.5 GB at C3: the copy alone took a third of the ingest); names keep pointing into the mapping
+    # the file is MAPPED, not copied (1.5 GB at C3: the copy alone took a third of the ingest).  Nothing keeps pointing into the mapping once this function returns
+    # (ADVICE r4: the background writers used to read the names from it while `--fastq <outfolder>/sorted.fastq` was being truncated by those very writers): bases,
+    # qualities AND names are gathered into owned arrays below and the mapping is dropped.  The input only has to stay unchanged for the duration of this call.
     buf = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) > 0 else np.zeros(0, dtype=np.uint8)
     n = C.c_uint64(0)
     rc = lib.ngsid_host_fastq_index(_p(buf), C.c_uint64(len(buf)), None, None, None, C.c_uint64(0), C.byref(n))
@@ -68,7 +70,12 @@ def read_fastq(path):
             so = np.ascontiguousarray(rec[1::4]); qo = np.ascontiguousarray(rec[3::4]); do = np.ascontiguousarray(off[:-1])
             lib.ngsid_host_gather(_p(buf), _p(so), _p(slen), C.c_uint64(nr), _p(seq), _p(do))
             lib.ngsid_host_gather(_p(buf), _p(qo), _p(slen), C.c_uint64(nr), _p(qual), _p(do))
-            return Names(buf, np.ascontiguousarray(rec[0::4]), nlen), ReadSet(seq, qual, off), True
+            no = np.ascontiguousarray(rec[0::4]); noff = np.zeros(nr, dtype=np.uint64)
+            if nr: noff[1:] = np.cumsum(nlen[:-1], dtype=np.uint64)
+            nbuf = np.empty(int(nlen.sum(dtype=np.uint64)), dtype=np.uint8)
+            lib.ngsid_host_gather(_p(buf), _p(no), _p(nlen), C.c_uint64(nr), _p(nbuf), _p(noff))      # (15 MB per million reads: 2 ms)
+            del buf
+            return Names(nbuf, noff, nlen), ReadSet(seq, qual, off), True
     # general reader (multi-line FASTQ / FASTA / empty file)
     accs, seqs, quals = [], [], []
     with open(path) as f:

@@ -127,7 +127,8 @@ def test_polished_sample_h1_is_pinned(oracle_backend):
 
 
 
-def test_centres_that_merge_only_after_trimming_are_polished_again(oracle_backend, tmp_path, monkeypatch):
+@pytest.mark.parametrize("sync_writes", [False, True])
+def test_centres_that_merge_only_after_trimming_are_polished_again(oracle_backend, tmp_path, monkeypatch, sync_writes):
     """the branch of consensus_and_polish where the merge decisions on the TRIMMED polished sequences differ from those on the drafts (NGSpeciesID:147-152:
     the reference re-runs detect_reverse_complements + polish_sequences after the second trim).  No natural amplicon pair separates at the clustering thresholds and
     then reaches 90 % identity once its primers are gone, so the second decision is forced here; checked: the folders and files of the absorbed centre are gone, the
@@ -152,6 +153,8 @@ def test_centres_that_merge_only_after_trimming_are_polished_again(oracle_backen
         return out
 
     monkeypatch.setattr(pipeline, "detect_reverse_complements", forced)
+    if sync_writes: monkeypatch.setenv("NGSID_CLI_SYNC_WRITES", "1")          # (both writer modes - background threads that start before the draft, and inline writes)
+    else: monkeypatch.delenv("NGSID_CLI_SYNC_WRITES", raising=False)
     flags = ["--t", "1", "--consensus", "--racon", "--racon_iter", "2", "--abundance_ratio", "0.05", "--remove_universal_tails"]
     files = _run(oracle_backend, flags, False, fastq=fq)
     assert calls[:3] == [2, 2, 2], calls                      # drafts, trimmed polished sequences, and the second _merge_and_polish
@@ -161,10 +164,16 @@ def test_centres_that_merge_only_after_trimming_are_polished_again(oracle_backen
     assert len(refs) == 1 and len(folders) == 1, (refs, folders)
     cid = refs[0][len("consensus_reference_"):-len(".fasta")]
     assert folders == ["racon_cl_id_" + cid] and ("reads_to_consensus_%s.fastq" % cid) in pooled
+    # (the absorbed centre's reads_to_consensus_* file of the FIRST pass stays on disk, as in the reference: polish_sequences removes the racon folders and the
+    #  consensus_reference_* files before a pass, consensus.py:195-200, not the pooled read files)
+    assert len(pooled) == 2
     clusters = [l.split("\t")[0] for l in files["final_clusters.tsv"].decode().splitlines()]
     n0, n1 = clusters.count("0"), clusters.count("1")
     assert n0 > n1 > 15
     assert files["reads_to_consensus_%s.fastq" % cid].count(b"\n+\n") == n0 + n1
+    pooled_names = [l[1:].split()[0] for l in files["reads_to_consensus_%s.fastq" % cid].decode().split("\n")[0::4] if l]
+    member_names = [l.split("\t")[1] for l in files["final_clusters.tsv"].decode().splitlines() if l.split("\t")[0] in ("0", "1")]
+    assert sorted(n.rsplit("_", 1)[0] for n in pooled_names) == sorted(member_names)          # (the pooled files carry the accession WITH its `_score` suffix, the TSV without: NGSpeciesID:104-106) the rewritten content: every read of both clusters, once
     hdr, seq = files["racon_cl_id_%s/consensus.fasta" % cid].decode().split("\n")[:2]
     assert hdr.startswith(">consensus_cl_id_%s_total_supporting_reads_%d " % (cid, n0 + n1)) and " LN:i:%d " % len(seq) in hdr
     assert seq == tails["1_F_fw"][-1] + bodies[0].tobytes().decode()          # polished by the pooled reads (4 : 1 its own), trimmed like the reference trims

@@ -151,3 +151,36 @@ def test_rank_engine_equals_node_engine(oracle):
     for a, b in zip(res[0], res[1]):
         assert a[0] == b[0]
         assert list(a[1]) == list(b[1])
+
+
+def test_reference_order_rules_of_round_5(oracle):
+    """round 5: the reference-order mode of the polisher - ONE graph per window, layers in first-position order, no trimming - degrades exact
+    backbones at ~2 000 layers per window (junction insertions).  The two racon rules this build replaces (overlap-span clipping, sub-graph alignment: oracle-only
+    switches, ongsid_debug_polish_rules bits 0 / 1) do not remove that; creating no source / sink nodes from layer ends (bit 2, a probe) does, which names the cause:
+    global alignment to a DAG may start at ANY in-edge-less node, so one layer's leading insertion captures the layers after it.  One cluster, one iteration from the
+    exact amplicon; the ten-cluster / three-iteration record is profiles/r05_reference_order.json (tools/r05_reference_order.py), whose summary is pinned here too."""
+    import ctypes, json, os
+    from ngspeciesid_amd.hostutil import subset_reads
+    from util_seq import edit_distance
+    sp = synth.make_species(5, 750, 0.15, seed=1)
+    rd = synth.make_reads([sp[2]], 2000, mu=17.0, seed=11)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    score, err, keep = oracle.score_reads(rs, 13, 7.0)
+    idx = np.nonzero(keep)[0]; idx = idx[np.argsort(-score[idx], kind="stable")]
+    sub = subset_reads(rs, idx)
+    truth = sp[2].tobytes().decode()
+    prm = polish_params(iters=1, k=13, w=20, tile_depth=0, band=0, node_cap=160, trim=1, stop_when_stable=0)
+    got = {}
+    try:
+        for rules in (0, 7):
+            oracle.lib.ongsid_debug_polish_rules(ctypes.c_int32(rules))
+            got[rules] = oracle.polish(ReadSet.from_strings([truth]), sub, [0, sub.n], prm)[0][0]
+    finally:
+        oracle.lib.ongsid_debug_polish_rules(ctypes.c_int32(0))
+    assert edit_distance(got[0], truth) >= 1 and len(got[0]) > len(truth)          # the round-4 restatement inserts at the window junction
+    assert got[7] == truth                                                          # both racon rules + no source / sink nodes from layer ends: a fixed point
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_reference_order.json")))
+    S = rec["summary_over_10_synthetic_clusters"]
+    assert S["0"]["clusters_where_polishing_increases_the_distance_of_the_draft"] == 9 and S["3"]["clusters_where_polishing_increases_the_distance_of_the_draft"] == 7
+    assert S["7"]["clusters_where_polishing_increases_the_distance_of_the_draft"] == 0 and S["7"]["clusters_where_the_exact_amplicon_is_not_a_fixed_point"] == 0
+    assert S["7"]["sum_of_edits_after_3_iterations_from_draft"] <= S["7"]["sum_of_edits_of_the_drafts"]

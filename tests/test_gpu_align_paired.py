@@ -108,3 +108,39 @@ def test_paired_kernel_break_points_and_spans(gpu_api):
     assert res[1][0] == res[0][0] and np.array_equal(res[1][1], res[0][1])
     assert sorted(res[1][0]) == sorted(s.tobytes().decode() for s in sp)
 
+
+
+def test_paired_kernel_extreme_scores_and_many_wildcards(gpu_api, oracle):
+    """the traceback flags of the paired kernel are sign bits of packed 16-bit differences - exact while nothing wraps (static_assert in k_align16p.hip).  The
+    corner of ngsid_align16_applicable: match 4, mismatch -8, open 16, ext 4, identical 896-base queries (score 3 584), unrelated pairs (long gap runs from the floor),
+    and reads that are a third wildcards (N scores 0 against everything, also against N)."""
+    rng = np.random.default_rng(31)
+    npairs = 4200
+    targets = [LET[rng.integers(0, 4, 896)] for _ in range(12)]
+    qs, ti = [], []
+    for p in range(npairs):
+        t = int(rng.integers(0, 12)); u = rng.random()
+        if u < 0.25: q = targets[t].copy()                                             # identical: the largest score
+        elif u < 0.5: q = LET[rng.integers(0, 4, 896)]                                  # unrelated
+        else: q = _mutate(rng, targets[t], 0.15)[:896]
+        if len(q) < 520: q = np.concatenate([q, LET[rng.integers(0, 4, 520 - len(q))]])
+        if rng.random() < 0.5: q = q.copy(); q[rng.random(len(q)) < 0.33] = ord("N")
+        qs.append(q); ti.append(t)
+    tw = [t.copy() for t in targets]
+    for t in tw[:4]: t[rng.random(len(t)) < 0.33] = ord("N")
+    Q = ReadSet(np.concatenate(qs), None, np.concatenate(([0], np.cumsum([len(x) for x in qs]))).astype(np.uint64))
+    T = ReadSet(np.concatenate(tw), None, np.concatenate(([0], np.cumsum([len(x) for x in tw]))).astype(np.uint64))
+    qi = np.arange(npairs, dtype=np.uint32); ti = np.array(ti, dtype=np.uint32)
+    kw = dict(ext=4, match=4, mismatch=-8, k=13)
+    try:
+        _opt(gpu_api, b"align_paired", 1); a = gpu_api.sg_align_batch(Q, T, qi, ti, 16, **kw)
+        _opt(gpu_api, b"align_paired", 0); b = gpu_api.sg_align_batch(Q, T, qi, ti, 16, **kw)
+    finally:
+        _opt(gpu_api, b"align_paired", 1)
+    for x, y, nm in zip(a, b, ("score", "ncols", "nmatch", "region")):
+        assert np.array_equal(x, y), nm
+    assert a[0].max() == 4 * 896
+    sub = rng.choice(npairs, 200, replace=False)
+    o = oracle.sg_align_batch(Q, T, qi[sub], ti[sub], 16, **kw)
+    for x, y, nm in zip(a, o, ("score", "ncols", "nmatch", "region")):
+        assert np.array_equal(x[sub], y), nm

@@ -77,15 +77,25 @@ def test_consensus_deviation_from_the_reference_order_mode(gpu_api):
     print("reference-order mode vs truth: %d edits over 5 clusters" % tot)
 
 
-def test_cli_exact_order_draft_option(gpu_api, tmp_path):
+def test_cli_exact_order_draft_option(gpu_api, oracle, tmp_path):
     """--poa_tile_depth 0 (extension flag): the draft of a cluster is ONE graph built in read order (spoa's order) instead of the depth-6 hierarchy; runs
-    through the CLI and gives the oracle's bytes (the accuracy comparison of the two shapes is test_consensus_deviation_from_the_reference_order_mode)."""
-    from ngspeciesid_amd.cli import cli
-    out = str(tmp_path / "out0")
-    cli(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", out, "--t", "1", "--consensus", "--max_seqs_for_consensus", "120", "--poa_tile_depth", "0"])
-    refs = sorted(f for f in os.listdir(out) if f.startswith("consensus_reference_"))
+    through the CLI on the HIP library and gives the oracle backend's bytes, file for file (the accuracy comparison of the two shapes is
+    test_consensus_deviation_from_the_reference_order_mode)."""
+    from ngspeciesid_amd import cli as _cli, fastpath
+    res = {}
+    for name, api in (("hip", gpu_api), ("oracle", oracle)):
+        out = str(tmp_path / ("out0_" + name))
+        args = _cli.build_parser().parse_args(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", out, "--t", "1", "--consensus", "--max_seqs_for_consensus", "120", "--poa_tile_depth", "0"])
+        args.k, args.w = 13, 20
+        os.makedirs(out, exist_ok=True)
+        fastpath.main(args, api=api)
+        res[name] = _files(out)
+    assert sorted(res["hip"]) == sorted(res["oracle"])
+    refs = sorted(f for f in res["hip"] if f.startswith("consensus_reference_"))
     assert len(refs) == 1
-    seq = open(os.path.join(out, refs[0])).read().split("\n")[1]
+    for k in res["hip"]:
+        if k != "logfile.txt": assert res["hip"][k] == res["oracle"][k], k
+    seq = res["hip"][refs[0]].decode().split("\n")[1]
     assert 600 < len(seq) < 720 and set(seq) <= set("ACGT")
 
 

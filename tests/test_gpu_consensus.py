@@ -254,3 +254,19 @@ def test_polish_trace_and_weighted_consensus_equal_the_oracle(gpu_api, oracle):
     w1 = gpu_api.poa_consensus_weighted(ReadSet.from_strings(seqs), [0, 3, 6], pr, wts)
     w2 = oracle.poa_consensus_weighted(ReadSet.from_strings(seqs), [0, 3, 6], pr, wts)
     assert w1 == w2 and w1[0] == seqs[0]
+
+
+def test_foreign_base_is_reported_by_every_polish_call(gpu_api):
+    """the context's minimizer cache was marked valid before the alphabet flag of the launch had been read - a second ngsid_polish on the same reads hit the
+    cache and went on without the error.  The error must come back every time, and a clean call afterwards must work."""
+    from ngspeciesid_amd._capi import NgsidError
+    sp, rd, rs = make_set(1500, L=400, mu=16.0, seed=21)
+    seq = rs.seq.copy(); seq[int(rs.off[700]) + 5] = ord("X")
+    bad = ReadSet(seq, rs.qual, rs.off)
+    bb = ReadSet.from_strings([sp[0].tobytes().decode()])
+    prm = polish_params(iters=1, k=13, w=20, tile_depth=6, band=0, trim=2)
+    for _ in range(2):
+        with pytest.raises(NgsidError) as e:
+            gpu_api.polish(bb, bad, [0, bad.n], prm)
+        assert "ACGTN" in str(e.value)
+    assert gpu_api.polish(bb, rs, [0, rs.n], prm)[0] == [sp[0].tobytes().decode()]
