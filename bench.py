@@ -405,6 +405,10 @@ def main():
                       "hbm_gb": {"peak_in_timed_steps": round(hbm_peak / 1e9, 2), "held_after": round(hbm_live / 1e9, 2), "what": "bytes handed out by the library's device allocator, whole process (read set included)", "context_scratch_by_purpose": mem_parts},
                       "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok, "sharded_consensus_equals_single_process": single_same}},
            "roofline": roof, "cpu_baseline": cpu}
+    if world > 1:
+        out["config"]["baseline_config_of_this_line"] = ("%s of BASELINE.json, %s" % (args.config.upper(), "ONE global set split into the reference's `--t %d` batches (strong scaling)" % world if args.scaling == "strong" else
+                                                         "its per-GPU shape repeated on every GPU with an independent read set per rank (weak scaling%s)" % ("; C3 is BASELINE's 1-GPU configuration" if args.config == "c3" else "")))
+        out["config"]["eight_gpu_configurations"] = "BASELINE.json quotes C4 (10 M x 750 bp, 50 species) and C5 (2 M x 2 kb CCS, 20 species) on 8 GPUs as ONE global set: python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench.py --gpus 8 --config c4 --scaling strong --check-membership   (likewise --config c5)"
     if cli_leg is not None: out["config"]["cli"] = cli_leg
     if res_stop is not None: out["config"]["with_stable_stop"] = {"reads_per_s": round(n_total / dt_stop, 1), "ms_per_step": round(dt_stop * 1e3, 2), "same_result": stop_same,
                                           "note": "library default stop_when_stable=1 (not used for `value`): a cluster whose polished sequence equals its backbone is not polished again"}

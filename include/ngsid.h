@@ -257,6 +257,7 @@ int32_t ngsid_host_list_positions(const int64_t* rep, uint64_t n, int64_t* pos);
  *   (the read lists form_draft_consensus feeds to spoa: representative first, members in processing order; consensus.py:257-266).  reps / counts: room for n
  *   entries, grp_off: n + 1. */
 int32_t ngsid_host_group_by_rep(const int64_t* rep, uint64_t n, int64_t* reps, uint64_t* n_reps, uint32_t* order, uint64_t* grp_off, int64_t* counts);
+int32_t ngsid_host_group_by_rep32(const int32_t* rep, uint64_t n, int64_t* reps, uint64_t* n_reps, uint32_t* order, uint64_t* grp_off, int64_t* counts);      /* the same on the int32 map ngsid_cluster_greedy returns */
 int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
                                  const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
                                  const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read, const uint8_t* seq, const uint8_t* qual, const uint64_t* off);

@@ -144,13 +144,14 @@ extern "C" int32_t ngsid_host_list_positions(const int64_t* rep, uint64_t n, int
 // grp_off[0..*n_reps] = their prefix sums, order[grp_off[c] .. grp_off[c+1]) = the reads of cluster c in ascending read index (a stable sort of the reads by
 // cluster: the representative first when it is the cluster's smallest index, the members in processing order - cluster.py:338-345).  reps / counts need room
 // for n entries, grp_off for n + 1.  Three counting passes instead of NumPy's compare + cumsum + gather + radix argsort + bincount.
-extern "C" int32_t ngsid_host_group_by_rep(const int64_t* rep, uint64_t n, int64_t* reps, uint64_t* n_reps, uint32_t* order, uint64_t* grp_off, int64_t* counts)
+template <typename RT>
+static int32_t group_by_rep_impl(const RT* rep, uint64_t n, int64_t* reps, uint64_t* n_reps, uint32_t* order, uint64_t* grp_off, int64_t* counts)
 {
     if ((!rep || !reps || !order || !grp_off || !counts) && n) return NGSID_ERR_ARG;
     if (!n_reps || n > 0xffffffffull) return NGSID_ERR_ARG;
     std::vector<uint32_t> dense(n);
     uint64_t R = 0;
-    for (uint64_t i = 0; i < n; ++i) { const int64_t r = rep[i]; if (r < 0 || (uint64_t)r >= n) return NGSID_ERR_ARG; dense[i] = (uint32_t)R; if ((uint64_t)r == i) { reps[R] = (int64_t)i; counts[R] = 0; ++R; } }
+    for (uint64_t i = 0; i < n; ++i) { const int64_t r = (int64_t)rep[i]; if (r < 0 || (uint64_t)r >= n) return NGSID_ERR_ARG; dense[i] = (uint32_t)R; if ((uint64_t)r == i) { reps[R] = (int64_t)i; counts[R] = 0; ++R; } }
     for (uint64_t i = 0; i < n; ++i) { const uint64_t r = (uint64_t)rep[i]; if ((uint64_t)rep[r] != r) return NGSID_ERR_ARG; ++counts[dense[r]]; }      // (a representative represents itself)
     std::vector<uint64_t> cur(R + 1);
     grp_off[0] = 0; for (uint64_t c = 0; c < R; ++c) { grp_off[c + 1] = grp_off[c] + (uint64_t)counts[c]; cur[c] = grp_off[c]; }
@@ -158,6 +159,11 @@ extern "C" int32_t ngsid_host_group_by_rep(const int64_t* rep, uint64_t n, int64
     *n_reps = R;
     return NGSID_OK;
 }
+extern "C" int32_t ngsid_host_group_by_rep(const int64_t* rep, uint64_t n, int64_t* reps, uint64_t* n_reps, uint32_t* order, uint64_t* grp_off, int64_t* counts)
+{ return group_by_rep_impl(rep, n, reps, n_reps, order, grp_off, counts); }
+// the same on the int32 map ngsid_cluster_greedy returns (no widening copy between the clustering call and the consensus call: the GPU idles while the host groups)
+extern "C" int32_t ngsid_host_group_by_rep32(const int32_t* rep, uint64_t n, int64_t* reps, uint64_t* n_reps, uint32_t* order, uint64_t* grp_off, int64_t* counts)
+{ return group_by_rep_impl(rep, n, reps, n_reps, order, grp_off, counts); }
 
 // order = the stable argsort of v in DESCENDING order (list.sort(key=score, reverse=True) of get_sorted_fastq_for_cluster.py:174: equal scores keep their
 // input order; -0.0 == 0.0; NaNs last, in input order).  LSD radix sort on the order-reversing bit pattern, 11-bit digits, digits that are equal for all keys

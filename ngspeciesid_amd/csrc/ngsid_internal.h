@@ -11,6 +11,7 @@
 #include <new>
 #include <mutex>
 #include <chrono>
+#include <memory>
 #include "../../include/ngsid.h"
 
 // Device memory goes through a small per-process cache of freed blocks (size classes with 4 significant bits): the drivers allocate
@@ -100,6 +101,8 @@ struct ngsid_ctx {
     // writes them sparsely at the reads' base offsets, but into a bounded scratch (mz_scode / mz_spos: one chunk of reads at a time, ngsid_minimizers_csr), so the
     // 12 bytes per BASE of round 1-4 (90 GB at the 10 M reads of C4) are 12 bytes per MINIMIZER (14 GB) + a fixed 3 GB
     DevBuf<uint64_t> mz_off, mz_scode; DevBuf<uint32_t> mz_spos; PinVec<uint64_t> h_mzoff;
+    // host offsets of the last DEVICE-resident read set (ngsid_upload_reads): pointer, count and a 64-bit device-side fingerprint of the offsets are the key
+    struct OffCache { const void* ptr = nullptr; uint64_t n = 0; unsigned long long fp = 0; std::shared_ptr<std::vector<uint64_t>> v; uint32_t maxlen = 0, minlen = 0; } offc;
     DevBuf<unsigned long long> stat;     // work counters while profiling is on (bench.py): [0] DP rows of k_poa_tile, [1] DP cells of the clustering aligner
     bool prof = false; std::vector<ProfEntry> prof_events; std::map<std::string, std::pair<double, uint64_t>> prof_acc;
     DevBuf<int32_t> poa_h; DevBuf<uint8_t> poa_d; DevBuf<uint8_t> poa_g; DevBuf<uint32_t> poa_cov;   // POA tile scratch (grow-only)
@@ -129,11 +132,22 @@ struct ProfScope {
     }
 };
 
+// host copy of a read set's offsets: a shared vector, so that the copy a context keeps of the LAST device-resident read set it was handed (ngsid_ctx::offc) is
+// reused by the next call on the same reads without another 8 MB download and scan (cluster -> draft consensus -> polish all see the same set)
+struct OffView {
+    std::shared_ptr<std::vector<uint64_t>> v;
+    uint64_t& operator[](size_t i) { return (*v)[i]; }
+    const uint64_t& operator[](size_t i) const { return (*v)[i]; }
+    uint64_t* data() { return v->data(); }
+    const uint64_t* data() const { return v->data(); }
+    void resize(size_t n) { v = std::make_shared<std::vector<uint64_t>>(n); }
+    size_t size() const { return v ? v->size() : 0; }
+};
 // A read set resident in HBM (+ host copy of the offsets, which every host-side planner needs)
 struct DevReads {
     const uint8_t* seq = nullptr; const uint8_t* qual = nullptr; const uint64_t* off = nullptr;
     uint64_t n = 0, total = 0; uint32_t maxlen = 0, minlen = 0;
-    std::vector<uint64_t> h_off;
+    OffView h_off;
     DevBuf<uint8_t> own_seq, own_qual; DevBuf<uint64_t> own_off;
 };
 int32_t ngsid_upload_reads(ngsid_ctx* ctx, const ngsid_reads_t* in, DevReads* out, bool need_qual);

@@ -130,12 +130,24 @@ def list_positions(rep) -> np.ndarray:
     return pos
 
 
+_GBR = {}          # scratch of group_by_rep, reused between calls (fresh 8 MB arrays page-fault on every call while the GPU waits for the consensus stage)
+
+
 def group_by_rep(rep_of):
-    """-> (reps, order, grp_off, counts) of a representative map - ngsid_host_group_by_rep"""
-    r = np.ascontiguousarray(rep_of, dtype=np.int64); n = len(r)
-    reps = np.empty(n, dtype=np.int64); counts = np.empty(n, dtype=np.int64); order = np.empty(n, dtype=np.uint32); goff = np.empty(n + 1, dtype=np.uint64)
+    """-> (reps, order, grp_off, counts) of a representative map - ngsid_host_group_by_rep / _rep32 (no widening copy for the int32 map of the clustering call)"""
+    a = np.asarray(rep_of)
+    r = np.ascontiguousarray(a) if a.dtype == np.int32 else np.ascontiguousarray(a, dtype=np.int64)
+    n = len(r)
+    if _GBR.get("n", -1) < n:
+        _GBR.update(n=n, reps=np.empty(n, dtype=np.int64), counts=np.empty(n, dtype=np.int64), goff=np.empty(n + 1, dtype=np.uint64))
+    reps, counts, goff = _GBR["reps"], _GBR["counts"], _GBR["goff"]
+    order = np.empty(n, dtype=np.uint32)
     nr = C.c_uint64(0)
-    rc = runtime.load_library().ngsid_host_group_by_rep(_p(r), C.c_uint64(n), _p(reps), C.byref(nr), _p(order), _p(goff), _p(counts))
+    lib = runtime.load_library()
+    fn = lib.ngsid_host_group_by_rep32 if r.dtype == np.int32 and hasattr(lib, "ngsid_host_group_by_rep32") else None
+    if fn is None:
+        r = np.ascontiguousarray(r, dtype=np.int64); fn = lib.ngsid_host_group_by_rep
+    rc = fn(_p(r), C.c_uint64(n), _p(reps), C.byref(nr), _p(order), _p(goff), _p(counts))
     if rc != 0:
         raise ValueError("ngsid_host_group_by_rep: not a representative map (an index out of range, or a representative that does not represent itself)")
     R = int(nr.value)

@@ -371,14 +371,19 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
     pooled = []
     seen_clusters = set(); polish_lists = []          # the polisher takes a read under one centre only (pipeline.pooled_read_lists): first centre wins
     early = getattr(args, "_pooled_early", {})        # pooled files whose writers were started before the draft: {c_id: cluster tuple the file holds}
+    first_pass = not getattr(args, "_merge_passes", 0); args._merge_passes = getattr(args, "_merge_passes", 0) + 1
     if early and any(early.get(int(c_id)) != tuple(cs) for _, c_id, _, cs in merged):
-        # some centre absorbed other clusters: wait for the early writers, then rewrite the merged files below and drop the files of the absorbed centres
+        # some centre absorbed other clusters: wait for the early writers, then rewrite the merged files below.  FIRST pass: the files of the absorbed centres go - the
+        # reference writes a pooled file per MERGED centre only (consensus.py:208-215), the early writers had started one per selected cluster.  Later passes (merge
+        # after trimming, NGSpeciesID:147-152): the reference's second polish_sequences removes the racon folders and the consensus_reference_* files
+        # (consensus.py:195-200) but leaves the pooled file an absorbed centre got in the first pass - so does this build, in both writer modes.
         args._writers.join()
         keep = {int(m[1]) for m in merged}
         for cid in list(early):
             if cid not in keep:
-                try: os.remove(os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(cid)))
-                except OSError: pass
+                if first_pass:
+                    try: os.remove(os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(cid)))
+                    except OSError: pass
                 del early[cid]
     for nr, c_id, center, cs in merged:
         with open(os.path.join(args.outfolder, "consensus_reference_{0}.fasta".format(c_id)), "w") as f:

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     txt = open(os.path.join(ROOT, "include", "ngsid.h")).read()
-    return sorted(set(re.findall(r"\b(ngsid_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(ngsid_[a-z_0-9]+)\s*\(", txt)))
 
 
 def test_exports_all_declared_symbols():

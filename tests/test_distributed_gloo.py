@@ -80,6 +80,23 @@ def test_four_rank_gloo_membership_equals_reference_t4():
     assert np.array_equal(final, g["t4_rep_of"])
 
 
+def test_eight_rank_gloo_membership_and_consensus_equal_reference_t8():
+    """eight gloo PROCESSES through TorchComm (the collectives had run with 2 and 4 ranks): merged membership == the reference's --t 8 result,
+    every rank reports the same centres, consensus == amplicons"""
+    from util_seq import edit_distance
+    from ngspeciesid_amd import synth
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cluster_synth2k_d15.npz"))
+    outs = _run("synth2k_d15", consensus=True, world=8)
+    final = np.full(len(g["t8_rep_of"]), -1)
+    for o in outs:
+        final[o["a"]:o["b"]] = o["final"]
+    assert np.array_equal(final, g["t8_rep_of"])
+    assert all(o["centers"] == outs[0]["centers"] for o in outs[1:]) and len(outs[0]["centers"]) == 5
+    truths = [t.tobytes().decode() for t in synth.make_species(5, 750, 0.15, seed=11)]
+    for n, seq in outs[0]["centers"]:
+        assert min(edit_distance(seq, t) for t in truths) == 0
+
+
 @pytest.mark.parametrize("world,tag", [(8, "synth2k_d15"), (2, "synth2k_d15"), (4, "synth600_d10_q14")])
 def test_virtual_ranks_membership_and_consensus(oracle, world, tag):
     """distributed.LocalComm (N virtual ranks = N threads of one process, what the one-GPU emulation of the 8-GPU configurations uses): the same

@@ -60,7 +60,9 @@ def test_clusters_from_rep_matches_the_plain_definition():
         rep_of = rep_of[rep_of]; rep_of = rep_of[rep_of]                   # make the map idempotent
         keep = rep_of[rep_of] == rep_of
         assert keep.all()
-        r, order, goff, counts = clusters_from_rep(rep_of)
+        r, order, goff, counts = clusters_from_rep(rep_of)                  # int32 map (what the clustering call returns): ngsid_host_group_by_rep32
+        r64, order64, goff64, counts64 = clusters_from_rep(rep_of.astype(np.int64))
+        assert np.array_equal(r, r64) and np.array_equal(order, order64) and np.array_equal(goff, goff64) and np.array_equal(counts, counts64)
         o2 = np.argsort(rep_of, kind="stable").astype(np.uint32)
         r2, st, c2 = np.unique(rep_of[o2], return_index=True, return_counts=True)
         assert np.array_equal(order, o2) and np.array_equal(r, r2) and np.array_equal(counts, c2) and np.array_equal(goff[:-1], st) and goff[-1] == n
