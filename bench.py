@@ -259,10 +259,11 @@ def main():
         traffic_src = None
         try:    # HBM bytes per launch from the committed PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, tools/r04_profiles.sh): a counter
                 # pass cannot run inside this process, so the figure is a measurement of the recorded commit on the recorded workload, not of this run
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")))
+            tj_file = next(f for f in ("r05_hbm_traffic.json", "r04_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            tj = json.load(open(os.path.join(ROOT, "profiles", tj_file)))
             if tj.get("workload_reads") == args.reads and tj.get("config", "c3") == args.config and dom[0] in tj and world == 1:
                 traffic = int(tj[dom[0]]["hbm_bytes_per_step"] * args.steps / max(cnt, 1))      # per launch, like `achieved`
-                traffic_src = {"file": "profiles/r04_hbm_traffic.json", "measured_at_commit": tj.get("commit"), "launches_per_step_then": tj[dom[0]].get("launches_per_step")}
+                traffic_src = {"file": "profiles/" + tj_file, "measured_at_commit": tj.get("commit"), "launches_per_step_then": tj[dom[0]].get("launches_per_step")}
         except Exception:
             traffic = None
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
@@ -275,16 +276,25 @@ def main():
         prop = torch.cuda.get_device_properties(dev)
         clk = float(getattr(prop, "clock_rate", 2400000)) * 1e3
         peak_issue = prop.multi_processor_count * 4 * clk / 4.0
+        # basis of that peak: MEASURED on this GPU - tools/micro/valu_issue.hip -> profiles/r05_valu_rates.txt: with two or more waves per SIMD a SIMD issues one
+        # plain VOP2 integer instruction (v_xor_b32, v_add_u32, v_mov_b32) per 4.0 cycles (3.0 - 3.3 for v_mov / v_fma_f32 at four waves), one DPP / packed-int16 / VOP3 form
+        # (v_max_i32, v_pk_*_i16, v_*_dpp, v_bfi, v_and_or, v_max3) per 4.9 - 5.8 cycles, and a lone wave one instruction per 8 - 9 cycles.  The guide's 2 cycles per wave64
+        # instruction (MI355X_MICROARCH.md:52-54) is not reached by any of these forms.  4.0 cycles is therefore an UPPER bound of the peak for the mixes of these kernels;
+        # `frac_at_4p9_cycles` prices the same work against the rate of the DPP / packed forms they are mostly made of.
+        peak_basis = {"cycles_per_wave_instruction_and_simd": 4.0, "source": "profiles/r05_valu_rates.txt (tools/micro/valu_issue.hip, measured on MI355X: plain VOP2 4.0, DPP / packed i16 / VOP3 4.9 - 5.8, lone wave 8 - 9 cycles)",
+                      "guide_value_not_observed": "2 cycles (MI355X_MICROARCH.md:52-54)"}
         band_cols = args.band if args.band else (64 if L <= 3000 else 128)          # NGSID_POA_BAND64_MAXLEN (include/ngsid.h)
         views = {}
         if "k_poa_tile" in kern and poa_rows:
             ms_p = kern["k_poa_tile"][1]; v = {"dp_rows": int(poa_rows), "band_columns": band_cols, "kernel_ms": round(ms_p, 2), "gcups": round(poa_rows * band_cols / (ms_p / 1e3) / 1e9, 1)}
             try:
-                ij = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_poa_tile.json")))
+                ij_file = next(f for f in ("r05_pmc_poa_tile.json", "r04_pmc_poa_tile.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                ij = json.load(open(os.path.join(ROOT, "profiles", ij_file)))
                 if ij.get("workload_reads") == args.reads and ij.get("config", "c3") == args.config:
                     wi = poa_rows * ij["valu_per_row"] / (ms_p / 1e3)
-                    v.update({"valu_per_row": ij["valu_per_row"], "salu_per_row": ij.get("salu_per_row"), "achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4),
-                              "instructions_per_row_source": {"file": "profiles/r04_pmc_poa_tile.json", "measured_at_commit": ij.get("commit"), "rows_then": ij.get("rows"), "pipe_busy_then": ij.get("pipe_busy")}})
+                    v.update({"valu_per_row": ij["valu_per_row"], "salu_per_row": ij.get("salu_per_row"), "achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "frac_at_4p9_cycles": round(wi / (peak_issue * 4.0 / 4.9), 4), "peak_basis": peak_basis,
+                              "pipe_busy_by_counters": ij.get("pipe_busy"),
+                              "instructions_per_row_source": {"file": "profiles/" + ij_file, "measured_at_commit": ij.get("commit"), "rows_then": ij.get("rows"), "pipe_busy_then": ij.get("pipe_busy")}})
             except Exception:
                 pass
             views["k_poa_tile"] = v
@@ -292,14 +302,15 @@ def main():
             ms_a = kern["k_sg_align"][1] + kern.get("k_sg_align_side", (0, 0.0))[1]
             per_cell, src = 14.4, "ISA count of the step loop of round 3 (378 VALU per step for two pairs of 12-14 rows per lane), DESIGN.md section 4"
             try:            # round 4: VALU instructions per DP cell from the SQ-counter pass of the bench workload (all k_sg_align* dispatches of one step / the cells the kernels counted in it)
-                aj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_sg_align.json")))
+                aj_file = next(f for f in ("r05_pmc_sg_align.json", "r04_pmc_sg_align.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                aj = json.load(open(os.path.join(ROOT, "profiles", aj_file)))
                 if aj.get("workload_reads") == args.reads and aj.get("config", "c3") == args.config:
-                    per_cell = float(aj["valu_per_cell"]); src = {"file": "profiles/r04_pmc_sg_align.json", "measured_at_commit": aj.get("commit"), "cells_then": aj.get("cells"), "pipe_busy_then": aj.get("pipe_busy")}
+                    per_cell = float(aj["valu_per_cell"]); src = {"file": "profiles/" + aj_file, "measured_at_commit": aj.get("commit"), "cells_then": aj.get("cells"), "pipe_busy_then": aj.get("pipe_busy")}
             except Exception:
                 pass
             wi = sg_cells / 64.0 * per_cell / (ms_a / 1e3)
             views["k_sg_align"] = {"dp_cells": int(sg_cells), "kernel_ms": round(ms_a, 2), "gcups": round(sg_cells / (ms_a / 1e3) / 1e9, 1), "valu_per_cell": per_cell, "achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2),
-                                   "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "instructions_per_cell_source": src}
+                                   "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "frac_at_4p9_cycles": round(wi / (peak_issue * 4.0 / 4.9), 4), "peak_basis": peak_basis, "instructions_per_cell_source": src}
         if dom[0] in views: roof["valu_issue"] = dict(views[dom[0]], kernel=dom[0])
         roof["dp_kernels"] = views
     # ---- the drop-in surface (runs before the CPU baseline leg): FASTQ file in -> the reference's output files out (python -m ngspeciesid_amd ...), same reads, same flags as C3

@@ -283,6 +283,10 @@ int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value);
  * every context on the same device. */
 int32_t ngsid_reads_upload(ngsid_ctx* ctx, const ngsid_reads_t* host, ngsid_reads_t* dev);
 int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev);
+/* (b, f2) the reads idx[0..n) (host array) of a device-resident read set, in that order, as a NEW device-resident read set (released like the one of ngsid_reads_upload).
+ * The CLI uploads the reads once in file order, scores them there and takes the score order (get_sorted_fastq_for_cluster.py:174) as a gather on the device.
+ * *foreign (may be NULL) = bases of the result outside A/C/G/T/N, what ngsid_host_count_foreign_bases counts on the host. */
+int32_t ngsid_reads_subset(ngsid_ctx* ctx, const ngsid_reads_t* dev_in, const uint64_t* idx, uint64_t n, ngsid_reads_t* dev_out, uint64_t* foreign);
 
 /* Measurement hooks (bench.py): when enabled every kernel launch of this ctx is bracketed by HIP events on the
  * ctx's own stream; ngsid_profile_read synchronises and writes "kernel_name launches total_ms\n" lines (and resets). */

@@ -165,6 +165,17 @@ class Api:
         if rc: self._err(rc)
         return ReadSet(out.seq, out.qual, out.off, MEM_DEVICE, dict(n=rs.n, api=self, host=rs))
 
+    def reads_subset(self, dev: "ReadSet", idx):
+        """reads idx (in that order) of a device-resident read set -> (new device-resident read set, number of bases outside ACGTN in it); None when the backend
+        has no such entry point (the test oracle) or the set is on the host"""
+        if dev.mem != MEM_DEVICE or not hasattr(self.lib, self.prefix + "reads_subset"):
+            return None
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        out = Reads(); foreign = C.c_uint64(0)
+        rc = self._call("reads_subset", C.byref(dev.c), _p(idx), C.c_uint64(len(idx)), C.byref(out), C.byref(foreign))
+        if rc: self._err(rc)
+        return ReadSet(out.seq, out.qual, out.off, MEM_DEVICE, dict(n=len(idx), api=self)), int(foreign.value)
+
     def _err(self, rc):
         if self.has_ctx:
             g = getattr(self.lib, self.prefix + "last_error"); g.restype = C.c_char_p

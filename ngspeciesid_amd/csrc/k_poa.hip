@@ -23,6 +23,13 @@
 #ifndef POA_LT
 #define POA_LT 0          // experiment (not kept: slower, register pressure): band starts per anchor from an LDS table instead of three divisions per rank
 #endif
+#ifndef POA_COLD
+#define POA_COLD 1       // round 5: cold fields of the job description read from the kernel-argument segment at their use (poa_tile_body)
+#endif
+#ifndef POA_PHASES
+#define POA_PHASES 0     // round 5: the phase-cycle instrumentation (NGSID_POA_PHASES dev aid) is compiled only into dev builds (-DPOA_PHASES=1, tools/micro/build_variant.sh): its pointer, counters and branches sat in the row paths of the product kernel
+#endif
+#define POA_PHC(J) (POA_PHASES ? (J).phase_cycles : (unsigned long long*)nullptr)
 #ifndef POA_REPEAT
 #define POA_REPEAT 0      // dev timing builds (tools/micro/build_repeat.sh): 1 / 2 / 3 / 4 = run the prepass / forward pass / traceback / emission twice (same results)
 #endif
@@ -153,7 +160,7 @@ __device__ __forceinline__ ngsid_v4u dir_pack32(const ngsid_v4u a, const ngsid_v
 
 // phase counters (NGSID_POA_PHASES): 256 slots of 24 counters, one slot per workgroup modulo 256, so that the instrumentation's atomics do not serialise
 #define PHS(J) ((J).phase_cycles + (blockIdx.x & 255u) * 24u)
-#define PH(J, idx, t0) do { if ((J).phase_cycles && lane == 0) { const unsigned long long t1_ = __builtin_readcyclecounter(); atomicAdd(&PHS(J)[idx], t1_ - (t0)); (t0) = t1_; } } while (0)
+#define PH(J, idx, t0) do { if (POA_PHC(J) && lane == 0) { const unsigned long long t1_ = __builtin_readcyclecounter(); atomicAdd(&PHS(J)[idx], t1_ - (t0)); (t0) = t1_; } } while (0)
 
 struct TS { int V, E, L0, members, nout, capV, capE, nov; unsigned long long cw_sum; };      // nov = entries of the overflow in-edge list
 
@@ -356,7 +363,7 @@ __device__ __forceinline__ void tile_emit(const GG& g, const LLT<BW>& w, const P
     uint8_t* dst = J.out + slot * (size_t)J.Vcap;
     uint32_t* dcov = J.out_cov ? J.out_cov + slot * (size_t)J.Vcap : nullptr;
     const int V = st.V;
-    unsigned long long tph = J.phase_cycles ? __builtin_readcyclecounter() : 0;
+    unsigned long long tph = POA_PHC(J) ? __builtin_readcyclecounter() : 0;
     mem_sync();
     for (int x = lane; x < (V + 31) / 32; x += 64) w.sinkbits[x] = 0;
     lds_sync();
@@ -447,7 +454,7 @@ __device__ __forceinline__ void tile_emit(const GG& g, const LLT<BW>& w, const P
         J.out_len[slot] = n; J.out_cw[slot] = st.cw_sum;
         if (J.out_span) { J.out_span[2 * slot] = n > 0 ? (int32_t)g.anchor(g.tmpo(poff + span_b)) : 0; J.out_span[2 * slot + 1] = n > 0 ? (int32_t)g.anchor(g.tmpo(poff + span_e)) : -1; }
     }
-    if (J.phase_cycles && lane == 0) atomicAdd(&PHS(J)[12], (unsigned long long)n);
+    if (POA_PHC(J) && lane == 0) atomicAdd(&PHS(J)[12], (unsigned long long)n);
     mem_sync();
     PH(J, 4, tph);
     st.nout += 1;
@@ -832,7 +839,7 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
     constexpr int BW = 64 * CPL;
     // wave-uniform by construction; tell the compiler so the row loops get scalar control flow
     const int L = __builtin_amdgcn_readfirstlane(S.len), mode = __builtin_amdgcn_readfirstlane(S.mode), gp = __builtin_amdgcn_readfirstlane(J.g), V = __builtin_amdgcn_readfirstlane(st.V);
-    unsigned long long tph = J.phase_cycles ? __builtin_readcyclecounter() : 0;
+    unsigned long long tph = POA_PHC(J) ? __builtin_readcyclecounter() : 0;
     // ---------- per-rank row info, built lane-parallel so that the serial row loop reads ONE 8-byte LDS word per row:
     //   lo:16 | dist0:8 | dist1:8 | dlo0:8 | dlo1:8 | letter:8 | flags:8
     //   dist = rank distance to the first / second predecessor (0 = none), dlo = band start of this row minus that of the predecessor
@@ -849,7 +856,7 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
     const bool seq_lds = (unsigned)L * 2u <= (unsigned)(HR * (BW + RPADL + RPADR) * 4) && (unsigned)L * 2u <= (unsigned)(TBR * BW) && (unsigned)((L + 63) / 64) * 12u <= (unsigned)(TBR * 8);
     const SeqU16 alnode = { POA_LDS(l16, LLT<BW>::HRING), &g.alnode(0), seq_lds }, nodeof = { POA_LDS(l16, LLT<BW>::DIRBLK), &g.nodeof(0), seq_lds };
     unsigned kinds[5] = {0, 0, 0, 0, 0};
-    const bool ph_detail = J.phase_cycles && J.phase_detail;
+    const bool ph_detail = POA_PHC(J) && J.phase_detail;
 #if POA_REPEAT == 1
     for (int rep_ = 0; rep_ < 2; ++rep_) {
 #endif
@@ -937,7 +944,7 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
     else if (mode == NGSID_POA_SEMI) poa_forward<CPL, NGSID_POA_SEMI>(g, w, Hg, Dg, Dfull, S, V, st.nov, gp, J.m, J.n, lane, bestv, bestpk, nslow);
     else poa_forward<CPL, NGSID_POA_GLOBAL>(g, w, Hg, Dg, Dfull, S, V, st.nov, gp, J.m, J.n, lane, bestv, bestpk, nslow);
 #endif
-    if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[5], (unsigned long long)V); atomicAdd(&PHS(J)[6], (unsigned long long)nslow); }
+    if (POA_PHC(J) && lane == 0) { atomicAdd(&PHS(J)[5], (unsigned long long)V); atomicAdd(&PHS(J)[6], (unsigned long long)nslow); }
     mem_sync();                                       // direction rows must have landed before the traceback pulls them back
     PH(J, 1, tph);
     // ---------- best end cell: max value, ties -> lowest rank, then lowest column
@@ -947,7 +954,7 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
         if (ov > bestv || (ov == bestv && opk < bestpk)) { bestv = ov; bestpk = opk; }
     }
     const int bestr = bestpk == 0x7fffffff ? -1 : (bestpk >> 8), bestc = bestpk & 0xff;
-    if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[8], (unsigned long long)(unsigned)bestv); atomicAdd(&PHS(J)[9], (unsigned long long)(unsigned)bestpk); }
+    if (POA_PHC(J) && lane == 0) { atomicAdd(&PHS(J)[8], (unsigned long long)(unsigned)bestv); atomicAdd(&PHS(J)[9], (unsigned long long)(unsigned)bestpk); }
     bool aligned_any = true;
     if (bestr < 0 || (mode == NGSID_POA_LOCAL && bestv <= 0)) {
         if (mode != NGSID_POA_LOCAL) return 0;
@@ -998,7 +1005,7 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
                 lds_sync();
                 blk_lo = r & ~(TBR - 1);                    // aligned blocks of TBR rows, same layout as the forward pass staged them
                 ++n_reload;
-                const unsigned long long trl0 = J.phase_cycles ? __builtin_readcyclecounter() : 0;
+                const unsigned long long trl0 = POA_PHC(J) ? __builtin_readcyclecounter() : 0;
                 if (blk_lo != pf_blk) prefetch(blk_lo);       // the path jumped further than one block (far predecessor): fetch it now
 #pragma unroll
                 for (int x = 0; x < NPF; ++x) *(LDSP ngsid_v4u*)(pkblk + (size_t)(lane + 64 * x) * 16) = pf[x];
@@ -1006,7 +1013,7 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
                 prefetch(blk_lo - TBR);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                if (J.phase_cycles) c_reload += __builtin_readcyclecounter() - trl0;
+                if (POA_PHC(J)) c_reload += __builtin_readcyclecounter() - trl0;
             }
             // lane k looks at row blk_lo + k: the cell the path reaches there if it only takes diagonal moves through chain rows from (r, j)
             const int top = r - blk_lo;                        // 0 .. TBR-1
@@ -1051,7 +1058,7 @@ __device__ __forceinline__ int tile_align_add(const GG& g, const LLT<64 * CPL>& 
             else { int e = -1; for (int t = 2; t <= slot; ++t) e = ov_next(g, st.nov, r, e + 1, lane); pr = __builtin_amdgcn_readfirstlane((int)g.ov_tail(e)); }
             r = pr;
         }
-        if (J.phase_cycles && lane == 0) { atomicAdd(&PHS(J)[7], (unsigned long long)n_iter); atomicAdd(&PHS(J)[13], (unsigned long long)n_reload); atomicAdd(&PHS(J)[14], c_reload); }
+        if (POA_PHC(J) && lane == 0) { atomicAdd(&PHS(J)[7], (unsigned long long)n_iter); atomicAdd(&PHS(J)[13], (unsigned long long)n_reload); atomicAdd(&PHS(J)[14], c_reload); }
         edge_out |= edge;
     }
 #if POA_REPEAT == 3
@@ -1310,48 +1317,58 @@ __device__ __forceinline__ void poa_tile_body(const PoaJobSet& J, uint8_t* gscra
     uint8_t* Dg = J.dirglob + (size_t)blockIdx.x * Vc * BW * 3 / 2;      // packed direction blocks (4 bits per cell) ...
     uint8_t* Dfull = Dg + (size_t)Vc * BW / 2;                            // ... and the byte rows of the ranks with more than two in-edges (sparse)
 
-    const uint32_t nrun_ = J.nrun_dev ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(J.nrun_dev)) : J.nrun;      // (written by an earlier kernel of the stream)
+#if POA_COLD
+    // Round 5: the fields of the job description that only the per-tile set-up and the emission read (15 pointers: sequence / tile lists, output arrays, flags) are
+    // read from the kernel-argument segment WHERE they are used, through a pointer the compiler cannot see through - kept in SGPRs across the alignment phases they
+    // were part of the 172 spilled SGPRs of the 64-column instance (v_writelane / v_readlane pairs = VALU instructions in the row paths).  J is the first kernel argument.
+    const PoaJobSet* Jc_ = (const PoaJobSet*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(Jc_));
+    const PoaJobSet& JC = *Jc_;
+#else
+    const PoaJobSet& JC = J;
+#endif
+    const uint32_t nrun_ = JC.nrun_dev ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(JC.nrun_dev)) : JC.nrun;      // (written by an earlier kernel of the stream)
     for (;;) {
         // persistent workgroups pull tiles from a queue (tiles differ a lot in cost: depth, graph growth, splits)
         uint32_t jq = 0; if (lane == 0) jq = atomicAdd(work_ctr, 1u);
         const uint32_t jqi = (uint32_t)__builtin_amdgcn_readfirstlane((int)jq);
         if (jqi >= nrun_) break;
-        const uint32_t job = J.job_list ? J.job_list[jqi] : jqi;          // a redo launch (wider band) runs a list of tiles
+        const uint32_t job = JC.job_list ? JC.job_list[jqi] : jqi;          // a redo launch (wider band) runs a list of tiles
         int edge = 0;
-        const uint32_t s0 = J.job_off[job], s1 = J.job_off[job + 1];
-        const int bbi = J.job_bb ? J.job_bb[job] : -1;
+        const uint32_t s0 = JC.job_off[job], s1 = JC.job_off[job + 1];
+        const int bbi = JC.job_bb ? JC.job_bb[job] : -1;
         TS st; st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.nout = 0; st.cw_sum = 0; st.nov = 0;
         uint32_t ndrop = 0; unsigned long long nrows = 0;
         {   // per-job capacity = oracle run_tile: cap_for(L0) but at least the longest member + 1; edges 1.5x
-            int maxlen = bbi >= 0 ? J.bbs[bbi].len : 0, first = bbi >= 0 ? J.bbs[bbi].len : 0;
-            for (uint32_t si = s0; si < s1; ++si) { const int l = J.seqs[J.seq_idx ? J.seq_idx[si] : si].len; if (l > maxlen) maxlen = l; if (first == 0 && bbi < 0 && si == s0) first = l; }
-            long long c = (long long)(first > 0 ? first : 1) * (J.node_cap > 0 ? J.node_cap : 28) / 16; if (c < (first > 0 ? first : 1) + 64) c = (first > 0 ? first : 1) + 64;
+            int maxlen = bbi >= 0 ? JC.bbs[bbi].len : 0, first = bbi >= 0 ? JC.bbs[bbi].len : 0;
+            for (uint32_t si = s0; si < s1; ++si) { const int l = JC.seqs[JC.seq_idx ? JC.seq_idx[si] : si].len; if (l > maxlen) maxlen = l; if (first == 0 && bbi < 0 && si == s0) first = l; }
+            long long c = (long long)(first > 0 ? first : 1) * (JC.node_cap > 0 ? JC.node_cap : 28) / 16; if (c < (first > 0 ? first : 1) + 64) c = (first > 0 ? first : 1) + 64;
             if (c < maxlen + 1) c = maxlen + 1;
             st.capV = (int)(c < Vc ? c : Vc); st.capE = 3 * st.capV / 2 < Ec ? 3 * st.capV / 2 : Ec;
         }
         for (uint32_t si = s0; si < s1; ++si) {
-            const PSeq S = J.seqs[J.seq_idx ? J.seq_idx[si] : si];
+            const PSeq S = JC.seqs[JC.seq_idx ? JC.seq_idx[si] : si];
             if (S.len <= 0) continue;
             if (S.len > Lm) { ++ndrop; continue; }
             // at most two attempts: when the graph is full (code 2) the tile is emitted and the sequence starts / joins a fresh one
             for (int attempt = 0; attempt < 2; ++attempt) {
                 if (st.V == 0) {
-                    if (bbi >= 0) { const PSeq B = J.bbs[bbi]; tile_add_first(g, B, st, lane); }
+                    if (bbi >= 0) { const PSeq B = JC.bbs[bbi]; tile_add_first(g, B, st, lane); }
                     else { if (S.len > st.capV) ++ndrop; else { tile_add_first(g, S, st, lane); st.members = 1; } break; }
                 }
                 nrows += (unsigned)st.V;
                 const int rcode = tile_align_add<CPL>(g, w, Hg, Dg, Dfull, J, S, st, lane, edge);
                 if (rcode == 1) { st.members += 1; break; }
                 if (rcode == 0 || attempt == 1) { ++ndrop; break; }
-                tile_emit(g, w, J, job, st, lane);
+                tile_emit(g, w, JC, job, st, lane);
                 st.V = 0; st.E = 0; st.L0 = 0; st.members = 0; st.cw_sum = 0; st.nov = 0;
             }
         }
 #if POA_REPEAT == 4
-        { const int no_ = st.nout; tile_emit(g, w, J, job, st, lane); st.nout = no_; }
+        { const int no_ = st.nout; tile_emit(g, w, JC, job, st, lane); st.nout = no_; }
 #endif
-        tile_emit(g, w, J, job, st, lane);
-        if (lane == 0) { J.out_n[job] = (uint32_t)st.nout | (edge ? 0x80000000u : 0u); if (ndrop && J.dropped) atomicAdd(J.dropped, ndrop); if (J.stat_rows) atomicAdd(J.stat_rows, nrows); }      // bit 31: a traceback touched a clipped band edge
+        tile_emit(g, w, JC, job, st, lane);
+        if (lane == 0) { JC.out_n[job] = (uint32_t)st.nout | (edge ? 0x80000000u : 0u); if (ndrop && JC.dropped) atomicAdd(JC.dropped, ndrop); if (JC.stat_rows) atomicAdd(JC.stat_rows, nrows); }      // bit 31: a traceback touched a clipped band edge
         mem_sync();
     }
 }

@@ -492,6 +492,56 @@ extern "C" int32_t ngsid_reads_upload(ngsid_ctx* ctx, const ngsid_reads_t* host,
     return NGSID_OK;
 }
 
+
+// (b, f2) the reads idx[0..n) of a DEVICE-resident read set, in that order, as a new device-resident read set (the CLI: the reads cross PCIe once in FILE order,
+// the score order is a gather on the device - get_sorted_fastq_for_cluster.py:174 sorts in host memory).  *foreign (may be NULL) = bases of the result outside
+// A/C/G/T/N (what ngsid_host_count_foreign_bases counts: the caller normalises a copy only when there are any).
+__global__ __launch_bounds__(256) void k_reads_subset(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, const uint64_t* __restrict__ idx,
+                                                      const uint64_t* __restrict__ noff, uint64_t n, uint8_t* __restrict__ oseq, uint8_t* __restrict__ oqual, unsigned long long* __restrict__ foreign)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const uint64_t src = off[idx[r]], dst = noff[r]; const uint64_t len = noff[r + 1] - dst;
+    unsigned bad = 0;
+    for (uint64_t x = lane; x < len; x += 64) {
+        const uint8_t c = seq[src + x]; oseq[dst + x] = c; if (oqual) oqual[dst + x] = qual[src + x];
+        bad += !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N');
+    }
+    if (foreign) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) bad += __shfl_xor(bad, d);
+        if (lane == 0 && bad) atomicAdd(foreign, (unsigned long long)bad);
+    }
+}
+extern "C" int32_t ngsid_reads_subset(ngsid_ctx* ctx, const ngsid_reads_t* dev_in, const uint64_t* idx, uint64_t n, ngsid_reads_t* dev_out, uint64_t* foreign)
+{
+    if (!ctx) return NGSID_ERR_ARG;
+    if (!dev_in || !dev_out || (n && !idx) || dev_in->mem != NGSID_MEM_DEVICE) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_subset: a device read set, an index list and an output are required");
+    DevReads R; int32_t rc = ngsid_upload_reads(ctx, dev_in, &R, false); if (rc) return rc;
+    static thread_local PinVec<uint64_t> h_noff; h_noff.resize(n + 1); h_noff[0] = 0;
+    for (uint64_t i = 0; i < n; ++i) { if (idx[i] >= R.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_subset: index %llu out of range", (unsigned long long)idx[i]); h_noff[i + 1] = h_noff[i] + (R.h_off[idx[i] + 1] - R.h_off[idx[i]]); }
+    const uint64_t total = h_noff[n];
+    void *ds = nullptr, *dq = nullptr, *dof = nullptr; size_t got = 0;
+    HIPCHK(ctx, ngsid_pool_alloc(&ds, total + 16, &got)); const size_t bs = got;
+    HIPCHK(ctx, ngsid_pool_alloc(&dof, sizeof(uint64_t) * (n + 1), &got)); const size_t bo = got;
+    size_t bq = 0;
+    if (dev_in->qual) { HIPCHK(ctx, ngsid_pool_alloc(&dq, total + 16, &got)); bq = got; }
+    DevBuf<uint64_t> d_idx; DevBuf<unsigned long long> d_bad; HIPCHK(ctx, d_idx.alloc(n)); HIPCHK(ctx, d_bad.alloc(1));
+    HIPCHK(ctx, hipMemsetAsync(d_bad.p, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dof, h_noff.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (n) HIPCHK(ctx, hipMemcpyAsync(d_idx.p, idx, sizeof(uint64_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (n) hipLaunchKernelGGL(k_reads_subset, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, R.seq, R.qual, R.off, d_idx.p, (const uint64_t*)dof, n, (uint8_t*)ds, (uint8_t*)dq, d_bad.p);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long hb = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&hb, d_bad.p, sizeof hb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (foreign) *foreign = hb;
+    { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.uploads[ds] = {bs, dq, bq, dof, bo}; }
+    dev_out->seq = (const uint8_t*)ds; dev_out->qual = (const uint8_t*)dq; dev_out->off = (const uint64_t*)dof; dev_out->n = n; dev_out->mem = NGSID_MEM_DEVICE; dev_out->_pad = 0;
+    return NGSID_OK;
+}
+
 extern "C" int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev)
 {
     if (!ctx) return NGSID_ERR_ARG;
@@ -508,6 +558,11 @@ extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t va
     if (!ctx || !name) return NGSID_ERR_ARG;
     static const char* known[] = {"poa_level_budget_mb", "cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
     for (const char* k : known) if (!strcmp(k, name)) { ctx->options[name] = (long long)value; return NGSID_OK; }
+    if (!strcmp(name, "touch")) {        // one trivial operation on the context's stream (+ wait): a caller that spends milliseconds on the host between two calls keeps the device out of its idle state
+        if (ctx->mzc_fp.n < 2) HIPCHK(ctx, ctx->mzc_fp.alloc(2));
+        HIPCHK(ctx, hipMemsetAsync(ctx->mzc_fp.p + 1, 0, sizeof(unsigned long long), ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return NGSID_OK;
+    }
     if (!strcmp(name, "release_scratch")) {        // gives the context's grow-only scratch (aligner traceback, POA tiles and levels, polisher arrays) and the cached blocks back to the driver
         (void)hipStreamSynchronize(ctx->stream);
         ctx->tb.release(); ctx->bnd.release(); ctx->aln_cls.release(); ctx->aln_psorted.release(); ctx->aln_pbin.release(); ctx->ed_tb.release(); ctx->ed_h.release(); ctx->ed_fail.release(); ctx->ed_fail2.release();

@@ -98,13 +98,35 @@ def _write(args, fn, *a, **kw):
         bg.submit(fn, *a, **kw)
 
 
+def _write_logfile(logf, err_kept):
+    """logfile.txt (get_sorted_fastq_for_cluster.py:184-188): error rates of the kept reads - lowest, highest, median, and the mean as the reference forms it (Python's
+    sum over the ascending list, so the digits are the reference's)"""
+    er = np.sort(err_kept)
+    with open(logf, "w") as lf:
+        if len(er):
+            lf.write("Lowest read error rate:{0}\n".format(float(er[0])))
+            lf.write("Highest read error rate:{0}\n".format(float(er[-1])))
+            lf.write("Median read error rate:{0}\n".format(float(er[int(len(er) / 2)])))
+            lf.write("Mean read error rate:{0}\n".format(float(sum(er.tolist()) / len(er))))
+        lf.write("\n")
+
+
 class SortedReads:
     """the content of sorted.fastq in memory: reads in score order, original names + '_score' suffixes (CSR bytes, one per read)"""
 
-    def __init__(self, names, rs, suffixes, score, err=None):
-        self.names, self.rs, self.score, self.err = names, rs, np.asarray(score, dtype=np.float64), err
+    def __init__(self, names, rs, suffixes, score, err=None, lens=None):
+        self.names, self._rs, self.score, self.err = names, rs, np.asarray(score, dtype=np.float64), err
         self.sfx = suffixes if isinstance(suffixes, tuple) else fastio._csr(suffixes)
-        self.n = rs.n
+        self.n = len(self.score)
+        self.lens = np.asarray(lens, dtype=np.int64) if lens is not None else np.diff(rs.off.astype(np.int64))      # read lengths (known before the host copy exists)
+        self.dev = None; self.foreign = None          # round 5: the same reads resident on the device in score order + bases outside ACGTN among them (score_and_sort)
+
+    @property
+    def rs(self):
+        """the host copy of the sorted reads; round 5: gathered by a worker thread while the device clusters (the device got its own copy by a gather in HBM)"""
+        if not isinstance(self._rs, ReadSet):
+            self._rs = self._rs.result()
+        return self._rs
 
     def suffix(self, i):
         b, o = self.sfx; return b[int(o[i]):int(o[i + 1])].tobytes().decode()
@@ -138,7 +160,11 @@ def score_and_sort(args, api, T=None):
     lens = np.diff(rs.off.astype(np.int64))
     if rs.n and lens.max() > 65535:
         raise SystemExit("a read of %d bases exceeds what the read scorer handles (65 535); filter the input first" % int(lens.max()))
-    score, err, keep = api.score_reads(rs, args.k, args.quality_threshold) if rs.n else (np.zeros(0), np.zeros(0), np.zeros(0, np.uint8))
+    # round 5: the reads cross PCIe ONCE, in file order; they are scored there, and the score order is a gather on the device (ngsid_reads_subset) - the host copy in
+    # score order (the writers' and the TSVs' source) is gathered by a worker thread while the device clusters.  Backends without the entry point (the test oracle) and
+    # empty inputs take the host route of round 4.
+    dev_raw = api.upload_reads(rs) if (rs.n and hasattr(api, "reads_subset") and hasattr(api.lib, api.prefix + "reads_subset") and hasattr(api.lib, api.prefix + "reads_upload")) else None
+    score, err, keep = api.score_reads(dev_raw if dev_raw is not None else rs, args.k, args.quality_threshold) if rs.n else (np.zeros(0), np.zeros(0), np.zeros(0, np.uint8))
     T["score"] = time() - t0; t0 = time()
     idx = np.nonzero(keep)[0]
     order = idx[fastio.argsort_desc(score[idx])]                          # read_array.sort(key=score, reverse=True) is stable (multi-threaded radix sort: numpy's stable float sort took 0.09 s per million reads)
@@ -150,14 +176,7 @@ def score_and_sort(args, api, T=None):
     getattr(args, "_deferred", []).append((fastio.write_fastq, (out_path, order, names, rs), dict(suffixes=sfx))) if hasattr(args, "_deferred") else _write(args, fastio.write_fastq, out_path, order, names, rs, suffixes=sfx, _threads=int(os.environ.get("NGSID_CLI_SORTED_WRITER_THREADS", "4")))
     T["write_sorted_fastq"] = time() - t0; t0 = time()
     logging.debug(f"{len(order)} reads passed quality critera (avg phred Q val over {args.quality_threshold} and length > 2*k) and will be clustered.")
-    er = np.sort(err[idx])
-    with open(logf, "w") as lf:
-        if len(er):
-            lf.write("Lowest read error rate:{0}\n".format(float(er[0])))
-            lf.write("Highest read error rate:{0}\n".format(float(er[-1])))
-            lf.write("Median read error rate:{0}\n".format(float(er[int(len(er) / 2)])))
-            lf.write("Mean read error rate:{0}\n".format(float(sum(er.tolist()) / len(er))))
-        lf.write("\n")
+    _write(args, _write_logfile, logf, err[idx])      # (a sort of a million doubles and a sequential Python sum: 0.06 s that nothing waits for - with the other writers)
     nm = names.compact(order)                       # names of the kept reads in their own small buffer (the file buffer can go)
     # the accession ranks of ALL sorted reads (the clustering's third sort key) are computed by a worker thread while the reads are gathered, normalised and
     # uploaded (numpy's sort releases the GIL); cluster() takes them when it clusters every read, which is the usual call
@@ -165,9 +184,20 @@ def score_and_sort(args, api, T=None):
     sfx_csr = sfx if isinstance(sfx, tuple) else fastio._csr(sfx)
     pool = ThreadPoolExecutor(max_workers=1)
     fut = pool.submit(_string_ranks, nm, sfx_csr, np.arange(len(order), dtype=np.int64)); pool.shutdown(wait=False)
-    sub = subset_reads(rs, order)
+    lens_sorted = lens[order]
+    if dev_raw is not None:
+        t1 = time()
+        got = api.reads_subset(dev_raw, order)
+        dev_raw.release()
+        T["device_gather_sorted"] = time() - t1
+        pool2 = ThreadPoolExecutor(max_workers=1)
+        sub = pool2.submit(subset_reads, rs, order); pool2.shutdown(wait=False)
+    else:
+        got = None
+        sub = subset_reads(rs, order)
     T["gather_sorted"] = time() - t0
-    sr = SortedReads(nm, sub, sfx_csr, score[order], err[order])
+    sr = SortedReads(nm, sub, sfx_csr, score[order], err[order], lens=lens_sorted)
+    if got is not None: sr.dev, sr.foreign = got
     sr.rank_all = fut
     return sr
 
@@ -193,13 +223,13 @@ def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None, T=Non
     rep_of = np.arange(n, dtype=np.int64); herr = np.full(n, np.nan); pos = np.zeros(n, dtype=np.int64)
     if len(sel) == 0:
         return rep_of, herr, pos, np.zeros(4, dtype=np.uint64), None
-    lens_all = np.diff(sr.rs.off.astype(np.int64))
+    lens_all = sr.lens
     too_long = lens_all[sel] > MAX_READ_LEN
     if too_long.any():
         logging.warning("%d reads are longer than %d bases: they are not clustered and stay singletons (use --m / --s to filter by length)", int(too_long.sum()), MAX_READ_LEN)
         sel = sel[~too_long]
     whole = work_dev is not None and len(sel) == n and args.nr_cores <= 1       # every read in one call: the device-resident set as it is
-    work = work_dev if whole else subset_reads(work, sel)
+    work = work_dev if whole else subset_reads(work if work is not None else sr.rs, sel)
     prm = cluster_params(k=args.k, w=args.w, min_shared=args.min_shared, min_fraction=args.min_fraction, mapped_threshold=args.mapped_threshold,
                          aligned_threshold=args.aligned_threshold, min_prob_no_hits=args.min_prob_no_hits,
                          symmetric=bool(getattr(args, "symmetric_map_align_thresholds", False)), p_shared=select_p_table(args.k, args.w))
@@ -314,7 +344,7 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
             _write(args, _write_pooled, path, groups[c], sr)
             args._pooled_early[int(reps[c])] = (c,)
     sub_off = np.concatenate(([0], np.cumsum([len(g) for g in groups]))).astype(np.uint64)
-    long_reads = bool(np.diff(sr.rs.off.astype(np.int64))[np.concatenate(groups)].max() > 1000)
+    long_reads = bool(sr.lens[np.concatenate(groups)].max() > 1000)
     node_cap = 22 if long_reads else 0
     drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=getattr(args, "poa_tile_depth", pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=pipeline.DRAFT_TRIM),
                                read_order=np.concatenate(groups).astype(np.uint32))
@@ -473,13 +503,18 @@ def _main(args, api):
     args.outfile = os.path.join(args.outfolder, "sorted.fastq")
     if os.environ.get("NGSID_CLI_DEFER_SORTED_WRITE", "0") == "1": args._deferred = []        # dev switch (A/B of the write schedule, round 4): with the parallel record writer the write is short enough to run beside the clustering call
     sr = score_and_sort(args, api, T)
-    work = normalized_reads(sr)
-    T["normalize"] = time() - t0 - sum(T.values()); t0 = time()
-    work_dev = api.upload_reads(work)               # ONE copy to HBM for the clustering, the draft consensus and the polishing calls
-    T["upload"] = time() - t0; t0 = time()
+    if sr.dev is not None and sr.foreign == 0:
+        work, work_dev = None, sr.dev               # the device holds the sorted reads already (gathered in HBM) and nothing needs normalising: `work` = sr.rs, taken when a caller needs the host copy
+        T["normalize"] = 0.0; T["upload"] = 0.0; t0 = time()
+    else:
+        if sr.dev is not None: sr.dev.release(); sr.dev = None
+        work = normalized_reads(sr)
+        T["normalize"] = time() - t0 - sum(T.values()); t0 = time()
+        work_dev = api.upload_reads(work)               # ONE copy to HBM for the clustering, the draft consensus and the polishing calls
+        T["upload"] = time() - t0; t0 = time()
     sel = np.arange(sr.n, dtype=np.int64)
     if args.target_length > 0 and args.target_deviation > 0:
-        lens = np.diff(sr.rs.off.astype(np.int64))
+        lens = sr.lens
         sel = sel[(lens >= args.target_length - args.target_deviation) & (lens <= args.target_length + args.target_deviation)]
         logging.debug("Number of reads with read length in interval [{0},{1}]: {2}".format(args.target_length - args.target_deviation, args.target_length + args.target_deviation, len(sel)))
     if args.top_reads:
@@ -501,6 +536,7 @@ def _main(args, api):
         prm = cluster_params(k=args.k, w=args.w, min_shared=args.min_shared, min_fraction=args.min_fraction, mapped_threshold=args.mapped_threshold,
                              aligned_threshold=args.aligned_threshold, min_prob_no_hits=args.min_prob_no_hits,
                              symmetric=bool(getattr(args, "symmetric_map_align_thresholds", False)), p_shared=select_p_table(args.k, args.w))
+        if work is None: work = sr.rs
         rep_of, flip, pos, sinfo = strand.strand_merge(api, work, rep_of, sr.score, prm, min_size=max(2, abundance_cutoff // 2), pos=pos)
         logging.debug("strand-aware merge: %d of %d candidate clusters joined their reverse complement" % (sinfo["merged"], sinfo["candidates"]))
         if flip.any():

@@ -16,6 +16,8 @@ from ._capi import Api, ReadSet, cluster_params, poa_params, polish_params, POA_
 # (exact from 5.6 % to 14.3 % read error at depths 8 / 6 / 5); 6 is the fastest at 1 M reads (depth 8: every second tile ends
 # with an eighth member that no longer fits the edge room and the graphs are largest when the last members are aligned).
 TILE_DEPTH = 6
+import os as _os
+_TOUCH = bool(_os.environ.get("NGSID_TOUCH"))          # dev probe (round 5): one trivial device operation in the middle of the host work between clustering and consensus
 DRAFT_TRIM = 1
 
 _COMP = np.zeros(256, dtype=np.uint8)
@@ -119,6 +121,9 @@ def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, 
         return res
     t0 = time.perf_counter()
     reps, order, grp_off, counts = clusters_from_rep(rep_of)
+    if _TOUCH and hasattr(api, "ctx"):
+        import ctypes as _C
+        api.lib.ngsid_ctx_option(api.ctx, b"touch", _C.c_int64(1))
     cutoff = int(abundance_ratio * n)                                           # NGSpeciesID:65
     sel = select_centers(reps, counts, score, cutoff)
     T["host_group"] = T.get("host_group", 0.0) + time.perf_counter() - t0

@@ -35,6 +35,6 @@ def test_no_device_fails_loudly():
 
 def test_oracle_twins_exist(oracle):
     for n in _declared():
-        if n in ("ngsid_create", "ngsid_destroy", "ngsid_profile_enable", "ngsid_profile_read", "ngsid_ctx_option", "ngsid_reads_upload", "ngsid_reads_release") or n.startswith("ngsid_host_"):      # device management / host-only helpers: tested directly (test_fastio_cpu.py, test_gpu_edge.py)
+        if n in ("ngsid_create", "ngsid_destroy", "ngsid_profile_enable", "ngsid_profile_read", "ngsid_ctx_option", "ngsid_reads_upload", "ngsid_reads_release", "ngsid_reads_subset") or n.startswith("ngsid_host_"):      # device management / host-only helpers: tested directly (test_fastio_cpu.py, test_gpu_edge.py)
             continue
         assert hasattr(oracle.lib, "o" + n), "oracle lacks o%s" % n

@@ -17,8 +17,6 @@ done
 rm -rf $O/pmc_sq; timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-trace --output-format csv -d $O/pmc_sq -o pmc -- python $R/bench.py --steps 1 --warmup 0 $BARGS --no-extra-step > $O/pmc_sq.log 2>&1
 # 4b. VALU pipe utilisation from counters alone: cycles in which the VALU executes an instruction / cycles the SQs are busy, + the FLAT (scratch / global) instruction split
 rm -rf $O/pmc_sq2; timeout 900 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_sq2 -o pmc -- python $R/bench.py --steps 1 --warmup 0 $BARGS --no-extra-step > $O/pmc_sq2.log 2>&1
-# 5. DP rows of the same step (phase counters of the host-driven loop: same tiles, same rows)
-NGSID_POA_PHASES=1 timeout 600 python $R/bench.py --steps 1 --warmup 0 $BARGS --no-extra-step > $O/phases.json 2> $O/r05_poa_phases.txt
 cd $R
 python - <<PY
 import csv,glob,collections,json,os,re
@@ -64,9 +62,12 @@ if fs:
     for r in csv.DictReader(open(fs[0])):
         if "k_poa_tile1" in r["Kernel_Name"]: sq[r["Counter_Name"]]+=float(r["Counter_Value"])
 rows=0
-for line in open("gpurun_out/r5/r05_poa_phases.txt"):
-    m=re.search(r"\| rows (\d+) non-chain",line)
-    if m: rows+=int(m.group(1))
+# DP rows of the SAME run as the counters: the kernels count them (poa_dp_rows of ngsid_profile_read -> roofline.dp_kernels of the bench line the counter pass printed);
+# the phase-cycle instrumentation that used to provide them is compiled out of the product kernel since round 5 (-DPOA_PHASES=1 dev builds only)
+for line in open("gpurun_out/r5/pmc_sq.log", errors="replace"):
+    if line.startswith("{") and '"roofline"' in line:
+        try: rows=int(json.loads(line)["roofline"]["dp_kernels"]["k_poa_tile"]["dp_rows"])
+        except Exception: pass
 kt=glob.glob("gpurun_out/r5/pmc_sq/**/*kernel_trace.csv",recursive=True)
 dur=0
 if kt:
@@ -81,7 +82,7 @@ if sq and rows:
        "pipe_busy":pb.get("k_poa_tile1"),"pipe_busy_how":"second counter pass (pmc_sq2): SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES summed over the kernel's dispatches, both normalised per SIMD as rocprofv3 reports them (VALU-active cycles x 4 SIMD-cycles of a wave instruction are NOT assumed); see raw_second_pass",
        "raw_second_pass":raw2.get("k_poa_tile1"),
        "raw":{k:int(v) for k,v in sq.items()},
-       "_how":"rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-extra-step, summed over every k_poa_tile1 dispatch of the step; rows = DP rows of the same step from NGSID_POA_PHASES=1 (r05_poa_phases.txt); pipe_busy = VALU instructions x 4 cycles / (1 024 SIMDs x busy cycles per shader engine)"}
+       "_how":"rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-extra-step, summed over every k_poa_tile1 dispatch of the step; rows = DP rows the kernels counted in the same run (poa_dp_rows); pipe_busy = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of a second counter pass"}
     json.dump(j,open("gpurun_out/r5/r05_pmc_poa_tile.json","w"),indent=1); print(json.dumps({k:v for k,v in j.items() if k not in ("raw","_how")}))
 PY
 python - <<PY
