@@ -24,14 +24,14 @@ CONFIGS = {
 }
 
 
-def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device, abundance=None, rc_fraction=0.0, k=13):
+def gen_sorted_reads(api, n_reads, n_species, L, mu, seed, device, abundance=None, rc_fraction=0.0, k=13, rng="torch"):
     """synthetic reads, scored (f1) and physically ordered by score descending (stable) = the greedy order."""
     from ngspeciesid_amd import synth
     from ngspeciesid_amd._capi import ReadSet
     tr = (lambda m: (sys.stderr.write("[gen pid %d] %s\n" % (os.getpid(), m)), sys.stderr.flush())) if os.environ.get("NGSID_BENCH_TRACE") else (lambda m: None)
     sp = synth.make_species(n_species, L, 0.15, seed=1)
     tr("species made")
-    rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed, device=device, abundance=abundance, rc_fraction=rc_fraction)
+    rd = synth.make_reads(sp, n_reads, mu=mu, seed=seed, device=device, abundance=abundance, rc_fraction=rc_fraction, rng=rng)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     torch.cuda.synchronize(device)       # the library runs on its own HIP stream: torch's generator kernels must have finished writing the reads
     tr("reads made")
@@ -123,11 +123,14 @@ def main():
         import ctypes as _C
         api.lib.ngsid_ctx_option(api.ctx, b"scratch_budget_mb", _C.c_int64(max(2048, 32768 // world)))
     ptab = select_p_table(K_, W_)
+    # multi-process runs draw their reads from plain integer tensor arithmetic (synth._HashRng) instead of torch generators: eight processes sharing one GPU were seen to
+    # stall inside torch's generator kernels; the one-GPU workload keeps the torch generator = the read set of every earlier round
+    RNG_ = os.environ.get("NGSID_BENCH_RNG", "hash" if world > 1 else "torch")
     rd_global = None
     if args.scaling == "strong" and (world > 1 or force_dist):
         # every rank builds the same global set (same seed, same device type) and keeps its own `--t N` batch of it
         from ngspeciesid_amd import parallelize
-        sp, rd_global = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7, device=dev, abundance=abundance, k=K_)
+        sp, rd_global = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7, device=dev, abundance=abundance, k=K_, rng=RNG_)
         goff = rd_global["off"]; glens = (goff[1:] - goff[:-1]).cpu().numpy()
         batches = parallelize.batch_list_total_nt(glens, world)
         a, b = batches[rank] if rank < len(batches) else (len(glens), len(glens))
@@ -137,7 +140,7 @@ def main():
         shard_start = a
         if not (args.check_membership and rank == 0): rd_global = None
     else:
-        sp, rd = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7 + rank, device=dev, abundance=abundance, k=K_)
+        sp, rd = gen_sorted_reads(api, args.reads, args.species, args.length, args.mu, seed=7 + rank, device=dev, abundance=abundance, k=K_, rng=RNG_)
     torch.cuda.synchronize()
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     n = rs.n
@@ -407,7 +410,7 @@ def main():
                          % (ns, args.tile_depth, per_core)}
     out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), %d bp %s" % (args.length, "CCS" if cfg["preset"] == "--isoseq" else "ONT"), "value": round(reads_per_s, 1), "unit": "reads/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-           "scaling": args.scaling if world > 1 or force_dist else "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic",
+           "scaling": args.scaling if world > 1 or force_dist else "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic" + (" (counter-based generator, no torch.Generator)" if RNG_ == "hash" else ""),
            "config": {"workload": (args.config.upper() + ": %d synthetic %d bp %s-profile reads " + ("in total, one `--t N` batch per GPU" if (args.scaling == "strong" and (world > 1 or force_dist)) else "per GPU") + " (mu=%.0f), %d species @15%% divergence%s, k=%d w=%d, cluster + spoa-style POA + racon-style polish x3, abundance_ratio %s, POA tile depth %d band %s")
                       % (args.reads, args.length, "CCS" if args.mu >= 25 else "ONT", args.mu, args.species, (" with geometric abundance %.1f^i" % cfg["geometric"]) if cfg["geometric"] else "", K_, W_, AB_, args.tile_depth, ("%d" % args.band) if args.band else "%d (library default, widened per tile by the band-edge check)" % (64 if args.length <= 3000 else 128)),
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
