@@ -26,6 +26,11 @@ torch.cuda.synchronize(); torch.cuda.empty_cache()
 t_gen = time.perf_counter() - t0
 rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
 free0, tot0 = torch.cuda.mem_get_info()
+kw_ = dict(acc_rank=np.asarray(rd["orig"], dtype=np.uint32), k=cfg["k"], w=cfg["w"], abundance_ratio=cfg["abundance_ratio"], racon_iter=3, tile_depth=pipeline.TILE_DEPTH, band=0,
+           p_shared=select_p_table(cfg["k"], cfg["w"]), polish_stop_when_stable=False)
+t0 = time.perf_counter()
+pipeline.run_hot_path(api, rs, rd["score"], **kw_)               # first pass: the context allocates its scratch (tens of GB of hipMalloc take seconds); timed separately
+dt_cold = time.perf_counter() - t0
 api.lib.ngsid_profile_enable(api.ctx, C.c_int32(1))
 T = {}
 t0 = time.perf_counter()
@@ -43,7 +48,7 @@ _check_clusters(rd, res, cfg["species"], 0.995)
 truths = sorted(s.tobytes().decode() for s in sp)
 got = sorted(c[3] for c in res["centers"])
 exact = got == truths
-out = dict(config=name, reads=int(rs.n), bases=int(rd["off"][-1].item()), species=cfg["species"], one_context=True, wall_s=round(dt, 3), reads_per_s=round(rs.n / dt, 1), generation_s=round(t_gen, 1),
+out = dict(config=name, reads=int(rs.n), bases=int(rd["off"][-1].item()), species=cfg["species"], one_context=True, wall_s_first_pass_incl_allocation=round(dt_cold, 3), wall_s=round(dt, 3), reads_per_s=round(rs.n / dt, 1), generation_s=round(t_gen, 1),
            stage_s={k_: round(v, 3) for k_, v in T.items()}, centres=len(got), every_consensus_equals_its_amplicon=bool(exact), clusters_pure_and_complete=True,
            library_hbm_peak_gb=round(kern.get("hbm_peak_bytes", (0, 0))[0] / 1e9, 2), library_hbm_held_after_gb=round(kern.get("hbm_live_bytes", (0, 0))[0] / 1e9, 2),
            device_free_before_gb=round(free0 / 1e9, 1), device_free_after_gb=round(free1 / 1e9, 1), device_total_gb=round(tot0 / 1e9, 1),

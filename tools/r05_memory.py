@@ -12,7 +12,7 @@ for name, n in (("c4", 10000000), ("c5", 2000000)):
     f = os.path.join(R5, "r05_full_%s_%d.json" % (name, n))
     if not os.path.exists(f): continue
     d = json.load(open(f))
-    out["configs"][name] = {k: d.get(k) for k in ("reads", "bases", "species", "one_context", "wall_s", "reads_per_s", "stage_s", "every_consensus_equals_its_amplicon", "clusters_pure_and_complete", "read_set_gb",
+    out["configs"][name] = {k: d.get(k) for k in ("reads", "bases", "species", "one_context", "wall_s_first_pass_incl_allocation", "wall_s", "reads_per_s", "stage_s", "every_consensus_equals_its_amplicon", "clusters_pure_and_complete", "read_set_gb",
                                                    "library_hbm_peak_gb", "library_hbm_held_after_gb", "device_total_gb", "context_scratch_gb_by_purpose", "poa_tiles_redone")}
 comp = os.path.join(ROOT, "gpurun_out", "composed_c4_8_shards_one_gpu.json")
 if os.path.exists(comp): out["c4_composed_eight_shards_on_one_gpu"] = json.load(open(comp))

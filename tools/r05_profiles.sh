@@ -52,7 +52,7 @@ if fs2:
         if k: acc[k][r["Counter_Name"]]+=float(r["Counter_Value"])
     for k,v in acc.items():
         raw2[k]={a:int(b) for a,b in v.items()}
-        if v.get("SQ_BUSY_CYCLES"): pb[k]=round(v["SQ_ACTIVE_INST_VALU"]/v["SQ_BUSY_CYCLES"],4)
+        if v.get("SQ_BUSY_CU_CYCLES"): pb[k]=round(v["SQ_ACTIVE_INST_VALU"]/v["SQ_BUSY_CU_CYCLES"],4)      # both in quad-cycles per SIMD (see _units of profiles/r05_pmc_pipe_busy.json)
     json.dump({"_how":"rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-extra-step; counters summed over all dispatches of the kernel family in the step","commit":commit,"active_valu_over_busy":pb,"raw":raw2},open("gpurun_out/r5/r05_pmc_pipe_busy.json","w"),indent=1)
     print(json.dumps({"active_valu_over_busy":pb}))
 # SQ counters of k_poa_tile1 over the step
@@ -79,7 +79,7 @@ if sq and rows:
        "wave_cycles_waiting_frac":round(sq["SQ_WAIT_ANY"]/max(sq["SQ_WAVE_CYCLES"],1),3),"wave_cycles_issuing_frac":round(sq["SQ_ACTIVE_INST_ANY"]/max(sq["SQ_WAVE_CYCLES"],1),3),
        "kernel_ns_under_the_counter_pass":dur,
        "pipe_busy_assuming_4_cycles_per_instruction":round(sq["SQ_INSTS_VALU"]*4/(1024*(sq["SQ_BUSY_CYCLES"]/32.0)),3) if sq.get("SQ_BUSY_CYCLES") else None,
-       "pipe_busy":pb.get("k_poa_tile1"),"pipe_busy_how":"second counter pass (pmc_sq2): SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES summed over the kernel's dispatches, both normalised per SIMD as rocprofv3 reports them (VALU-active cycles x 4 SIMD-cycles of a wave instruction are NOT assumed); see raw_second_pass",
+       "pipe_busy":pb.get("k_poa_tile1"),"pipe_busy_how":"second counter pass (pmc_sq2): SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES summed over the kernel's dispatches (both in quad-cycles per SIMD: no cycle count per instruction is assumed); see raw_second_pass and profiles/r05_pmc_pipe_busy.json",
        "raw_second_pass":raw2.get("k_poa_tile1"),
        "raw":{k:int(v) for k,v in sq.items()},
        "_how":"rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli --no-extra-step, summed over every k_poa_tile1 dispatch of the step; rows = DP rows the kernels counted in the same run (poa_dp_rows); pipe_busy = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of a second counter pass"}
