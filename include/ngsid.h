@@ -270,7 +270,7 @@ int32_t ngsid_host_infix_locate(const uint8_t* query, int32_t qlen, const uint8_
 
 /* Scheduling options of a context, for tests and tools: "cluster_block" (reads per speculative block, 0 = adaptive), "ed_band" (Ukkonen band of the
  * polisher's first aligner launch, 0 = off, -1 = automatic), "ed_win_all", "align32" (force the int32 clustering aligner), "align_noclass" (no
- * query-length classes), "align_paired" (0 = the one-pair-per-wave kernel for every length class; default 1: two pairs per wave for every single-strip length class, i.e. queries of up to 896 bases, in batches of at least 4 096 pairs), "poa_tiles_per_cu", "poa_out_slots" (output slots per POA tile of the first attempt, default 4: memory of the level buffers; a tile with more outputs is retried with more), "minimizers_lean" (the long-read LDS layout of the minimizer kernel for every read), "poa_host_levels" (hierarchy levels driven by the host), "scratch_budget_mb" (cap of the aligners' traceback scratch: several contexts on one GPU), "release_scratch" (frees the context's grow-only scratch and the block cache now).  RESULTS NEVER
+ * query-length classes), "align_paired" (0 = the one-pair-per-wave kernel for every length class; default 1: two pairs per wave for every single-strip length class, i.e. queries of up to 896 bases, in batches of at least 4 096 pairs), "poa_tiles_per_cu", "poa_out_slots" (output slots per POA tile of the first attempt, default 4: memory of the level buffers; a tile with more outputs is retried with more), "minimizers_lean" (the long-read LDS layout of the minimizer kernel for every read), "poa_host_levels" (hierarchy levels driven by the host), "scratch_budget_mb" (cap of the aligners' traceback scratch: several contexts on one GPU), "poa_level_budget_mb" (byte budget of the POA hierarchy's level buffers: a call runs in batches of whole units under it; default a third of the free device memory per live context, 1 - 48 GB), "minimizers_chunk_bases" (reads per launch of the minimizer kernel, by bases; default 256 M), "touch" (one trivial device operation), "release_scratch" (frees the context's grow-only scratch and the block cache now).  RESULTS NEVER
  * DEPEND ON THEM (tests/test_gpu_stress.py runs the parity suites under several settings); the library reads no environment variable for them.
  * Environment variables the library does read, none of which changes a result: NGSID_HOST_THREADS (thread count of the ngsid_host_* helpers,
  * default = hardware threads, at most 32), and three developer aids - NGSID_DEBUG_SYNC (synchronise and log after every launch),

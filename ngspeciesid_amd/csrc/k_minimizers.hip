@@ -353,7 +353,8 @@ int32_t ngsid_minimizers_csr(ngsid_ctx* ctx, const DevReads& R, int k, int w, co
     HIPCHK(ctx, o_off.reserve(n + 1));
     if (n == 0) { HIPCHK(ctx, hipMemsetAsync(o_off.p, 0, 8, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); return NGSID_OK; }
     const bool wide = k > 21;
-    const uint64_t chunk_bases = std::max<uint64_t>(MZ_CHUNK_BASES / (uint64_t)ngsid_pool_contexts(), (uint64_t)32 << 20);      // (several contexts on one GPU: a share each)
+    const long long chunk_opt = ngsid_opt(ctx, "minimizers_chunk_bases", 0);      // tests: many small chunks (results never depend on it)
+    const uint64_t chunk_bases = chunk_opt > 0 ? (uint64_t)chunk_opt : std::max<uint64_t>(MZ_CHUNK_BASES / (uint64_t)ngsid_pool_contexts(), (uint64_t)32 << 20);      // (several contexts on one GPU: a share each)
     DevBuf<int> d_flag; HIPCHK(ctx, d_flag.alloc(1));
     DevBuf<uint64_t> s_hi, c_hi;                 // k > 21: second code word, sparse per chunk and compact over the call (until the rename pass)
     uint64_t done = 0, total = 0;                                  // reads finished, minimizers so far

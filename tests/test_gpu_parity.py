@@ -109,6 +109,34 @@ def test_minimizer_layouts_agree(gpu_api, oracle, kw):
         assert np.array_equal(got[4], exp[4], equal_nan=True)
 
 
+@pytest.mark.parametrize("kw", [(13, 20), (25, 30), (32, 40)])
+def test_minimizers_in_many_small_chunks(gpu_api, oracle, kw):
+    """round 5: the minimizer kernel writes into a bounded sparse scratch, one chunk of reads at a time, and a gather appends every chunk to the compact CSR
+    (ngsid_minimizers_csr).  With chunks of ~2 000 bases (option minimizers_chunk_bases; the default is 256 M) the golden read set takes dozens of chunks: same CSR, same
+    HPC lengths and error rates as one chunk and as the oracle - also for k > 21, where the second code word travels through the chunks and the rename pass runs on the
+    compact arrays; and the clustering built on it equals the oracle's."""
+    from ngspeciesid_amd import runtime
+    from ngspeciesid_amd._capi import cluster_params
+    from ngspeciesid_amd.ptable import select_p_table
+    k, w = kw
+    g = _load("minimizers_sample_h1.npz")
+    rs = ReadSet(g["seq"], g["qual"], g["off"])
+    exp = oracle.hpc_minimizers(rs, k, w)
+    small = runtime.new_api(options={"minimizers_chunk_bases": 2000})
+    try:
+        for api in (gpu_api, small):
+            got = api.hpc_minimizers(rs, k, w)
+            for nm, a, b in zip(["moff", "codes", "pos", "hpc_len"], got[:4], exp[:4]):
+                assert np.array_equal(a, b), nm
+            assert np.array_equal(got[4], exp[4], equal_nan=True)
+        if k <= 30:
+            prm = cluster_params(k=k, w=w, p_shared=select_p_table(k, w))
+            a = small.cluster_greedy(rs, prm); b = oracle.cluster_greedy(rs, prm)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    finally:
+        small.close()
+
+
 def _rand_pairs(rng, n, lmin, lmax, sim=True):
     qs, ts = [], []
     for _ in range(n):
