@@ -51,7 +51,10 @@ def test_consensus_deviation_from_the_reference_order_mode(gpu_api):
     graph per cluster / window in file order, spoa's untrimmed bundle, racon's window rule), POLISHED vs POLISHED, on the reference's own reads and on
     C3-shaped clusters.  The numbers are those of profiles/r04_consensus_deviation.json (same tool, 2 000 reads per cluster, oracle backend); here 400 reads
     per cluster at mu = 14 on the HIP library.  On synthetic reads the shipped mode returns the amplicon and every difference between the modes is an error
-    of the reference-order mode; on sample_h1 (no truth known) the two polished sequences differ by 10 interior edits + 21 bases of end overhang."""
+    of the reference-order mode; on sample_h1 (no truth known) the two polished sequences differ by 10 interior edits + 21 bases of end overhang.
+    Round 5 took the reference-order mode apart rule by rule on the oracle (profiles/r05_reference_order.json, tests/test_consensus_oracle.py::
+    test_reference_order_rules_of_round_5): its errors are junction insertions that come from source / sink nodes at the window edges, which the two
+    racon rules this build replaces do not remove; the HIP library implements rule set 0 = the mode asserted here."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import r04_consensus_deviation as D

@@ -71,6 +71,20 @@ def test_strong_scaling_ranks_on_one_gpu_membership_equals_t_n(world):
     assert chk["centers"] == 5 and chk["consensus_edit_distance_vs_truth"] == [0, 0, 0, 0, 0] and chk["cluster_purity"] == 1.0
 
 
+def test_rccl_collectives_single_rank_strong_scaling():
+    """the `nccl` (= RCCL) branch of distributed.TorchComm on the GPU box: the sharded path with its collectives through torch.distributed backend nccl, world size 1
+    (NGSID_FORCE_DIST=1 - the test box has one GPU; 2-, 4- and 8-rank runs use gloo).  Payloads travel device -> all_gather_into_tensor -> host as they will on a node."""
+    env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"; env["NGSID_FORCE_DIST"] = "1"; env.pop("NGSID_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29571",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--reads", "200000", "--scaling", "strong", "--check-membership", "--no-cpu-baseline", "--no-extra-step", "--no-cli"]
+    p = subprocess.run(cmd, env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    chk = out["config"]["check"]
+    assert out["scaling"] == "strong" and chk["membership_equals_reference_t_n"] is True and chk["sharded_consensus_equals_single_process"] is True
+    assert chk["centers"] == 5 and chk["consensus_edit_distance_vs_truth"] == [0, 0, 0, 0, 0]
+
+
 def test_long_ont_reads_5kb_five_species(gpu_api):
     """beyond the BASELINE shapes: 40 k x 5 kb ONT-profile reads (ten polishing windows, amplicon lengths a few bases over a multiple of 500:
     the merged tail window; 128-column first band): every polished consensus == its amplicon"""
