@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256)
 void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t nreads,
                       int k, int w, uint32_t maxlen, uint32_t lds_per_wave,
                       uint64_t* __restrict__ out_codes, uint64_t* __restrict__ out_hi, uint32_t* __restrict__ out_pos, uint32_t* __restrict__ out_cnt,
-                      uint32_t* __restrict__ out_hlen, double* __restrict__ out_herr, double* __restrict__ out_rawerr, int* __restrict__ flag)
+                      uint32_t* __restrict__ out_hlen, double* __restrict__ out_herr, double* __restrict__ out_rawerr, int* __restrict__ flag, uint64_t out_base)
 {
+    // out_base: base offset of the first read of this launch - the sparse outputs (out_codes / out_hi / out_pos) start there (round 5: a launch covers one chunk of reads
+    // and writes into a scratch of that chunk's size)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr bool LEAN = MODE == 1, REG = MODE == 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -188,7 +190,7 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
             const bool f = valid && best != prev;
             const unsigned long long m = __ballot(f);
             if (f) {
-                const uint64_t o = base + (uint64_t)(emitted + __popcll(m & ((1ull << lane) - 1ull)));
+                const uint64_t o = base - out_base + (uint64_t)(emitted + __popcll(m & ((1ull << lane) - 1ull)));
                 out_codes[o] = code; out_pos[o] = (uint32_t)best;
             }
             emitted += __popcll(m);
@@ -231,7 +233,7 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
         const bool f = sidx < nwin && best != prev;
         const unsigned long long m = __ballot(f);
         if (f) {
-            const uint64_t o = base + (uint64_t)(emitted + __popcll(m & ((1ull << lane) - 1ull)));
+            const uint64_t o = base - out_base + (uint64_t)(emitted + __popcll(m & ((1ull << lane) - 1ull)));
             if (LEAN) { uint64_t l, h; kmer_code(best, l, h); out_codes[o] = l; if (KW == 2) out_hi[o] = h; }
             else { out_codes[o] = clo[best]; if (KW == 2) out_hi[o] = chi[best]; }
             out_pos[o] = (uint32_t)best;
@@ -296,8 +298,8 @@ static int32_t mz_rename_wide(ngsid_ctx* ctx, uint64_t* d_lo, const uint64_t* d_
 }
 
 // one launch over the reads of R (a view: R.off may point into a longer offset array); every output pointer is indexed by the view's read number, the
-// sparse arrays d_codes / d_hi / d_pos by the reads' ABSOLUTE base offsets (the caller shifts them when its scratch starts at another base)
-static int32_t mz_launch(ngsid_ctx* ctx, const DevReads& R, int k, int w,
+// sparse arrays d_codes / d_hi / d_pos by the reads' base offsets minus out_base (= the base offset of the view's first read: the scratch holds one chunk)
+static int32_t mz_launch(ngsid_ctx* ctx, const DevReads& R, int k, int w, uint64_t out_base,
                          uint64_t* d_codes, uint64_t* d_hi, uint32_t* d_pos, uint32_t* d_cnt, uint32_t* d_hlen, double* d_herr, double* d_rawerr, int* d_flag)
 {
     if (R.n == 0) return NGSID_OK;
@@ -319,7 +321,7 @@ static int32_t mz_launch(ngsid_ctx* ctx, const DevReads& R, int k, int w,
         ProfScope ps_(ctx, "k_hpc_minimizers");
         auto go = [&](auto kern, uint64_t* hi_p) -> hipError_t {
             if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, R.maxlen, (uint32_t)lpw, d_codes, hi_p, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, R.maxlen, (uint32_t)lpw, d_codes, hi_p, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag, out_base);
             return hipSuccess;
         };
         if (KW == 1) HIPCHK(ctx, mode == 2 ? go(k_hpc_minimizers<1, 2>, nullptr) : mode == 1 ? go(k_hpc_minimizers<1, 1>, nullptr) : go(k_hpc_minimizers<1, 0>, nullptr));
@@ -367,7 +369,7 @@ int32_t ngsid_minimizers_csr(ngsid_ctx* ctx, const DevReads& R, int k, int w, co
         HIPCHK(ctx, ctx->mz_scode.reserve(cb + 1)); HIPCHK(ctx, ctx->mz_spos.reserve(cb + 1)); if (wide) HIPCHK(ctx, s_hi.reserve(cb + 1));
         DevReads V; V.seq = R.seq; V.qual = R.qual; V.off = R.off + done; V.n = nr; V.total = cb; V.maxlen = R.maxlen; V.minlen = R.minlen;
         HIPCHK(ctx, hipMemsetAsync(d_flag.p, 0, sizeof(int), ctx->stream));
-        int32_t rc = mz_launch(ctx, V, k, w, ctx->mz_scode.p - b0, wide ? s_hi.p - b0 : nullptr, ctx->mz_spos.p - b0, d_cnt + done, d_hlen + done, d_herr + done, d_rawerr + done, d_flag.p);
+        int32_t rc = mz_launch(ctx, V, k, w, b0, ctx->mz_scode.p, wide ? s_hi.p : nullptr, ctx->mz_spos.p, d_cnt + done, d_hlen + done, d_herr + done, d_rawerr + done, d_flag.p);
         if (rc) return rc;
         int hf = 0;
         HIPCHK(ctx, hipMemcpyAsync(h_cnt + done, d_cnt + done, 4 * nr, hipMemcpyDeviceToHost, ctx->stream));
