@@ -1,6 +1,6 @@
 """dev tool: cost of the multi-GPU representative merge (distributed.merge_representatives) emulated in ONE process.
 
-    python tools/micro/time_merge.py [shards] [reads_per_shard]
+    python tools/micro/time_merge.py [shards] [reads_per_shard] [species]
 
 Clusters `shards` independent synthetic shards one after the other on cuda:0 (what each rank does locally), collects the
 payloads the all-gather would deliver, and times the tree merge every rank replays, for world = 2, 4, ... shards.
@@ -16,11 +16,12 @@ from ngspeciesid_amd.ptable import select_p_table
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+NSP = int(sys.argv[3]) if len(sys.argv) > 3 else 5          # species (C4: 50)
 api = runtime.get_api(0); dev = torch.device("cuda", 0)
 prm = cluster_params(k=13, w=20, p_shared=select_p_table(13, 20))
 gathered = []
 for r in range(W):
-    sp, rd = bench.gen_sorted_reads(api, n, 5, 750, 17.0, seed=7 + r, device=dev)
+    sp, rd = bench.gen_sorted_reads(api, n, NSP, 750, 17.0, seed=7 + r, device=dev)
     rs = ReadSet.from_torch(rd["seq"], rd["qual"], rd["off"])
     acc = np.asarray(rd["orig"], dtype=np.uint32)
     t0 = time.perf_counter()
