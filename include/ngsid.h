@@ -191,12 +191,19 @@ typedef struct {
     int32_t k, w;             /* minimizer parameters used for strand detection (replaces minimap2 -x map-ont) */
     int32_t tile_depth, band, node_cap;
     int32_t aln_match, aln_mismatch, aln_open, aln_ext;  /* read->backbone aligner (replaces the edlib NW path of racon) */
-    int32_t trim;             /* 0 none; 1 = racon: coverage-trim the consensus of TGS windows (mean read length > 1000); 2 = trim every window */
+    int32_t trim;             /* 0 none; 1 = racon: coverage-trim the consensus of TGS windows (mean read length > 1000); 2 = trim every window AND every tile consensus of the
+                                 hierarchy (+ the one-third rule on its upper levels): the shipped default; 3 (round 5) = tiles as in 2, windows as in 1: a window keeps the ends
+                                 of its backbone where no layer reaches them - what aln_mode 3 needs, whose clipped layers stop short of the backbone's ends */
     int32_t aln_mode;         /* read->backbone aligner: 0 = semi-global affine (aln_* scores, all end gaps free);
                                  1 = unit-cost edit distance, read end to end, backbone ends free (what racon gets from edlib inside the
                                  minimap2 span); traceback prefers match/mismatch, then a read-only column, then a backbone-only column;
                                  end column = leftmost minimum of the last row; non-ACGT letters match nothing;
-                                 2 = the library's default (currently mode 1) */
+                                 2 = the library's default (currently mode 1);
+                                 3 = mode 1 + OVERLAP-SPAN CLIPPING (round 5): of the alignment only the columns from the first to the last run of at least 15 equal
+                                 columns count - read ends that do not align stay out of the layers, as minimap2's q_begin / q_end keep them out of racon's edlib call
+                                 (consensus.py:121: PAF without CIGAR = first anchor to last anchor of the chain, k = 15 for -x map-ont; racon src/overlap.cpp
+                                 find_breaking_points aligns only that span).  A read without such a run contributes nothing.  The CLI uses it where read ends are KNOWN
+                                 to overhang the backbone: polishing primer-trimmed drafts (--primer_file / --remove_universal_tails) */
     int32_t stop_when_stable; /* 1 = a group whose backbone comes back unchanged from an iteration is not polished again: the polisher is a
                                  deterministic function of (backbone, reads), so every further iteration would return the same string and
                                  the same n_used - the result is identical, only the time differs.  0 = always run `iters` iterations */

@@ -17,7 +17,11 @@
 typedef unsigned long long u64;
 #define LDSP __attribute__((address_space(3)))
 
-template <int BMAX, bool WIN>
+// CLIP (round 5, ngsid_polish_params_t.aln_mode = 3): overlap-span clipping - only the columns from the first to the last run of at least CLIP_RUN equal columns are recorded
+// (span and window break points), as the oracle does (ongsid_polish, clip_span): what minimap2's chain ends do before racon's edlib call.  One instance only (unbanded,
+// 16-block groups): the mode serves the primer-trimming flow of the CLI, a handful of centres.
+#define CLIP_RUN 15
+template <int BMAX, bool WIN, bool CLIP = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
 void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-byte units */, uint32_t mstride, uint32_t* __restrict__ work_ctr, int32_t* __restrict__ dist_out,
                 int8_t* __restrict__ hcar /* per wave mstride x 64: horizontal delta below the last block of a block group */,
@@ -178,6 +182,7 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
         if (bpp) for (int x = 0; x < J.bp_windows * 4; ++x) bpp[x] = -1;
         const int W = J.window > 0 ? J.window : 0x7fffffff;
         int cw = -1, w_qf = 0, w_ql = 0, w_tf = 0, w_tl = 0;
+        int c_run = 0, c_x0q = -1, c_x0t = -1; bool c_started = false;       // CLIP state (unused otherwise)
         int wsn = j > 0 ? (j - 1) / W : 0, ws = wsn * W;       // window of the current target position, tracked without divisions
         // The lanes walk their paths IN LOCKSTEP OVER THE TARGET COLUMNS (round 3): in round jj every lane whose path stands in column jj handles that column (any
         // number of vertical moves, then one diagonal or horizontal move), so the 64 loads of a round go to the same column - one or two coalesced KB instead of
@@ -212,17 +217,35 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
                     const u64 dv = ((u64)w.y << 32) | w.x, uv = ((u64)w.w << 32) | w.z;
                     const bool diag = (dv >> bit) & 1, up = (uv >> bit) & 1;
                     if (diag) {
-                        const int qi = i - 1, ti = j - 1;
-                        if (q_end < 0) { q_end = qi; t_end = ti; }
-                        q_beg = qi; t_beg = ti;
-                        if (bpp) {
-                            while (ti < ws) { ws -= W; --wsn; }
-                            const int wn_ = wsn;
-                            if (wn_ != cw) { if (cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn_; w_ql = qi; w_tl = ti; }
-                            w_qf = qi; w_tf = ti;
-                        }
+                        const int qi0 = i - 1, ti0 = j - 1;
+                        auto record = [&](int qi, int ti) {
+                            if (q_end < 0) { q_end = qi; t_end = ti; }
+                            q_beg = qi; t_beg = ti;
+                            if (bpp) {
+                                while (ti < ws) { ws -= W; --wsn; }
+                                const int wn_ = wsn;
+                                if (wn_ != cw) { if (cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; } cw = wn_; w_ql = qi; w_tl = ti; }
+                                w_qf = qi; w_tf = ti;
+                            }
+                        };
+                        if constexpr (CLIP) {
+                            const uint8_t cq = q[qi0] & 0xDF, ct = t[ti0] & 0xDF;              // equal letters of A/C/G/T, any case (oracle ed_code)
+                            const bool eq = cq == ct && (cq == 'A' || cq == 'C' || cq == 'G' || cq == 'T');
+                            c_run = eq ? c_run + 1 : 0;
+                            if (!c_started) {
+                                if (c_run >= CLIP_RUN) {        // the LAST run of the alignment (walking backwards, the first): its end lies CLIP_RUN - 1 columns behind - record the run
+                                    c_started = true;
+                                    for (int d = CLIP_RUN - 1; d >= 0; --d) record(qi0 + d, ti0 + d);
+                                    c_x0q = qi0; c_x0t = ti0;
+                                }
+                            } else {
+                                record(qi0, ti0);
+                                if (c_run >= CLIP_RUN) { c_x0q = qi0; c_x0t = ti0; }        // inside a long run: the earliest such column so far
+                            }
+                        } else record(qi0, ti0);
                         --i; --j; break;
                     }
+                    if constexpr (CLIP) c_run = 0;                                              // a gap column ends a run
                     if (!up) { --j; break; }
                     --i;
                     if (i == 0) break;
@@ -232,6 +255,13 @@ void k_ed_align(AlignJob J, ngsid_v4u* __restrict__ tb, u64 tb_per_wave /* 16-by
         }
         i = 0;
         if (bpp && ok && cw >= 0 && cw < J.bp_windows) { bpp[cw * 4 + 0] = w_qf; bpp[cw * 4 + 1] = w_ql; bpp[cw * 4 + 2] = w_tf; bpp[cw * 4 + 3] = w_tl; }
+        if constexpr (CLIP) {
+            if (have && ok && c_started) {      // head side: everything in front of the first run of CLIP_RUN equal columns goes
+                q_beg = c_x0q; t_beg = c_x0t;
+                if (bpp) { const int w0 = c_x0t / W; for (int x = 0; x < w0 && x < J.bp_windows; ++x) { bpp[x * 4 + 0] = -1; bpp[x * 4 + 1] = -1; bpp[x * 4 + 2] = -1; bpp[x * 4 + 3] = -1; }
+                           if (w0 < J.bp_windows) { bpp[w0 * 4 + 0] = c_x0q; bpp[w0 * 4 + 2] = c_x0t; } }
+            }
+        }
         if (have && ok) {
             if (dist_out) dist_out[p] = best;
             if (J.span) { J.span[p * 4 + 0] = q_beg; J.span[p * 4 + 1] = q_end; J.span[p * 4 + 2] = t_beg; J.span[p * 4 + 3] = t_end; }
@@ -254,7 +284,7 @@ static int32_t ed_reserve(ngsid_ctx* ctx, u64& want, u64 per_wave)
     }
 }
 
-template <int BMAX, bool WIN = false>
+template <int BMAX, bool WIN = false, bool CLIP = false>
 static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out, uint32_t ctr_slot = 14, int bandK = 0, uint32_t fail_slot = 15, uint32_t* fail_list = nullptr)
 {
     const u64 nbundles = (job.npairs + 63) / 64;
@@ -263,7 +293,7 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen,
     const u64 per_wave = nblocks * mstride * 64;                           // 16-byte units
     const size_t lds = (size_t)BMAX * 3 * 64 * 8 + (size_t)ngsid_opt(ctx, "ed_lds_pad_kb", 0) * 1024;      // (dev option: extra LDS per wave = fewer resident waves, for occupancy measurements)
     int occ = 0;
-    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ed_align<BMAX, WIN>, 64, lds));
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ed_align<BMAX, WIN, CLIP>, 64, lds));
     if (occ < 1) occ = 1;
     u64 want = std::min<u64>(nbundles, (u64)occ * ctx->n_cu);
     const u64 by_mem = std::max<u64>(1, std::min<size_t>((size_t)24 << 30, ctx->scratch_budget) / (per_wave * 16));
@@ -272,7 +302,7 @@ static int32_t launch_ed(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen,
     if (ctx->ed_h.n < want * (u64)mstride * 64) HIPCHK(ctx, ctx->ed_h.reserve(want * (u64)mstride * 64));
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
     HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), ctx->stream));
-    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX, WIN>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + ctr_slot, dist_out, ctx->ed_h.p,
+    { ProfScope ps_(ctx, "k_ed_align"); hipLaunchKernelGGL((k_ed_align<BMAX, WIN, CLIP>), dim3((unsigned)want), dim3(64), lds, ctx->stream, job, ctx->ed_tb.p, per_wave, mstride, ctx->aln_ctr.p + ctr_slot, dist_out, ctx->ed_h.p,
                                                             bandK, fail_list ? fail_list : ctx->ed_fail.p, ctx->aln_ctr.p + fail_slot); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
@@ -297,6 +327,7 @@ int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_
 {
     if (job.npairs == 0) return NGSID_OK;
     if (max_qlen > NGSID_MAX_READ_LEN || max_tlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in the edit-distance aligner", NGSID_MAX_READ_LEN);
+    if (job.clip) return launch_ed<16, false, true>(ctx, job, max_qlen, max_tlen, dist_out, 14, 0);      // overlap-span clipping (aln_mode 3): the one CLIP instance, unbanded
     // band: wide enough for the usual read-to-draft distance, pairs beyond it take the unbanded launch (the result does not depend on it)
     int bandK = 64 + (int)(max_qlen / 32);
     const bool band_set = ngsid_opt(ctx, "ed_band", -1) >= 0;

@@ -6,6 +6,7 @@ struct PSeq { const uint8_t* s; const uint8_t* q; int32_t len, uw; uint32_t cw; 
 
 struct PoaJobSet {
     const PSeq* seqs; const PSeq* bbs; const uint32_t* seq_idx; const uint32_t* job_off; const int32_t* job_bb; uint32_t njobs; const uint32_t* job_list; uint32_t nrun;   /* job_list != null: this launch runs tiles job_list[0..nrun) (band-edge redo); else all njobs */
+    const uint8_t* job_final;                 /* != null (round 5, polish trim 3): job_final[j] != 0 = tile j ends its unit: its consensus is NOT trimmed (trim_tiles counts as 0) */
     const uint32_t* nrun_dev;                 /* != null: the number of tiles to run is read from device memory (device-driven hierarchy: no host round trip between levels) */
     int m, n, g, Vcap, Ecap, Lmax, D, node_cap, trim_tiles;       // D = output slots per job
     int32_t* Hglob; uint8_t* dirglob; uint32_t* covglob;           // per resident workgroup scratch (filled by poa_run_jobs)

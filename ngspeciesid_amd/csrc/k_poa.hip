@@ -413,7 +413,8 @@ __device__ __forceinline__ void tile_emit(const GG& g, const LLT<BW>& w, const P
     const int poff = V - n;
     mem_sync();
     PH(J, 15, tph2);
-    const bool trim = J.trim_tiles && dcov && n > 0;        // oracle EMIT: coverage-trim the tile consensus ends
+    const int trim_tiles = (J.job_final && J.job_final[job]) ? 0 : J.trim_tiles;      // (trim 3: the tile that ends a unit is not trimmed)
+    const bool trim = trim_tiles && dcov && n > 0;        // oracle EMIT: coverage-trim the tile consensus ends
     const uint32_t thr = (uint32_t)(st.cw_sum / 2);
     int tb = 0x7fffffff, te = -1;                            // first / last position whose column carries at least half of the merged weight
     for (int i = lane; i < n; i += 64) {
@@ -432,7 +433,7 @@ __device__ __forceinline__ void tile_emit(const GG& g, const LLT<BW>& w, const P
             // beats the direct edge W of the rest when (k + 1) w > W - a third for one base, a seventh for five).  Level-0 tiles keep spoa's / racon's behaviour.
             // Ordered in-place compaction, 64 positions per round: a round's stores land below the next round's loads (an output index never exceeds the input
             // index), and a round's own loads have returned before its stores issue (they carry the loaded values): one drain in front of the loop suffices.
-            const uint32_t thr3 = (J.trim_tiles & 2) ? (uint32_t)(st.cw_sum / 3) : 0u;
+            const uint32_t thr3 = (trim_tiles & 2) ? (uint32_t)(st.cw_sum / 3) : 0u;
             const int m2 = e - b + 1;
             if (thr3 == 0u && b == 0) n = m2;                 // nothing moves
             else {

@@ -567,7 +567,7 @@ extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t va
         (void)hipStreamSynchronize(ctx->stream);
         ctx->tb.release(); ctx->bnd.release(); ctx->aln_cls.release(); ctx->aln_psorted.release(); ctx->aln_pbin.release(); ctx->ed_tb.release(); ctx->ed_h.release(); ctx->ed_fail.release(); ctx->ed_fail2.release();
         ctx->poa_h.release(); ctx->poa_d.release(); ctx->poa_g.release(); ctx->poa_cov.release();
-        for (auto& L : ctx->poa_lv) { L.out.release(); L.seqs.release(); L.out_len.release(); L.out_span.release(); L.job_bb.release(); L.out_cw.release(); L.out_n.release(); L.out_cov.release(); L.job_off.release(); L.seq_idx.release(); L.flags.release(); L.job_list.release(); L.job_unit.release(); L.job_pos.release(); }
+        for (auto& L : ctx->poa_lv) { L.out.release(); L.seqs.release(); L.job_final.release(); L.out_len.release(); L.out_span.release(); L.job_bb.release(); L.out_cw.release(); L.out_n.release(); L.out_cov.release(); L.job_off.release(); L.seq_idx.release(); L.flags.release(); L.job_list.release(); L.job_unit.release(); L.job_pos.release(); }
         ctx->mzc.valid = false; ctx->mzc_cnt.release(); ctx->mzc_hlen.release(); ctx->mz_off.release(); ctx->mz_scode.release(); ctx->mz_spos.release();
         ctx->pol_mzcode.release(); ctx->pol_mzpos.release(); ctx->pol_oseq.release(); ctx->pol_oqual.release(); ctx->pol_valid.release(); ctx->pol_bp.release(); ctx->pol_lay.release();
         ngsid_pool_release_all();

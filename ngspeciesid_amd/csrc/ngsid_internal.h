@@ -84,7 +84,7 @@ struct ngsid_ctx {
     DevBuf<uint32_t> ed_fail2; // ... and beyond the wider band of the retry launch
     DevBuf<uint32_t> poa_ctr; // POA tile work-queue counter
     uint64_t poa_redo_tiles = 0;   // tiles redone with a wider band since the context was created (band-edge check)
-    struct PoaLevelBufs { DevBuf<uint8_t> out, seqs /* PSeq[] */; DevBuf<int32_t> out_len, out_span, job_bb; DevBuf<uint64_t> out_cw; DevBuf<uint32_t> out_n, out_cov, job_off, seq_idx, flags, job_list, job_unit, job_pos; };
+    struct PoaLevelBufs { DevBuf<uint8_t> out, seqs /* PSeq[] */, job_final; DevBuf<int32_t> out_len, out_span, job_bb; DevBuf<uint64_t> out_cw; DevBuf<uint32_t> out_n, out_cov, job_off, seq_idx, flags, job_list, job_unit, job_pos; };
     PoaLevelBufs poa_lv[2];   // hierarchy levels ping-pong between two buffer sets (level L+1 reads what level L wrote)
     DevBuf<uint64_t> pol_mzcode; DevBuf<uint32_t> pol_mzpos; DevBuf<uint8_t> pol_oseq, pol_oqual; DevBuf<uint16_t> pol_valid; DevBuf<int32_t> pol_bp; DevBuf<uint8_t> pol_lay;   // polisher scratch (grow-only)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams: the launches of the small length classes overlap the big one
@@ -176,6 +176,7 @@ struct AlignJob {            // device pointers
     uint8_t* ops; const uint64_t* ops_off;
     // optional SECOND index list behind the first (k_ed_align only: two query-length classes in one launch): item k >= *npairs_dev is pair_list2[k - *npairs_dev]
     const uint32_t* pair_list2; const uint32_t* npairs_dev2;
+    int clip;        // k_ed_align only (round 5, aln_mode 3): != 0 = overlap-span clipping of the recorded span / break points
 };
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20, uint32_t min_qlen = 0);   // min_qlen: lower bound of the query lengths (lets empty length classes be skipped)
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);

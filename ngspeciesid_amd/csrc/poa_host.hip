@@ -50,6 +50,7 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
         // host lists of a level: kept across levels and calls (a million entries per level; fresh allocations would page-fault every time)
         static thread_local PinVec<uint32_t> job_off, seq_idx; static thread_local std::vector<uint32_t> job_unit; static thread_local PinVec<int32_t> job_bb;
         job_off.clear(); job_off.push_back(0); seq_idx.clear(); job_unit.clear(); job_bb.clear();
+        static thread_local PinVec<uint8_t> job_final; job_final.clear();      // trim 3 (hp.trim_tiles & 4): tiles that end their unit
         { size_t tot = 0; for (const Unit& U : units) if (!U.done) tot += U.seqs.size(); seq_idx.reserve(tot); }
         uint32_t maxD = 0; int maxL0 = 1; bool any_nobb = false;
         for (size_t u = 0; u < units.size(); ++u) {
@@ -60,7 +61,7 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
             for (uint32_t t = 0; t < nt; ++t) {
                 const uint32_t a = t * Dl, b = t + 1 == nt ? ncur : a + Dl;
                 for (uint32_t x = a; x < b; ++x) seq_idx.push_back(U.seqs[x]);
-                job_off.push_back((uint32_t)seq_idx.size()); job_bb.push_back(U.bb); job_unit.push_back((uint32_t)u);
+                job_off.push_back((uint32_t)seq_idx.size()); job_bb.push_back(U.bb); job_unit.push_back((uint32_t)u); job_final.push_back(nt == 1 ? 1 : 0);
                 maxD = std::max(maxD, b - a);
             }
             if (U.bb >= 0) maxL0 = std::max(maxL0, bb_len[U.bb]); else any_nobb = true;
@@ -79,6 +80,7 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
         HIPCHK(ctx, hipMemcpyAsync(d_job_off.p, job_off.data(), 4 * job_off.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_seq_idx.p, seq_idx.data(), 4 * seq_idx.size(), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(d_job_bb.p, job_bb.data(), 4 * job_bb.size(), hipMemcpyHostToDevice, ctx->stream));
+        if (hp.trim_tiles & 4) { HIPCHK(ctx, Lv->job_final.reserve(job_final.size())); HIPCHK(ctx, hipMemcpyAsync(Lv->job_final.p, job_final.data(), job_final.size(), hipMemcpyHostToDevice, ctx->stream)); }
         int slots = slots_cap ? slots_cap : (int)std::min<uint32_t>(maxD, (uint32_t)std::max<long long>(1, ngsid_opt(ctx, "poa_out_slots", 4)));
         static thread_local PinVec<uint32_t> h_out_n; static thread_local PinVec<int32_t> h_out_len, h_out_span; static thread_local PinVec<uint64_t> h_out_cw;
         const bool need_cov = hp.want_cov || hp.trim_tiles;
@@ -88,7 +90,7 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
             HIPCHK(ctx, hipMemsetAsync(d_flags.p, 0, 16, ctx->stream));
             PoaJobSet J{};
             J.seqs = cur; J.bbs = d_bbs; J.seq_idx = d_seq_idx.p; J.job_off = d_job_off.p; J.job_bb = d_job_bb.p; J.njobs = njobs;
-            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles | ((level > 0 && hp.trim_tiles) ? 2 : 0);
+            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = (hp.trim_tiles & 1) | ((level > 0 && (hp.trim_tiles & 1)) ? 2 : 0); J.job_final = (hp.trim_tiles & 4) ? Lv->job_final.p : nullptr;
             J.out = Lv->out.p; J.out_len = Lv->out_len.p; J.out_cw = Lv->out_cw.p; J.out_n = Lv->out_n.p; J.out_cov = need_cov ? Lv->out_cov.p : nullptr; J.out_span = Lv->out_span.p;
             J.dropped = d_flags.p; J.slot_overflow = d_flags.p + 1;
             DevBuf<unsigned long long> d_ph; static const bool want_ph = getenv("NGSID_POA_PHASES") != nullptr;
@@ -186,13 +188,13 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
 enum { C_NJOBS = 0 /* 2 words: level parity */, C_NSEQ = 2, C_OVERFLOW = 3, C_RES_USED = 4, C_REDO_TOTAL = 5, C_FLAGS = 8 /* dropped, slot_overflow (2 words) */, C_REDO = 16 /* + 2 * level + stage */, C_MAXLV = 48, C_WORK = C_REDO + 2 * C_MAXLV /* + 3 * level + instance */, C_WORDS = C_WORK + 3 * C_MAXLV };
 
 struct HierDev {
-    uint32_t U; int D, slots, capV, upper_mode, want_cov, Lmax; uint32_t cap_jobs[2];
+    uint32_t U; int D, slots, capV, upper_mode, want_cov, Lmax, keep_final; uint32_t cap_jobs[2];
     const int32_t* unit_bb; const int32_t* unit_wlen;
     uint32_t* unit_ncur; uint32_t* unit_job0[2]; uint32_t* unit_njobs[2]; uint32_t* unit_seq0; int32_t* unit_pick; uint32_t* unit_tmp /* njobs_next, nseq_next, res_len of this level: 3 U */;
     uint32_t* res_off; int32_t* res_len; uint8_t* res; uint32_t* res_cov;
     uint32_t* ctrl;
 };
-struct LevelDev { PSeq* seqs; uint8_t* out; int32_t* out_len; int32_t* out_span; uint64_t* out_cw; uint32_t* out_n; uint32_t* out_cov; uint32_t* job_off; int32_t* job_bb; uint32_t* job_unit; uint32_t* job_pos; uint32_t* job_list; };
+struct LevelDev { PSeq* seqs; uint8_t* out; int32_t* out_len; int32_t* out_span; uint64_t* out_cw; uint32_t* out_n; uint32_t* out_cov; uint32_t* job_off; int32_t* job_bb; uint32_t* job_unit; uint32_t* job_pos; uint32_t* job_list; uint8_t* job_final; };
 
 // tiles whose traceback touched a clipped band edge (bit 31 of out_n) -> list for the launch with twice the band
 __global__ __launch_bounds__(256) void k_poa_redo_list(const uint32_t* __restrict__ out_n, const uint32_t* __restrict__ njobs, uint32_t* __restrict__ list, uint32_t* __restrict__ cnt, uint32_t* __restrict__ total)
@@ -359,6 +361,7 @@ __global__ __launch_bounds__(256) void k_poa_fill_jobs(HierDev H, LevelDev Nx, i
     const uint32_t u = lo, tl = t - j0[u];
     const uint32_t T = H.unit_ncur[u]; const uint32_t Dl = H.D > 0 ? (uint32_t)H.D : T;
     Nx.job_off[t] = H.unit_seq0[u] + tl * Dl; Nx.job_bb[t] = H.unit_bb[u]; Nx.job_unit[t] = u;
+    if (H.keep_final) Nx.job_final[t] = H.unit_njobs[par ^ 1][u] == 1 ? 1 : 0;            // (trim 3: the tile that ends its unit)
     if (t == nj - 1) Nx.job_off[nj] = H.ctrl[C_NSEQ];
     }
 }
@@ -374,8 +377,8 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
     const uint32_t U = (uint32_t)units.size();
     HostTimer ht(ctx->stream, "hierarchy (device levels)");
     // ---- level-0 tile lists (as in the host-driven loop) + per-unit records
-    static thread_local PinVec<uint32_t> job_off, seq_idx, job_unit, u_u32; static thread_local PinVec<int32_t> job_bb, u_i32;
-    job_off.clear(); job_off.push_back(0); seq_idx.clear(); job_unit.clear(); job_bb.clear();
+    static thread_local PinVec<uint32_t> job_off, seq_idx, job_unit, u_u32; static thread_local PinVec<int32_t> job_bb, u_i32; static thread_local PinVec<uint8_t> job_final;
+    job_off.clear(); job_off.push_back(0); seq_idx.clear(); job_unit.clear(); job_bb.clear(); job_final.clear();
     { size_t tot = 0; for (const Unit& Un : units) if (!Un.done) tot += Un.seqs.size(); seq_idx.reserve(tot); }
     u_u32.assign(3ull * U, 0); u_i32.assign(3ull * U, 0);        // ncur | job0 | njobs   and   bb | wlen | pick
     uint32_t maxD = 0; int maxbb = 0; bool any_nobb = false; uint64_t maxn = 0;
@@ -390,7 +393,7 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
             const uint32_t nt = poa_ntiles(ncur, Dl);
             for (uint32_t t = 0; t < nt; ++t) {
                 const uint32_t a = t * Dl, b = t + 1 == nt ? ncur : a + Dl;
-                job_off.push_back(base + b); job_bb.push_back(Un.bb); job_unit.push_back(u);
+                job_off.push_back(base + b); job_bb.push_back(Un.bb); job_unit.push_back(u); job_final.push_back(nt == 1 ? 1 : 0);
                 maxD = std::max(maxD, b - a);
             }
             if (Un.bb >= 0) maxbb = std::max(maxbb, bb_len[Un.bb]); else any_nobb = true;
@@ -424,15 +427,15 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
         HIPCHK(ctx, B->out.reserve(ns * capV)); HIPCHK(ctx, B->out_len.reserve(ns)); HIPCHK(ctx, B->out_cw.reserve(ns)); HIPCHK(ctx, B->out_span.reserve(ns * 2)); HIPCHK(ctx, B->out_n.reserve(cap[q]));
         if (need_cov) HIPCHK(ctx, B->out_cov.reserve(ns * capV));
         HIPCHK(ctx, B->seqs.reserve(sizeof(PSeq) * ns)); HIPCHK(ctx, B->job_off.reserve((size_t)cap[q] + 1)); HIPCHK(ctx, B->job_bb.reserve(cap[q])); HIPCHK(ctx, B->job_list.reserve(cap[q]));
-        HIPCHK(ctx, B->job_unit.reserve(cap[q])); HIPCHK(ctx, B->job_pos.reserve(cap[q]));
-        L[q] = LevelDev{(PSeq*)B->seqs.p, B->out.p, B->out_len.p, B->out_span.p, B->out_cw.p, B->out_n.p, need_cov ? B->out_cov.p : nullptr, B->job_off.p, B->job_bb.p, B->job_unit.p, B->job_pos.p, B->job_list.p};
+        HIPCHK(ctx, B->job_unit.reserve(cap[q])); HIPCHK(ctx, B->job_pos.reserve(cap[q])); HIPCHK(ctx, B->job_final.reserve(cap[q]));
+        L[q] = LevelDev{(PSeq*)B->seqs.p, B->out.p, B->out_len.p, B->out_span.p, B->out_cw.p, B->out_n.p, need_cov ? B->out_cov.p : nullptr, B->job_off.p, B->job_bb.p, B->job_unit.p, B->job_pos.p, B->job_list.p, B->job_final.p};
     }
     HIPCHK(ctx, ctx->poa_lv[0].seq_idx.reserve(seq_idx.size()));
     DevBuf<uint32_t> d_u32, d_ctrl, d_res_off, d_res_cov; DevBuf<int32_t> d_i32, d_res_len; DevBuf<uint8_t> d_res;
     HIPCHK(ctx, d_u32.alloc(9ull * U + 4)); HIPCHK(ctx, d_i32.alloc(3ull * U)); HIPCHK(ctx, d_ctrl.alloc(C_WORDS)); HIPCHK(ctx, d_res_off.alloc(U)); HIPCHK(ctx, d_res_len.alloc(U));
     HIPCHK(ctx, d_res.alloc((size_t)U * capV)); if (hp.want_cov) HIPCHK(ctx, d_res_cov.alloc((size_t)U * capV));
     HierDev H{};
-    H.U = U; H.D = hp.D; H.slots = slots; H.capV = (int)capV; H.upper_mode = hp.upper_mode; H.want_cov = hp.want_cov ? 1 : 0; H.Lmax = Lmax; H.cap_jobs[0] = cap[0]; H.cap_jobs[1] = cap[1];
+    H.U = U; H.D = hp.D; H.slots = slots; H.capV = (int)capV; H.upper_mode = hp.upper_mode; H.want_cov = hp.want_cov ? 1 : 0; H.Lmax = Lmax; H.keep_final = (hp.trim_tiles & 4) ? 1 : 0; H.cap_jobs[0] = cap[0]; H.cap_jobs[1] = cap[1];
     H.unit_bb = d_i32.p; H.unit_wlen = d_i32.p + U; H.unit_pick = d_i32.p + 2ull * U;
     H.unit_ncur = d_u32.p; H.unit_job0[0] = d_u32.p + U; H.unit_njobs[0] = d_u32.p + 2ull * U + 1; H.unit_job0[1] = d_u32.p + 3ull * U + 1; H.unit_njobs[1] = d_u32.p + 4ull * U + 2; H.unit_seq0 = d_u32.p + 5ull * U + 2; H.unit_tmp = d_u32.p + 6ull * U + 2;
     H.res_off = d_res_off.p; H.res_len = d_res_len.p; H.res = d_res.p; H.res_cov = hp.want_cov ? d_res_cov.p : nullptr; H.ctrl = d_ctrl.p;
@@ -446,6 +449,7 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
     HIPCHK(ctx, hipMemcpyAsync(ctx->poa_lv[0].seq_idx.p, seq_idx.data(), 4 * seq_idx.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(L[0].job_bb, job_bb.data(), 4 * job_bb.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(L[0].job_unit, job_unit.data(), 4 * job_unit.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (hp.trim_tiles & 4) HIPCHK(ctx, hipMemcpyAsync(L[0].job_final, job_final.data(), job_final.size(), hipMemcpyHostToDevice, ctx->stream));
     static thread_local PinVec<uint32_t> h_nj; h_nj.assign(1, njobs0);
     HIPCHK(ctx, hipMemcpyAsync(d_ctrl.p + C_NJOBS, h_nj.data(), 4, hipMemcpyHostToDevice, ctx->stream));
     ht.mark("L0 lists + upload");
@@ -457,7 +461,7 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
             const int par = level & 1; LevelDev& Lv = L[par]; LevelDev& Nx = L[par ^ 1];
             PoaJobSet J{};
             J.seqs = level == 0 ? d_level0 : (const PSeq*)Nx.seqs; J.bbs = d_bbs; J.seq_idx = level == 0 ? ctx->poa_lv[0].seq_idx.p : nullptr; J.job_off = Lv.job_off; J.job_bb = Lv.job_bb; J.njobs = cap[par];
-            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = hp.trim_tiles | ((level > 0 && hp.trim_tiles) ? 2 : 0);
+            J.m = hp.m; J.n = hp.n; J.g = hp.g; J.Vcap = (int)capV; J.Ecap = (int)(3 * capV / 2); J.Lmax = Lmax; J.D = slots; J.node_cap = hp.node_cap; J.trim_tiles = (hp.trim_tiles & 1) | ((level > 0 && (hp.trim_tiles & 1)) ? 2 : 0); J.job_final = (hp.trim_tiles & 4) ? Lv.job_final : nullptr;
             J.out = Lv.out; J.out_len = Lv.out_len; J.out_cw = Lv.out_cw; J.out_n = Lv.out_n; J.out_cov = Lv.out_cov; J.out_span = Lv.out_span;
             J.dropped = d_ctrl.p + C_FLAGS; J.slot_overflow = d_ctrl.p + C_FLAGS + 1;
             J.job_list = nullptr; J.nrun = 0; J.nrun_dev = d_ctrl.p + C_NJOBS + par;
@@ -892,7 +896,8 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
             J.qseq = oseq.p; J.qoff = RD.off; J.tseq = BB.seq; J.toff = BB.off; J.qidx = d_pair_read.p; J.tidx = d_pair_group.p; J.npairs = NP;
             J.match = prm->aln_match; J.mismatch = prm->aln_mismatch; J.ext = prm->aln_ext; J.k = 1; J.open = d_open.p; J.match_id = nullptr;
             J.score = nullptr; J.ncols = nullptr; J.nmatch = nullptr; J.region = nullptr; J.bp = d_bp.p; J.bp_windows = nwinmax; J.window = W; J.span = d_span.p;
-            const int aln_mode = prm->aln_mode == 2 ? 1 : prm->aln_mode;
+            int aln_mode = prm->aln_mode == 2 ? 1 : prm->aln_mode;
+            if (aln_mode == 3) { aln_mode = 1; J.clip = 1; }          // edit distance + overlap-span clipping (include/ngsid.h)
             if (aln_mode == 1) rc = ngsid_launch_ed_align(ctx, J, RD.maxlen, maxb, nullptr);          // unit-cost, bit-parallel (k_ed_align.hip)
             else rc = ngsid_launch_align(ctx, J, RD.maxlen, maxb, prm->aln_open);
             if (rc) return rc;
@@ -983,8 +988,8 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         }
         DevBuf<PSeq> d_bbs; HIPCHK(ctx, d_bbs.alloc(bbs.size()));
         if (!bbs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_bbs.p, bbs.data(), sizeof(PSeq) * bbs.size(), hipMemcpyHostToDevice, ctx->stream));
-        bool any_tgs = prm->trim >= 2; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
-        HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, prm->trim >= 2 ? 1 : 0};
+        bool any_tgs = prm->trim == 2; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
+        HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, (prm->trim >= 2 ? 1 : 0) | (prm->trim == 3 ? 4 : 0)};      // trim_tiles: 1 = trim tile consensuses, 4 = except the tile that ends a unit (trim 3)
         ht.mark("unit lists");
         rc = run_hierarchy(ctx, (const PSeq*)d_lay_raw.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
         ht.mark("hierarchy");
@@ -993,7 +998,7 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         for (size_t u = 0; u < units.size(); ++u) {
             const uint32_t g = unit_gw[u].first; const int ws = unit_gw[u].second * W; const int wlen = polish_wlen((int)B[g].size(), W, unit_gw[u].second);
             std::string c = units[u].has_result ? units[u].result : std::string();
-            if (!c.empty() && prm->trim && (tgs[g] || prm->trim >= 2) && units[u].cov.size() == c.size()) {
+            if (!c.empty() && prm->trim && (tgs[g] || prm->trim == 2) && units[u].cov.size() == c.size()) {      // trim 3: racon's window rule (TGS only) with trimmed tiles
                 const uint32_t avg = (uint32_t)(nlayers[u] / 2); int b = 0, e = (int)c.size() - 1;
                 for (; b < (int)c.size(); ++b) if (units[u].cov[b] >= avg) break;
                 for (; e >= 0; --e) if (units[u].cov[e] >= avg) break;

@@ -386,7 +386,8 @@ static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P
         int Dl = D > 0 ? D : ncur;
         int ntiles = ntiles_of(ncur, Dl);
         pout* outs = malloc(sizeof(pout) * (size_t)(ncur + 1)); int nout = 0;
-        pprm PL = *P; if (level > 0 && P->trim_tiles) PL.trim_tiles |= 2;      /* upper levels: minority-insertion rule of EMIT */
+        pprm PL = *P; PL.trim_tiles = P->trim_tiles & 1; if (level > 0 && PL.trim_tiles) PL.trim_tiles |= 2;      /* upper levels: minority-insertion rule of EMIT */
+        if ((P->trim_tiles & 4) && ntiles == 1) PL.trim_tiles = 0;      /* trim 3: the tile that ends a unit keeps the ends of its backbone where no member reaches them (racon's NGS windows) */
         for (int t = 0; t < ntiles; ++t) { int a = t * Dl, b = t + 1 == ntiles ? ncur : a + Dl; nout += run_tile(cur + a, b - a, backbone, &PL, outs + nout, want_cov && ntiles == 1); }
         if (getenv("ODBG_HIER") && backbone && backbone->len < atoi(getenv("ODBG_HIER"))) {      /* dev aid: tile outputs of a short (last) window, level by level */
             int nshort = 0, nlong = 0, nsemi = 0; const int wl = backbone->len;
@@ -519,10 +520,12 @@ int32_t ongsid_polish_trace(const ngsid_reads_t* backbones, const ngsid_reads_t*
 }
 static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                            const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used, ptrace* tr) {
-    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : default_band(reads), prm->node_cap, prm->trim >= 2 };
+    pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : default_band(reads), prm->node_cap, (prm->trim >= 2 ? 1 : 0) | (prm->trim == 3 ? 4 : 0) };      /* trim_tiles: 1 = trim tile consensuses, 4 = but not the LAST tile of a unit (trim 3) */
     const int W = prm->window > 0 ? prm->window : 500;
     int aln_mode = prm->aln_mode;
     if (aln_mode == 2) aln_mode = 1;
+    const int clip_span = (g_polish_rules & 1) || aln_mode == 3;      /* aln_mode 3 (round 5): edit distance + overlap-span clipping, see include/ngsid.h */
+    if (aln_mode == 3) aln_mode = 1;
     uint64_t total = 0; int overflow = 0; out_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         int Blen = (int)(backbones->off[g + 1] - backbones->off[g]);
@@ -568,7 +571,7 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                 int qi = 0, ti = 0, qb = -1, tb = -1, qe = -1, te = -1;
                 int* wf = malloc(sizeof(int) * 4 * ((size_t)nwin + 1)); for (int x = 0; x < 4 * nwin; ++x) wf[x] = -1;
                 int x0 = 0, x1 = c - 1;
-                if (g_polish_rules & 1) {        /* overlap span: first .. last run of >= 15 equal columns */
+                if (clip_span) {        /* overlap span: first .. last run of >= 15 equal columns */
                     int run = 0, first = -1, last = -1;
                     for (int x = 0; x < c; ++x) { if (ops[x] == 0) { if (++run >= 15) { if (first < 0) first = x - 14; last = x; } } else run = 0; }
                     if (first < 0) { x0 = c; x1 = c - 1; } else { x0 = first; x1 = last; }
@@ -615,7 +618,7 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                 if (LV[wdx].n >= 2) {
                     pseq bb; bb.s = B + ws; bb.q = NULL; bb.len = wlen; bb.uw = 0; bb.cw = 0; bb.mode = NGSID_POA_GLOBAL; bb.a0 = 0; bb.a1 = -1;
                     len = run_hierarchy(LV[wdx].v, LV[wdx].n, &bb, &P, prm->tile_depth, NGSID_POA_GLOBAL, &c, &cov, 1);
-                    if (len > 0 && prm->trim && (tgs || prm->trim >= 2) && cov) {      /* racon trims TGS windows only; trim>=2 = every window (build choice) */
+                    if (len > 0 && prm->trim && (tgs || prm->trim == 2) && cov) {      /* racon trims TGS windows only; trim == 2 = every window (build choice); trim == 3 = racon's window rule, tiles trimmed */
                         uint32_t avg = (uint32_t)(LV[wdx].n / 2); int b = 0, e = len - 1;
                         for (; b < len; ++b) if (cov[b] >= avg) break;
                         for (; e >= 0; --e) if (cov[e] >= avg) break;

@@ -184,3 +184,23 @@ def test_reference_order_rules_of_round_5(oracle):
     assert S["0"]["clusters_where_polishing_increases_the_distance_of_the_draft"] == 9 and S["3"]["clusters_where_polishing_increases_the_distance_of_the_draft"] == 7
     assert S["7"]["clusters_where_polishing_increases_the_distance_of_the_draft"] == 0 and S["7"]["clusters_where_the_exact_amplicon_is_not_a_fixed_point"] == 0
     assert S["7"]["sum_of_edits_after_3_iterations_from_draft"] <= S["7"]["sum_of_edits_of_the_drafts"]
+
+
+def test_overlap_span_clipping_polishes_a_trimmed_backbone(oracle):
+    """round 5, ngsid_polish_params_t.aln_mode = 3: of the read -> backbone alignment only the columns between the first and the last run of 15 equal columns count
+    (minimap2's chain ends in front of racon's edlib call).  Reads that carry primers at both ends against a backbone that has been primer-trimmed: the whole-read
+    aligner (mode 1) forces the primer bases into the backbone's ends and the polished sequence grows by a primer; with clipping and trim 3 (tile consensuses trimmed as in
+    the shipped mode, but the tile that ends a window keeps the ends of its backbone where no layer reaches them - racon's rule for NGS windows) the trimmed backbone comes
+    back as the amplicon body, and an untrimmed backbone is returned as it is under either mode."""
+    from ngspeciesid_amd import barcode_trimmer
+    tails = barcode_trimmer.get_universal_tails()
+    body = synth.make_species(1, 520, 0.15, seed=8)[0].tobytes().decode()
+    amp = tails["1_F_fw"] + body + tails["2_R_fw"]
+    rd = synth.make_reads([np.frombuffer(amp.encode(), dtype=np.uint8)], 300, mu=16.0, seed=3, rc_fraction=0.5)
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    def run(bb, mode, trim):
+        return oracle.polish(ReadSet.from_strings([bb]), rs, [0, rs.n], polish_params(iters=2, k=13, w=20, tile_depth=6, band=0, trim=trim, aln_mode=mode, stop_when_stable=0))[0][0]
+    assert run(body, 3, 3) == body
+    grown = run(body, 1, 2)
+    assert len(grown) > len(body) + 15 and body in grown or edit_distance(grown, body) >= 15          # mode 1 pulls a primer back in
+    assert run(amp, 3, 3) == amp and run(amp, 1, 2) == amp

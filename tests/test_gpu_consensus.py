@@ -270,3 +270,35 @@ def test_foreign_base_is_reported_by_every_polish_call(gpu_api):
             gpu_api.polish(bb, bad, [0, bad.n], prm)
         assert "ACGTN" in str(e.value)
     assert gpu_api.polish(bb, rs, [0, rs.n], prm)[0] == [sp[0].tobytes().decode()]
+
+
+def test_overlap_span_clipping_equals_the_oracle(gpu_api, oracle):
+    """round 5, aln_mode 3 (edit distance + overlap-span clipping; csrc/k_ed_align.hip CLIP instance): HIP == oracle bytes and read counts - reads with primers at both ends
+    and both strands against primer-trimmed backbones (clipping at both ends of every read), against untrimmed ones, with racon's trimming rule and with trim 2, two groups,
+    a read too noisy to hold a run of 15 equal columns among them"""
+    from ngspeciesid_amd import barcode_trimmer
+    tails = barcode_trimmer.get_universal_tails()
+    bodies = [b.tobytes().decode() for b in synth.make_species(2, 520, 0.15, seed=8)]
+    amps = [tails["1_F_fw"] + b + tails["2_R_fw"] for b in bodies]
+    rd = synth.make_reads([np.frombuffer(a.encode(), dtype=np.uint8) for a in amps], 1200, mu=15.0, seed=3, rc_fraction=0.5)
+    seq = rd["seq"].numpy().copy(); off = rd["off"].numpy()
+    rng = np.random.default_rng(5); a0, a1 = int(off[7]), int(off[8]); seq[a0:a1:6] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, len(seq[a0:a1:6]))]      # read 7: an error every six bases
+    rs = ReadSet(seq, rd["qual"].numpy(), off.astype(np.uint64))
+    spc = rd["species"].numpy(); order = np.argsort(spc, kind="stable").astype(np.uint32); n0 = int((spc == 0).sum())
+    from ngspeciesid_amd import runtime
+    host = runtime.new_api(options={"poa_host_levels": 1})
+    try:
+        for bbs in (bodies, amps):
+            for trim in (3, 2, 1):
+                prm = polish_params(iters=2, k=13, w=20, tile_depth=6, band=0, trim=trim, aln_mode=3, stop_when_stable=0)
+                a, ua = gpu_api.polish(ReadSet.from_strings(bbs), rs, [0, n0, rs.n], prm, read_order=order)
+                b, ub = oracle.polish(ReadSet.from_strings(bbs), rs, [0, n0, rs.n], prm, read_order=order)
+                assert a == b and np.array_equal(ua, ub), (len(bbs[0]), trim)
+                if trim == 3:
+                    # trim 3 = tile consensuses trimmed as in the shipped mode, EXCEPT the tile that ends a window (racon's NGS windows keep their backbone ends): with clipped
+                    # layers a trimmed backbone and an untrimmed one are both fixed points; the host-driven level loop gives the same bytes as the device-driven one
+                    assert a == bbs
+                    c, uc = host.polish(ReadSet.from_strings(bbs), rs, [0, n0, rs.n], prm, read_order=order)
+                    assert c == a and np.array_equal(uc, ua)
+    finally:
+        host.close()
