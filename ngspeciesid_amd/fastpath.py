@@ -355,41 +355,22 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
         from . import barcode_trimmer
         barcodes = barcode_trimmer.get_universal_tails() if args.remove_universal_tails else barcode_trimmer.read_barcodes(args.primer_file)
         logging.debug("Detecting and removing universal tails" if args.remove_universal_tails else "Detecting and removing primers")
-        # The reference trims the drafts, polishes the trimmed sequences (minimap2 clips the primer ends of the reads, which lie outside the
-        # overlap), trims again and re-polishes if something was found.  This build's polisher aligns every read END TO END, so reads that
-        # overhang a trimmed backbone would carry the primers back in as insertions.  Hence: merge decisions and the reference files use the
-        # trimmed drafts, polishing runs on the UNTRIMMED drafts (every read base has a place), and the polished sequences are trimmed once more.
-        full = [c[2] for c in centers]
+        # The reference's order (round 5; NGSpeciesID:134-152): trim the drafts, merge, polish the TRIMMED sequences - minimap2 keeps the primer ends of the reads out of
+        # racon's alignment, here the polisher's overlap-span clipping does (aln_mode 3: of a read only the columns between its first and last run of 15 equal columns
+        # count) together with trim 3 (a window keeps the ends of its backbone where no layer reaches them, as racon's NGS windows do) - then look for primers again and,
+        # only if one was removed, run detect_reverse_complements + polish_sequences a second time.  (Rounds 2 - 4 polished the UNTRIMMED drafts and trimmed afterwards,
+        # because the whole-read aligner carried the primers back into a trimmed backbone.)
         barcode_trimmer.remove_barcodes(centers, barcodes, args)
         logging.debug("{0} centers formed".format(len(centers)))
-        used = {}
-        merged = _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, polish_backbones={c[1]: f for c, f in zip(centers, full)}, used_out=used)
-        full_pol = {m[1]: m[2] for m in merged}                                                       # polished, untrimmed
-        if barcode_trimmer.remove_barcodes(merged, barcodes, args):                                   # NGSpeciesID:147-152
-            # the reference now runs detect_reverse_complements + polish_sequences again on the trimmed sequences.  Here: the merge decisions are
-            # taken again on the TRIMMED polished sequences; only if they change the set of centres are the merged groups polished again (from the
-            # surviving centre's untrimmed polished sequence, then trimmed) - a group whose centre list did not change would be polished from the
-            # sequence the polisher just returned, i.e. from its own fixed point.
-            again = pipeline.detect_reverse_complements(api, [list(m) for m in merged], args.rc_identity_threshold)
-            if len(again) != len(merged):
-                logging.debug("%d centres merge after trimming: polishing the merged groups again" % (len(merged) - len(again)))
-                used = {}
-                merged = _merge_and_polish(args, sr, work, [list(m) for m in merged], groups, node_cap, api, acc_id, T, polish_backbones=full_pol, used_out=used)
-                barcode_trimmer.remove_barcodes(merged, barcodes, args)
-            for nr, c_id, seq, cs in merged:          # the trimmed result is what the run reports, in the last iteration's file and in consensus.fasta alike (same header tags)
-                folder = os.path.join(args.outfolder, "racon_cl_id_{0}".format(c_id))
-                if os.path.isdir(folder):
-                    name = "consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr)
-                    last = os.path.join(folder, "racon_polished_it_{0}.fasta".format(max(args.racon_iter - 1, 0)))
-                    with open(last, "w") as f:
-                        f.write(">{0} LN:i:{1} RC:i:{2} XC:f:1.000000\n{3}\n".format(name, len(seq), int(used.get(c_id, nr)), seq))
-                    shutil.copyfile(last, os.path.join(folder, "consensus.fasta"))
+        merged = _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, clip=True)
+        if barcode_trimmer.remove_barcodes(merged, barcodes, args):                                   # NGSpeciesID:147-152: a primer was still there after polishing
+            merged = _merge_and_polish(args, sr, work, [list(m) for m in merged], groups, node_cap, api, acc_id, T, clip=True)
         return merged
     logging.debug("{0} centers formed".format(len(centers)))
     return _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T)
 
 
-def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, polish_backbones=None, used_out=None):
+def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T, polish_backbones=None, used_out=None, clip=False):
     """detect_reverse_complements + polish_sequences (consensus.py:148-183,186-246): centers = [n_reads, c_id, sequence, cluster indices]"""
     t0 = time()
     for folder in glob.glob(os.path.join(args.outfolder, "racon_cl_id_*")):
@@ -444,7 +425,7 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
     if getattr(args, "racon", False) and args.racon_iter >= 0:
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in polish_lists]))).astype(np.uint64)
         bb = ReadSet.from_strings([(polish_backbones or {}).get(m[1], m[2]) for m in merged])
-        prm = polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=2)
+        prm = polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=3 if clip else 2, aln_mode=3 if clip else 2)      # clip: backbones are primer-trimmed (include/ngsid.h: aln_mode 3, trim 3)
         ro = np.concatenate(polish_lists).astype(np.uint32)
         if args.racon_iter >= 1:                     # every iteration's sequence: run_racon leaves racon_polished_it_{i}.fasta behind (consensus.py:112-120)
             its, its_used = api.polish_trace(bb, work, p_off, prm, read_order=ro)

@@ -129,10 +129,11 @@ def test_polished_sample_h1_is_pinned(oracle_backend):
 
 @pytest.mark.parametrize("sync_writes", [False, True])
 def test_centres_that_merge_only_after_trimming_are_polished_again(oracle_backend, tmp_path, monkeypatch, sync_writes):
-    """the branch of consensus_and_polish where the merge decisions on the TRIMMED polished sequences differ from those on the drafts (NGSpeciesID:147-152:
-    the reference re-runs detect_reverse_complements + polish_sequences after the second trim).  No natural amplicon pair separates at the clustering thresholds and
-    then reaches 90 % identity once its primers are gone, so the second decision is forced here; checked: the folders and files of the absorbed centre are gone, the
-    surviving centre's files carry the pooled reads of both clusters, the supporting-read count in every header is the sum, and the reported sequence is trimmed."""
+    """The second pass of the trimming flow (NGSpeciesID:147-152: when a primer is still found after polishing, the reference runs detect_reverse_complements +
+    polish_sequences again).  Round 5: the flow has the reference's order - trim the drafts, polish the trimmed sequences with clipped reads, look again - so on clean data
+    the second look finds nothing and there is no second pass; both are forced here (the second remove_barcodes reports a removal, the second merge decision joins the two
+    centres).  Checked: the folders and files of the absorbed centre are gone, the surviving centre's files carry the pooled reads of both clusters, the supporting-read
+    count in every header is the sum, and the reported sequence is the trimmed amplicon body."""
     from ngspeciesid_amd import synth, fastio, barcode_trimmer, pipeline
     from ngspeciesid_amd._capi import ReadSet
     tails = barcode_trimmer.get_universal_tails()
@@ -147,17 +148,26 @@ def test_centres_that_merge_only_after_trimming_are_polished_again(oracle_backen
     def forced(api, centers, thr):
         calls.append(len(centers))
         out = real(api, centers, thr)
-        if len(calls) >= 2 and len(out) == 2:                 # from the second decision on: the smaller centre joins the larger one
+        if len(calls) >= 2 and len(out) == 2:                 # the second decision (second pass): the smaller centre joins the larger one
             a, b = out
             return [[a[0] + b[0], a[1], a[2], list(a[3]) + list(b[3])]]
         return out
 
     monkeypatch.setattr(pipeline, "detect_reverse_complements", forced)
+    real_rm = barcode_trimmer.remove_barcodes
+    rm_calls = []
+
+    def rm(centers, barcodes, args):
+        rm_calls.append(len(centers))
+        found = real_rm(centers, barcodes, args)
+        return True if len(rm_calls) == 2 else found          # the look after polishing "finds" a primer: the reference's second pass runs
+
+    monkeypatch.setattr(barcode_trimmer, "remove_barcodes", rm)
     if sync_writes: monkeypatch.setenv("NGSID_CLI_SYNC_WRITES", "1")          # (both writer modes - background threads that start before the draft, and inline writes)
     else: monkeypatch.delenv("NGSID_CLI_SYNC_WRITES", raising=False)
     flags = ["--t", "1", "--consensus", "--racon", "--racon_iter", "2", "--abundance_ratio", "0.05", "--remove_universal_tails"]
     files = _run(oracle_backend, flags, False, fastq=fq)
-    assert calls[:3] == [2, 2, 2], calls                      # drafts, trimmed polished sequences, and the second _merge_and_polish
+    assert calls == [2, 2] and rm_calls == [2, 2], (calls, rm_calls)          # merge on the trimmed drafts, look after polishing, merge of the second pass
     refs = sorted(k for k in files if k.startswith("consensus_reference_"))
     folders = sorted({k.split("/")[0] for k in files if k.startswith("racon_cl_id_")})
     pooled = sorted(k for k in files if k.startswith("reads_to_consensus_"))
