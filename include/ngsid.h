@@ -30,7 +30,7 @@ extern "C" {
 #define NGSID_ERR_ALPHABET      -3   /* base outside {A,C,G,T,N} met by the minimizer encoder */
 #define NGSID_ERR_CAPACITY      -4   /* caller buffer too small; required size reported in *needed */
 #define NGSID_ERR_HIP           -5   /* HIP runtime error (text in ngsid_last_error) */
-#define NGSID_ERR_TOO_LONG      -6   /* a read exceeds NGSID_MAX_READ_LEN */
+#define NGSID_ERR_TOO_LONG      -6   /* a read exceeds NGSID_MAX_READ_LEN (consensus stages: NGSID_MAX_CONSENSUS_LEN / the POA engine's bounds) */
 #define NGSID_ERR_NO_PTABLE     -7   /* (e1,e2) looked up in a p_shared table with a NaN hole (KeyError in cluster.py:367) */
 
 #define NGSID_MEM_HOST   0u
@@ -38,7 +38,10 @@ extern "C" {
 
 #define NGSID_MAX_K          32      /* k <= 21: 3-bit order-preserving k-mer codes (0=end,A,C,G,N,T) in a uint64; 22..32: two-word codes inside the
                                         library, handed on as dense order-preserving ranks per call (the reference's table has rows for k = 10..30) */
-#define NGSID_MAX_READ_LEN   16384   /* bases per read handled by the LDS-staged kernels */
+#define NGSID_MAX_READ_LEN   65535   /* bases per read: scoring, minimizers, clustering (round 5; reads above 16 384 bases run the minimizer kernel's LONG layout, pairs with a
+                                        sequence above 4 000 bases the int32 aligner) */
+#define NGSID_MAX_CONSENSUS_LEN 16384 /* bases per sequence in the edit-distance aligner / polisher; the POA engine's own bounds are tighter for local-mode scoring
+                                        (match x length < 65 536: 13 107 bases at the reference's match = 5) - NGSID_ERR_TOO_LONG beyond */
 #define NGSID_POA_BAND64_MAXLEN 3000 /* default POA band (ngsid_poa_params_t.band <= 0): 64 columns when every read of the call has at most this many bases, else 128 (round 4: was 1 024; measured on 2 kb reads at 0.1 / 5 / 10 % error the 64-column first attempt + the redo of the tiles that touch the band edge is 26 - 31 % faster, at 5 kb ONT it is a wash) */
 
 typedef struct ngsid_ctx ngsid_ctx;

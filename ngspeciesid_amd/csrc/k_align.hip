@@ -36,8 +36,9 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
     for (;;) {
         // persistent waves pull pairs from a queue: the grid is sized to what is resident, so there is no tail of idle SIMDs
         uint32_t pq = 0; if (lane == 0) pq = atomicAdd(work_ctr, 1u);
-        const uint64_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)pq);
-        if (p >= J.npairs) break;
+        const uint64_t px = (uint32_t)__builtin_amdgcn_readfirstlane((int)pq);
+        if (px >= (J.npairs_dev ? (uint64_t)*J.npairs_dev : J.npairs)) break;
+        const uint64_t p = J.pair_list ? (uint64_t)J.pair_list[px] : px;       // (round 5: the long-pair class of a partitioned batch comes as an index list with its count on the device)
         const uint32_t qi = J.qidx[p], ti = J.tidx[p];
         const uint8_t* q = J.qseq + J.qoff[qi]; const int n = (int)(J.qoff[qi + 1] - J.qoff[qi]);
         const uint8_t* t = J.tseq + J.toff[ti]; const int m = (int)(J.toff[ti + 1] - J.toff[ti]);
@@ -219,8 +220,11 @@ void k_sg_align(AlignJob J, uint64_t* __restrict__ tb, uint64_t tb_words_per_wav
 }
 
 template <int RPL>
-static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen)
+static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, bool long_class = false)
 {
+    // long_class: the pairs above the int16 lengths of a partitioned batch - own scratch (the class launches of the same call are still running on theirs), own queue counter
+    DevBuf<uint64_t>& TB = long_class ? ctx->tb_long : ctx->tb; DevBuf<int32_t>& BND = long_class ? ctx->bnd_long : ctx->bnd;
+    const uint32_t ctr_slot = long_class ? 6u : 0u;
     const uint64_t strip = 64ull * RPL;
     const uint64_t nstrips = (max_qlen + strip - 1) / strip;
     const uint64_t words = (nstrips ? nstrips : 1) * ((uint64_t)max_tlen + 63) * 64;
@@ -232,6 +236,8 @@ static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen
     const uint32_t lds_per_wave = 2 * seq_lds + 4096;
     int wpb = 4;
     while (wpb > 1 && (uint64_t)wpb * lds_per_wave > 40 * 1024) wpb >>= 1;
+    if ((size_t)wpb * lds_per_wave > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "aligner needs %zu bytes of LDS per wave", (size_t)wpb * lds_per_wave);
+    if ((size_t)wpb * lds_per_wave > 64 * 1024) HIPCHK(ctx, hipFuncSetAttribute((const void*)k_sg_align<RPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)wpb * lds_per_wave)));   // reads above 30 k bases: both sequences of a pair in LDS are more than the default limit
     int occ = 0;
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_sg_align<RPL>, 64 * wpb, (size_t)wpb * lds_per_wave));
     if (occ < 1) occ = 1;
@@ -239,13 +245,13 @@ static int32_t launch_rpl(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen
     if (want > resident) want = resident;
     const uint64_t blocks = (want + wpb - 1) / wpb;
     const uint64_t nwaves = blocks * wpb;
-    if (ctx->aln_ctr.n < 1) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
-    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p, 0, sizeof(uint32_t), ctx->stream));
+    if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
+    HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p + ctr_slot, 0, sizeof(uint32_t), ctx->stream));
     const uint32_t bnd_stride = (max_tlen + 15u) & ~15u;
-    if (ctx->tb.n < nwaves * words) HIPCHK(ctx, ctx->tb.alloc(nwaves * words));
-    if (ctx->bnd.n < nwaves * 2ull * bnd_stride) HIPCHK(ctx, ctx->bnd.alloc(nwaves * 2ull * bnd_stride));
+    if (TB.n < nwaves * words) HIPCHK(ctx, TB.alloc(nwaves * words));
+    if (BND.n < nwaves * 2ull * bnd_stride) HIPCHK(ctx, BND.alloc(nwaves * 2ull * bnd_stride));
     { ProfScope ps_(ctx, "k_sg_align"); hipLaunchKernelGGL((k_sg_align<RPL>), dim3((unsigned)blocks), dim3(64 * wpb), (size_t)wpb * lds_per_wave, ctx->stream,
-                       job, ctx->tb.p, words, ctx->bnd.p, bnd_stride, lds_per_wave, ctx->aln_ctr.p); }
+                       job, TB.p, words, BND.p, bnd_stride, lds_per_wave, ctx->aln_ctr.p + ctr_slot); }
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }
@@ -274,7 +280,18 @@ int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qle
     if (job.npairs > 0xf0000000ull) NGSID_FAIL(ctx, NGSID_ERR_ARG, "more than 2^32 pairs in one aligner call");
     if (max_tlen > NGSID_MAX_READ_LEN || max_qlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in aligner", NGSID_MAX_READ_LEN);
     if (job.k > 64) NGSID_FAIL(ctx, NGSID_ERR_ARG, "window k > 64 unsupported");
-    if (!job.ops && !ngsid_opt(ctx, "align32", 0) && ngsid_align16_applicable(job, max_qlen, max_tlen, max_open)) return ngsid_launch_align16(ctx, job, max_qlen, max_tlen, min_qlen);   // packed int16 path (bit-identical)
+    if (!job.ops && !ngsid_opt(ctx, "align32", 0)) {
+        if (ngsid_align16_applicable(job, max_qlen, max_tlen, max_open)) return ngsid_launch_align16(ctx, job, max_qlen, max_tlen, min_qlen);   // packed int16 path (bit-identical)
+        // Round 5 (reads up to 65 535 bases): a large batch with a few long sequences keeps its short pairs in the int16 instances - the pairs with a query or a
+        // target above NGSID_ALIGN16_MAXLEN become a class of their own that runs here, in int32, after the others (without this one 40 kb read among the
+        // representatives would send a million 750-base pairs through the int32 kernel at one wave per CU)
+        const uint32_t q16 = std::min<uint32_t>(max_qlen, NGSID_ALIGN16_MAXLEN), t16 = std::min<uint32_t>(max_tlen, NGSID_ALIGN16_MAXLEN);
+        if (job.npairs >= 4096 && q16 > 256 && !job.pair_list && !ngsid_opt(ctx, "align_noclass", 0) && ngsid_align16_applicable(job, q16, t16, max_open)) {      // (= the conditions of the class path of ngsid_launch_align16)
+            int32_t rc = ngsid_launch_align16(ctx, job, q16, t16, min_qlen, NGSID_ALIGN16_MAXLEN); if (rc) return rc;
+            AlignJob jl = job; jl.pair_list = ctx->aln_cls.p + (size_t)NGSID_ALIGN_LONG_CLASS * job.npairs; jl.npairs_dev = ctx->aln_ctr.p + 8 + NGSID_ALIGN_LONG_CLASS;
+            return launch_rpl<16>(ctx, jl, max_qlen, max_tlen, true);
+        }
+    }
     if (max_qlen <= 256) return launch_rpl<4>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 512) return launch_rpl<8>(ctx, job, max_qlen, max_tlen);
     if (max_qlen <= 768) return launch_rpl<12>(ctx, job, max_qlen, max_tlen);

@@ -329,14 +329,18 @@ __constant__ const uint32_t k_cls_bound[NCLS] = {256, 512, 768, 896, 0xffffffffu
 
 // pairs -> per-class index lists (order inside a class is irrelevant: results are written by pair index)
 __global__ __launch_bounds__(256)
-void k_pair_classes(AlignJob J, uint32_t* __restrict__ lists, uint32_t* __restrict__ counts)
+void k_pair_classes(AlignJob J, uint32_t* __restrict__ lists, uint32_t* __restrict__ counts, uint32_t long_len)
 {
+    // long_len > 0: pairs with a query or a target above it form class NCLS (the int32 kernel of k_align.hip takes them)
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int cls = -1;
-    if (p < J.npairs) { const uint32_t qi = J.qidx[p]; const uint32_t ql = (uint32_t)(J.qoff[qi + 1] - J.qoff[qi]); cls = 0; while (ql > k_cls_bound[cls]) ++cls; }
+    if (p < J.npairs) {
+        const uint32_t qi = J.qidx[p]; const uint32_t ql = (uint32_t)(J.qoff[qi + 1] - J.qoff[qi]); cls = 0; while (ql > k_cls_bound[cls]) ++cls;
+        if (long_len) { const uint32_t ti = J.tidx[p]; const uint32_t tl = (uint32_t)(J.toff[ti + 1] - J.toff[ti]); if (ql > long_len || tl > long_len) cls = NCLS; }
+    }
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) {                      // one atomic per wave and class
+    for (int c = 0; c < NCLS + 1; ++c) {                      // one atomic per wave and class
         const unsigned long long m = __ballot(cls == c);
         if (!m) continue;
         const int leader = __ffsll((long long)m) - 1;
@@ -397,7 +401,7 @@ static int32_t launch16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, 
 // the 16-bit path is exact when every score fits comfortably in int16 (see the range argument in DESIGN.md)
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open)
 {
-    return max_qlen <= 4000 && max_tlen <= 4000 && job.match >= 0 && job.match <= 4 && job.mismatch <= 0 && job.mismatch >= -8 &&
+    return max_qlen <= NGSID_ALIGN16_MAXLEN && max_tlen <= NGSID_ALIGN16_MAXLEN && job.match >= 0 && job.match <= 4 && job.mismatch <= 0 && job.mismatch >= -8 &&
            job.ext >= 0 && job.ext <= 4 && max_open >= 0 && max_open <= 16;
 }
 
@@ -410,24 +414,26 @@ static int32_t launch_class(ngsid_ctx* ctx, AlignJob job, int cls, uint32_t max_
 }
 
 // pairs -> NCLS index lists in ctx->aln_cls (class c at offset c * npairs), counts in ctx->aln_ctr[8 + c]; all 16 counters are zeroed first
-int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job)
+int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job, uint32_t long_len)
 {
     const uint64_t n = job.npairs;
+    static_assert(NCLS == NGSID_ALIGN_LONG_CLASS, "the long-pair class is list NCLS");
     if (ctx->aln_ctr.n < 16) HIPCHK(ctx, ctx->aln_ctr.alloc(16));
-    if (ctx->aln_cls.n < (size_t)NCLS * n) HIPCHK(ctx, ctx->aln_cls.reserve((size_t)NCLS * n));
+    if (ctx->aln_cls.n < (size_t)(NCLS + 1) * n) HIPCHK(ctx, ctx->aln_cls.reserve((size_t)(NCLS + 1) * n));
     HIPCHK(ctx, hipMemsetAsync(ctx->aln_ctr.p, 0, 16 * sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_pair_classes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, job, ctx->aln_cls.p, ctx->aln_ctr.p + 8);
+    hipLaunchKernelGGL(k_pair_classes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, job, ctx->aln_cls.p, ctx->aln_ctr.p + 8, long_len);
     HIPCHK(ctx, hipGetLastError());
     return NGSID_OK;
 }
 
-int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t min_qlen)
+int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t min_qlen, uint32_t long_len)
 {
+    // long_len > 0 (the caller has checked the conditions of the class path): max_qlen / max_tlen are clamped to it, longer pairs land in list NCLS for the caller
     // Large batches with mixed query lengths: split the pairs by query-length class so that every pair runs in the instance with the
     // fewest idle rows (a lane owns 2*RP rows; 750-base reads with a few 800-base ones would otherwise all run with RP = 7).
     if (job.npairs >= 4096 && max_qlen > 256 && !job.pair_list && !ngsid_opt(ctx, "align_noclass", 0)) {
         const uint64_t n = job.npairs;
-        { int32_t rcp = ngsid_partition_pairs(ctx, job); if (rcp) return rcp; }
+        { int32_t rcp = ngsid_partition_pairs(ctx, job, long_len); if (rcp) return rcp; }
         // The class launches run CONCURRENTLY (the big class on the context's stream, the others on side streams): a class with a few hundred
         // pairs costs the latency of one pair, which would otherwise be paid once per class and call.  Every launch has its own scratch slice.
         { int32_t rs = ngsid_side_streams(ctx); if (rs) return rs; }

@@ -326,7 +326,7 @@ static int32_t launch_ed_fallback(ngsid_ctx* ctx, const AlignJob& job, uint32_t 
 int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out)
 {
     if (job.npairs == 0) return NGSID_OK;
-    if (max_qlen > NGSID_MAX_READ_LEN || max_tlen > NGSID_MAX_READ_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in the edit-distance aligner", NGSID_MAX_READ_LEN);
+    if (max_qlen > NGSID_MAX_CONSENSUS_LEN || max_tlen > NGSID_MAX_CONSENSUS_LEN) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "sequence longer than %d in the edit-distance aligner", NGSID_MAX_CONSENSUS_LEN);
     if (job.clip) return launch_ed<16, false, true>(ctx, job, max_qlen, max_tlen, dist_out, 14, 0);      // overlap-span clipping (aln_mode 3): the one CLIP instance, unbanded
     // band: wide enough for the usual read-to-draft distance, pairs beyond it take the unbanded launch (the result does not depend on it)
     int bandK = 64 + (int)(max_qlen / 32);

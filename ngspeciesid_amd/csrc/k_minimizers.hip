@@ -39,10 +39,14 @@ template <> struct CodeT<2> { uint64_t hi, lo; __device__ __forceinline__ bool l
 // REG (round 3; windows of up to 16 k-mers, k <= 21 - the ONT default k13 / w20 has 8): no code array and no argmin array either.  The window minima are formed in REGISTERS:
 // 64 consecutive k-mer codes, one per lane, rebuilt from the HPC letters; log2(window) doubling steps with lane shifts (the leftmost-minimum sparse table of the stored layout,
 // without the table); a chunk yields 64 - (window - 1) windows.  3.5 KB of LDS per 800-base read instead of 8.9 KB: the waves per CU are no longer bound by LDS.
-__host__ __device__ inline size_t mz_lds_per_wave(uint32_t maxlen, int W, int KW, int mode = 0 /* 0 stored, 1 lean, 2 reg */)
+// LONG (round 5: reads above MZ_SHORT_LEN = 16 384 and up to NGSID_MAX_READ_LEN = 65 535 bases): the raw read is NOT staged - phases 1-2 read bases and qualities from HBM -, LDS holds
+// the HPC letters and the two histograms only (65 KB at 65 535 bases), and every window scans its k-mers directly (codes rebuilt from the HPC letters).  Such reads are rare in amplicon
+// data; they get a launch of their own (the other reads keep their layout), one wave per read.
+__host__ __device__ inline size_t mz_lds_per_wave(uint32_t maxlen, int W, int KW, int mode = 0 /* 0 stored, 1 lean, 2 reg, 3 long */)
 {
     const size_t ML4 = ((size_t)maxlen + 7) & ~(size_t)3;
     const size_t NC = (((size_t)maxlen > (size_t)W ? (size_t)maxlen : (size_t)W) + 4 + 3) & ~(size_t)3;
+    if (mode == 3) return (NC + 64) + 1024;
     const size_t phase12 = 2 * ML4 + 1024, phase34 = mode ? 0 : NC * 8 * (size_t)KW;      // staged read + histograms | k-mer codes: never live together
     return (NC + 64) + (mode == 2 ? 0 : NC * 2) + (phase12 > phase34 ? phase12 : phase34);
 }
@@ -52,12 +56,13 @@ __global__ __launch_bounds__(256)
 void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t nreads,
                       int k, int w, uint32_t maxlen, uint32_t lds_per_wave,
                       uint64_t* __restrict__ out_codes, uint64_t* __restrict__ out_hi, uint32_t* __restrict__ out_pos, uint32_t* __restrict__ out_cnt,
-                      uint32_t* __restrict__ out_hlen, double* __restrict__ out_herr, double* __restrict__ out_rawerr, int* __restrict__ flag, uint64_t out_base)
+                      uint32_t* __restrict__ out_hlen, double* __restrict__ out_herr, double* __restrict__ out_rawerr, int* __restrict__ flag, uint64_t out_base, uint32_t skip_le)
 {
+    // skip_le: reads of at most that many bases belong to another launch of the same call (0: none); reads above maxlen (the layout bound) likewise
     // out_base: base offset of the first read of this launch - the sparse outputs (out_codes / out_hi / out_pos) start there (round 5: a launch covers one chunk of reads
     // and writes into a scratch of that chunk's size)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool LEAN = MODE == 1, REG = MODE == 2;
+    constexpr bool LEAN = MODE == 1, REG = MODE == 2, LONG = MODE == 3;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv;
     if (r >= nreads) return;
@@ -67,17 +72,19 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
     unsigned char* base_l = smem + (size_t)wv * lds_per_wave;
     uint8_t* hs = base_l; uint16_t* am = (uint16_t*)(hs + NC + 64);
     unsigned char* un = (unsigned char*)am + (REG ? 0 : NC * 2);                          // 8-aligned: NC is a multiple of 4, the wave slice of 16 (REG: no argmin array)
-    uint8_t* sraw = un; uint8_t* qraw = sraw + ML4; int* hist_h = (int*)(un + 2 * ML4); int* hist_r = hist_h + 128;
-    uint64_t* clo = (uint64_t*)un; uint64_t* chi = clo + NC;
     const uint64_t base = off[r];
     const int n = (int)(off[r + 1] - base);
+    if ((uint32_t)n > maxlen || (skip_le && (uint32_t)n <= skip_le)) return;
     const uint8_t* s = seq + base; const uint8_t* q = qual ? qual + base : nullptr;
+    const uint8_t* sraw = LONG ? s : un; const uint8_t* qraw = LONG ? q : un + ML4;                      // LONG: the read stays in HBM
+    int* hist_h = LONG ? (int*)(hs + NC + 64) : (int*)(un + 2 * ML4); int* hist_r = hist_h + 128;
+    uint64_t* clo = (uint64_t*)un; uint64_t* chi = clo + NC;
     // wave-private LDS: instructions of one wave execute in order, so a wave barrier + a drained LDS queue orders its own traffic
     auto lsync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
 
     // ---- 1. stage bases / qualities (dword loads where the read's start allows it), clear the histograms
     for (int c = lane; c < 256; c += 64) hist_h[c] = 0;
-    {
+    if constexpr (!LONG) {
         // the LDS copy starts at the same offset modulo 4 as the global address, so the body moves as aligned dwords on both sides
         auto stage = [&](const uint8_t* g, uint8_t* l) {
             const int head = (int)((4 - ((uintptr_t)g & 3)) & 3);          // bytes until the global address is dword aligned
@@ -92,8 +99,8 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
             }
             for (int i = head + 4 * nd + lane; i < n; i += 64) l[i] = g[i];
         };
-        sraw += (uintptr_t)s & 3; stage(s, sraw);
-        if (q) { qraw += (uintptr_t)q & 3; stage(q, qraw); }
+        sraw += (uintptr_t)s & 3; stage(s, (uint8_t*)sraw);
+        if (q) { qraw += (uintptr_t)q & 3; stage(q, (uint8_t*)qraw); }
     }
     lsync();
 
@@ -164,6 +171,33 @@ void k_hpc_minimizers(const uint8_t* __restrict__ seq, const uint8_t* __restrict
         }
     };
     const int nwin = nk >= W ? nk - W + 1 : 1;
+    if constexpr (LONG) {
+        // ---- 3 + 4 directly: lane l of a round owns window s0 + l and scans its k-mers left to right (leftmost minimum: a later k-mer wins only if strictly smaller)
+        int emitted = 0, carry = -1;
+        for (int s0 = 0; s0 < nwin; s0 += 64) {
+            const int sidx = s0 + lane; int best = -1; CodeT<KW> cb; cb.lo = 0; if constexpr (KW == 2) cb.hi = 0;
+            if (sidx < nwin) {
+                const int e = min(sidx + W, nc);
+                uint64_t l, h; kmer_code(sidx, l, h); cb.lo = l; if constexpr (KW == 2) cb.hi = h; best = sidx;
+                for (int j = sidx + 1; j < e; ++j) {
+                    CodeT<KW> cj; kmer_code(j, l, h); cj.lo = l; if constexpr (KW == 2) cj.hi = h;
+                    if (cj.less(cb)) { cb = cj; best = j; }
+                }
+            }
+            int prev = __shfl_up(best, 1); if (lane == 0) prev = carry;
+            const bool f = sidx < nwin && best != prev;
+            const unsigned long long m = __ballot(f);
+            if (f) {
+                const uint64_t o = base - out_base + (uint64_t)(emitted + __popcll(m & ((1ull << lane) - 1ull)));
+                out_codes[o] = cb.lo; if constexpr (KW == 2) out_hi[o] = cb.hi;
+                out_pos[o] = (uint32_t)best;
+            }
+            emitted += __popcll(m);
+            const int nv = min(64, nwin - s0); carry = __shfl(best, nv - 1);
+        }
+        if (lane == 0) out_cnt[r] = (uint32_t)emitted;
+        return;
+    }
     if constexpr (REG) {
         // ---- 3 + 4 in registers (KW == 1, W <= 16): lane l of a chunk holds the code of k-mer b + l (positions past nc: +infinity); after the doubling steps it holds the
         //      leftmost minimum of [b + l, b + l + W) - valid for the first 64 - (W - 1) lanes, which are the windows of this chunk.  Ties keep the left candidate.
@@ -299,35 +333,42 @@ static int32_t mz_rename_wide(ngsid_ctx* ctx, uint64_t* d_lo, const uint64_t* d_
 
 // one launch over the reads of R (a view: R.off may point into a longer offset array); every output pointer is indexed by the view's read number, the
 // sparse arrays d_codes / d_hi / d_pos by the reads' base offsets minus out_base (= the base offset of the view's first read: the scratch holds one chunk)
+#define MZ_SHORT_LEN 16384u             // reads up to this length run the LDS-staged layouts; longer ones (up to NGSID_MAX_READ_LEN) the LONG layout in a launch of their own
 static int32_t mz_launch(ngsid_ctx* ctx, const DevReads& R, int k, int w, uint64_t out_base,
                          uint64_t* d_codes, uint64_t* d_hi, uint32_t* d_pos, uint32_t* d_cnt, uint32_t* d_hlen, double* d_herr, double* d_rawerr, int* d_flag)
 {
     if (R.n == 0) return NGSID_OK;
     const int W = w - k + 1;
     const int KW = k <= 21 ? 1 : 2;
-    size_t lpw = (mz_lds_per_wave(R.maxlen, W, KW) + 15) & ~(size_t)15;
     const int wpb = 1;                   // one wave per workgroup: the LDS slice of a read (8.3 KB at 750 bases) is what bounds the waves per CU (measured: 9.5 ms per 10^6 reads, 10.2 ms with four waves per workgroup)
-    // layout: 2 = registers (windows of up to 16 k-mers, one-word codes), 1 = lean (long reads: the stored layout needs 180 KB at 16 384 bases, ADVICE r2), 0 = stored;
-    // ngsid_ctx_option "minimizers_mode" (1 stored, 2 lean, 3 registers) / "minimizers_lean" pick one for tests - same output from all three
-    int mode = (KW == 1 && W <= 16) ? 2 : 0;
-    const long long want = ngsid_opt(ctx, "minimizers_mode", 0);
-    if (want == 1) mode = 0; else if (want == 2 || ngsid_opt(ctx, "minimizers_lean", 0) != 0) mode = 1; else if (want == 3 && KW == 1 && W <= 32) mode = 2;
-    if (mode == 0 && lpw * wpb > 160 * 1024) mode = 1;
-    if (mode) lpw = (mz_lds_per_wave(R.maxlen, W, KW, mode) + 15) & ~(size_t)15;
-    const size_t lds = lpw * wpb;
-    if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "minimizer kernel needs %zu bytes of LDS", lds);
     const unsigned blocks = (unsigned)((R.n + wpb - 1) / wpb);
-    {
+    auto run = [&](int mode, uint32_t maxlen, uint32_t skip_le) -> int32_t {
+        const size_t lpw = (mz_lds_per_wave(maxlen, W, KW, mode) + 15) & ~(size_t)15;
+        const size_t lds = lpw * wpb;
+        if (lds > 160 * 1024) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "minimizer kernel needs %zu bytes of LDS", lds);
         ProfScope ps_(ctx, "k_hpc_minimizers");
         auto go = [&](auto kern, uint64_t* hi_p) -> hipError_t {
             if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; }
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, R.maxlen, (uint32_t)lpw, d_codes, hi_p, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag, out_base);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * wpb), lds, ctx->stream, R.seq, R.qual, R.off, R.n, k, w, maxlen, (uint32_t)lpw, d_codes, hi_p, d_pos, d_cnt, d_hlen, d_herr, d_rawerr, d_flag, out_base, skip_le);
             return hipSuccess;
         };
-        if (KW == 1) HIPCHK(ctx, mode == 2 ? go(k_hpc_minimizers<1, 2>, nullptr) : mode == 1 ? go(k_hpc_minimizers<1, 1>, nullptr) : go(k_hpc_minimizers<1, 0>, nullptr));
-        else HIPCHK(ctx, mode == 1 ? go(k_hpc_minimizers<2, 1>, d_hi) : go(k_hpc_minimizers<2, 0>, d_hi));
+        if (KW == 1) HIPCHK(ctx, mode == 3 ? go(k_hpc_minimizers<1, 3>, nullptr) : mode == 2 ? go(k_hpc_minimizers<1, 2>, nullptr) : mode == 1 ? go(k_hpc_minimizers<1, 1>, nullptr) : go(k_hpc_minimizers<1, 0>, nullptr));
+        else HIPCHK(ctx, mode == 3 ? go(k_hpc_minimizers<2, 3>, d_hi) : mode == 1 ? go(k_hpc_minimizers<2, 1>, d_hi) : go(k_hpc_minimizers<2, 0>, d_hi));
+        HIPCHK(ctx, hipGetLastError());
+        return NGSID_OK;
+    };
+    // layout: 2 = registers (windows of up to 16 k-mers, one-word codes), 1 = lean (long reads: the stored layout needs 180 KB at 16 384 bases, ADVICE r2), 0 = stored;
+    // ngsid_ctx_option "minimizers_mode" (1 stored, 2 lean, 3 registers, 4 long) / "minimizers_lean" pick one for tests - same output from all
+    const long long want = ngsid_opt(ctx, "minimizers_mode", 0);
+    if (want == 4) return run(3, R.maxlen, 0);
+    const uint32_t smax = R.maxlen < MZ_SHORT_LEN ? R.maxlen : MZ_SHORT_LEN;
+    if (R.minlen <= MZ_SHORT_LEN) {
+        int mode = (KW == 1 && W <= 16) ? 2 : 0;
+        if (want == 1) mode = 0; else if (want == 2 || ngsid_opt(ctx, "minimizers_lean", 0) != 0) mode = 1; else if (want == 3 && KW == 1 && W <= 32) mode = 2;
+        if (mode == 0 && ((mz_lds_per_wave(smax, W, KW) + 15) & ~(size_t)15) * wpb > 160 * 1024) mode = 1;
+        const int32_t rc = run(mode, smax, 0); if (rc) return rc;
     }
-    HIPCHK(ctx, hipGetLastError());
+    if (R.maxlen > MZ_SHORT_LEN) { const int32_t rc = run(3, R.maxlen, MZ_SHORT_LEN); if (rc) return rc; }
     return NGSID_OK;
 }
 

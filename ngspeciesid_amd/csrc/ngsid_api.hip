@@ -366,13 +366,14 @@ static bool g_score_tables[16] = {false};
 
 #define SC_QS 132      /* quality ring row: two 64-byte slices + pad (33 dwords: lanes hit different banks) */
 #define SC_SS 68       /* sequence slice row */
+template <typename HT>       // histogram counter: 16 bits for reads up to 65 535 bases, 32 bits beyond (round 5: such reads are scored and written, not clustered)
 __global__ __launch_bounds__(64)
 void k_score_reads(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, const uint64_t* __restrict__ off, uint64_t n,
                    int k, double qthr, double* __restrict__ score, double* __restrict__ err, uint8_t* __restrict__ keep)
 {
     __shared__ __attribute__((aligned(16))) uint8_t qt[64 * SC_QS];
     __shared__ __attribute__((aligned(16))) uint8_t st[64 * SC_SS];
-    __shared__ unsigned short hist[128 * 64];
+    __shared__ HT hist[128 * 64];
     __shared__ double tp[128], tn[128];
     const int lane = threadIdx.x;
     const uint64_t r = (uint64_t)blockIdx.x * 64 + lane;
@@ -436,7 +437,6 @@ extern "C" int32_t ngsid_score_reads(ngsid_ctx* ctx, const ngsid_reads_t* reads,
     if (!reads || !score || !err_rate || !keep || k < 1) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
     if (k > 64) NGSID_FAIL(ctx, NGSID_ERR_ARG, "score_reads: k = %d exceeds 64 (the quality ring of the kernel)", (int)k);
     DevReads R; int32_t rc = ngsid_upload_reads(ctx, reads, &R, true); if (rc) return rc;
-    if (R.maxlen > 65535u) NGSID_FAIL(ctx, NGSID_ERR_TOO_LONG, "score_reads: a read of %u bases exceeds 65535 (16-bit quality histogram)", R.maxlen);
     if (!g_score_tables[ctx->device & 15]) {
         HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_p_clamped), NGSID_PHRED_P, sizeof(double) * 128));
         HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_p_nomin), NGSID_PHRED_P_NOMIN, sizeof(double) * 128));
@@ -445,7 +445,9 @@ extern "C" int32_t ngsid_score_reads(ngsid_ctx* ctx, const ngsid_reads_t* reads,
     const uint64_t n = R.n; if (!n) return NGSID_OK;
     DevBuf<double> ds, de; DevBuf<uint8_t> dk;
     HIPCHK(ctx, ds.alloc(n)); HIPCHK(ctx, de.alloc(n)); HIPCHK(ctx, dk.alloc(n));
-    { ProfScope ps_(ctx, "k_score_reads"); hipLaunchKernelGGL(k_score_reads, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, R.seq, R.qual, R.off, n, k, q_threshold, ds.p, de.p, dk.p); }
+    { ProfScope ps_(ctx, "k_score_reads");
+      if (R.maxlen <= 65535u) hipLaunchKernelGGL(k_score_reads<unsigned short>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, R.seq, R.qual, R.off, n, k, q_threshold, ds.p, de.p, dk.p);
+      else hipLaunchKernelGGL(k_score_reads<unsigned int>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, R.seq, R.qual, R.off, n, k, q_threshold, ds.p, de.p, dk.p); }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(score, ds.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(err_rate, de.p, 8 * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -565,7 +567,7 @@ extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t va
     }
     if (!strcmp(name, "release_scratch")) {        // gives the context's grow-only scratch (aligner traceback, POA tiles and levels, polisher arrays) and the cached blocks back to the driver
         (void)hipStreamSynchronize(ctx->stream);
-        ctx->tb.release(); ctx->bnd.release(); ctx->aln_cls.release(); ctx->aln_psorted.release(); ctx->aln_pbin.release(); ctx->ed_tb.release(); ctx->ed_h.release(); ctx->ed_fail.release(); ctx->ed_fail2.release();
+        ctx->tb.release(); ctx->bnd.release(); ctx->tb_long.release(); ctx->bnd_long.release(); ctx->aln_cls.release(); ctx->aln_psorted.release(); ctx->aln_pbin.release(); ctx->ed_tb.release(); ctx->ed_h.release(); ctx->ed_fail.release(); ctx->ed_fail2.release();
         ctx->poa_h.release(); ctx->poa_d.release(); ctx->poa_g.release(); ctx->poa_cov.release();
         for (auto& L : ctx->poa_lv) { L.out.release(); L.seqs.release(); L.job_final.release(); L.out_len.release(); L.out_span.release(); L.job_bb.release(); L.out_cw.release(); L.out_n.release(); L.out_cov.release(); L.job_off.release(); L.seq_idx.release(); L.flags.release(); L.job_list.release(); L.job_unit.release(); L.job_pos.release(); }
         ctx->mzc.valid = false; ctx->mzc_cnt.release(); ctx->mzc_hlen.release(); ctx->mz_off.release(); ctx->mz_scode.release(); ctx->mz_spos.release();
@@ -594,7 +596,7 @@ extern "C" int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap)
         // ... and what THIS context holds in its grow-only scratch buffers (bytes), by purpose
         size_t lv = 0; for (auto& L : ctx->poa_lv) lv += L.out.abytes + L.seqs.abytes + L.out_len.abytes + L.out_span.abytes + L.job_bb.abytes + L.out_cw.abytes + L.out_n.abytes + L.out_cov.abytes + L.job_off.abytes + L.seq_idx.abytes + L.job_list.abytes + L.job_unit.abytes + L.job_pos.abytes;
         const struct { const char* nm; size_t b; } parts[] = {
-            {"mem_cluster_aligner_traceback", ctx->tb.abytes + ctx->bnd.abytes + ctx->aln_cls.abytes + ctx->aln_psorted.abytes + ctx->aln_pbin.abytes + ctx->aln_pint.abytes},
+            {"mem_cluster_aligner_traceback", ctx->tb.abytes + ctx->bnd.abytes + ctx->tb_long.abytes + ctx->bnd_long.abytes + ctx->aln_cls.abytes + ctx->aln_psorted.abytes + ctx->aln_pbin.abytes + ctx->aln_pint.abytes},
             {"mem_polish_aligner_traceback", ctx->ed_tb.abytes + ctx->ed_h.abytes + ctx->ed_fail.abytes + ctx->ed_fail2.abytes},
             {"mem_poa_resident_tiles", ctx->poa_h.abytes + ctx->poa_d.abytes + ctx->poa_g.abytes + ctx->poa_cov.abytes},
             {"mem_poa_level_buffers", lv},

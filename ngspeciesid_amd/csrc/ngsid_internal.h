@@ -75,6 +75,7 @@ struct ngsid_ctx {
     int n_cu = 256;
     DevBuf<uint64_t> tb;      // aligner traceback scratch (grow-only)
     DevBuf<int32_t> bnd;      // aligner strip boundary rows
+    DevBuf<uint64_t> tb_long; DevBuf<int32_t> bnd_long;      // the same for the long-pair class of a partitioned batch (round 5: reads up to 65 535 bases)
     DevBuf<uint32_t> aln_ctr; // aligner work-queue counters (one per launch in flight) + length-class counts
     DevBuf<uint32_t> aln_cls; // pair lists of the length classes
     DevBuf<uint32_t> aln_pint, aln_psorted; DevBuf<uint8_t> aln_pbin;   // paired aligner (k_align16p.hip): bin counters / offsets, pairs sorted by bin, bin of every class entry
@@ -180,11 +181,13 @@ struct AlignJob {            // device pointers
 };
 int32_t ngsid_launch_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open = 1 << 20, uint32_t min_qlen = 0);   // min_qlen: lower bound of the query lengths (lets empty length classes be skipped)
 bool ngsid_align16_applicable(const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int max_open);
-int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t min_qlen = 0);
+#define NGSID_ALIGN16_MAXLEN 4000u      // sequences up to this length run the packed int16 aligners (score range)
+#define NGSID_ALIGN_LONG_CLASS 5        // list / counter index of the pairs above it in a partitioned batch (aln_cls list 5, aln_ctr[13])
+int32_t ngsid_launch_align16(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, uint32_t min_qlen = 0, uint32_t long_len = 0);
 int32_t ngsid_side_streams(ngsid_ctx* ctx);          // creates ctx->side / events on first use
 int32_t ngsid_paired_tb_words(ngsid_ctx* ctx, int cls, uint64_t npairs, uint32_t max_tlen, uint64_t* words);      // k_align16p.hip: two pairs per wave for every single-strip length class (queries of up to 896 bases)
 int32_t ngsid_launch_paired_class(ngsid_ctx* ctx, const AlignJob& job, int cls, uint32_t max_tlen, hipStream_t st, uint64_t* tb);
-int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job);      // query-length classes {<=256, <=512, <=768, <=896, rest}: lists in ctx->aln_cls, counts in ctx->aln_ctr[8..12]
+int32_t ngsid_partition_pairs(ngsid_ctx* ctx, const AlignJob& job, uint32_t long_len = 0);      // query-length classes {<=256, <=512, <=768, <=896, rest}: lists in ctx->aln_cls, counts in ctx->aln_ctr[8..12]
 int32_t ngsid_launch_ed_align(ngsid_ctx* ctx, const AlignJob& job, uint32_t max_qlen, uint32_t max_tlen, int32_t* dist_out);   // k_ed_align.hip (uses qseq..npairs, bp, bp_windows, window, span)
 
 typedef unsigned int ngsid_v4u __attribute__((ext_vector_type(4)));

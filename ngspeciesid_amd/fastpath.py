@@ -24,7 +24,8 @@ from ._capi import ReadSet, cluster_params, poa_params, polish_params, POA_LOCAL
 from .hostutil import subset_reads
 from .ptable import select_p_table
 
-MAX_READ_LEN = 16384          # NGSID_MAX_READ_LEN (include/ngsid.h)
+MAX_READ_LEN = 65535          # NGSID_MAX_READ_LEN (include/ngsid.h): scoring, minimizers, clustering
+MAX_CONSENSUS_LEN = 13107     # local-mode POA at the reference's match = 5 (5 x length < 65 536, include/ngsid.h NGSID_MAX_CONSENSUS_LEN)
 
 
 def _repr_floats(x):
@@ -158,8 +159,6 @@ def score_and_sort(args, api, T=None):
     names, rs, _ = fastio.read_fastq(args.fastq)
     T["read_fastq"] = time() - t0; t0 = time()
     lens = np.diff(rs.off.astype(np.int64))
-    if rs.n and lens.max() > 65535:
-        raise SystemExit("a read of %d bases exceeds what the read scorer handles (65 535); filter the input first" % int(lens.max()))
     # round 5: the reads cross PCIe ONCE, in file order; they are scored there, and the score order is a gather on the device (ngsid_reads_subset) - the host copy in
     # score order (the writers' and the TSVs' source) is gathered by a worker thread while the device clusters.  Backends without the entry point (the test oracle) and
     # empty inputs take the host route of round 4.
@@ -344,7 +343,12 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
             _write(args, _write_pooled, path, groups[c], sr)
             args._pooled_early[int(reps[c])] = (c,)
     sub_off = np.concatenate(([0], np.cumsum([len(g) for g in groups]))).astype(np.uint64)
-    long_reads = bool(sr.lens[np.concatenate(groups)].max() > 1000)
+    gmax = int(sr.lens[np.concatenate(groups)].max())
+    if gmax > MAX_CONSENSUS_LEN:
+        bad = [int(reps[c]) for c in range(nsel) if int(sr.lens[groups[c]].max()) > MAX_CONSENSUS_LEN]
+        raise ValueError("clusters %s hold reads of up to %d bases: this build's POA engine forms consensus of reads up to %d bases (clustering itself handles %d); "
+                         "filter by length (--m / --s) or raise --abundance_ratio so that these clusters are not polished" % (bad[:10], gmax, MAX_CONSENSUS_LEN, MAX_READ_LEN))
+    long_reads = gmax > 1000
     node_cap = 22 if long_reads else 0
     drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=getattr(args, "poa_tile_depth", pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=pipeline.DRAFT_TRIM),
                                read_order=np.concatenate(groups).astype(np.uint32))

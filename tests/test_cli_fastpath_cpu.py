@@ -51,7 +51,7 @@ def test_soft_masked_iupac_and_overlong_reads_do_not_abort(oracle_backend, tmp_p
     recs = [src[i:i + 4] for i in range(0, len(src) - 3, 4)]
     recs[3][1] = recs[3][1][:50].lower() + recs[3][1][50:]                       # soft-masked prefix
     recs[7][1] = recs[7][1][:20] + "RYKM" + recs[7][1][24:]                      # IUPAC codes
-    long_seq = (recs[0][1] * 30)[:17000]
+    long_seq = (recs[0][1] * 120)[:70000]                                         # beyond NGSID_MAX_READ_LEN = 65 535 (round 5; 16 384 before)
     recs.append(["@too_long_read", long_seq, "+", "I" * len(long_seq)])
     fq = tmp_path / "in.fastq"; fq.write_text("\n".join("\n".join(r) for r in recs) + "\n")
     import logging
