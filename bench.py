@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--species", type=int, default=None)
     ap.add_argument("--length", type=int, default=None)
     ap.add_argument("--mu", type=float, default=None)
-    ap.add_argument("--tile-depth", type=int, default=6, help="reads per POA tile (library / CLI default 6)")
+    ap.add_argument("--tile-depth", type=int, default=4, help="reads per POA tile (pipeline / CLI default 4 since round 5)")
     ap.add_argument("--band", type=int, default=0, help="POA band width in columns of the first attempt (64 / 128 / 256); 0 = library default (64 for reads up to 3 000 bases)")
     ap.add_argument("--node-cap", type=int, default=0, help="POA graph capacity in 1/16 of the first sequence length (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=1500, help="reads per worker process of the cpu_baseline leg")

@@ -12,10 +12,12 @@ from ._capi import Api, ReadSet, cluster_params, poa_params, polish_params, POA_
 # Draft consensus: coverage-trim the ends of every tile consensus (ngsid_poa_params_t.trim).  spoa itself completes the heaviest bundle to
 # a sink, so its consensus can end in the unsupported tail of a single read, and racon cannot shorten or extend a backbone end; with the
 # trim the drafts of the noisy synthetic sets equal their amplicons before polishing.
-# Reads per exact-order POA tile (draft and polishing windows).  With coverage-trimmed tile consensuses the depth does not matter for the accuracy
-# (exact from 5.6 % to 14.3 % read error at depths 8 / 6 / 5); 6 is the fastest at 1 M reads (depth 8: every second tile ends
-# with an eighth member that no longer fits the edge room and the graphs are largest when the last members are aligned).
-TILE_DEPTH = 6
+# Reads per exact-order POA tile (draft and polishing windows).  With coverage-trimmed tile consensuses the depth does not matter for the accuracy on deep
+# clusters (exact from 5.6 % to 14.3 % read error at depths 8 / 6 / 5 / 4: 0 of 250 polished sequences wrong per depth, 40 000 reads per cluster), and on shallow,
+# noisy ones the SMALLER tile is the better one (100 reads per cluster at 14.3 % error: 12 of 100 polished sequences wrong at depth 4, 25 at depth 6; 200 reads and
+# more: none at either) - profiles/r05_tile_depth_sweep.txt.  Round 5: 4 (was 6 since round 3): the graphs of a tile stay smaller (fewer rows per alignment), k_poa_tile
+# 396 -> 363 ms per C3 step, the step 780 -> 748 ms; depth 3 loses the majority inside a tile (2 edits per amplicon on the bench workload) and is slower again.
+TILE_DEPTH = 4
 import os as _os
 _TOUCH = bool(_os.environ.get("NGSID_TOUCH"))          # dev probe (round 5): one trivial device operation in the middle of the host work between clustering and consensus
 DRAFT_TRIM = 1

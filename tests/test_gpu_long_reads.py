@@ -148,3 +148,36 @@ def test_a_40kb_read_clusters_like_the_oracle_says(gpu_api, oracle):
         members = [i for i, t in enumerate(tags) if t == tag]
         assert len(members) >= 3 and len({int(rep[i]) for i in members}) == 1, (tag, [int(rep[i]) for i in members])      # one cluster per long template
     assert int(np.asarray(got[3]).max()) > 0
+
+
+def test_cli_clusters_long_reads_and_names_the_consensus_limit(gpu_api, oracle, tmp_path):
+    """the CLI with 20 kb reads among the reference's sample_h1 reads: without --consensus every output file == the run with the oracle as the backend (the long reads
+    are clustered, not singletons); with --consensus and a cutoff that selects the long cluster the run ends with a message that names the cluster and the limit"""
+    import os
+    from oracle_lib import GOLD
+    from ngspeciesid_amd import cli as _cli, fastpath
+    from test_gpu_cli import _files
+    rng = np.random.default_rng(23)
+    tpl = rng.integers(0, 4, 20000)
+    recs = open(os.path.join(GOLD, "sample_h1.fastq")).read().rstrip("\n").split("\n")
+    for i in range(4):
+        a = _noisy(rng, tpl, 0.04)
+        recs += ["@long_%d" % i, _s(a), "+", _q(rng, len(a), 18, 30)]
+    fq = tmp_path / "in.fastq"; fq.write_text("\n".join(recs) + "\n")
+    res = {}
+    for name, api in (("hip", gpu_api), ("oracle", oracle)):
+        out = str(tmp_path / ("out_" + name))
+        args = _cli.build_parser().parse_args(["--ont", "--fastq", str(fq), "--outfolder", out, "--t", "1"])
+        os.makedirs(out, exist_ok=True)
+        fastpath.main(args, api=api)
+        res[name] = _files(out)
+    assert sorted(res["hip"]) == sorted(res["oracle"])
+    for k in res["hip"]:
+        assert res["hip"][k] == res["oracle"][k], k
+    rows = [l.split("\t") for l in res["hip"]["final_clusters.tsv"].decode().splitlines()]
+    longs = {r[0] for r in rows if r[1].startswith("long_")}
+    assert len(longs) == 1 and sum(1 for r in rows if r[0] in longs) == 4          # one cluster of the four long reads
+    out = str(tmp_path / "out_cons"); os.makedirs(out, exist_ok=True)
+    args = _cli.build_parser().parse_args(["--ont", "--fastq", str(fq), "--outfolder", out, "--t", "1", "--consensus", "--racon", "--abundance_ratio", "0.01", "--rc_identity_threshold", "0.9"])
+    with pytest.raises(ValueError, match="POA engine forms consensus of reads up to 13107"):
+        fastpath.main(args, api=gpu_api)
