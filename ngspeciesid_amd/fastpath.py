@@ -381,7 +381,9 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
         shutil.rmtree(folder)
     for file in glob.glob(os.path.join(args.outfolder, "consensus_reference_*")):
         os.remove(file)
+    T["rc_merge_cleanup"] = T.get("rc_merge_cleanup", 0.0) + time() - t0; t1 = time()
     merged = pipeline.detect_reverse_complements(api, centers, args.rc_identity_threshold)
+    T["rc_merge_detect"] = T.get("rc_merge_detect", 0.0) + time() - t1
     logging.debug(f"{len(merged)} consensus formed.")
     pooled = []
     seen_clusters = set(); polish_lists = []          # the polisher takes a read under one centre only (pipeline.pooled_read_lists): first centre wins

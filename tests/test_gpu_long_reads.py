@@ -181,3 +181,38 @@ def test_cli_clusters_long_reads_and_names_the_consensus_limit(gpu_api, oracle, 
     args = _cli.build_parser().parse_args(["--ont", "--fastq", str(fq), "--outfolder", out, "--t", "1", "--consensus", "--racon", "--abundance_ratio", "0.01", "--rc_identity_threshold", "0.9"])
     with pytest.raises(ValueError, match="POA engine forms consensus of reads up to 13107"):
         fastpath.main(args, api=gpu_api)
+
+
+def test_lengths_around_the_layout_and_class_boundaries(gpu_api, oracle):
+    """reads of 16 382 ... 16 387 bases (the LDS-staged layouts end at 16 384, the LONG layout starts at 16 385) at four (k, w) pairs = the register, the stored / lean and the
+    two-word layouts on the short side; and a partitioned batch whose queries and targets sit at 3 998 ... 4 002 bases (the int16 classes end at 4 000): all == the oracle"""
+    rng = np.random.default_rng(29)
+    seqs, quals = [], []
+    for L in (16382, 16383, 16384, 16385, 16386, 16387, 800, 16385):
+        a = rng.integers(0, 4, L); rep = rng.random(L) < 0.2; a[1:][rep[1:]] = a[:-1][rep[1:]]
+        seqs.append(_s(a)); quals.append(_q(rng, L, 2, 45))
+    rs = ReadSet.from_strings(seqs, quals)
+    for k, w in ((13, 20), (15, 50), (21, 21), (28, 40)):
+        got = gpu_api.hpc_minimizers(rs, k, w); exp = oracle.hpc_minimizers(rs, k, w)
+        for nm, a, b in zip(["moff", "codes", "pos", "hpc_len"], got[:4], exp[:4]):
+            assert np.array_equal(a, b), (k, w, nm)
+        assert np.array_equal(got[4], exp[4], equal_nan=True)
+    qs, ts = [], []
+    for i in range(4200):
+        L = int(rng.integers(257, 300)); a = rng.integers(0, 4, L); qs.append(_s(_noisy(rng, a, 0.07))); ts.append(_s(a))
+    base = rng.integers(0, 4, 4100); j = 0
+    for ql in (3998, 3999, 4000, 4001, 4002):
+        for tl in (3999, 4000, 4001):
+            p = 7 + 270 * j; j += 1
+            q = _noisy(rng, base, 0.03)
+            q = q[:ql] if len(q) >= ql else np.concatenate([q, rng.integers(0, 4, ql - len(q))])
+            qs[p] = _s(q); ts[p] = _s(base[:tl])
+    q = ReadSet.from_strings(qs); t = ReadSet.from_strings(ts)
+    assert int(np.diff(q.off.astype(np.int64)).max()) == 4002
+    idx = np.arange(len(qs), dtype=np.uint32)
+    opens = rng.integers(2, 6, len(qs)).astype(np.int32); mids = rng.integers(5, 12, len(qs)).astype(np.int32)
+    got = gpu_api.sg_align_batch(q, t, idx, idx, opens, 1, 2, -2, 13, mids)
+    exp = oracle.sg_align_batch(q, t, idx, idx, opens, 1, 2, -2, 13, mids)
+    for nm, a, b in zip(["score", "ncols", "nmatch", "region"], got, exp):
+        bad = np.nonzero(a != b)[0]
+        assert len(bad) == 0, (nm, bad[:8], a[bad[:8]], b[bad[:8]])

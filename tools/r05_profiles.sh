@@ -34,7 +34,7 @@ for C in ("FETCH_SIZE","WRITE_SIZE"):
         k=cls(r["Kernel_Name"])
         if k and r["Counter_Name"]==C: agg[k]+=float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
     for k in agg: res[k][C]=agg[k]; res[k]["launches_"+C]=len(disp[k])
-out={"_how":"tools/r05_profiles.sh on the GPU box: rocprofv3 --pmc FETCH_SIZE --kernel-trace and (separate pass) --pmc WRITE_SIZE -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-step --no-cli (C3: 1 M reads, POA tile depth 6, device-driven hierarchy levels)",
+out={"_how":"tools/r05_profiles.sh on the GPU box: rocprofv3 --pmc FETCH_SIZE --kernel-trace and (separate pass) --pmc WRITE_SIZE -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-step --no-cli (C3: 1 M reads, POA tile depth 4, device-driven hierarchy levels)",
      "_units":"counter values are KiB summed over all dispatches of the kernel in ONE bench step; FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section): hbm_bytes_per_step = 2 x fetch + write",
      "workload_reads":1000000,"config":"c3","commit":commit}
 for k,v in res.items():
