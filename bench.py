@@ -333,12 +333,23 @@ def main():
             outd = os.path.join(tmp, "out"); os.makedirs(outd)
             cargs = _cli.build_parser().parse_args([cfg["preset"], "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", str(AB_)])
             cargs.k, cargs.w = K_, W_
+            def _cg():          # CPU-quota throttling of the container during the leg (cgroup v2 cpu.stat / v1): the writers and the launch thread share one quota
+                for f_ in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+                    try:
+                        kv = dict(l.split() for l in open(f_).read().splitlines() if len(l.split()) == 2)
+                        return {"nr_throttled": int(kv.get("nr_throttled", 0)), "throttled_ms": int(kv.get("throttled_usec", int(kv.get("throttled_time", 0)) // 1000)) / 1e3, "usage_s": int(kv.get("usage_usec", 0)) / 1e6}
+                    except Exception:
+                        pass
+                return None
+            cg0 = _cg()
             tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl
+            cg1 = _cg()
             out_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs)
             got = sorted(m[2] for m in r["centers"])
             cli_leg = {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "ratio_to_hot_path": round((n / dcl) / reads_per_s, 3), "t": args.cli_t,
                        "stage_s": {k_: round(v, 3) for k_, v in r["timings"].items()}, "input_fastq_bytes": in_bytes, "output_bytes": out_bytes,
                        "files_on": "tmpfs (/dev/shm)" if base else "disk (tmp dir)", "consensus_equals_amplicons": got == sorted(truths),
+                       "cgroup_cpu_during_the_leg": None if not (cg0 and cg1) else {"throttled_periods": cg1["nr_throttled"] - cg0["nr_throttled"], "throttled_ms": round(cg1["throttled_ms"] - cg0["throttled_ms"], 1), "cpu_seconds_used": round(cg1["usage_s"] - cg0["usage_s"], 2)},
                        "what": "python -m ngspeciesid_amd %s --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio %s: FASTQ parse, score, sort, sorted.fastq, "
                                "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % (cfg["preset"], args.cli_t, AB_)}
         finally:
