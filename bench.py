@@ -342,13 +342,18 @@ def main():
                         pass
                 return None
             cg0 = _cg()
+            api.__dict__["call_s"] = {}; api.lib.ngsid_profile_enable(api.ctx, C.c_int32(1))
             tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl
             cg1 = _cg()
+            pbuf = C.create_string_buffer(1 << 16); api.lib.ngsid_profile_read(api.ctx, pbuf, C.c_uint64(len(pbuf))); api.lib.ngsid_profile_enable(api.ctx, C.c_int32(0))
+            lib_s = {l.split()[0][5:]: float(l.split()[2]) / 1e3 for l in pbuf.value.decode().splitlines() if l.startswith("host_")}
+            bind = {nm: {"caller_s": round(api.call_s.get(nm, 0.0), 3), "library_s": round(v, 3), "difference_s": round(api.call_s.get(nm, 0.0) - v, 3)} for nm, v in lib_s.items()}
             out_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs)
             got = sorted(m[2] for m in r["centers"])
             cli_leg = {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "ratio_to_hot_path": round((n / dcl) / reads_per_s, 3), "t": args.cli_t,
                        "stage_s": {k_: round(v, 3) for k_, v in r["timings"].items()}, "input_fastq_bytes": in_bytes, "output_bytes": out_bytes,
                        "files_on": "tmpfs (/dev/shm)" if base else "disk (tmp dir)", "consensus_equals_amplicons": got == sorted(truths),
+                       "binding_overhead_s": bind,
                        "cgroup_cpu_during_the_leg": None if not (cg0 and cg1) else {"throttled_periods": cg1["nr_throttled"] - cg0["nr_throttled"], "throttled_ms": round(cg1["throttled_ms"] - cg0["throttled_ms"], 1), "cpu_seconds_used": round(cg1["usage_s"] - cg0["usage_s"], 2)},
                        "what": "python -m ngspeciesid_amd %s --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio %s: FASTQ parse, score, sort, sorted.fastq, "
                                "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % (cfg["preset"], args.cli_t, AB_)}

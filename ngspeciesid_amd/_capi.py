@@ -6,6 +6,7 @@ never bound from inside this package.
 """
 from __future__ import annotations
 import ctypes as C
+from time import perf_counter as _perf
 import numpy as np
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -152,7 +153,10 @@ class Api:
 
     def _call(self, name, *args):
         f = self._fn(name)
+        t0 = _perf()
         rc = f(self.ctx, *args) if self.has_ctx else f(*args)
+        cs = self.__dict__.setdefault("call_s", {})        # wall time per entry point as THIS side sees it (ctypes call + the wait for the interpreter lock on return); the library's
+        cs[name] = cs.get(name, 0.0) + _perf() - t0        # own clock for the same calls: "host_<name>" lines of ngsid_profile_read (bench.py config.cli.binding_overhead_s)
         return rc
 
     def upload_reads(self, rs: "ReadSet") -> "ReadSet":

@@ -7,6 +7,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <sched.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -51,11 +53,25 @@ int n_threads(uint64_t work_bytes)
     const uint64_t by_size = work_bytes / (4u << 20) + 1;           // at least 4 MB per thread
     return (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(hw, 32u), by_size));
 }
+// Process-wide bound on the helper threads that RUN at the same time (round 5): every call splits its work into T ranges as before (the partition, and with it every per-range
+// array of the callers, is unchanged), but a range of a background caller only starts once it holds one of usable_cpus() - 3 slots.  The CLI's eight background writers with up to eight helper threads each
+// could put 40+ runnable threads into a 16-CPU quota; an exhausted CFS period stops every thread of the container, the one that drives the GPU included (bench.py
+// config.cli.cgroup_cpu_during_the_leg: one throttled period per leg without the bound, none with it).
+struct HelperSlots {
+    std::mutex m; std::condition_variable cv; int free_;
+    HelperSlots() { int v = (int)usable_cpus() - 3; if (const char* e = getenv("NGSID_HOST_SLOTS")) { const int x = atoi(e); if (x > 0) v = x; } free_ = std::max(2, v); }
+    void acquire() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return free_ > 0; }); --free_; }
+    void release() { { std::lock_guard<std::mutex> l(m); ++free_; } cv.notify_one(); }
+};
+HelperSlots& helper_slots() { static HelperSlots s; return s; }
 template <class F> void parallel_ranges(uint64_t n, int T, F f)
 {
     if (T <= 1 || n < 2) { f(0, n, 0); return; }
+    // the bound applies to BACKGROUND callers (threads that took a cap with ngsid_host_thread_cap: the CLI's writers and gather workers); the thread that drives the GPU never has
+    // helper calls of its own in flight while it launches, so its calls run unbounded and three CPUs of the quota stay free for it and the runtime's threads
+    HelperSlots& S = helper_slots(); const bool bg = t_thread_cap > 0;
     std::vector<std::thread> th; th.reserve(T);
-    for (int t = 0; t < T; ++t) { const uint64_t a = n * t / T, b = n * (t + 1) / T; th.emplace_back([=] { f(a, b, t); }); }
+    for (int t = 0; t < T; ++t) { const uint64_t a = n * t / T, b = n * (t + 1) / T; th.emplace_back([=, &S] { if (bg) S.acquire(); f(a, b, t); if (bg) S.release(); }); }      // (the ranges are leaves: no helper call inside f)
     for (auto& x : th) x.join();
 }
 }  // namespace

@@ -540,6 +540,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
                                         const uint32_t* acc_rank, const int32_t* prev_batch, const double* known_err,
                                         int32_t* rep_of_read, double* hpc_err_out, uint8_t* status_out, uint64_t counters[4])
 {
+    ApiClock api_clock_(ctx, "cluster_greedy");
     if (!ctx) return NGSID_ERR_ARG;
     if (!reads || !prm || !rep_of_read) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
     const int k = prm->k, w = prm->w;

@@ -252,6 +252,7 @@ extern "C" int32_t ngsid_sg_align_batch(ngsid_ctx* ctx, const ngsid_reads_t* que
                                         int32_t k, const int32_t* match_id,
                                         int32_t* score, int32_t* n_cols, int32_t* n_match, int32_t* region)
 {
+    ApiClock api_clock_(ctx, "sg_align_batch");
     if (!ctx) return NGSID_ERR_ARG;
     if (!queries || !targets || (n_pairs && (!q_idx || !t_idx || !open))) NGSID_FAIL(ctx, NGSID_ERR_ARG, "null argument");
     DevReads Q, T;
@@ -558,7 +559,7 @@ extern "C" int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev)
 extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return NGSID_ERR_ARG;
-    static const char* known[] = {"poa_upper_depth", "minimizers_chunk_bases", "poa_level_budget_mb", "cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
+    static const char* known[] = {"minimizers_chunk_bases", "poa_level_budget_mb", "cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
     for (const char* k : known) if (!strcmp(k, name)) { ctx->options[name] = (long long)value; return NGSID_OK; }
     if (!strcmp(name, "touch")) {        // one trivial operation on the context's stream (+ wait): a caller that spends milliseconds on the host between two calls keeps the device out of its idle state
         if (ctx->mzc_fp.n < 2) HIPCHK(ctx, ctx->mzc_fp.alloc(2));

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <chrono>
 #include <memory>
+#include <time.h>
 #include "../../include/ngsid.h"
 
 // Device memory goes through a small per-process cache of freed blocks (size classes with 4 significant bits): the drivers allocate
@@ -118,6 +119,14 @@ static inline long long ngsid_opt(const ngsid_ctx* ctx, const char* name, long l
     snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return NGSID_ERR_HIP; } } while (0)
 
 // brackets one kernel launch with HIP events on the ctx stream when profiling is enabled
+// wall time of an API call as the LIBRARY sees it (profiling on): "host_<name> <calls> <ms>" lines of ngsid_profile_read.  The caller's own clock around the same call, minus this, is
+// what the binding layer adds (for a Python caller with busy worker threads: the wait for the interpreter lock when the call returns) - round 5, the CLI's sporadic stalls
+struct ApiClock {
+    ngsid_ctx* c; const char* nm; struct timespec t0; bool on;
+    ApiClock(ngsid_ctx* ctx, const char* name) : c(ctx), nm(name), on(ctx && ctx->prof) { if (on) clock_gettime(CLOCK_MONOTONIC, &t0); }
+    ~ApiClock() { if (!on) return; struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); auto& a = c->prof_acc[std::string("host_") + nm]; a.first += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6; a.second += 1; }
+};
+
 struct ProfScope {
     ngsid_ctx* c; ProfEntry e; bool on;
     const char* dbg_name; hipStream_t st;

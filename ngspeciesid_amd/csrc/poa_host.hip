@@ -35,7 +35,7 @@ __global__ void k_make_pseq_reads(const uint8_t* seq, const uint8_t* qual, const
     out[i] = S;
 }
 
-struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; int trim_tiles; int Dup = 0 /* members per tile on the levels above 0 (0: D) */; };
+struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; int trim_tiles; };
 
 // Runs all units to completion.  level0: device PSeq array (nseq0 entries) whose max length is maxlen0;
 // bbs: device backbone PSeqs (may be null), maxbb = longest backbone.
@@ -57,8 +57,7 @@ int32_t run_hierarchy_host(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen
             Unit& U = units[u]; if (U.done) continue;
             const uint32_t ncur = (uint32_t)U.seqs.size();
             if (ncur == 0) { U.done = true; continue; }
-            const int Dsel = (level > 0 && hp.Dup > 0 && hp.D > 0) ? hp.Dup : hp.D;
-            const uint32_t Dl = Dsel > 0 ? (uint32_t)Dsel : ncur; const uint32_t nt = poa_ntiles(ncur, Dl);
+            const uint32_t Dl = hp.D > 0 ? (uint32_t)hp.D : ncur; const uint32_t nt = poa_ntiles(ncur, Dl);
             for (uint32_t t = 0; t < nt; ++t) {
                 const uint32_t a = t * Dl, b = t + 1 == nt ? ncur : a + Dl;
                 for (uint32_t x = a; x < b; ++x) seq_idx.push_back(U.seqs[x]);
@@ -436,7 +435,7 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
     HIPCHK(ctx, d_u32.alloc(9ull * U + 4)); HIPCHK(ctx, d_i32.alloc(3ull * U)); HIPCHK(ctx, d_ctrl.alloc(C_WORDS)); HIPCHK(ctx, d_res_off.alloc(U)); HIPCHK(ctx, d_res_len.alloc(U));
     HIPCHK(ctx, d_res.alloc((size_t)U * capV)); if (hp.want_cov) HIPCHK(ctx, d_res_cov.alloc((size_t)U * capV));
     HierDev H{};
-    H.U = U; H.D = (hp.Dup > 0 && hp.D > 0) ? hp.Dup : hp.D /* the device builds the levels above 0 */; H.slots = slots; H.capV = (int)capV; H.upper_mode = hp.upper_mode; H.want_cov = hp.want_cov ? 1 : 0; H.Lmax = Lmax; H.keep_final = (hp.trim_tiles & 4) ? 1 : 0; H.cap_jobs[0] = cap[0]; H.cap_jobs[1] = cap[1];
+    H.U = U; H.D = hp.D; H.slots = slots; H.capV = (int)capV; H.upper_mode = hp.upper_mode; H.want_cov = hp.want_cov ? 1 : 0; H.Lmax = Lmax; H.keep_final = (hp.trim_tiles & 4) ? 1 : 0; H.cap_jobs[0] = cap[0]; H.cap_jobs[1] = cap[1];
     H.unit_bb = d_i32.p; H.unit_wlen = d_i32.p + U; H.unit_pick = d_i32.p + 2ull * U;
     H.unit_ncur = d_u32.p; H.unit_job0[0] = d_u32.p + U; H.unit_njobs[0] = d_u32.p + 2ull * U + 1; H.unit_job0[1] = d_u32.p + 3ull * U + 1; H.unit_njobs[1] = d_u32.p + 4ull * U + 2; H.unit_seq0 = d_u32.p + 5ull * U + 2; H.unit_tmp = d_u32.p + 6ull * U + 2;
     H.res_off = d_res_off.p; H.res_len = d_res_len.p; H.res = d_res.p; H.res_cov = hp.want_cov ? d_res_cov.p : nullptr; H.ctrl = d_ctrl.p;
@@ -583,6 +582,7 @@ extern "C" int32_t ngsid_poa_consensus_weighted(ngsid_ctx* ctx, const ngsid_read
 extern "C" int32_t ngsid_poa_consensus(ngsid_ctx* ctx, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                                        const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed)
 {
+    ApiClock api_clock_(ctx, "poa_consensus");
     return poa_consensus_impl(ctx, reads, read_order, grp_off, n_groups, prm, cons_off, cons, cons_cap, needed, nullptr);
 }
 
@@ -615,7 +615,6 @@ static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, co
         else { units[g].seqs.resize(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs[r - grp_off[g]] = (uint32_t)r; }
     }
     HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, prm->mode, cov != nullptr, prm->trim > 0 ? 1 : 0};
-    hp.Dup = (int)ngsid_opt(ctx, "poa_upper_depth", 0);
     std::vector<int> nobb;
     htc.mark("units");
     rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;
@@ -736,6 +735,7 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
                                 const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                                 uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used)
 {
+    ApiClock api_clock_(ctx, "polish");
     return polish_impl(ctx, backbones, reads, read_order, grp_off, n_groups, prm, out_off, out, out_cap, needed, n_used, nullptr);
 }
 
@@ -743,6 +743,7 @@ extern "C" int32_t ngsid_polish_trace(ngsid_ctx* ctx, const ngsid_reads_t* backb
                                       const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                                       uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used)
 {
+    ApiClock api_clock_(ctx, "polish_trace");
     if (!ctx) return NGSID_ERR_ARG;
     if (!prm || !it_off || prm->iters < 1) NGSID_FAIL(ctx, NGSID_ERR_ARG, "ngsid_polish_trace: null argument or iters < 1");
     PolishTrace tr; std::vector<uint64_t> ooff(n_groups + 1, 0); uint64_t need1 = 0;
@@ -992,7 +993,6 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         if (!bbs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_bbs.p, bbs.data(), sizeof(PSeq) * bbs.size(), hipMemcpyHostToDevice, ctx->stream));
         bool any_tgs = prm->trim == 2; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
         HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, (prm->trim >= 2 ? 1 : 0) | (prm->trim == 3 ? 4 : 0)};      // trim_tiles: 1 = trim tile consensuses, 4 = except the tile that ends a unit (trim 3)
-        hp.Dup = (int)ngsid_opt(ctx, "poa_upper_depth", 0);
         ht.mark("unit lists");
         rc = run_hierarchy(ctx, (const PSeq*)d_lay_raw.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
         ht.mark("hierarchy");

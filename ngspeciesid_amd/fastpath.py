@@ -134,11 +134,16 @@ class SortedReads:
 
     def name_has_blank(self):
         """per read: does the name contain white space (str.split() would cut it)?  computed once on the compact name buffer"""
-        if getattr(self, "_blank", None) is None:
-            nb = self.names
-            spaces = np.flatnonzero((nb.buf == 32) | ((nb.buf >= 9) & (nb.buf <= 13)))
-            a = nb.off.astype(np.int64); b = a + nb.len.astype(np.int64)
-            self._blank = (np.searchsorted(spaces, b, "left") > np.searchsorted(spaces, a, "left")) if len(spaces) else np.zeros(len(nb), dtype=bool)
+        # (round 5: ONE computation, under a lock, started by the worker that gathers the host copy while the device clusters - the five early writers of the pooled files used to
+        # find it missing at the same moment and each ran these array passes beside the main thread: a convoy on the interpreter lock, 90 ms in the sampled stacks)
+        import threading
+        lock = self.__dict__.setdefault("_blank_lock", threading.Lock())
+        with lock:
+            if getattr(self, "_blank", None) is None:
+                nb = self.names
+                spaces = np.flatnonzero((nb.buf == 32) | ((nb.buf >= 9) & (nb.buf <= 13)))
+                a = nb.off.astype(np.int64); b = a + nb.len.astype(np.int64)
+                self._blank = (np.searchsorted(spaces, b, "left") > np.searchsorted(spaces, a, "left")) if len(spaces) else np.zeros(len(nb), dtype=bool)
         return self._blank
 
 
@@ -181,8 +186,13 @@ def score_and_sort(args, api, T=None):
     # uploaded (numpy's sort releases the GIL); cluster() takes them when it clusters every read, which is the usual call
     from concurrent.futures import ThreadPoolExecutor
     sfx_csr = sfx if isinstance(sfx, tuple) else fastio._csr(sfx)
+    def _bg(fn, *a):           # a worker beside the launch thread: its helper calls count as background (csrc/host_io.hip: bounded process-wide)
+        import ctypes as C
+        try: runtime.load_library().ngsid_host_thread_cap(C.c_int32(8))
+        except Exception: pass
+        return fn(*a)
     pool = ThreadPoolExecutor(max_workers=1)
-    fut = pool.submit(_string_ranks, nm, sfx_csr, np.arange(len(order), dtype=np.int64)); pool.shutdown(wait=False)
+    fut = pool.submit(_bg, _string_ranks, nm, sfx_csr, np.arange(len(order), dtype=np.int64)); pool.shutdown(wait=False)
     lens_sorted = lens[order]
     if dev_raw is not None:
         t1 = time()
@@ -190,7 +200,7 @@ def score_and_sort(args, api, T=None):
         dev_raw.release()
         T["device_gather_sorted"] = time() - t1
         pool2 = ThreadPoolExecutor(max_workers=1)
-        sub = pool2.submit(subset_reads, rs, order); pool2.shutdown(wait=False)
+        sub = pool2.submit(_bg, subset_reads, rs, order); pool2.shutdown(wait=False)
     else:
         got = None
         sub = subset_reads(rs, order)
@@ -198,6 +208,8 @@ def score_and_sort(args, api, T=None):
     sr = SortedReads(nm, sub, sfx_csr, score[order], err[order], lens=lens_sorted)
     if got is not None: sr.dev, sr.foreign = got
     sr.rank_all = fut
+    if dev_raw is not None:
+        pool3 = ThreadPoolExecutor(max_workers=1); pool3.submit(sr.name_has_blank); pool3.shutdown(wait=False)      # ready before the pooled writers ask for it (they run beside the draft stage)
     return sr
 
 
@@ -336,22 +348,25 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
     # consensus instead of after the reverse-complement merge, so the 1.5 GB of reads_to_consensus_*.fastq at C3 have the draft AND the polishing stage to reach the disk.
     # A centre that does absorb others (rare) has its file rewritten after the merge, when these writers are done.  (Not with duplicate accessions: the pooled file of
     # the reference de-duplicates by header, handled in _merge_and_polish.)
+    # (round 5: everything the main thread computes with arrays comes BEFORE the writers start - with six threads in array code every operation of this thread waited its turn for the
+    # interpreter lock: 90 ms for the three lines below in the sampled stacks of a stalled run)
+    sub_off = np.concatenate(([0], np.cumsum([len(g) for g in groups]))).astype(np.uint64)
+    read_order = np.concatenate(groups); read_order32 = read_order.astype(np.uint32)
+    gmax = int(sr.lens[read_order].max())
+    if gmax > MAX_CONSENSUS_LEN:
+        bad = [int(reps[c]) for c in range(nsel) if int(sr.lens[groups[c]].max()) > MAX_CONSENSUS_LEN]
+        raise ValueError("clusters %s hold reads of up to %d bases: this build's POA engine forms consensus of reads up to %d bases (clustering itself handles %d); "
+                         "filter by length (--m / --s) or raise --abundance_ratio so that these clusters are not polished" % (bad[:10], gmax, MAX_CONSENSUS_LEN, MAX_READ_LEN))
     args._pooled_early = {}
     if acc_id is None and getattr(args, "_writers", None) is not None and os.environ.get("NGSID_CLI_EARLY_POOLED", "1") == "1":
         for c in range(nsel):
             path = os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(int(reps[c])))
             _write(args, _write_pooled, path, groups[c], sr)
             args._pooled_early[int(reps[c])] = (c,)
-    sub_off = np.concatenate(([0], np.cumsum([len(g) for g in groups]))).astype(np.uint64)
-    gmax = int(sr.lens[np.concatenate(groups)].max())
-    if gmax > MAX_CONSENSUS_LEN:
-        bad = [int(reps[c]) for c in range(nsel) if int(sr.lens[groups[c]].max()) > MAX_CONSENSUS_LEN]
-        raise ValueError("clusters %s hold reads of up to %d bases: this build's POA engine forms consensus of reads up to %d bases (clustering itself handles %d); "
-                         "filter by length (--m / --s) or raise --abundance_ratio so that these clusters are not polished" % (bad[:10], gmax, MAX_CONSENSUS_LEN, MAX_READ_LEN))
     long_reads = gmax > 1000
     node_cap = 22 if long_reads else 0
     drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=getattr(args, "poa_tile_depth", pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=pipeline.DRAFT_TRIM),
-                               read_order=np.concatenate(groups).astype(np.uint32))
+                               read_order=read_order32)
     T["draft_consensus"] = time() - t0
     centers = [[int(sizes[c]), int(reps[c]), drafts[c], [c]] for c in range(nsel)]
     barcodes = None
@@ -469,9 +484,19 @@ def _write_pooled(path, ids, sr):
 def main(args, api=None):
     api = api or runtime.get_api()
     args._writers = BackgroundWriters() if not os.environ.get("NGSID_CLI_SYNC_WRITES") else None
+    import sys
+    _swi = sys.getswitchinterval(); sys.setswitchinterval(5e-4)      # a thread that wants the interpreter lock asks for it after 0.5 ms instead of 5 ms: the launch thread comes back from every library call beside up to eight writers
+    _fd = None
+    if os.environ.get("NGSID_CLI_STACKS"):          # dev aid (round 5): the stacks of ALL threads every 5 ms, written by faulthandler's own watchdog thread (it needs no interpreter lock)
+        import faulthandler
+        _fd = open(os.environ["NGSID_CLI_STACKS"], "a"); faulthandler.dump_traceback_later(0.005, repeat=True, file=_fd)
     try:
         res = _main(args, api)
     finally:
+        sys.setswitchinterval(_swi)
+        if _fd is not None:
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later(); _fd.close()
         if args._writers is not None:
             t0 = time()
             try:
