@@ -59,8 +59,9 @@ def _string_ranks(names: fastio.Names, sfx, idx):
 class BackgroundWriters:
     """Output files are written by worker threads while the GPU stages run (the native writers release the GIL).  join() waits for all of them
     and re-raises the first failure; main() joins before it returns, whatever happens, so the files are complete whenever the call is over."""
-    def __init__(self, workers=8):
+    def __init__(self, workers=None):
         from concurrent.futures import ThreadPoolExecutor
+        workers = int(workers or os.environ.get("NGSID_CLI_WRITERS", "8"))
         self.pool = ThreadPoolExecutor(max_workers=workers); self.futures = []
 
     def submit(self, fn, *a, **kw):

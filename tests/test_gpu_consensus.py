@@ -179,26 +179,27 @@ def test_device_driven_levels_equal_host_driven_levels(gpu_api, oracle):
                 seqs.append(rd["seq"].numpy()[o[i]:o[i + 1]].tobytes().decode()); quals.append(rd["qual"].numpy()[o[i]:o[i + 1]].tobytes().decode())
         rs = ReadSet.from_strings(seqs, quals)
         goff = np.concatenate(([0], np.cumsum(sizes))).astype(np.uint64)
-        for prm in (poa_params(tile_depth=6, band=0, trim=1), poa_params(tile_depth=8, band=128, trim=0), poa_params(tile_depth=3, band=64, trim=1, mode=POA_GLOBAL, match=3, mismatch=-5, gap=-4),
+        for prm in (poa_params(tile_depth=4, band=0, trim=1), poa_params(tile_depth=6, band=0, trim=1), poa_params(tile_depth=8, band=128, trim=0), poa_params(tile_depth=3, band=64, trim=1, mode=POA_GLOBAL, match=3, mismatch=-5, gap=-4),
                     poa_params(tile_depth=0, band=128, node_cap=40)):
             a = gpu_api.poa_consensus_cov(rs, goff, prm); b = host.poa_consensus_cov(rs, goff, prm)           # [(consensus, coverage)] per group
             assert [x[0] for x in a] == [y[0] for y in b]
             assert all(np.array_equal(x[1], y[1]) for x, y in zip(a, b))
-            if prm.tile_depth in (6, 3):
+            if prm.tile_depth in (4, 6, 3):
                 c = small.poa_consensus_cov(rs, goff, prm)
                 assert [x[0] for x in a] == [y[0] for y in c] and all(np.array_equal(x[1], y[1]) for x, y in zip(a, c))
         first = [0, 1, 3, 4]                                   # groups checked against the oracle as well (the whole set would take the scalar oracle minutes)
         sub_off = np.concatenate(([0], np.cumsum([sizes[g] for g in first]))).astype(np.uint64)
         order = np.concatenate([np.arange(int(goff[g]), int(goff[g + 1])) for g in first]).astype(np.uint32)
-        prm = poa_params(tile_depth=6, band=0, trim=1)
-        assert gpu_api.poa_consensus(rs, sub_off, prm, read_order=order) == oracle.poa_consensus(rs, sub_off, prm, read_order=order)
+        for dpt in (6, 4):                                     # 4 = the depth the pipeline ships with since round 5
+            prm = poa_params(tile_depth=dpt, band=0, trim=1)
+            assert gpu_api.poa_consensus(rs, sub_off, prm, read_order=order) == oracle.poa_consensus(rs, sub_off, prm, read_order=order), dpt
         # polishing: two groups, 3 iterations, early stop on and off
         big = [4, 10]
         p_off = np.concatenate(([0], np.cumsum([sizes[g] for g in big]))).astype(np.uint64)
         p_order = np.concatenate([np.arange(int(goff[g]), int(goff[g + 1])) for g in big]).astype(np.uint32)
         bb = ReadSet.from_strings([seqs[int(goff[g])] for g in big])
-        for stop in (0, 1):
-            pp = polish_params(iters=3, k=13, w=20, tile_depth=6, band=0, trim=2, stop_when_stable=stop)
+        for stop, dpt in ((0, 6), (1, 6), (0, 4)):
+            pp = polish_params(iters=3, k=13, w=20, tile_depth=dpt, band=0, trim=2, stop_when_stable=stop)
             x, ux = gpu_api.polish(bb, rs, p_off, pp, read_order=p_order); y, uy = host.polish(bb, rs, p_off, pp, read_order=p_order)
             assert x == y and np.array_equal(ux, uy)
             z, uz = small.polish(bb, rs, p_off, pp, read_order=p_order)
