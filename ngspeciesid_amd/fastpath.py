@@ -485,7 +485,9 @@ def _write_pooled(path, ids, sr):
 def main(args, api=None):
     api = api or runtime.get_api()
     args._writers = BackgroundWriters() if not os.environ.get("NGSID_CLI_SYNC_WRITES") else None
-    import sys
+    import sys, gc
+    _gc = gc.isenabled() and os.environ.get("NGSID_CLI_GC", "0") != "1"
+    if _gc: gc.disable()            # no cyclic collection during the run: a full collection of the interpreter's heap (torch is loaded) holds the lock for tens of ms in whichever thread triggers it
     _swi = sys.getswitchinterval(); sys.setswitchinterval(5e-4)      # a thread that wants the interpreter lock asks for it after 0.5 ms instead of 5 ms: the launch thread comes back from every library call beside up to eight writers
     _fd = None
     if os.environ.get("NGSID_CLI_STACKS"):          # dev aid (round 5): the stacks of ALL threads every 5 ms, written by faulthandler's own watchdog thread (it needs no interpreter lock)
@@ -495,6 +497,7 @@ def main(args, api=None):
         res = _main(args, api)
     finally:
         sys.setswitchinterval(_swi)
+        if _gc: gc.enable()
         if _fd is not None:
             import faulthandler
             faulthandler.cancel_dump_traceback_later(); _fd.close()
