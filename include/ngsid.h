@@ -271,6 +271,17 @@ int32_t ngsid_host_group_by_rep32(const int32_t* rep, uint64_t n, int64_t* reps,
 int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
                                  const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
                                  const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read, const uint8_t* seq, const uint8_t* qual, const uint64_t* off);
+/* (f2, round 5) the same writer as a BACKGROUND job of the library: returns at once with a job id; eight native worker threads run the jobs, ngsid_host_async_wait(job) blocks until
+ * the job is done and returns ITS result (NGSID_ERR_ARG for an id that is unknown or was waited for already).  Every pointer of the call (path excepted: copied) must stay valid
+ * until the job was waited for.  Why: a caller with an interpreter lock (the Python CLI) that runs its writers as interpreter threads makes its GPU-launching thread compete for
+ * that lock at every return from the library (get_sorted_fastq_for_cluster.py:174-182 and consensus.py:203-215 write synchronously; this is the overlap, without the lock). */
+int32_t ngsid_host_write_records_async(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
+                                       const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
+                                       const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read, const uint8_t* seq, const uint8_t* qual, const uint64_t* off,
+                                       int32_t max_threads /* helper threads of this job; <= 0: 8.  A job that runs beside a launch-bound GPU stage should take few (the CLI: 4 for sorted.fastq) */, uint64_t* job);
+int32_t ngsid_host_async_wait(uint64_t job);
+/* decimal strings of n integers as CSR (buf, off[n + 1]); *needed = bytes of buf (cap = 0 sizes): the output ids of final_clusters.tsv (NGSpeciesID:30-50 formats them line by line) */
+int32_t ngsid_host_int_prefixes(const int64_t* v, uint64_t n, uint8_t* buf, uint64_t cap, uint64_t* off, uint64_t* needed);
 
 /* (f4) infix ("HW") location of a primer inside a consensus end = edlib.align(primer, window, mode="HW", task="locations", k=max_ed,
  * additionalEqualities=IUPAC)["locations"][0] as barcode_trimmer.find_barcode_locations uses it (barcode_trimmer.py:34-60): *ed = smallest edit

@@ -7,6 +7,10 @@
 #include <string.h>
 #include <stdlib.h>
 #include <thread>
+#include <string>
+#include <map>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <condition_variable>
 #include <sched.h>
@@ -232,15 +236,16 @@ extern "C" int32_t ngsid_host_argsort_desc(const double* v, uint64_t n, uint64_t
 //   kind 1 (TSV):    pre_j '\t' name '\n'                                  (final_clusters.tsv: pre_j = the cluster's output id)
 // name = names[name_off[i] .. +name_len[i]) truncated at the first white space when first_token != 0; sfx / pre are CSR strings indexed by j
 // (sfx_off == NULL: none), or by the read index idx[j] when sfx_by_read != 0.  The file is created (append == 0) or appended to.  Returns NGSID_ERR_ARG when the file cannot be written.
-extern "C" int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
-                                            const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
-                                            const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read,
-                                            const uint8_t* seq, const uint8_t* qual, const uint64_t* off)
+static int32_t write_records_impl(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
+                                  const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
+                                  const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read,
+                                  const uint8_t* seq, const uint8_t* qual, const uint64_t* off)
 {
     if (!path || (n && (!idx || !names || !name_off || !name_len))) return NGSID_ERR_ARG;
     if (kind == 0 && n && (!seq || !qual || !off)) return NGSID_ERR_ARG;
     // Two passes: record sizes -> file offsets (prefix sum), then every worker thread assembles its records piece by piece and writes each piece with pwrite() at
     // its own offset (round 4: one fwrite() per 65 536-record chunk was a serial 1.5 GB copy into the page cache, 0.45 s of the CLI's 1.4 s at C3)
+    if (getenv("NGSID_WRITE_TRACE")) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[write] %s: start %.3f\n", path, ts.tv_sec % 1000 + ts.tv_nsec / 1e9); }
     const int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666); if (fd < 0) return NGSID_ERR_ARG;       // (0666 & ~umask, like fopen; append mode takes its base offset once: the caller must be the only writer of the file)
     const off_t base = append ? lseek(fd, 0, SEEK_END) : 0;
     if (base < 0) { close(fd); return NGSID_ERR_ARG; }
@@ -283,10 +288,71 @@ extern "C" int32_t ngsid_host_write_records(const char* path, int32_t append, in
                 j0 = j1;
             } });
     }
+    if (getenv("NGSID_WRITE_TRACE")) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[write] %s: %llu records, %.1f MB, cap %d, end %.3f\n", path, (unsigned long long)n, total / 1e6, t_thread_cap, ts.tv_sec % 1000 + ts.tv_nsec / 1e9); }
     int32_t rc = failed.load() ? NGSID_ERR_ARG : NGSID_OK;
     if (rc != NGSID_OK) (void)!ftruncate(fd, base);           // a failed write leaves the file as it was found, not a sparse image at its full length
     if (close(fd) != 0) rc = NGSID_ERR_ARG;
     return rc;
+}
+extern "C" int32_t ngsid_host_write_records(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
+                                            const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
+                                            const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read,
+                                            const uint8_t* seq, const uint8_t* qual, const uint64_t* off)
+{
+    return write_records_impl(path, append, kind, n, idx, names, name_off, name_len, first_token, sfx, sfx_off, sfx_by_read, seq, qual, off);
+}
+
+// ---- native background writers (round 5).  A caller whose host language has an interpreter lock (the Python CLI) used to run its writers as interpreter threads: every return of the
+// launch thread from a library call then competed with up to eight of them for the lock (30 - 110 ms waits in about a quarter of the CLI runs, profiles/NOTES.md).  The queue below
+// takes a record-writer job and returns at once; eight native worker threads run the jobs (as background callers: their helper threads count against the process-wide bound above).
+// Every pointer of a job must stay valid until the job was waited for.
+namespace {
+struct AsyncJobs {
+    struct Job { std::function<int32_t()> fn; int32_t rc = 0; bool done = false; int threads = 8; };
+    std::mutex m; std::condition_variable cv_work, cv_done; std::deque<uint64_t> q; std::map<uint64_t, Job> jobs; uint64_t next_id = 1; std::vector<std::thread> workers; bool stop = false;
+    void start() { if (!workers.empty()) return; for (int i = 0; i < 8; ++i) workers.emplace_back([this] { run(); }); }
+    void run() {
+        for (;;) {
+            uint64_t id; std::function<int32_t()> fn;
+            { std::unique_lock<std::mutex> l(m); cv_work.wait(l, [&] { return stop || !q.empty(); }); if (stop && q.empty()) return; id = q.front(); q.pop_front(); fn = jobs[id].fn; t_thread_cap = jobs[id].threads; }      // (> 0: a background caller, bounded process-wide)
+            const int32_t rc = fn();
+            { std::lock_guard<std::mutex> l(m); Job& j = jobs[id]; j.rc = rc; j.done = true; j.fn = nullptr; }
+            cv_done.notify_all();
+        }
+    }
+    uint64_t submit(std::function<int32_t()> fn, int threads) { std::lock_guard<std::mutex> l(m); start(); const uint64_t id = next_id++; jobs[id].fn = std::move(fn); jobs[id].threads = threads > 0 ? threads : 8; q.push_back(id); cv_work.notify_one(); return id; }
+    int32_t wait(uint64_t id) { std::unique_lock<std::mutex> l(m); auto it = jobs.find(id); if (it == jobs.end()) return NGSID_ERR_ARG; cv_done.wait(l, [&] { return jobs[id].done; }); const int32_t rc = jobs[id].rc; jobs.erase(id); return rc; }
+    ~AsyncJobs() { { std::lock_guard<std::mutex> l(m); stop = true; } cv_work.notify_all(); for (auto& w : workers) if (w.joinable()) w.join(); }
+};
+AsyncJobs& async_jobs() { static AsyncJobs* a = new AsyncJobs(); return *a; }       // (never destroyed: worker threads must not be joined from a static destructor at interpreter exit)
+}  // namespace
+extern "C" int32_t ngsid_host_write_records_async(const char* path, int32_t append, int32_t kind, uint64_t n, const uint64_t* idx,
+                                                  const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len, int32_t first_token,
+                                                  const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read,
+                                                  const uint8_t* seq, const uint8_t* qual, const uint64_t* off, int32_t max_threads, uint64_t* job)
+{
+    if (!path || !job) return NGSID_ERR_ARG;
+    std::string p(path);
+    *job = async_jobs().submit([=] { return write_records_impl(p.c_str(), append, kind, n, idx, names, name_off, name_len, first_token, sfx, sfx_off, sfx_by_read, seq, qual, off); }, max_threads);
+    return NGSID_OK;
+}
+extern "C" int32_t ngsid_host_async_wait(uint64_t job) { return async_jobs().wait(job); }
+
+// decimal strings of n integers as a CSR (buf: sum of the digit counts, off: n + 1) - the output ids of final_clusters.tsv; *needed = bytes of buf (call with cap = 0 to size)
+extern "C" int32_t ngsid_host_int_prefixes(const int64_t* v, uint64_t n, uint8_t* buf, uint64_t cap, uint64_t* off, uint64_t* needed)
+{
+    if ((n && !v) || !off || !needed) return NGSID_ERR_ARG;
+    auto ndig = [](int64_t x) { uint64_t u = x < 0 ? (uint64_t)(-(x + 1)) + 1 : (uint64_t)x; int d = 1; while (u >= 10) { u /= 10; ++d; } return d + (x < 0 ? 1 : 0); };
+    off[0] = 0;
+    parallel_ranges(n, n_threads(n * 16), [&](uint64_t a, uint64_t b, int) { for (uint64_t i = a; i < b; ++i) off[i + 1] = (uint64_t)ndig(v[i]); });
+    for (uint64_t i = 0; i < n; ++i) off[i + 1] += off[i];
+    *needed = off[n];
+    if (cap < off[n] || (off[n] && !buf)) return cap == 0 ? NGSID_OK : NGSID_ERR_ARG;
+    parallel_ranges(n, n_threads(n * 16), [&](uint64_t a, uint64_t b, int) { for (uint64_t i = a; i < b; ++i) {
+        uint8_t* e = buf + off[i + 1]; int64_t x = v[i]; uint64_t u = x < 0 ? (uint64_t)(-(x + 1)) + 1 : (uint64_t)x;
+        do { *--e = (uint8_t)('0' + u % 10); u /= 10; } while (u);
+        if (x < 0) *--e = '-'; } });
+    return NGSID_OK;
 }
 
 // Number of bases that ngsid_host_normalize_bases would change (no copy needed when it is 0).

@@ -6,7 +6,9 @@ Replaces the per-record Python of help_functions.py:13-42, get_sorted_fastq_for_
 """
 from __future__ import annotations
 import ctypes as C
+import os
 import numpy as np
+from time import perf_counter as _perf
 from . import runtime
 from ._capi import ReadSet
 from .help_functions import readfq
@@ -162,49 +164,73 @@ def _csr(strs):
     return (np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(1, np.uint8)), off
 
 
-def write_fastq(path, idx, names: Names, rs: ReadSet, suffixes=None, first_token=False, append=False, sfx_by_read=False):
-    """FASTQ records of reads idx (in that order); a suffix is appended to each record's name (the '_score' of sorted.fastq): suffixes = list of
-    strings or a CSR (bytes, offsets), one per OUTPUT record, or one per READ (indexed by idx[j]) with sfx_by_read."""
+class NativeJobs:
+    """background record-writer jobs of the LIBRARY (ngsid_host_write_records_async): the job runs on native worker threads, this object keeps the arrays of every job alive
+    until wait() has collected its result.  No interpreter thread is involved, so the thread that drives the GPU never meets a writer at the interpreter lock (round 5)."""
+    def __init__(self):
+        self.jobs = []                      # (job id, path, arrays kept alive)
+
+    def wait(self):
+        lib = runtime.load_library()
+        jobs, self.jobs = self.jobs, []
+        bad = []
+        for jid, path, _ in jobs:                     # (waits for ALL of them before it reports)
+            t0 = _perf()
+            if lib.ngsid_host_async_wait(C.c_uint64(jid)) != 0: bad.append(path)
+            if os.environ.get("NGSID_WRITE_TRACE"):
+                import sys; sys.stderr.write("[wait] %s %.3f s\n" % (os.path.basename(path), _perf() - t0))
+        # The arrays the jobs kept alive (among them the last reference to the 1.5 GB file-order copy of the reads at C3) are released LATER, by a helper thread: unmapping them
+        # takes 0.1 - 0.17 s with the interpreter lock held, whichever thread does it (traced: every write had ended 0.13 s before the stages were done and the wait itself
+        # took 0.000 s, yet the caller lost 0.165 s here; a helper thread that released them at once held the lock against the caller just as long).  Half a second later the
+        # caller of a CLI run has returned (a process that ends before that never unmaps them at all).
+        import threading, time as _time
+        box = [jobs]; del jobs
+        def _later(b=box):
+            _time.sleep(0.5); b.clear()
+        threading.Thread(target=_later, daemon=True).start(); del box
+        if bad:
+            raise OSError("cannot write %s" % ", ".join(bad))
+
+
+def _write_records(path, append, kind, idx, names, first_token, sb, so, sfx_by_read, rs, jobs, threads=0):
     lib = runtime.load_library()
+    seq, qual, off = (rs.seq, rs.qual, rs.off) if rs is not None else (None, None, None)
+    args = (path.encode(), C.c_int32(int(append)), C.c_int32(kind), C.c_uint64(len(idx)), _p(idx), _p(names.buf), _p(names.off), _p(names.len),
+            C.c_int32(int(first_token)), _p(sb), _p(so), C.c_int32(int(sfx_by_read)), _p(seq), _p(qual), _p(off))
+    if jobs is None:
+        if lib.ngsid_host_write_records(*args):
+            raise OSError("cannot write %s" % path)
+        return
+    jid = C.c_uint64(0)
+    if lib.ngsid_host_write_records_async(*args, C.c_int32(int(threads or 0)), C.byref(jid)):
+        raise OSError("cannot write %s" % path)
+    jobs.jobs.append((jid.value, path, (idx, names, sb, so, seq, qual, off, rs)))
+
+
+def write_fastq(path, idx, names: Names, rs: ReadSet, suffixes=None, first_token=False, append=False, sfx_by_read=False, jobs: NativeJobs = None, threads=0):
+    """FASTQ records of reads idx (in that order); a suffix is appended to each record's name (the '_score' of sorted.fastq): suffixes = list of
+    strings or a CSR (bytes, offsets), one per OUTPUT record, or one per READ (indexed by idx[j]) with sfx_by_read.  jobs: run as a background job of the library."""
     idx = np.ascontiguousarray(idx, dtype=np.uint64)
     sb, so = (None, None) if suffixes is None else (suffixes if isinstance(suffixes, tuple) else _csr(suffixes))
-    rc = lib.ngsid_host_write_records(path.encode(), C.c_int32(int(append)), C.c_int32(0), C.c_uint64(len(idx)), _p(idx), _p(names.buf), _p(names.off), _p(names.len),
-                                      C.c_int32(int(first_token)), _p(sb), _p(so), C.c_int32(int(sfx_by_read)), _p(rs.seq), _p(rs.qual), _p(rs.off))
-    if rc:
-        raise OSError("cannot write %s" % path)
+    _write_records(path, append, 0, idx, names, first_token, sb, so, sfx_by_read, rs, jobs, threads)
 
 
-def write_tsv(path, idx, names: Names, prefixes, append=False):
+def write_tsv(path, idx, names: Names, prefixes, append=False, jobs: NativeJobs = None):
     """lines 'prefix<TAB>name' for reads idx; prefixes = (byte buffer, offsets) CSR or a list of strings, one per line."""
-    lib = runtime.load_library()
     idx = np.ascontiguousarray(idx, dtype=np.uint64)
     pb, po = prefixes if isinstance(prefixes, tuple) else _csr(prefixes)
-    rc = lib.ngsid_host_write_records(path.encode(), C.c_int32(int(append)), C.c_int32(1), C.c_uint64(len(idx)), _p(idx), _p(names.buf), _p(names.off), _p(names.len),
-                                      C.c_int32(0), _p(pb), _p(po), C.c_int32(0), None, None, None)
-    if rc:
-        raise OSError("cannot write %s" % path)
+    _write_records(path, append, 1, idx, names, False, pb, po, False, None, jobs)
 
 
 def int_prefixes(values):
-    """CSR of the decimal strings of an integer array without a Python loop over the lines."""
-    values = np.asarray(values, dtype=np.int64)
+    """CSR of the decimal strings of an integer array (ngsid_host_int_prefixes: two passes in the host library; round 5 - the NumPy digit loops took 30 ms of the launch thread)."""
+    values = np.ascontiguousarray(values, dtype=np.int64)
     if len(values) == 0:
         return np.zeros(1, np.uint8), np.zeros(1, dtype=np.uint64)
-    digits = np.ones(len(values), dtype=np.int64)
-    v = values.copy()
-    while True:
-        v //= 10
-        m = v > 0
-        if not m.any():
-            break
-        digits += m
-    off = np.zeros(len(values) + 1, dtype=np.uint64); off[1:] = np.cumsum(digits, dtype=np.uint64)
-    buf = np.empty(int(off[-1]), dtype=np.uint8)
-    v = values.copy(); pos = off[1:].astype(np.int64) - 1
-    lo = off[:-1].astype(np.int64)
-    alive = np.ones(len(values), dtype=bool)
-    while alive.any():
-        buf[pos[alive]] = 48 + (v[alive] % 10)
-        v //= 10; pos -= 1
-        alive &= pos >= lo
-    return buf, off
+    lib = runtime.load_library()
+    off = np.zeros(len(values) + 1, dtype=np.uint64); need = C.c_uint64(0)
+    lib.ngsid_host_int_prefixes(_p(values), C.c_uint64(len(values)), None, C.c_uint64(0), _p(off), C.byref(need))
+    buf = np.empty(max(int(need.value), 1), dtype=np.uint8)
+    if lib.ngsid_host_int_prefixes(_p(values), C.c_uint64(len(values)), _p(buf), C.c_uint64(len(buf)), _p(off), C.byref(need)):
+        raise ValueError("int_prefixes failed")
+    return buf[:int(need.value)], off

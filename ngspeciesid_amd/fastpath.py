@@ -63,6 +63,7 @@ class BackgroundWriters:
         from concurrent.futures import ThreadPoolExecutor
         workers = int(workers or os.environ.get("NGSID_CLI_WRITERS", "8"))
         self.pool = ThreadPoolExecutor(max_workers=workers); self.futures = []
+        self.native = fastio.NativeJobs()          # round 5: the record writers run as background jobs of the LIBRARY (native threads, no interpreter lock); the pool is left for the few jobs that are Python
 
     def submit(self, fn, *a, **kw):
         threads = kw.pop("_threads", None)
@@ -81,14 +82,24 @@ class BackgroundWriters:
 
     def join(self):
         futures, self.futures = self.futures, []
-        err = None
+        err = None; _t0 = time()
         for f in futures:
             try:
                 f.result()
             except BaseException as e:          # keep waiting for the others, report the first
                 err = err or e
+        _t1 = time()
+        try:
+            self.native.wait()
+        except BaseException as e:
+            err = err or e
+        if os.environ.get("NGSID_WRITE_TRACE"):
+            import sys; sys.stderr.write("[join] python jobs %.3f s, native jobs %.3f s\n" % (_t1 - _t0, time() - _t1))
         if err is not None:
             raise err
+
+
+_NATIVE = (fastio.write_fastq, fastio.write_tsv)       # + _write_pooled (below): their work is ONE call of the library's record writer
 
 
 def _write(args, fn, *a, **kw):
@@ -96,6 +107,10 @@ def _write(args, fn, *a, **kw):
     if bg is None:
         kw.pop("_threads", None)
         fn(*a, **kw)
+    elif (fn in _NATIVE or fn is _write_pooled) and os.environ.get("NGSID_CLI_PY_WRITERS") != "1":
+        th = kw.pop("_threads", None)
+        if th and fn is fastio.write_fastq: kw["threads"] = int(th)
+        fn(*a, jobs=bg.native, **kw)           # prepared here, written by the library's own background threads
     else:
         bg.submit(fn, *a, **kw)
 
@@ -313,7 +328,7 @@ def cluster_table(sr, sel, rep_of, pos, single_pass=False):
 
 
 def write_cluster_files(args, sr, reps, sizes, herr, file_order, cl_sorted):
-    _write(args, lambda: fastio.write_tsv(os.path.join(args.outfolder, "final_clusters.tsv"), file_order, sr.names, fastio.int_prefixes(cl_sorted)))
+    _write(args, fastio.write_tsv, os.path.join(args.outfolder, "final_clusters.tsv"), file_order, sr.names, fastio.int_prefixes(cl_sorted))
     with open(os.path.join(args.outfolder, "final_cluster_origins.tsv"), "w") as f:
         for out_id, r in enumerate(reps.tolist()):
             seq, qual = sr.rs.get(r)
@@ -471,15 +486,15 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
     return merged
 
 
-def _write_pooled(path, ids, sr):
+def _write_pooled(path, ids, sr, jobs=None):
     # names in the pooled file = first token of the sorted-file accession "name_score" (consensus.py:213): the suffix belongs to the name, so the
     # cut is applied to name + suffix; names with blanks lose their suffix with everything behind the blank
     blank = sr.name_has_blank()[ids] if len(ids) else np.zeros(0, dtype=bool)
     if not blank.any():
-        fastio.write_fastq(path, ids, sr.names, sr.rs, suffixes=sr.sfx, first_token=True, sfx_by_read=True)
+        fastio.write_fastq(path, ids, sr.names, sr.rs, suffixes=sr.sfx, first_token=True, sfx_by_read=True, jobs=jobs)
     else:
         sfx = [("" if bl else sr.suffix(int(i))) for i, bl in zip(ids.tolist(), blank.tolist())]
-        fastio.write_fastq(path, ids, sr.names, sr.rs, suffixes=sfx, first_token=True)
+        fastio.write_fastq(path, ids, sr.names, sr.rs, suffixes=sfx, first_token=True, jobs=jobs)
 
 
 def main(args, api=None):
@@ -493,8 +508,12 @@ def main(args, api=None):
     if os.environ.get("NGSID_CLI_STACKS"):          # dev aid (round 5): the stacks of ALL threads every 5 ms, written by faulthandler's own watchdog thread (it needs no interpreter lock)
         import faulthandler
         _fd = open(os.environ["NGSID_CLI_STACKS"], "a"); faulthandler.dump_traceback_later(0.005, repeat=True, file=_fd)
+    if os.environ.get("NGSID_WRITE_TRACE"):
+        import time as _t; sys.stderr.write("[cli] start %.3f\n" % (_t.monotonic() % 1000))
     try:
         res = _main(args, api)
+        if os.environ.get("NGSID_WRITE_TRACE"):
+            import time as _t; sys.stderr.write("[cli] stages done %.3f %s\n" % (_t.monotonic() % 1000, {k: round(v, 3) for k, v in res["timings"].items()}))
     finally:
         sys.setswitchinterval(_swi)
         if _gc: gc.enable()

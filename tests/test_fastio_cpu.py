@@ -149,3 +149,43 @@ def test_list_positions_counts_earlier_reads_of_the_cluster():
     assert len(fastio.list_positions(np.zeros(0, dtype=np.int64))) == 0
     with pytest.raises(ValueError):
         fastio.list_positions(np.array([0, 5], dtype=np.int64))
+
+
+def test_native_background_writers_equal_the_synchronous_ones(tmp_path):
+    """round 5: ngsid_host_write_records_async - the record writer as a background job of the library (native worker threads, no interpreter thread): same bytes as the
+    synchronous call for FASTQ (suffix per record / per read, first token) and TSV, many jobs in flight at once, the failure of one job reported after ALL were waited for"""
+    import ctypes as C
+    from ngspeciesid_amd import runtime
+    names, rs, plain = fastio.read_fastq(os.path.join(GOLD, "sample_h1.fastq"))
+    rng = np.random.default_rng(5)
+    jobs = fastio.NativeJobs(); want = {}
+    for j in range(12):
+        idx = rng.permutation(rs.n)[: int(rng.integers(1, rs.n))]
+        sfx = ["_%d" % int(x) for x in rng.integers(0, 10 ** int(rng.integers(1, 9)), len(idx))]
+        a, b = str(tmp_path / ("a%d.fq" % j)), str(tmp_path / ("b%d.fq" % j))
+        fastio.write_fastq(a, idx, names, rs, suffixes=sfx, first_token=bool(j % 2))
+        fastio.write_fastq(b, idx, names, rs, suffixes=sfx, first_token=bool(j % 2), jobs=jobs)
+        want[b] = a
+    pre = fastio.int_prefixes(rng.integers(0, 100000, rs.n))
+    fastio.write_tsv(str(tmp_path / "a.tsv"), np.arange(rs.n), names, pre)
+    fastio.write_tsv(str(tmp_path / "b.tsv"), np.arange(rs.n), names, pre, jobs=jobs); want[str(tmp_path / "b.tsv")] = str(tmp_path / "a.tsv")
+    assert len(jobs.jobs) == 13
+    jobs.wait()
+    assert jobs.jobs == []
+    for b, a in want.items():
+        assert open(b, "rb").read() == open(a, "rb").read(), b
+    fastio.write_fastq(str(tmp_path / "no_such_dir" / "x.fq"), np.arange(3), names, rs, jobs=jobs)
+    fastio.write_fastq(str(tmp_path / "ok.fq"), np.arange(3), names, rs, jobs=jobs)
+    with pytest.raises(OSError, match="no_such_dir"):
+        jobs.wait()
+    assert os.path.getsize(str(tmp_path / "ok.fq")) > 0                       # the other job of the batch was completed
+    assert runtime.load_library().ngsid_host_async_wait(C.c_uint64(123456789)) != 0      # unknown job id
+
+
+def test_int_prefixes_are_the_decimal_strings():
+    rng = np.random.default_rng(9)
+    v = np.concatenate([[0, 9, 10, 99, 100, 2 ** 62, -1, -10, -(2 ** 63)], rng.integers(0, 10 ** 7, 20000), rng.integers(-1000, 1000, 500)]).astype(np.int64)
+    buf, off = fastio.int_prefixes(v)
+    got = [buf[int(off[i]):int(off[i + 1])].tobytes().decode() for i in range(len(v))]
+    assert got == [str(int(x)) for x in v]
+    assert fastio.int_prefixes(np.zeros(0, dtype=np.int64))[1].tolist() == [0]
