@@ -20,7 +20,7 @@ for trial in range(ntr):
     pt = select_p_table(k, w)
     if np.isnan(pt).all(): continue
     nsp = int(rng.integers(1, 4)); L = int(rng.choice([90, 180, 420, 507, 760, 1003, 1300])); n = int(rng.integers(30, 260)); mu = float(rng.choice([12.0, 14.0, 17.0, 25.0]))
-    rcf = float(rng.choice([0.0, 0.0, 0.5])); D = int(rng.choice([0, 3, 6, 8])); band = int(rng.choice([0, 64, 128])); iters = int(rng.integers(0, 4))
+    rcf = float(rng.choice([0.0, 0.0, 0.5])); D = int(rng.choice([0, 3, 4, 4, 6, 8])); band = int(rng.choice([0, 64, 128])); iters = int(rng.integers(0, 4))
     sp = synth.make_species(nsp, L, float(rng.choice([0.1, 0.2])), seed=int(rng.integers(1, 1 << 30)))
     rd = synth.make_reads(sp, n, mu=mu, seed=int(rng.integers(1, 1 << 30)), rc_fraction=rcf)
     rs0 = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
