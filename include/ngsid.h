@@ -280,6 +280,10 @@ int32_t ngsid_host_write_records_async(const char* path, int32_t append, int32_t
                                        const uint8_t* sfx, const uint64_t* sfx_off, int32_t sfx_by_read, const uint8_t* seq, const uint8_t* qual, const uint64_t* off,
                                        int32_t max_threads /* helper threads of this job; <= 0: 8.  A job that runs beside a launch-bound GPU stage should take few (the CLI: 4 for sorted.fastq) */, uint64_t* job);
 int32_t ngsid_host_async_wait(uint64_t job);
+/* (f2, round 5) read-only mapping of an input file (an empty file: *data = NULL, *len = 0) and its release; in_background != 0: a detached native thread unmaps (gigabytes take
+ * tens of milliseconds, which a caller in the middle of its ingest - help_functions.readfq reads the file line by line instead - need not wait for) */
+int32_t ngsid_host_map_file(const char* path, const uint8_t** data, uint64_t* len);
+int32_t ngsid_host_unmap_file(const uint8_t* data, uint64_t len, int32_t in_background);
 /* decimal strings of n integers as CSR (buf, off[n + 1]); *needed = bytes of buf (cap = 0 sizes): the output ids of final_clusters.tsv (NGSpeciesID:30-50 formats them line by line) */
 int32_t ngsid_host_int_prefixes(const int64_t* v, uint64_t n, uint8_t* buf, uint64_t cap, uint64_t* off, uint64_t* needed);
 

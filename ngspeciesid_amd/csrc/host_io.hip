@@ -15,6 +15,8 @@
 #include <condition_variable>
 #include <sched.h>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <sys/types.h>
 #include <cstdio>
@@ -337,6 +339,28 @@ extern "C" int32_t ngsid_host_write_records_async(const char* path, int32_t appe
     return NGSID_OK;
 }
 extern "C" int32_t ngsid_host_async_wait(uint64_t job) { return async_jobs().wait(job); }
+
+// Read-only mapping of an input file and its release (round 5).  Unmapping the 1.5 GB FASTQ of C3 takes ~75 ms (page-table teardown); done by the interpreter's own mmap object it
+// happened on the launch thread, with the interpreter lock held, in the middle of the ingest.  ngsid_host_unmap_file(..., 1) hands it to a detached native thread.
+extern "C" int32_t ngsid_host_map_file(const char* path, const uint8_t** data, uint64_t* len)
+{
+    if (!path || !data || !len) return NGSID_ERR_ARG;
+    *data = nullptr; *len = 0;
+    const int fd = open(path, O_RDONLY); if (fd < 0) return NGSID_ERR_ARG;
+    struct stat st; if (fstat(fd, &st) != 0) { close(fd); return NGSID_ERR_ARG; }
+    if (st.st_size == 0) { close(fd); return NGSID_OK; }
+    void* p = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return NGSID_ERR_ARG;
+    *data = (const uint8_t*)p; *len = (uint64_t)st.st_size;
+    return NGSID_OK;
+}
+extern "C" int32_t ngsid_host_unmap_file(const uint8_t* data, uint64_t len, int32_t in_background)
+{
+    if (!data || !len) return NGSID_OK;
+    if (in_background) { std::thread([=] { (void)munmap((void*)data, (size_t)len); }).detach(); return NGSID_OK; }
+    return munmap((void*)data, (size_t)len) == 0 ? NGSID_OK : NGSID_ERR_ARG;
+}
 
 // decimal strings of n integers as a CSR (buf: sum of the digit counts, off: n + 1) - the output ids of final_clusters.tsv; *needed = bytes of buf (call with cap = 0 to size)
 extern "C" int32_t ngsid_host_int_prefixes(const int64_t* v, uint64_t n, uint8_t* buf, uint64_t cap, uint64_t* off, uint64_t* needed)

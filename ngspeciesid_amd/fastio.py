@@ -58,7 +58,33 @@ def read_fastq(path):
     # the file is MAPPED, not copied (1.5 GB at C3: the copy alone took a third of the ingest).  Nothing keeps pointing into the mapping once this function returns
     # (the background writers used to read the names from it while `--fastq <outfolder>/sorted.fastq` was being truncated by those very writers): bases,
     # qualities AND names are gathered into owned arrays below and the mapping is dropped.  The input only has to stay unchanged for the duration of this call.
-    buf = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) > 0 else np.zeros(0, dtype=np.uint8)
+    # (round 5: mapped and unmapped by the library.  NumPy's memmap object unmapped the 1.5 GB of C3 on this thread with the interpreter lock held - 75 ms of the ingest's 130 ms -, and
+    # a background unmap right after the ingest slows the upload that follows by as much (both want the address-space lock).  The mapping is therefore RELEASED LATER: by
+    # release_mapped() - the CLI calls it when its run is over - or by the next read_fastq; until then nothing reads from it.)
+    release_mapped()
+    mptr = C.POINTER(C.c_ubyte)(); mlen = C.c_uint64(0)
+    if lib.ngsid_host_map_file(os.fsencode(path), C.byref(mptr), C.byref(mlen)):
+        raise OSError("cannot read %s" % path)
+    buf = np.ctypeslib.as_array(mptr, shape=(mlen.value,)) if mlen.value else np.zeros(0, dtype=np.uint8)
+    try:
+        return _read_fastq_mapped(lib, path, buf)
+    finally:
+        del buf
+        if mlen.value: _MAPPED.append((mptr, mlen))
+
+
+_MAPPED = []
+
+
+def release_mapped():
+    """unmaps the input files read_fastq left mapped (a detached native thread does it: gigabytes take tens of milliseconds)"""
+    lib = runtime.load_library()
+    while _MAPPED:
+        mptr, mlen = _MAPPED.pop()
+        lib.ngsid_host_unmap_file(mptr, mlen, C.c_int32(1))
+
+
+def _read_fastq_mapped(lib, path, buf):
     n = C.c_uint64(0)
     rc = lib.ngsid_host_fastq_index(_p(buf), C.c_uint64(len(buf)), None, None, None, C.c_uint64(0), C.byref(n))
     if rc == 0 and n.value > 0:
@@ -76,7 +102,6 @@ def read_fastq(path):
             if nr: noff[1:] = np.cumsum(nlen[:-1], dtype=np.uint64)
             nbuf = np.empty(int(nlen.sum(dtype=np.uint64)), dtype=np.uint8)
             lib.ngsid_host_gather(_p(buf), _p(no), _p(nlen), C.c_uint64(nr), _p(nbuf), _p(noff))      # (15 MB per million reads: 2 ms)
-            del buf
             return Names(nbuf, noff, nlen), ReadSet(seq, qual, off), True
     # general reader (multi-line FASTQ / FASTA / empty file)
     accs, seqs, quals = [], [], []

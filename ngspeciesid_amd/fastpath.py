@@ -517,6 +517,7 @@ def main(args, api=None):
     finally:
         sys.setswitchinterval(_swi)
         if _gc: gc.enable()
+        fastio.release_mapped()            # the input file's mapping (read_fastq leaves it to the end of the run: fastio.py)
         if _fd is not None:
             import faulthandler
             faulthandler.cancel_dump_traceback_later(); _fd.close()
