@@ -334,9 +334,11 @@ extern "C" int32_t ngsid_host_write_records_async(const char* path, int32_t appe
                                                   const uint8_t* seq, const uint8_t* qual, const uint64_t* off, int32_t max_threads, uint64_t* job)
 {
     if (!path || !job) return NGSID_ERR_ARG;
-    std::string p(path);
-    *job = async_jobs().submit([=] { return write_records_impl(p.c_str(), append, kind, n, idx, names, name_off, name_len, first_token, sfx, sfx_off, sfx_by_read, seq, qual, off); }, max_threads);
-    return NGSID_OK;
+    try {
+        std::string p(path);
+        *job = async_jobs().submit([=] { return write_records_impl(p.c_str(), append, kind, n, idx, names, name_off, name_len, first_token, sfx, sfx_off, sfx_by_read, seq, qual, off); }, max_threads);
+        return NGSID_OK;
+    } catch (...) { return NGSID_ERR_ARG; }          // (no worker thread / no memory: the caller falls back to the synchronous writer or reports it)
 }
 extern "C" int32_t ngsid_host_async_wait(uint64_t job) { return async_jobs().wait(job); }
 
@@ -358,7 +360,10 @@ extern "C" int32_t ngsid_host_map_file(const char* path, const uint8_t** data, u
 extern "C" int32_t ngsid_host_unmap_file(const uint8_t* data, uint64_t len, int32_t in_background)
 {
     if (!data || !len) return NGSID_OK;
-    if (in_background) { std::thread([=] { (void)munmap((void*)data, (size_t)len); }).detach(); return NGSID_OK; }
+    if (in_background) {
+        try { std::thread([=] { (void)munmap((void*)data, (size_t)len); }).detach(); return NGSID_OK; }
+        catch (...) { /* no thread to be had: unmap here */ }
+    }
     return munmap((void*)data, (size_t)len) == 0 ? NGSID_OK : NGSID_ERR_ARG;
 }
 

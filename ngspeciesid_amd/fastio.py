@@ -228,7 +228,9 @@ def _write_records(path, append, kind, idx, names, first_token, sb, so, sfx_by_r
         return
     jid = C.c_uint64(0)
     if lib.ngsid_host_write_records_async(*args, C.c_int32(int(threads or 0)), C.byref(jid)):
-        raise OSError("cannot write %s" % path)
+        if lib.ngsid_host_write_records(*args):            # the queue could not take the job (no thread to be had): write it here
+            raise OSError("cannot write %s" % path)
+        return
     jobs.jobs.append((jid.value, path, (idx, names, sb, so, seq, qual, off, rs)))
 
 
