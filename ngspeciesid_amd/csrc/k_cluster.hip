@@ -252,13 +252,16 @@ __global__ void k_cache_insert(ClDev D, const uint32_t* __restrict__ req_q, cons
 }
 
 // one bit per block item: the item decided "new representative" (word w covers the items row0 + 64 w ... of the block)
+// Round 5: the word behind the mask (index w_tail) carries the round's two scalars - pairs requested by k_aln_next (low half) and the p-table error flag (high half) - so that a
+// round's results travel to the host as ONE copy instead of three, and the request counter is reset here, by its reader, instead of by a memset in front of the next k_aln_next.
 __global__ void k_newrep_mask(const int32_t* __restrict__ dec, const uint32_t* __restrict__ items, uint32_t it_first /* row0 + multiple of 64 */, uint32_t it_lo, uint32_t it_hi,
-                              uint32_t row0, unsigned long long* __restrict__ mask)
+                              uint32_t row0, unsigned long long* __restrict__ mask, uint32_t w_tail, uint32_t* __restrict__ nreq, const int* __restrict__ eflag)
 {
     const uint32_t it = it_first + blockIdx.x * blockDim.x + threadIdx.x;
     const bool v = it >= it_lo && it < it_hi && dec[items[it]] == DEC_NEWREP;
     const unsigned long long bits = __ballot(v);
     if ((threadIdx.x & 63) == 0 && it < it_hi) mask[(it - row0) >> 6] = bits;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { mask[w_tail] = ((unsigned long long)(unsigned)*eflag << 32) | (unsigned long long)*nreq; *nreq = 0u; }
 }
 
 // hits of the block items [it_lo,it_hi) against ONE freshly built representative (its sorted unique codes in the pool; the offsets are read on the
@@ -647,7 +650,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     DevBuf<uint64_t> cnt; uint32_t stride = 0;
     DevBuf<uint32_t> req_q, req_t, req_slot, d_scal; DevBuf<int32_t> req_open, req_mid, req_region;
     HIPCHK(ctx, req_q.alloc(BLK)); HIPCHK(ctx, req_t.alloc(BLK)); HIPCHK(ctx, req_slot.alloc(BLK)); HIPCHK(ctx, req_open.alloc(BLK)); HIPCHK(ctx, req_mid.alloc(BLK)); HIPCHK(ctx, req_region.alloc(BLK));
-    HIPCHK(ctx, d_scal.alloc(4));
+    HIPCHK(ctx, d_scal.alloc(4)); HIPCHK(ctx, hipMemsetAsync(d_scal.p, 0, 16, ctx->stream));
     uint32_t tcur = 1;
     constexpr uint32_t TMAX = 64;             // new representatives committed per pass (one lane per tentative column in k_first_affected)
     DevBuf<unsigned long long> d_mask; HIPCHK(ctx, d_mask.alloc(BLK / 64 + 1)); PinVec<unsigned long long> h_mask(BLK / 64 + 1);
@@ -678,8 +681,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             HIPCHK(ctx, hipGetLastError());
             const uint32_t w0 = (lo - b0) >> 6, w1 = (b1 - b0 + 63) >> 6;
             int eflag = 0;
-            for (;;) {      // alignment rounds: resolve from cache or request pairs, align, cache, repeat
-                HIPCHK(ctx, hipMemsetAsync(d_scal.p, 0, 4, ctx->stream));
+            for (;;) {      // alignment rounds: resolve from cache or request pairs, align, cache, repeat  (d_scal[0] is zero here: set at the start, reset by k_newrep_mask)
                 { ProfScope ps_(ctx, "k_aln_next"); hipLaunchKernelGGL(k_aln_next, dim3((b1 - lo + 15) / 16), dim3(1024), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, S.R,
                                    req_q.p, req_t.p, req_slot.p, req_open.p, req_mid.p, d_scal.p); }
                 HIPCHK(ctx, hipGetLastError());
@@ -687,12 +689,11 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
                 // of [lo, b1) is decided and the mask is the one the next step needs (most rounds of a noisy tail; one host round trip less per round); when pairs are
                 // requested it is recomputed after the alignments
                 uint32_t nreq = 0;
-                hipLaunchKernelGGL(k_newrep_mask, dim3(((w1 - w0) * 64 + 255) / 256), dim3(256), 0, ctx->stream, dec.p, d_items.p, b0 + w0 * 64, lo, b1, b0, d_mask.p);
+                hipLaunchKernelGGL(k_newrep_mask, dim3(((w1 - w0) * 64 + 255) / 256), dim3(256), 0, ctx->stream, dec.p, d_items.p, b0 + w0 * 64, lo, b1, b0, d_mask.p, w1, d_scal.p, flag.p + 1);
                 HIPCHK(ctx, hipGetLastError());
-                HIPCHK(ctx, hipMemcpyAsync(&nreq, d_scal.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipMemcpyAsync(h_mask.data() + w0, d_mask.p + w0, 8ull * (w1 - w0), hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipMemcpyAsync(&eflag, flag.p + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipMemcpyAsync(h_mask.data() + w0, d_mask.p + w0, 8ull * (w1 - w0 + 1), hipMemcpyDeviceToHost, ctx->stream));      // mask words + the tail word (nreq | eflag << 32)
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                nreq = (uint32_t)(h_mask[w1] & 0xffffffffull); eflag = (int)(h_mask[w1] >> 32);
                 if (!nreq) break;
                 AlignJob J{};
                 J.qseq = RD.seq; J.qoff = RD.off; J.tseq = RD.seq; J.toff = RD.off; J.qidx = req_q.p; J.tidx = req_t.p; J.npairs = nreq;
