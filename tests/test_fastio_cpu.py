@@ -189,3 +189,32 @@ def test_int_prefixes_are_the_decimal_strings():
     got = [buf[int(off[i]):int(off[i + 1])].tobytes().decode() for i in range(len(v))]
     assert got == [str(int(x)) for x in v]
     assert fastio.int_prefixes(np.zeros(0, dtype=np.int64))[1].tolist() == [0]
+
+
+def test_library_maps_and_unmaps_the_input_file(tmp_path):
+    """round 5: ngsid_host_map_file / ngsid_host_unmap_file (the ingest's mapping, released off the launch thread): the mapped bytes are the file's, an empty file maps to
+    nothing, a missing file is an error; read_fastq leaves its mapping to release_mapped() / the next read_fastq and the arrays it returned stay valid after the release"""
+    import ctypes as C
+    from ngspeciesid_amd import runtime
+    lib = runtime.load_library()
+    src = os.path.join(GOLD, "sample_h1.fastq"); raw = open(src, "rb").read()
+    ptr = C.POINTER(C.c_ubyte)(); n = C.c_uint64(0)
+    assert lib.ngsid_host_map_file(os.fsencode(src), C.byref(ptr), C.byref(n)) == 0 and n.value == len(raw)
+    assert bytes(np.ctypeslib.as_array(ptr, shape=(n.value,))) == raw
+    assert lib.ngsid_host_unmap_file(ptr, n, C.c_int32(0)) == 0
+    empty = tmp_path / "empty.fq"; empty.write_bytes(b"")
+    assert lib.ngsid_host_map_file(os.fsencode(str(empty)), C.byref(ptr), C.byref(n)) == 0 and n.value == 0
+    assert lib.ngsid_host_map_file(os.fsencode(str(tmp_path / "missing.fq")), C.byref(ptr), C.byref(n)) != 0
+    with pytest.raises(OSError):
+        fastio.read_fastq(str(tmp_path / "missing.fq"))
+    names, rs, plain = fastio.read_fastq(src)
+    assert plain and len(fastio._MAPPED) == 1
+    seq0 = rs.seq.copy(); nm0 = names.get(0)
+    fastio.release_mapped()
+    assert fastio._MAPPED == []
+    import time; time.sleep(0.2)                                  # the background unmap has happened: nothing returned points into the mapping
+    assert np.array_equal(rs.seq, seq0) and names.get(0) == nm0
+    names2, rs2, _ = fastio.read_fastq(src)                       # the next call releases what the previous one left
+    names3, rs3, _ = fastio.read_fastq(src)
+    assert len(fastio._MAPPED) == 1 and np.array_equal(rs3.seq, seq0)
+    fastio.release_mapped()
