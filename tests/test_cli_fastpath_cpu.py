@@ -188,3 +188,18 @@ def test_centres_that_merge_only_after_trimming_are_polished_again(oracle_backen
     assert hdr.startswith(">consensus_cl_id_%s_total_supporting_reads_%d " % (cid, n0 + n1)) and " LN:i:%d " % len(seq) in hdr
     assert seq == tails["1_F_fw"][-1] + bodies[0].tobytes().decode()          # polished by the pooled reads (4 : 1 its own), trimmed like the reference trims
     assert files["racon_cl_id_%s/racon_polished_it_1.fasta" % cid] == files["racon_cl_id_%s/consensus.fasta" % cid]
+
+
+def test_writer_modes_leave_the_same_files(oracle_backend, monkeypatch):
+    """round 5: the record writers as background jobs of the library (default), as interpreter threads (NGSID_CLI_PY_WRITERS=1, rounds 2 - 5) and synchronous
+    (NGSID_CLI_SYNC_WRITES=1): the same file set with the same bytes, consensus stage and rc merge included"""
+    extra = ["--t", "1", "--consensus", "--racon", "--racon_iter", "2", "--abundance_ratio", "0.02", "--rc_identity_threshold", "0.9"]
+    native = _run(oracle_backend, extra, False)
+    monkeypatch.setenv("NGSID_CLI_PY_WRITERS", "1")
+    threads = _run(oracle_backend, extra, False)
+    monkeypatch.delenv("NGSID_CLI_PY_WRITERS"); monkeypatch.setenv("NGSID_CLI_SYNC_WRITES", "1")
+    sync = _run(oracle_backend, extra, False)
+    assert sorted(native) == sorted(threads) == sorted(sync)
+    assert any(k.startswith("reads_to_consensus_") for k in native) and "final_clusters.tsv" in native and "sorted.fastq" in native
+    for k in native:
+        assert native[k] == threads[k] == sync[k], k
