@@ -79,12 +79,27 @@ def main():
     ap.add_argument("--no-extra-step", action="store_true", help="skip the extra step with stop_when_stable (profiling runs that count per-step traffic)")
     ap.add_argument("--no-cli", action="store_true", help="skip the file-in -> files-out leg (the drop-in CLI on the same reads, reported as config.cli)")
     ap.add_argument("--cli-t", type=int, default=1, help="--t of the CLI leg (the reference's batch count; 1 = one clustering pass)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default): --reads per GPU, an independent set per rank.  strong: ONE global score-sorted set of --reads reads, rank g gets batch g+1 of the "
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong for --config c4 / c5 with --gpus N > 1 (BASELINE quotes them as ONE global set over 8 GPUs), weak otherwise.  weak: --reads per GPU, an independent set per rank.  strong: ONE global score-sorted set of --reads reads, rank g gets batch g+1 of the "
                          "reference's `--t N` partition (parallelize.batch_list total_nt), so the N-GPU membership is the reference's --t N membership of that set")
     ap.add_argument("--check-membership", action="store_true", help="strong scaling: after the timed region rank 0 replays the `--t N` schedule on one GPU and compares the membership")
+    ap.add_argument("--master-port", type=int, default=0, help="--gpus N > 1 started directly: the rendezvous port of the ranks this process launches (0 = a free one)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` IS the N-GPU run: this process becomes `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>`,
+        # one rank per GPU over RCCL (backend nccl; NGSID_DIST_BACKEND=gloo only as a dev aid for more ranks than GPUs).  stdout is inherited, so rank 0's JSON line is this command's.
+        port = args.master_port
+        if not port:
+            import socket
+            with socket.socket() as s_: s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+        if os.environ.get("NGSID_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
+            sys.exit("bench.py --gpus %d: this node shows %d GPU(s); one RCCL rank per GPU is required (NGSID_DIST_BACKEND=gloo lets ranks share a GPU, as a dev aid)" % (args.gpus, torch.cuda.device_count()))
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:])
     cfg = CONFIGS[args.config]
+    if args.scaling is None:      # the BASELINE shape of the configuration: C4 / C5 are ONE global set over the GPUs of a node (strong); C2 / C3 are per-GPU workloads (weak)
+        args.scaling = "strong" if (args.config in ("c4", "c5") and args.gpus > 1) else "weak"
     if args.reads is None: args.reads = int(os.environ.get("NGSID_BENCH_READS", cfg["total"] if args.scaling == "strong" else cfg["reads"]))
     if args.species is None: args.species = cfg["species"]
     if args.length is None: args.length = cfg["length"]
@@ -95,6 +110,7 @@ def main():
     # stdout carries exactly ONE line (the JSON): everything native code prints to fd 1 (RCCL's banner, rocm warnings) goes to stderr instead
     sys.stdout.flush(); json_fd = os.dup(1); os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or os.environ.get("NGSID_FORCE_DIST") == "1", "--gpus %d but the launcher started %d rank(s): n_gpus of the line would not be what ran" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
     ndev = torch.cuda.device_count()
     local = local % ndev                      # (dev aid: more ranks than GPUs only with NGSID_DIST_BACKEND=gloo, e.g. 2 ranks on a 1-GPU box)
@@ -193,8 +209,13 @@ def main():
         barrier(); t1 = time.perf_counter()
         res_stop = step(polish_stop_when_stable=True)
         barrier(); dt_stop = time.perf_counter() - t1
+    ranks_seen = 1; stage_max = None
     if dist is not None:
         t = torch.tensor([dt], device=comm_dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        ones = torch.ones(1, device=comm_dev, dtype=torch.int64); dist.all_reduce(ones); ranks_seen = int(ones.item())        # how many ranks took part in the collectives of this run
+        gpus_seen = torch.zeros(64, device=comm_dev, dtype=torch.int64); gpus_seen[local] = 1; dist.all_reduce(gpus_seen); gpus_seen = int((gpus_seen > 0).sum().item())
+        names_ = sorted(T); tv = torch.tensor([T[k_] for k_ in names_], device=comm_dev, dtype=torch.float64)
+        if len(names_): dist.all_reduce(tv, op=dist.ReduceOp.MAX); stage_max = {k_: float(v) for k_, v in zip(names_, tv.tolist())}
         tn = torch.tensor([n], device=comm_dev, dtype=torch.float64); dist.all_reduce(tn); n_total = int(tn.item())
     else:
         n_total = n
@@ -242,36 +263,55 @@ def main():
     mem_parts = {k_[4:]: round(kern.pop(k_)[0] / 1e9, 2) for k_ in [x for x in kern if x.startswith("mem_")]}      # grow-only scratch of the context by purpose (GB)
     hbm_peak = kern.pop("hbm_peak_bytes", (0, 0.0))[0]; hbm_live = kern.pop("hbm_live_bytes", (0, 0.0))[0]      # device memory handed out by the library's allocator (process wide): high-water mark of the timed steps / still held after them
     poa_rows = kern.pop("poa_dp_rows", (0, 0.0))[0]; sg_cells = kern.pop("sg_dp_cells", (0, 0.0))[0]      # work counters of the timed steps (counted by the kernels themselves, ngsid_profile_read)
+    # the dominant KERNEL: ngsid_profile_read also carries the library's host-side wall-clock lines (`host_<api>`, round 5) and counters - only `k_*` lines are kernels
+    host_lines = {k_: kern.pop(k_) for k_ in [x for x in kern if not x.startswith("k_")]}
     dom = max(kern.items(), key=lambda kv: kv[1][1]) if kern else (None, (0, 0.0))
     f_aln = float(res["counters"][2]) / n
     L = args.length; M = int(round(0.21 * 0.75 * L)) if K_ <= 13 else int(round(0.054 * 0.75 * L))          # minimizers per read (118 at 750 bp k13/w20, 80 at 2 kb k15/w50)
-    per_read_bytes = {"k_sg_align": 4 * L, "k_poa_tile": 2 * L, "k_hpc_minimizers": 2 * L + 12 * M, "k_count_hits": 12 * M + 8, "k_decide_map": 12 * M + 8, "k_aln_next": 8}
+    n_pol = float(sum(c[0] for c in res["centers"]))                                                                # reads that go through the draft POA and the polisher (clusters above the abundance cut-off)
+    # algorithmic bytes per STEP (one byte per base and per quality, every stage streams its input once): aligner f_aln x (2L read + 2L representative); POA 2L per read
+    # and pass, 1 draft + 3 polishing passes; the polisher's read -> backbone aligner 2L read + 2L backbone per read and iteration; minimizers 2L in + 12M out
+    alg_step = {"k_sg_align": f_aln * n * 4 * L, "k_poa_tile": 4.0 * n * 2 * L, "k_ed_align": 3.0 * n_pol * 4 * L, "k_hpc_minimizers": n * (2 * L + 12 * M),
+                "k_count_hits": n * (12 * M + 8), "k_decide_map": n * (12 * M + 8), "k_aln_next": n * 8.0}
+    tj, tj_file = None, None
+    try:    # HBM bytes per step from the committed PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, tools/r06_profiles.sh): a counter pass
+            # cannot run inside this process, so the figure is a measurement of the recorded commit on the recorded workload, not of this run
+        tj_file = next(f for f in ("r06_hbm_traffic.json", "r05_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        tj = json.load(open(os.path.join(ROOT, "profiles", tj_file)))
+        if not (tj.get("workload_reads") == args.reads and tj.get("config", "c3") == args.config and tj.get("tile_depth", args.tile_depth) == args.tile_depth): tj = None
+    except Exception:
+        tj = None
+    def kernel_line(nm):
+        cnt, ms = kern[nm]
+        alg = alg_step.get(nm, n * 2.0 * L) * args.steps           # bytes over the timed steps
+        sec = ms / 1e3
+        v = {"launches_per_step": round(cnt / args.steps, 1), "ms_per_step": round(ms / args.steps, 3), "algorithmic_bytes_per_step": int(alg / args.steps),
+             "achieved": round(alg / sec / 1e9, 3) if sec > 0 else None, "unit": "GB/s", "frac": round(alg / sec / 8e12, 6) if sec > 0 else None}
+        if tj is not None and nm in tj:
+            tb = float(tj[nm]["hbm_bytes_per_step"])
+            v.update({"traffic_bytes_per_step": int(tb), "traffic_over_algorithmic": round(tb * args.steps / alg, 1) if alg else None,
+                      "traffic_GBps": round(tb * args.steps / sec / 1e9, 1) if sec > 0 else None, "traffic_frac_of_peak": round(tb * args.steps / sec / 8e12, 4) if sec > 0 else None})
+        return v
     roof = None
     if dom[0]:
         cnt, ms = dom[1]
-        if dom[0] == "k_sg_align":      # cluster aligner: f_aln*N pairs (the polisher aligns with k_ed_align)
-            units = f_aln * n * args.steps
-        elif dom[0] == "k_poa_tile":    # 1 spoa pass + 3 polish passes per read
-            units = 4.0 * n * args.steps
-        else:
-            units = 1.0 * n * args.steps
-        alg_bytes_per_launch = units * per_read_bytes.get(dom[0], 2 * L) / max(cnt, 1)
+        alg_bytes_per_launch = alg_step.get(dom[0], n * 2.0 * L) * args.steps / max(cnt, 1)
         avg_s = ms / 1e3 / max(cnt, 1)
         ach = alg_bytes_per_launch / avg_s / 1e9
-        traffic = None
-        traffic_src = None
-        try:    # HBM bytes per launch from the committed PMC passes of THIS round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, tools/r04_profiles.sh): a counter
-                # pass cannot run inside this process, so the figure is a measurement of the recorded commit on the recorded workload, not of this run
-            tj_file = next(f for f in ("r05_hbm_traffic.json", "r04_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
-            tj = json.load(open(os.path.join(ROOT, "profiles", tj_file)))
-            if tj.get("workload_reads") == args.reads and tj.get("config", "c3") == args.config and dom[0] in tj and world == 1:
-                traffic = int(tj[dom[0]]["hbm_bytes_per_step"] * args.steps / max(cnt, 1))      # per launch, like `achieved`
-                traffic_src = {"file": "profiles/" + tj_file, "measured_at_commit": tj.get("commit"), "launches_per_step_then": tj[dom[0]].get("launches_per_step")}
-        except Exception:
-            traffic = None
+        traffic = None; traffic_src = None
+        if tj is not None and dom[0] in tj and world == 1:
+            traffic = int(tj[dom[0]]["hbm_bytes_per_step"] * args.steps / max(cnt, 1))      # per launch, like `achieved`
+            traffic_src = {"file": "profiles/" + tj_file, "measured_at_commit": tj.get("commit"), "launches_per_step_then": tj[dom[0]].get("launches_per_step"),
+                           "how": "rocprofv3 --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE over one bench step; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB as MI355X_MICROARCH.md prescribes for gfx950"}
+        whole = n * ((10 + 4 * f_aln) * L + 24 * M + 8)            # the path's algorithmic bytes per read x reads
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_over_algorithmic": round(traffic / alg_bytes_per_launch, 1) if traffic else None,
+                "traffic_GBps": round(traffic / avg_s / 1e9, 1) if traffic else None,
                 "limited_by": "VALU instruction issue (the DP rows and the graph bookkeeping of one wave per tile), not HBM bandwidth: see `valu_issue` / `dp_kernels` and DESIGN.md section 4",
                 "launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 4), "algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
+                "kernels": {nm: kernel_line(nm) for nm in ("k_poa_tile", "k_sg_align", "k_ed_align", "k_hpc_minimizers") if nm in kern},
+                "whole_path": {"algorithmic_bytes_per_read": round(whole / n, 1), "achieved": round(whole * args.steps / dt / 1e9, 3), "unit": "GB/s", "frac": round(whole * args.steps / dt / 8e12, 6),
+                               "what": "SURVEY 8d: ((10 + 4 f_aln) L + 24 M + 8) bytes per read x reads per second of `value`"},
                 "note": "integer DP kernel, one wave per tile: bound by VALU issue (`valu_issue`: DP rows counted in this run x instructions per row of the committed counter pass / this run's kernel time), so the fraction of the HBM roofline is small by construction (DESIGN.md sections 4 and 10)"}
         # ---- what actually bounds the two DP kernels: VALU issue.  Work (DP rows / cells) is counted by the kernels in THIS run; the instructions per unit of
         #      work come from the committed SQ-counter pass (POA: profiles/r04_pmc_poa_tile.json, with its commit) or the ISA (aligner): a counter pass cannot run
@@ -279,23 +319,24 @@ def main():
         prop = torch.cuda.get_device_properties(dev)
         clk = float(getattr(prop, "clock_rate", 2400000)) * 1e3
         peak_issue = prop.multi_processor_count * 4 * clk / 4.0
-        # basis of that peak: MEASURED on this GPU - tools/micro/valu_issue.hip -> profiles/r05_valu_rates.txt: with two or more waves per SIMD a SIMD issues one
-        # plain VOP2 integer instruction (v_xor_b32, v_add_u32, v_mov_b32) per 4.0 cycles (3.0 - 3.3 for v_mov / v_fma_f32 at four waves), one DPP / packed-int16 / VOP3 form
-        # (v_max_i32, v_pk_*_i16, v_*_dpp, v_bfi, v_and_or, v_max3) per 4.9 - 5.8 cycles, and a lone wave one instruction per 8 - 9 cycles.  The guide's 2 cycles per wave64
-        # instruction (MI355X_MICROARCH.md:52-54) is not reached by any of these forms.  4.0 cycles is therefore an UPPER bound of the peak for the mixes of these kernels;
-        # `frac_at_4p9_cycles` prices the same work against the rate of the DPP / packed forms they are mostly made of.
-        peak_basis = {"cycles_per_wave_instruction_and_simd": 4.0, "source": "profiles/r05_valu_rates.txt (tools/micro/valu_issue.hip, measured on MI355X: plain VOP2 4.0, DPP / packed i16 / VOP3 4.9 - 5.8, lone wave 8 - 9 cycles)",
-                      "guide_value_not_observed": "2 cycles (MI355X_MICROARCH.md:52-54)"}
+        # basis of that peak: MEASURED on this GPU - tools/micro/valu_issue.hip -> profiles/r06_valu_rates.txt (round 6: up to 8 waves per SIMD, 8 and 16 independent registers per
+        # stream, two mixes at the kernels' own ratios).  v_mov_b32 / v_fma_f32 reach 2.4 - 2.7 cycles per wave64 instruction and SIMD (the guide's 2 cycles, MI355X_MICROARCH.md:52-54, is
+        # approached by these two forms only), plain VOP2 integer adds 3.1 - 3.4, and every form these kernels are made of (v_max_i32, v_pk_*_i16, v_*_dpp, v_bfi, v_and_or, v_max3,
+        # v_lshl_add) is flat at 4.3 - 4.4 from 4 to 8 waves per SIMD; the aligner-step mix 4.3 - 4.4, the POA-row mix 4.2 - 4.3.  `frac` divides by 4.0 cycles (an upper bound of the
+        # peak for these mixes); `frac_at_measured_mix_rate` by 4.3; `frac_at_the_guides_2_cycles` by 2.0 - all three are printed.
+        peak_basis = {"cycles_per_wave_instruction_and_simd": 4.0, "measured_mix_rate_cycles": 4.3,
+                      "source": "profiles/r06_valu_rates.txt (tools/micro/valu_issue.hip on MI355X, 1 - 8 waves per SIMD: v_mov / v_fma_f32 2.4 - 2.7 cycles, plain VOP2 integer 3.1 - 3.4, DPP / packed i16 / VOP3 forms and both kernel mixes flat at 4.2 - 4.4)",
+                      "guide_value": "2 cycles (MI355X_MICROARCH.md:52-54): approached only by v_mov_b32 / v_fma_f32 (2.4 - 2.7)"}
         band_cols = args.band if args.band else (64 if L <= 3000 else 128)          # NGSID_POA_BAND64_MAXLEN (include/ngsid.h)
         views = {}
         if "k_poa_tile" in kern and poa_rows:
             ms_p = kern["k_poa_tile"][1]; v = {"dp_rows": int(poa_rows), "band_columns": band_cols, "kernel_ms": round(ms_p, 2), "gcups": round(poa_rows * band_cols / (ms_p / 1e3) / 1e9, 1)}
             try:
-                ij_file = next(f for f in ("r05_pmc_poa_tile.json", "r04_pmc_poa_tile.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                ij_file = next(f for f in ("r06_pmc_poa_tile.json", "r05_pmc_poa_tile.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 ij = json.load(open(os.path.join(ROOT, "profiles", ij_file)))
                 if ij.get("workload_reads") == args.reads and ij.get("config", "c3") == args.config:
                     wi = poa_rows * ij["valu_per_row"] / (ms_p / 1e3)
-                    v.update({"valu_per_row": ij["valu_per_row"], "salu_per_row": ij.get("salu_per_row"), "achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "frac_at_4p9_cycles": round(wi / (peak_issue * 4.0 / 4.9), 4), "peak_basis": peak_basis,
+                    v.update({"valu_per_row": ij["valu_per_row"], "salu_per_row": ij.get("salu_per_row"), "achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2), "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "frac_at_measured_mix_rate": round(wi / (peak_issue * 4.0 / 4.3), 4), "frac_at_the_guides_2_cycles": round(wi / (peak_issue * 2.0), 4), "peak_basis": peak_basis,
                               "pipe_busy_by_counters": ij.get("pipe_busy"),
                               "instructions_per_row_source": {"file": "profiles/" + ij_file, "measured_at_commit": ij.get("commit"), "rows_then": ij.get("rows"), "pipe_busy_then": ij.get("pipe_busy")}})
             except Exception:
@@ -305,7 +346,7 @@ def main():
             ms_a = kern["k_sg_align"][1] + kern.get("k_sg_align_side", (0, 0.0))[1]
             per_cell, src = 14.4, "ISA count of the step loop of round 3 (378 VALU per step for two pairs of 12-14 rows per lane), DESIGN.md section 4"
             try:            # round 4: VALU instructions per DP cell from the SQ-counter pass of the bench workload (all k_sg_align* dispatches of one step / the cells the kernels counted in it)
-                aj_file = next(f for f in ("r05_pmc_sg_align.json", "r04_pmc_sg_align.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                aj_file = next(f for f in ("r06_pmc_sg_align.json", "r05_pmc_sg_align.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 aj = json.load(open(os.path.join(ROOT, "profiles", aj_file)))
                 if aj.get("workload_reads") == args.reads and aj.get("config", "c3") == args.config:
                     per_cell = float(aj["valu_per_cell"]); src = {"file": "profiles/" + aj_file, "measured_at_commit": aj.get("commit"), "cells_then": aj.get("cells"), "pipe_busy_then": aj.get("pipe_busy")}
@@ -313,7 +354,7 @@ def main():
                 pass
             wi = sg_cells / 64.0 * per_cell / (ms_a / 1e3)
             views["k_sg_align"] = {"dp_cells": int(sg_cells), "kernel_ms": round(ms_a, 2), "gcups": round(sg_cells / (ms_a / 1e3) / 1e9, 1), "valu_per_cell": per_cell, "achieved": round(wi / 1e9, 2), "peak": round(peak_issue / 1e9, 2),
-                                   "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "frac_at_4p9_cycles": round(wi / (peak_issue * 4.0 / 4.9), 4), "peak_basis": peak_basis, "instructions_per_cell_source": src}
+                                   "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "frac_at_measured_mix_rate": round(wi / (peak_issue * 4.0 / 4.3), 4), "frac_at_the_guides_2_cycles": round(wi / (peak_issue * 2.0), 4), "peak_basis": peak_basis, "instructions_per_cell_source": src}
         if dom[0] in views: roof["valu_issue"] = dict(views[dom[0]], kernel=dom[0])
         roof["dp_kernels"] = views
     # ---- the drop-in surface (runs before the CPU baseline leg): FASTQ file in -> the reference's output files out (python -m ngspeciesid_amd ...), same reads, same flags as C3
@@ -425,16 +466,18 @@ def main():
                          "(scalar C port of this build's algorithms; the reference's own tools - parasail, spoa, racon - are SIMD codes and are not in the image, see BASELINE.md)"
                          % (ns, args.tile_depth, per_core)}
     out = {"metric": "reads/sec end-to-end (cluster + spoa consensus + racon x3), %d bp %s" % (args.length, "CCS" if cfg["preset"] == "--isoseq" else "ONT"), "value": round(reads_per_s, 1), "unit": "reads/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+           "n_gpus": world, "rccl_ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
            "scaling": args.scaling if world > 1 or force_dist else "weak", "vs_baseline": None, "dtype": "u8 / int16 / int32 DP, 64-bit bit-vectors (f64 thresholds)", "data": "synthetic" + (" (counter-based generator, no torch.Generator)" if RNG_ == "hash" else ""),
            "config": {"workload": (args.config.upper() + ": %d synthetic %d bp %s-profile reads " + ("in total, one `--t N` batch per GPU" if (args.scaling == "strong" and (world > 1 or force_dist)) else "per GPU") + " (mu=%.0f), %d species @15%% divergence%s, k=%d w=%d, cluster + spoa-style POA + racon-style polish x3, abundance_ratio %s, POA tile depth %d band %s")
                       % (args.reads, args.length, "CCS" if args.mu >= 25 else "ONT", args.mu, args.species, (" with geometric abundance %.1f^i" % cfg["geometric"]) if cfg["geometric"] else "", K_, W_, AB_, args.tile_depth, ("%d" % args.band) if args.band else "%d (library default, widened per tile by the band-edge check)" % (64 if args.length <= 3000 else 128)),
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
-                      "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()},
-                      "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),
+                      "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()}, "stage_s_per_step_max_over_ranks": None if stage_max is None else {k_: round(v / args.steps, 4) for k_, v in stage_max.items()},
+                      "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "library_host_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in host_lines.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),
                       "hbm_gb": {"peak_in_timed_steps": round(hbm_peak / 1e9, 2), "held_after": round(hbm_live / 1e9, 2), "what": "bytes handed out by the library's device allocator, whole process (read set included)", "context_scratch_by_purpose": mem_parts},
                       "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok, "sharded_consensus_equals_single_process": single_same}},
            "roofline": roof, "cpu_baseline": cpu}
+    if dist is not None:
+        out["config"]["ranks"] = {"world_size": world, "ranks_in_the_all_reduce": ranks_seen, "distinct_gpus": gpus_seen, "backend": backend + (" (= RCCL)" if backend == "nccl" else " (dev aid: collectives on the host, ranks may share a GPU)")}
     if world > 1:
         out["config"]["baseline_config_of_this_line"] = ("%s of BASELINE.json, %s" % (args.config.upper(), "ONE global set split into the reference's `--t %d` batches (strong scaling)" % world if args.scaling == "strong" else
                                                          "its per-GPU shape repeated on every GPU with an independent read set per rank (weak scaling%s)" % ("; C3 is BASELINE's 1-GPU configuration" if args.config == "c3" else "")))
