@@ -164,7 +164,13 @@ typedef struct {
                               on the upper levels of the hierarchy (members = weighted tile consensuses, the final tile included), drop interior bases
                               whose column carries less than a third of the merged weight (round 3; a genuine insertion carried by under a third of the
                               reads goes as well - with tile_depth <= 0 there is one level and the rule never applies).  DESIGN.md section 2 */
+    int32_t single_below;  /* round 6: a group with FEWER sequences than this is aligned as ONE graph in file order - spoa's own order (consensus.py:257-266 hands a cluster's
+                              reads to one spoa process) - whatever tile_depth says, with a graph capacity of NGSID_POA_SINGLE_NODE_CAP / 16 times its first sequence when the
+                              longest sequence of the call has at most NGSID_POA_SINGLE_MAXLEN bases (else node_cap).  Depth tiling is a throughput device for deep groups; below
+                              ~100 sequences one graph is at least as accurate (profiles/r06_tile_depth_sweep.txt).  0 = off (every group is tiled at tile_depth) */
 } ngsid_poa_params_t;
+#define NGSID_POA_SINGLE_NODE_CAP 160      /* one-graph units: room for ten times the first sequence, so that no graph is closed early */
+#define NGSID_POA_SINGLE_MAXLEN   4096     /* ... while 10 x 1.25 x the longest sequence stays inside the tile engine's 16-bit node indices */
 
 /* (a13,a14) replaces form_draft_consensus' per-cluster `spoa reads.fq -l 0 -r 0 -g -2` (consensus.py:83-92,249-278).
  * Group g = positions [grp_off[g], grp_off[g+1]) of `read_order` (host array of read indices; NULL = identity),
@@ -210,6 +216,8 @@ typedef struct {
     int32_t stop_when_stable; /* 1 = a group whose backbone comes back unchanged from an iteration is not polished again: the polisher is a
                                  deterministic function of (backbone, reads), so every further iteration would return the same string and
                                  the same n_used - the result is identical, only the time differs.  0 = always run `iters` iterations */
+    int32_t single_below;     /* round 6: a polishing window with FEWER layers than this is built as ONE graph (racon's own order: backbone, then the layers by first
+                                 position), see ngsid_poa_params_t.single_below; 0 = off */
 } ngsid_polish_params_t;
 
 /* (a16,a17) replaces run_racon's (minimap2 -> racon) x racon_iter chain (consensus.py:107-126).

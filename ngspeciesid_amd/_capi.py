@@ -34,14 +34,14 @@ class ClusterParams(C.Structure):
 
 class PoaParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32), ("gap", C.c_int32),
-                ("tile_depth", C.c_int32), ("band", C.c_int32), ("node_cap", C.c_int32), ("trim", C.c_int32)]
+                ("tile_depth", C.c_int32), ("band", C.c_int32), ("node_cap", C.c_int32), ("trim", C.c_int32), ("single_below", C.c_int32)]
 
 
 class PolishParams(C.Structure):
     _fields_ = [("iters", C.c_int32), ("window", C.c_int32), ("quality_threshold", C.c_double), ("error_threshold", C.c_double),
                 ("match", C.c_int32), ("mismatch", C.c_int32), ("gap", C.c_int32), ("k", C.c_int32), ("w", C.c_int32),
                 ("tile_depth", C.c_int32), ("band", C.c_int32), ("node_cap", C.c_int32),
-                ("aln_match", C.c_int32), ("aln_mismatch", C.c_int32), ("aln_open", C.c_int32), ("aln_ext", C.c_int32), ("trim", C.c_int32), ("aln_mode", C.c_int32), ("stop_when_stable", C.c_int32)]
+                ("aln_match", C.c_int32), ("aln_mismatch", C.c_int32), ("aln_open", C.c_int32), ("aln_ext", C.c_int32), ("trim", C.c_int32), ("aln_mode", C.c_int32), ("stop_when_stable", C.c_int32), ("single_below", C.c_int32)]
 
 
 def cluster_params(k=13, w=20, min_shared=5, min_fraction=0.8, mapped_threshold=0.7, aligned_threshold=0.4,
@@ -55,16 +55,16 @@ def cluster_params(k=13, w=20, min_shared=5, min_fraction=0.8, mapped_threshold=
     return p
 
 
-def poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=0, node_cap=0, trim=0):
+def poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=0, band=0, node_cap=0, trim=0, single_below=0):
     """Defaults = `spoa -l 0 -r 0 -g -2` (consensus.py:87; spoa 4.0.x m=5 n=-4, linear because g>=e)."""
-    return PoaParams(int(mode), int(match), int(mismatch), int(gap), int(tile_depth), int(band), int(node_cap), int(trim))
+    return PoaParams(int(mode), int(match), int(mismatch), int(gap), int(tile_depth), int(band), int(node_cap), int(trim), int(single_below))
 
 
 def polish_params(iters=2, window=500, quality_threshold=10.0, error_threshold=0.3, match=3, mismatch=-5, gap=-4,
-                  k=13, w=20, tile_depth=0, band=0, node_cap=0, aln_match=2, aln_mismatch=-2, aln_open=3, aln_ext=1, trim=1, aln_mode=2, stop_when_stable=1):
+                  k=13, w=20, tile_depth=0, band=0, node_cap=0, aln_match=2, aln_mismatch=-2, aln_open=3, aln_ext=1, trim=1, aln_mode=2, stop_when_stable=1, single_below=0):
     """Defaults = racon 1.4.x (-w 500 -q 10 -e 0.3 -m 3 -x -5 -g -4), iters = --racon_iter (NGSpeciesID:212)."""
     return PolishParams(int(iters), int(window), float(quality_threshold), float(error_threshold), int(match), int(mismatch), int(gap),
-                        int(k), int(w), int(tile_depth), int(band), int(node_cap), int(aln_match), int(aln_mismatch), int(aln_open), int(aln_ext), int(trim), int(aln_mode), int(stop_when_stable))
+                        int(k), int(w), int(tile_depth), int(band), int(node_cap), int(aln_match), int(aln_mismatch), int(aln_open), int(aln_ext), int(trim), int(aln_mode), int(stop_when_stable), int(single_below))
 
 
 class ReadSet:

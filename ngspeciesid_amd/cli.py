@@ -5,73 +5,15 @@ consensus_reference_*.fasta, reads_to_consensus_*.fastq, racon_cl_id_*/consensus
 --remove_universal_tails (barcode_trimmer.py).  --medaka is outside the hot path and is refused.
 """
 from __future__ import annotations
-import argparse, logging, os, random, shutil, sys, tempfile
-from time import time
-from . import get_sorted_fastq_for_cluster, parallelize, cluster, consensus, help_functions
-from .ptable import p_emp_probs_dict
-
-
-def single_clustering(read_array, p_emp_probs, args):
-    clusters, representatives = {}, {}
-    for i, b_i, acc, seq, qual, score in read_array:
-        clusters[i] = [acc]; representatives[i] = (i, b_i, acc, seq, qual, score)
-    res = cluster.reads_to_clusters(clusters, representatives, read_array, p_emp_probs, {}, 1, args)
-    clusters, representatives, _, _ = list(res.values())[0]
-    return clusters, representatives
+import argparse, logging, os, sys
 
 
 def main(args, api=None):
-    """The CLI's work: the array path (fastpath.py).  NGSID_CLI_REFERENCE_SHAPED=1 selects the dict / file layer below instead (same results;
-    it exists for callers of the reference's Python functions and as a cross-check in the tests)."""
-    if os.environ.get("NGSID_CLI_REFERENCE_SHAPED") == "1":
-        return main_reference_shaped(args)
+    """The CLI's work = the array path (fastpath.py).  The dict / file functions with the reference's Python signatures (cluster.reads_to_clusters, parallelize.parallel_clustering,
+    consensus.run_spoa / run_racon / form_draft_consensus / polish_sequences) stay importable for callers of the reference's modules; tests/dict_layer.py drives them and compares
+    the files they leave with the ones written here."""
     from . import fastpath
     return fastpath.main(args, api=api)
-
-
-def main_reference_shaped(args):
-    args.outfile = os.path.join(args.outfolder, "sorted.fastq")
-    sorted_reads_fastq_file = get_sorted_fastq_for_cluster.main(args)
-    with open(sorted_reads_fastq_file) as f:
-        read_array = [(i, 0, acc, seq, qual, float(acc.split("_")[-1])) for i, (acc, (seq, qual)) in enumerate(help_functions.readfq(f))]
-    if args.target_length > 0 and args.target_deviation > 0:
-        read_array = [r for r in read_array if args.target_length - args.target_deviation <= len(r[3]) <= args.target_length + args.target_deviation]
-    if args.top_reads:
-        read_array = read_array[:args.sample_size]
-    elif 0 < args.sample_size < len(read_array):
-        read_array = [read_array[i] for i in sorted(random.sample(range(len(read_array)), args.sample_size))]
-    abundance_cutoff = int(args.abundance_ratio * len(read_array))
-    p_emp_probs = p_emp_probs_dict(args.k, args.w)
-    logging.info(f"Starting Clustering: {len(read_array)} reads")
-    start = time()
-    if args.nr_cores > 1:
-        clusters, representatives = parallelize.parallel_clustering(read_array, p_emp_probs, args)
-    else:
-        clusters, representatives = single_clustering(read_array, p_emp_probs, args)
-    logging.debug(f"Time elapsed clustering: {time() - start}")
-    nontrivial, out_id = 0, 0
-    with open(os.path.join(args.outfolder, "final_clusters.tsv"), "w") as outfile, open(os.path.join(args.outfolder, "final_cluster_origins.tsv"), "w") as origins:
-        for c_id, all_read_acc in sorted(clusters.items(), key=lambda x: (len(x[1]), representatives[x[0]][5]), reverse=True):
-            tup = representatives[c_id]
-            read_cl_id, b_i, acc, c_seq, c_qual, score = tup[:6]
-            error_rate = tup[6] if len(tup) == 8 else ""
-            origins.write("{0}\t{1}\t{2}\t{3}\t{4}\t{5}\n".format(out_id, "_".join(acc.split("_")[:-1]), c_seq, c_qual, score, error_rate))
-            for r_acc in sorted(all_read_acc, key=lambda x: float(x.split("_")[-1]), reverse=True):
-                outfile.write("{0}\t{1}\n".format(out_id, "_".join(r_acc.split("_")[:-1])))
-            if len(all_read_acc) > 1:
-                nontrivial += 1
-            out_id += 1
-    logging.info(f"Finished Clustering: {nontrivial} clusters formed")
-    if args.consensus:
-        logging.info("Starting Consensus creation and polishing")
-        work_dir = tempfile.mkdtemp()
-        centers = consensus.form_draft_consensus(clusters, representatives, sorted_reads_fastq_file, work_dir, abundance_cutoff, args)
-        if args.primer_file or args.remove_universal_tails:
-            raise NotImplementedError("--primer_file / --remove_universal_tails are implemented in the array path of the CLI (the default; unset NGSID_CLI_REFERENCE_SHAPED)")
-        centers_filtered = consensus.detect_reverse_complements(centers, args.rc_identity_threshold)
-        consensus.polish_sequences(centers_filtered, args)
-        shutil.rmtree(work_dir)
-        logging.info(f"Finished Consensus creation: {len(centers_filtered)} created")
 
 
 def build_parser():

@@ -5,7 +5,7 @@
 #include <math.h>
 #include <algorithm>
 
-extern "C" uint32_t ngsid_abi_version(void) { return 1u; }
+extern "C" uint32_t ngsid_abi_version(void) { return 2u; }
 
 static char g_static_err[256] = "";
 extern "C" const char* ngsid_last_error(ngsid_ctx* ctx) { return ctx ? ctx->err : g_static_err; }

@@ -35,7 +35,7 @@ __global__ void k_make_pseq_reads(const uint8_t* seq, const uint8_t* qual, const
     out[i] = S;
 }
 
-struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; int trim_tiles; };
+struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; int trim_tiles; int single_below = 0, single_cap = 0; };      // single_below / single_cap: ngsid_poa_params_t.single_below and the node capacity of such units (0 = node_cap)
 
 // Runs all units to completion.  level0: device PSeq array (nseq0 entries) whose max length is maxlen0;
 // bbs: device backbone PSeqs (may be null), maxbb = longest backbone.
@@ -529,6 +529,22 @@ static int32_t run_hierarchy_batch(ngsid_ctx* ctx, const PSeq* d_level0, uint32_
 int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, const PSeq* d_bbs, const std::vector<int>& bb_len,
                       std::vector<Unit>& units, const HierParams& hp)
 {
+    if (hp.single_below > 0) {
+        // round 6 (ngsid_poa_params_t.single_below, oracle run_unit): units with fewer sequences than that run as ONE graph in the given order, as a hierarchy of their own (launch
+        // geometry for ten times the first sequence); the others are tiled at depth D exactly as before.  A call without small units takes the unchanged path.
+        std::vector<size_t> small; for (size_t u = 0; u < units.size(); ++u) if (!units[u].done && units[u].seqs.size() < (size_t)hp.single_below) small.push_back(u);
+        HierParams hb = hp; hb.single_below = 0;
+        if (small.empty()) return run_hierarchy(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hb);
+        HierParams hs = hb; hs.D = 0; if (hp.single_cap > 0) hs.node_cap = hp.single_cap;
+        std::vector<Unit> sub; sub.reserve(small.size());
+        for (size_t u : small) sub.push_back(std::move(units[u]));
+        int32_t rc = run_hierarchy(ctx, d_level0, maxlen0, d_bbs, bb_len, sub, hs);
+        for (size_t x = 0; x < small.size(); ++x) { units[small[x]] = std::move(sub[x]); units[small[x]].done = true; }
+        if (rc) return rc;
+        if (small.size() == units.size()) return NGSID_OK;
+        // the large units: the small ones are done (their results stay in place), every loop below skips them
+        return run_hierarchy(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hb);
+    }
     size_t budget = 0;
     { const long long mb = ngsid_opt(ctx, "poa_level_budget_mb", 0);
       if (mb > 0) budget = (size_t)mb << 20;
@@ -615,6 +631,7 @@ static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, co
         else { units[g].seqs.resize(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs[r - grp_off[g]] = (uint32_t)r; }
     }
     HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, prm->mode, cov != nullptr, prm->trim > 0 ? 1 : 0};
+    hp.single_below = prm->single_below > 0 ? prm->single_below : 0; hp.single_cap = RD.maxlen <= NGSID_POA_SINGLE_MAXLEN ? NGSID_POA_SINGLE_NODE_CAP : 0;
     std::vector<int> nobb;
     htc.mark("units");
     rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;
@@ -993,6 +1010,7 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         if (!bbs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_bbs.p, bbs.data(), sizeof(PSeq) * bbs.size(), hipMemcpyHostToDevice, ctx->stream));
         bool any_tgs = prm->trim == 2; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
         HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, (prm->trim >= 2 ? 1 : 0) | (prm->trim == 3 ? 4 : 0)};      // trim_tiles: 1 = trim tile consensuses, 4 = except the tile that ends a unit (trim 3)
+        hp.single_below = prm->single_below > 0 ? prm->single_below : 0; hp.single_cap = RD.maxlen <= NGSID_POA_SINGLE_MAXLEN ? NGSID_POA_SINGLE_NODE_CAP : 0;
         ht.mark("unit lists");
         rc = run_hierarchy(ctx, (const PSeq*)d_lay_raw.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
         ht.mark("hierarchy");

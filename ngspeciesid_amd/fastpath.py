@@ -2,7 +2,7 @@
 polishing call on a resident read set (no per-read Python, no temporary per-cluster files that are read back).
 
 Same steps, same file contracts and the same results as the reference's main (NGSpeciesID:36-152) and as the reference-shaped dict layer of
-this package (cli.main_reference_shaped, kept for callers of cluster.reads_to_clusters / consensus.run_spoa / run_racon):
+this package (cluster.reads_to_clusters, consensus.run_spoa / run_racon, ... - kept for callers of the reference's modules, driven by tests/dict_layer.py):
   get_sorted_fastq_for_cluster.main (:124-191)  -> score_and_sort()     sorted.fastq, logfile.txt
   length filter / sub-sampling (NGSpeciesID:54-63)
   single_clustering / parallel_clustering      -> cluster()            (parallelize.tree_cluster for --t N: same batches, same merge rounds)

@@ -18,6 +18,9 @@ from ._capi import Api, ReadSet, cluster_params, poa_params, polish_params, POA_
 # more: none at either) - profiles/r05_tile_depth_sweep.txt.  Round 5: 4 (was 6 since round 3): the graphs of a tile stay smaller (fewer rows per alignment), k_poa_tile
 # 396 -> 363 ms per C3 step, the step 780 -> 748 ms; depth 3 loses the majority inside a tile (2 edits per amplicon on the bench workload) and is slower again.
 TILE_DEPTH = 4
+# Round 6: a unit (a cluster in the draft, a window in the polisher) with FEWER sequences than this is aligned as ONE graph in file order - spoa's / racon's own order
+# (consensus.py:257-266,87) - instead of being tiled (ngsid_poa_params_t.single_below).  Tiling is a throughput device for deep clusters; profiles/r06_tile_depth_sweep.txt.
+SINGLE_BELOW = 0
 import os as _os
 _TOUCH = bool(_os.environ.get("NGSID_TOUCH"))          # dev probe (round 5): one trivial device operation in the middle of the host work between clustering and consensus
 DRAFT_TRIM = 1
@@ -100,10 +103,11 @@ def pooled_read_lists(merged, group_reads):
 def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, w=20, abundance_ratio=0.1,
                  rc_identity_threshold=0.9, max_seqs_for_consensus=-1, racon_iter=3, tile_depth=None, band=0, node_cap=0,
                  p_shared=None, cluster_kwargs=None, do_consensus=True, do_polish=True, timings=None, polish_trim=2, polish_aln_mode=2, polish_stop_when_stable=True,
-                 strand_aware=False, draft_trim=None):
+                 strand_aware=False, draft_trim=None, single_below=None):
     """Returns dict(rep_of, status, counters, hpc_err, centers=[(n_reads, c_id, draft, polished, groups)]); with strand_aware (extension, off by
     default: strand.py) also flip [n] = reads that were reverse-complemented for the consensus stages, and rep_of is the merged membership."""
     tile_depth = TILE_DEPTH if tile_depth is None else tile_depth
+    single_below = SINGLE_BELOW if single_below is None else single_below
     T = timings if timings is not None else {}
     t0 = time.perf_counter()
     prm = cluster_params(k=k, w=w, p_shared=p_shared, **(cluster_kwargs or {}))
@@ -139,7 +143,7 @@ def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, 
             b = min(b, a + max_seqs_for_consensus)                              # consensus.py:260
         sub_order.append(order[a:b]); sub_off.append(sub_off[-1] + (b - a))
     sub_order = np.concatenate(sub_order) if sub_order else np.zeros(0, np.uint32)
-    drafts = api.poa_consensus(rs, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=DRAFT_TRIM if draft_trim is None else draft_trim),
+    drafts = api.poa_consensus(rs, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=DRAFT_TRIM if draft_trim is None else draft_trim, single_below=single_below),
                                read_order=sub_order)
     T["consensus"] = T.get("consensus", 0.0) + time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -158,7 +162,7 @@ def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, 
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in lists])))
         p_order = np.concatenate(lists)
         bb = ReadSet.from_strings([m[2] for m in merged])
-        polished, used = api.polish(bb, rs, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=polish_trim, aln_mode=polish_aln_mode, stop_when_stable=polish_stop_when_stable), read_order=p_order)
+        polished, used = api.polish(bb, rs, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=polish_trim, aln_mode=polish_aln_mode, stop_when_stable=polish_stop_when_stable, single_below=single_below), read_order=p_order)
         T["polish"] = T.get("polish", 0.0) + time.perf_counter() - t0
     res["centers"] = [(m[0], m[1], m[2], polished[i], [int(reps[ci]) for ci in m[3]]) for i, m in enumerate(merged)]
     return res

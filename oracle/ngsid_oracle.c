@@ -18,7 +18,7 @@ __attribute__((constructor)) static void ongsid_malloc_setup(void) { mallopt(M_M
 
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
-uint32_t ongsid_abi_version(void) { return 1u; }
+uint32_t ongsid_abi_version(void) { return 2u; }
 const char* ongsid_last_error(void) { return g_err; }
 
 /* ------------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ def test_exports_all_declared_symbols():
     assert "ngsid_cluster_greedy" in names and "ngsid_polish" in names
     for n in names:
         assert hasattr(lib, n), "libngsid_hip.so does not export %s" % n
-    assert lib.ngsid_abi_version() == 1
+    assert lib.ngsid_abi_version() == 2
 
 
 def test_no_device_fails_loudly():

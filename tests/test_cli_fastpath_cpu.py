@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 from oracle_lib import GOLD
 from ngspeciesid_amd import cli, fastpath
+import dict_layer
 
 
 def _run(api, extra, shaped, fastq=None, monkeypatch=None):
@@ -12,7 +13,7 @@ def _run(api, extra, shaped, fastq=None, monkeypatch=None):
     args = cli.build_parser().parse_args(["--ont", "--fastq", fastq or os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", out] + extra)
     args.k, args.w = 13, 20
     if shaped:
-        cli.main_reference_shaped(args)
+        dict_layer.run(args)
     else:
         fastpath.main(args, api=api)
     files = {}

@@ -204,3 +204,20 @@ def test_overlap_span_clipping_polishes_a_trimmed_backbone(oracle):
     grown = run(body, 1, 2)
     assert len(grown) > len(body) + 15 and body in grown or edit_distance(grown, body) >= 15          # mode 1 pulls a primer back in
     assert run(amp, 3, 3) == amp and run(amp, 1, 2) == amp
+
+
+def test_small_units_run_as_one_graph(oracle):
+    """round 6, single_below (oracle run_unit): a group below the threshold == the plain single-graph order with room for ten times its first sequence (tile_depth 0,
+    node_cap NGSID_POA_SINGLE_NODE_CAP), a group at or above it == the tiled hierarchy; the polisher applies the same rule per window."""
+    sp, rd, rs = make_set(90, L=300, mu=13.0, seed=31)
+    goff = [0, 20, 60, 90]                                  # 20, 40 and 30 reads
+    prm = poa_params(tile_depth=4, band=0, trim=1, single_below=32)
+    got = oracle.poa_consensus(rs, goff, prm)
+    one = oracle.poa_consensus(rs, goff, poa_params(tile_depth=0, band=0, trim=1, node_cap=160))
+    tiled = oracle.poa_consensus(rs, goff, poa_params(tile_depth=4, band=0, trim=1))
+    assert got == [one[0], tiled[1], one[2]]
+    assert oracle.poa_consensus(rs, goff, poa_params(tile_depth=4, band=0, trim=1, single_below=0)) == tiled
+    bb = ReadSet.from_strings([rs.get(0)[0]])
+    a = oracle.polish(bb, rs, [0, 30], polish_params(iters=2, tile_depth=4, band=0, trim=2, single_below=32))[0]
+    b = oracle.polish(bb, rs, [0, 30], polish_params(iters=2, tile_depth=0, band=0, trim=2, node_cap=160))[0]
+    assert a == b

@@ -115,11 +115,13 @@ def _files(out):
                                    ["--t", "2", "--m", "620", "--s", "40", "--top_reads", "--sample_size", "150"]])
 def test_cli_array_path_equals_reference_shaped_layer(gpu_api, tmp_path, monkeypatch, extra):
     """the array path (default) and the dict / file layer that mirrors the reference's Python functions write byte-identical files (HIP backend)"""
-    from ngspeciesid_amd.cli import cli
+    from ngspeciesid_amd.cli import cli, build_parser
+    import dict_layer
     a, b = str(tmp_path / "a"), str(tmp_path / "b")
     cli(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", a] + extra)
-    monkeypatch.setenv("NGSID_CLI_REFERENCE_SHAPED", "1")
-    cli(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", b] + extra)
+    os.makedirs(b)
+    args = build_parser().parse_args(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", b] + extra); args.k, args.w = 13, 20
+    dict_layer.run(args)
     fa, fb = _files(a), _files(b)
     assert sorted(fa) == sorted(fb)
     for k in fa:

@@ -303,3 +303,43 @@ def test_overlap_span_clipping_equals_the_oracle(gpu_api, oracle):
                     assert c == a and np.array_equal(uc, ua)
     finally:
         host.close()
+
+
+@pytest.mark.parametrize("host_levels", [0, 1])
+def test_small_units_as_one_graph_equal_the_oracle(gpu_api, oracle, host_levels):
+    """round 6, ngsid_poa_params_t.single_below: groups with fewer sequences than the threshold run as ONE graph in file order (spoa's own order) - a hierarchy of their own
+    with room for ten times the first sequence -, the others are tiled at tile_depth as before.  Mixed call (groups of 3 ... 150 reads, an empty one, noisy reads): HIP == oracle
+    byte for byte, with device-driven and with host-driven levels; small groups == what tile_depth 0 / node_cap 160 returns for them alone, large groups == the call without the rule."""
+    import ctypes as C
+    sp, rd, rs = make_set(1300, L=500, nsp=6, mu=13.0, seed=23)
+    spc = rd["species"].numpy()
+    sizes = [3, 150, 0, 40, 90, 17, 64]                       # reads per group, taken species by species so that a group is one amplicon
+    idx, goff = [], [0]
+    for g, n_ in enumerate(sizes):
+        pool = np.nonzero(spc == (g % 6))[0][:n_]
+        assert len(pool) == n_
+        idx += pool.tolist(); goff.append(len(idx))
+    rs2 = ReadSet.from_strings([rs.get(i)[0] for i in idx], [rs.get(i)[1] for i in idx])
+    gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"poa_host_levels", C.c_int64(host_levels))
+    try:
+        for mode in (POA_LOCAL, POA_GLOBAL):
+            prm = poa_params(mode=mode, tile_depth=4, band=0, trim=1, single_below=64)
+            got = gpu_api.poa_consensus(rs2, goff, prm); exp = oracle.poa_consensus(rs2, goff, prm)
+            assert got == exp
+            plain = gpu_api.poa_consensus(rs2, goff, poa_params(mode=mode, tile_depth=4, band=0, trim=1))
+            one = gpu_api.poa_consensus(rs2, goff, poa_params(mode=mode, tile_depth=0, band=0, trim=1, node_cap=160))
+            for g in range(len(sizes)):
+                n_ = goff[g + 1] - goff[g]
+                assert got[g] == (one[g] if n_ < 64 else plain[g]), "group %d of %d reads" % (g, n_)
+        # the polisher: windows of a 40-read group are small units, those of a 150-read group are tiled
+        bb = ReadSet.from_strings([sp[1].tobytes().decode()[3:-4], sp[3].tobytes().decode()])
+        a = [i for i in range(goff[1], goff[2])] + [i for i in range(goff[3], goff[4])]
+        rs3 = ReadSet.from_strings([rs2.get(i)[0] for i in a], [rs2.get(i)[1] for i in a])
+        for trim in (2, 1):
+            prm = polish_params(iters=2, tile_depth=4, band=0, trim=trim, single_below=64)
+            got, gused = gpu_api.polish(bb, rs3, [0, 150, 190], prm); exp, eused = oracle.polish(bb, rs3, [0, 150, 190], prm)
+            assert got == exp and np.array_equal(gused, eused)
+        off = gpu_api.polish(bb, rs3, [0, 150, 190], polish_params(iters=2, tile_depth=4, band=0, trim=2))[0]
+        assert got is not None and off[0] == gpu_api.polish(bb, rs3, [0, 150, 190], polish_params(iters=2, tile_depth=4, band=0, trim=2, single_below=64))[0][0]      # the deep group is untouched by the rule
+    finally:
+        gpu_api.lib.ngsid_ctx_option(gpu_api.ctx, b"poa_host_levels", C.c_int64(0))
