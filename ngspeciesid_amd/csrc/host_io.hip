@@ -7,6 +7,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <thread>
+#include <system_error>
 #include <string>
 #include <map>
 #include <deque>
@@ -102,7 +103,7 @@ extern "C" int32_t ngsid_host_fastq_index(const uint8_t* buf, uint64_t len, uint
     auto signature = [&]() { uint64_t h = len * 0x9E3779B97F4A7C15ull; const uint64_t m = len < 64 ? len : 64; for (uint64_t i = 0; i < m; ++i) { h = (h ^ buf[i]) * 0x100000001B3ull; h = (h ^ buf[len - 1 - i]) * 0x100000001B3ull; } return h; };
     const uint64_t sig = signature();
     std::vector<uint64_t> cnt(T + 1, 0);
-    if (rec && cc.buf == buf && cc.len == len && cc.T == T && cc.sig == sig && cc.cnt.size() == (size_t)T + 1) cnt = cc.cnt;
+    if (rec && cc.buf == buf && cc.len == len && cc.T == T && cc.sig == sig && cc.cnt.size() == (size_t)T + 1) { cnt = cc.cnt; cc.buf = nullptr; cc.cnt.clear(); }      // single use: a caller that refills the same buffer and indexes again without counting gets a fresh count
     else {
         parallel_ranges(len, T, [&](uint64_t a, uint64_t b, int t) { uint64_t c = 0; const uint8_t* p = buf + a; const uint8_t* e = buf + b;
             while (p < e) { const uint8_t* q = (const uint8_t*)memchr(p, '\n', (size_t)(e - p)); if (!q) break; ++c; p = q + 1; } cnt[t + 1] = c; });

@@ -17,7 +17,9 @@ struct DevPool { std::mutex mu; std::multimap<unsigned long long, void*> free_; 
 };
 DevPool g_pool;
 const size_t POOL_LIMIT = (size_t)48 << 30;          // bytes kept for reuse; beyond it blocks go back to the driver
-const size_t POOL_HEADROOM = (size_t)3 << 30;        // device memory the library leaves to the runtime (ngsid_pool_alloc)
+const size_t POOL_HEADROOM = (size_t)3 << 30;        // device memory the library leaves to the runtime (ngsid_pool_alloc); at most a sixteenth of the device (small or partitioned GPUs)
+// blocks taken from the pool by a function that can still fail: given back unless ownership is released (ngsid_reads_upload / _subset leaked them on a later error)
+struct PoolBlocks { void* p[3] = {nullptr, nullptr, nullptr}; size_t b[3] = {0, 0, 0}; bool owned = true; ~PoolBlocks() { if (owned) for (int i = 0; i < 3; ++i) if (p[i]) ngsid_pool_free(p[i], b[i]); } };
 inline size_t pool_class(size_t b) { if (b < 4096) return 4096; int sh = 63 - __builtin_clzll((unsigned long long)b) - 3; size_t m = ((size_t)1 << sh) - 1; return (b + m) & ~m; }
 inline unsigned long long pool_key(int dev, size_t cls) { return ((unsigned long long)dev << 56) | (unsigned long long)cls; }
 }
@@ -36,7 +38,7 @@ hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got)
     for (int attempt = 0; attempt < 2; ++attempt) {
         size_t freeb = 0, totalb = 0;
         const bool known = hipMemGetInfo(&freeb, &totalb) == hipSuccess;
-        if (!known || freeb >= cls + POOL_HEADROOM) { e = hipMalloc(p, cls); if (e == hipSuccess) break; (void)hipGetLastError(); }
+        if (!known || freeb >= cls + std::min<size_t>(POOL_HEADROOM, totalb / 16)) { e = hipMalloc(p, cls); if (e == hipSuccess) break; (void)hipGetLastError(); }
         if (attempt == 0) ngsid_pool_release_all();          // out of memory (or too close to it): give the cached blocks back and retry once
     }
     *got = e == hipSuccess ? cls : 0;
@@ -481,16 +483,16 @@ extern "C" int32_t ngsid_reads_upload(ngsid_ctx* ctx, const ngsid_reads_t* host,
     if (!host || !dev || !host->off || (host->n && !host->seq) || host->mem != NGSID_MEM_HOST) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_upload: a host read set and an output are required");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t n = host->n, total = host->off[n];
-    void *ds = nullptr, *dq = nullptr, *dof = nullptr; size_t got = 0;
-    HIPCHK(ctx, ngsid_pool_alloc(&ds, total + 16, &got)); const size_t bs = got;
-    HIPCHK(ctx, ngsid_pool_alloc(&dof, sizeof(uint64_t) * (n + 1), &got)); const size_t bo = got;
-    size_t bq = 0;
-    if (host->qual) { HIPCHK(ctx, ngsid_pool_alloc(&dq, total + 16, &got)); bq = got; }
+    PoolBlocks PB; void *&ds = PB.p[0], *&dq = PB.p[1], *&dof = PB.p[2]; size_t &bs = PB.b[0], &bq = PB.b[1], &bo = PB.b[2];
+    HIPCHK(ctx, ngsid_pool_alloc(&ds, total + 16, &bs));
+    HIPCHK(ctx, ngsid_pool_alloc(&dof, sizeof(uint64_t) * (n + 1), &bo));
+    if (host->qual) HIPCHK(ctx, ngsid_pool_alloc(&dq, total + 16, &bq));
     if (total) HIPCHK(ctx, hipMemcpyAsync(ds, host->seq, total, hipMemcpyHostToDevice, ctx->stream));
     if (total && host->qual) HIPCHK(ctx, hipMemcpyAsync(dq, host->qual, total, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dof, host->off, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.uploads[ds] = {bs, dq, bq, dof, bo}; }
+    PB.owned = false;
     dev->seq = (const uint8_t*)ds; dev->qual = (const uint8_t*)dq; dev->off = (const uint64_t*)dof; dev->n = n; dev->mem = NGSID_MEM_DEVICE; dev->_pad = 0;
     return NGSID_OK;
 }
@@ -525,11 +527,10 @@ extern "C" int32_t ngsid_reads_subset(ngsid_ctx* ctx, const ngsid_reads_t* dev_i
     static thread_local PinVec<uint64_t> h_noff; h_noff.resize(n + 1); h_noff[0] = 0;
     for (uint64_t i = 0; i < n; ++i) { if (idx[i] >= R.n) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_subset: index %llu out of range", (unsigned long long)idx[i]); h_noff[i + 1] = h_noff[i] + (R.h_off[idx[i] + 1] - R.h_off[idx[i]]); }
     const uint64_t total = h_noff[n];
-    void *ds = nullptr, *dq = nullptr, *dof = nullptr; size_t got = 0;
-    HIPCHK(ctx, ngsid_pool_alloc(&ds, total + 16, &got)); const size_t bs = got;
-    HIPCHK(ctx, ngsid_pool_alloc(&dof, sizeof(uint64_t) * (n + 1), &got)); const size_t bo = got;
-    size_t bq = 0;
-    if (dev_in->qual) { HIPCHK(ctx, ngsid_pool_alloc(&dq, total + 16, &got)); bq = got; }
+    PoolBlocks PB; void *&ds = PB.p[0], *&dq = PB.p[1], *&dof = PB.p[2]; size_t &bs = PB.b[0], &bq = PB.b[1], &bo = PB.b[2];
+    HIPCHK(ctx, ngsid_pool_alloc(&ds, total + 16, &bs));
+    HIPCHK(ctx, ngsid_pool_alloc(&dof, sizeof(uint64_t) * (n + 1), &bo));
+    if (dev_in->qual) HIPCHK(ctx, ngsid_pool_alloc(&dq, total + 16, &bq));
     DevBuf<uint64_t> d_idx; DevBuf<unsigned long long> d_bad; HIPCHK(ctx, d_idx.alloc(n)); HIPCHK(ctx, d_bad.alloc(1));
     HIPCHK(ctx, hipMemsetAsync(d_bad.p, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dof, h_noff.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
@@ -541,6 +542,7 @@ extern "C" int32_t ngsid_reads_subset(ngsid_ctx* ctx, const ngsid_reads_t* dev_i
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (foreign) *foreign = hb;
     { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.uploads[ds] = {bs, dq, bq, dof, bo}; }
+    PB.owned = false;
     dev_out->seq = (const uint8_t*)ds; dev_out->qual = (const uint8_t*)dq; dev_out->off = (const uint64_t*)dof; dev_out->n = n; dev_out->mem = NGSID_MEM_DEVICE; dev_out->_pad = 0;
     return NGSID_OK;
 }

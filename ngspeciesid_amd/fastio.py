@@ -157,7 +157,9 @@ def list_positions(rep) -> np.ndarray:
     return pos
 
 
-_GBR = {}          # scratch of group_by_rep, reused between calls (fresh 8 MB arrays page-fault on every call while the GPU waits for the consensus stage)
+import threading as _threading
+_GBR_TLS = _threading.local()          # scratch of group_by_rep, reused between calls (fresh 8 MB arrays page-fault on every call while the GPU waits for the consensus stage); per thread
+                                       # (the ctypes call releases the interpreter lock, virtual ranks are threads)
 
 
 def group_by_rep(rep_of):
@@ -165,6 +167,7 @@ def group_by_rep(rep_of):
     a = np.asarray(rep_of)
     r = np.ascontiguousarray(a) if a.dtype == np.int32 else np.ascontiguousarray(a, dtype=np.int64)
     n = len(r)
+    _GBR = _GBR_TLS.__dict__
     if _GBR.get("n", -1) < n:
         _GBR.update(n=n, reps=np.empty(n, dtype=np.int64), counts=np.empty(n, dtype=np.int64), goff=np.empty(n + 1, dtype=np.uint64))
     reps, counts, goff = _GBR["reps"], _GBR["counts"], _GBR["goff"]

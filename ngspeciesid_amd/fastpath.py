@@ -366,13 +366,24 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
     # the reference de-duplicates by header, handled in _merge_and_polish.)
     # (round 5: everything the main thread computes with arrays comes BEFORE the writers start - with six threads in array code every operation of this thread waited its turn for the
     # interpreter lock: 90 ms for the three lines below in the sampled stacks of a stalled run)
-    sub_off = np.concatenate(([0], np.cumsum([len(g) for g in groups]))).astype(np.uint64)
-    read_order = np.concatenate(groups); read_order32 = read_order.astype(np.uint32)
-    gmax = int(sr.lens[read_order].max())
+    gmax = int(sr.lens[np.concatenate(groups)].max())
+    cgroups = groups                                                       # the reads the consensus stages see
+    args._overlong = False
     if gmax > MAX_CONSENSUS_LEN:
-        bad = [int(reps[c]) for c in range(nsel) if int(sr.lens[groups[c]].max()) > MAX_CONSENSUS_LEN]
-        raise ValueError("clusters %s hold reads of up to %d bases: this build's POA engine forms consensus of reads up to %d bases (clustering itself handles %d); "
-                         "filter by length (--m / --s) or raise --abundance_ratio so that these clusters are not polished" % (bad[:10], gmax, MAX_CONSENSUS_LEN, MAX_READ_LEN))
+        # one over-long read (a concatemer) in an abundant cluster must not end the run.  Such reads stay in the TSVs and in the pooled read files; the draft and
+        # the polisher leave them out, with a warning.  Only a cluster left without any usable read is an error.
+        cgroups = [g[sr.lens[g] <= MAX_CONSENSUS_LEN] for g in groups]
+        ndrop = sum(len(g) - len(cg) for g, cg in zip(groups, cgroups))
+        empty = [int(reps[c]) for c in range(nsel) if len(cgroups[c]) == 0]
+        if empty:
+            raise ValueError("clusters %s hold only reads longer than %d bases (up to %d): this build's POA engine forms consensus of reads up to %d bases (clustering itself handles %d); "
+                             "filter by length (--m / --s) or raise --abundance_ratio so that these clusters are not polished" % (empty[:10], MAX_CONSENSUS_LEN, gmax, MAX_CONSENSUS_LEN, MAX_READ_LEN))
+        logging.warning("%d read(s) longer than %d bases (up to %d) are left out of the consensus and polishing of their clusters (they stay in final_clusters.tsv and in the pooled read files)", ndrop, MAX_CONSENSUS_LEN, gmax)
+        args._overlong = True
+        gmax = int(max(sr.lens[cg].max() for cg in cgroups))
+    sub_off = np.concatenate(([0], np.cumsum([len(g) for g in cgroups]))).astype(np.uint64)
+    read_order = np.concatenate(cgroups); read_order32 = read_order.astype(np.uint32)
+    args._merge_passes = 0                                                 # (a reused args namespace must not look like a later pass)
     args._pooled_early = {}
     if acc_id is None and getattr(args, "_writers", None) is not None and os.environ.get("NGSID_CLI_EARLY_POOLED", "1") == "1":
         for c in range(nsel):
@@ -420,6 +431,8 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
     seen_clusters = set(); polish_lists = []          # the polisher takes a read under one centre only (pipeline.pooled_read_lists): first centre wins
     early = getattr(args, "_pooled_early", {})        # pooled files whose writers were started before the draft: {c_id: cluster tuple the file holds}
     first_pass = not getattr(args, "_merge_passes", 0); args._merge_passes = getattr(args, "_merge_passes", 0) + 1
+    if not first_pass and getattr(args, "_writers", None) is not None:
+        args._writers.join()          # a later pass may queue a writer for a pooled file a job of the pass before is still writing
     if early and any(early.get(int(c_id)) != tuple(cs) for _, c_id, _, cs in merged):
         # some centre absorbed other clusters: wait for the early writers, then rewrite the merged files below.  FIRST pass: the files of the absorbed centres go - the
         # reference writes a pooled file per MERGED centre only (consensus.py:208-215), the early writers had started one per selected cluster.  Later passes (merge
@@ -454,7 +467,9 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
         if len(fresh) < len(parts):
             logging.warning("centre %d: %d cluster(s) were merged into an earlier centre as well; their reads polish that one only", c_id, len(parts) - len(fresh))
         seen_clusters.update(cs)
-        polish_lists.append(np.concatenate(fresh) if fresh else np.zeros(0, dtype=ids.dtype))
+        pl = np.concatenate(fresh) if fresh else np.zeros(0, dtype=ids.dtype)
+        if getattr(args, "_overlong", False): pl = pl[sr.lens[pl] <= MAX_CONSENSUS_LEN]          # over-long reads stay in the pooled file, the polisher leaves them out
+        polish_lists.append(pl)
         if early.get(int(c_id)) != tuple(cs):
             _write(args, _write_pooled, os.path.join(args.outfolder, "reads_to_consensus_{0}.fastq".format(c_id)), ids, sr)     # while the polisher runs
             if early: early[int(c_id)] = tuple(cs)

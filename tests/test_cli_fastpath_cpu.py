@@ -204,3 +204,26 @@ def test_writer_modes_leave_the_same_files(oracle_backend, monkeypatch):
     assert any(k.startswith("reads_to_consensus_") for k in native) and "final_clusters.tsv" in native and "sorted.fastq" in native
     for k in native:
         assert native[k] == threads[k] == sync[k], k
+
+
+def test_a_concatemer_in_an_abundant_cluster_is_left_out_of_the_consensus(oracle_backend, tmp_path, caplog):
+    """a read longer than MAX_CONSENSUS_LEN (13 107 bases) that joins an abundant cluster used to end the run with a ValueError after the cluster files were
+    written.  Now it stays in final_clusters.tsv and in the pooled read file, the draft and the polisher leave it out (warning), and the consensus is the one of the run without it."""
+    import logging
+    src = open(os.path.join(GOLD, "sample_h1.fastq")).read().split("\n")
+    recs = [src[i:i + 4] for i in range(0, len(src) - 3, 4)]
+    base = _run(oracle_backend, ["--t", "1", "--consensus", "--racon", "--racon_iter", "1"], False)
+    unit = recs[0][1]; n = fastpath.MAX_CONSENSUS_LEN // len(unit) + 1
+    recs.append(["@concatemer", unit * n, "+", recs[0][3] * n])
+    assert len(recs[-1][1]) > fastpath.MAX_CONSENSUS_LEN
+    fq = tmp_path / "in.fastq"; fq.write_text("\n".join("\n".join(r) for r in recs) + "\n")
+    with caplog.at_level(logging.WARNING):
+        files = _run(oracle_backend, ["--t", "1", "--consensus", "--racon", "--racon_iter", "1"], False, fastq=str(fq))
+    assert "left out of the consensus" in caplog.text
+    cl = [l.split("\t") for l in files["final_clusters.tsv"].decode().splitlines()]
+    cid = [c for c, a in cl if a == "concatemer"][0]
+    assert sum(1 for c, a in cl if c == cid) > 50                                   # it sits in an abundant cluster
+    pooled = [k for k in files if k.startswith("reads_to_consensus_") and b"@concatemer_" in files[k]]
+    assert len(pooled) == 1
+    cons = sorted(v.split(b"\n")[1] for k, v in files.items() if k.endswith("consensus.fasta"))
+    assert len(cons) == len([k for k in base if k.endswith("consensus.fasta")]) and all(600 < len(c) < 720 for c in cons)
