@@ -234,6 +234,13 @@ int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid
 int32_t ngsid_polish_trace(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                            const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                            uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used);
+/* (a17, boundary 8b(1)) ngsid_polish_trace + what `minimap2 -x map-ont center reads` leaves in read_alignments_it_{i}.paf (consensus.py:112-121): the read -> backbone
+ * alignment of every LISTED read x (x < n_listed = grp_off[n_groups]) in every iteration, it_aln[(it * n_listed + x) * 6 ...] = { strand (0 '+', 1 '-', -1 = no alignment: no
+ * PAF line), q_begin, q_end, t_begin, t_end, distance } in PAF coordinates (0-based, end exclusive, the query interval on the read's ORIGINAL strand); distance = unit-cost edit
+ * distance of the whole read against the backbone with free backbone ends (-1 with aln_mode 0).  A group that is stable (stop_when_stable) repeats its records. */
+int32_t ngsid_polish_trace_aln(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
+                               const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                               uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used, int32_t* it_aln);
 
 /* (8e step 3, boundary 8b) the merge rounds of parallel_clustering (parallelize.py:169-217) on the all-gathered representatives of `n_batches`
  * shards: reps = host read set with qualities, batch[i] = 1-based shard index of representative i, score / hpc_err / acc_rank as in
@@ -255,6 +262,11 @@ int32_t ngsid_merge_representatives(ngsid_ctx* ctx, const ngsid_reads_t* reps, c
 /* ngsid_host_thread_cap: upper bound of the worker threads the helpers below start when called from the CALLING thread (0 = none; default: the CPUs the process
  * may use - hardware threads, affinity mask, container quota - at most 32).  Returns the previous bound.  The CLI's background writers take 4 each. */
 int32_t ngsid_host_thread_cap(int32_t n);
+/* ngsid_host_write_paf: read_alignments_it_{i}.paf of run_racon (consensus.py:112-121), one 12-column PAF line per record of ngsid_polish_trace_aln with strand >= 0: query name
+ *   (first token of name + per-read suffix), query length off[i+1]-off[i], q_begin, q_end, strand, tname, tlen, t_begin, t_end, matches (block - distance), block length (the longer
+ *   span), 255.  job == NULL writes synchronously, else the call is queued on the background writers (ngsid_host_async_wait). */
+int32_t ngsid_host_write_paf(const char* path, uint64_t n, const uint64_t* idx, const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len,
+                             const uint8_t* sfx, const uint64_t* sfx_off, const uint64_t* off, const int32_t* aln, const char* tname, uint32_t tlen, int32_t max_threads, uint64_t* job);
 int32_t ngsid_host_fastq_index(const uint8_t* buf, uint64_t len, uint64_t* rec, uint32_t* name_len, uint32_t* seq_len, uint64_t cap_records, uint64_t* n_records);
 int32_t ngsid_host_gather(const uint8_t* src, const uint64_t* src_off, const uint32_t* len, uint64_t n, uint8_t* dst, const uint64_t* dst_off);
 int32_t ngsid_host_normalize_bases(uint8_t* seq, uint64_t len, uint64_t* changed);

@@ -318,16 +318,22 @@ class Api:
         if rc: self._err(rc)
         return [out[int(ooff[g]):int(ooff[g + 1])].tobytes().decode() for g in range(ng)], used[:ng]
 
-    def polish_trace(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None, read_order=None):
-        """ngsid_polish_trace: -> (seqs[it][g], used[it][g]): every group's sequence after every iteration (the last one is what polish() returns)."""
+    def polish_trace(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None, read_order=None, aln=False):
+        """ngsid_polish_trace: -> (seqs[it][g], used[it][g]): every group's sequence after every iteration (the last one is what polish() returns).
+        aln=True (ngsid_polish_trace_aln): -> (seqs, used, aln[it][x] = (strand, q_begin, q_end, t_begin, t_end, distance) of listed read x) - the PAF records of every iteration."""
         grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
         ro = None if read_order is None else np.ascontiguousarray(read_order, dtype=np.uint32)
         ng = len(grp_off) - 1; iters = int(prm.iters); n = iters * ng
         if cap is None:
             cap = (int(4 * len(backbones.seq) + 4096) if backbones.mem == MEM_HOST else 1 << 24) * max(iters, 1)
         ooff = np.zeros(n + 1, dtype=np.uint64); out = np.zeros(cap, dtype=np.uint8); needed = C.c_uint64(0); used = np.zeros(max(n, 1), dtype=np.uint64)
-        rc = self._call("polish_trace", C.byref(backbones.c), C.byref(rs.c), _p(ro), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(ooff), _p(out), C.c_uint64(cap), C.byref(needed), _p(used))
+        if aln:
+            nl = int(grp_off[-1]); rec = np.empty((iters, nl, 6), dtype=np.int32)
+            rc = self._call("polish_trace_aln", C.byref(backbones.c), C.byref(rs.c), _p(ro), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(ooff), _p(out), C.c_uint64(cap), C.byref(needed), _p(used), _p(rec))
+        else:
+            rc = self._call("polish_trace", C.byref(backbones.c), C.byref(rs.c), _p(ro), _p(grp_off), C.c_uint64(ng), C.byref(prm), _p(ooff), _p(out), C.c_uint64(cap), C.byref(needed), _p(used))
         if rc: self._err(rc)
         seqs = [[out[int(ooff[it * ng + g]):int(ooff[it * ng + g + 1])].tobytes().decode() for g in range(ng)] for it in range(iters)]
-        return seqs, used[:n].reshape(iters, ng) if n else used[:0].reshape(0, ng)
+        u = used[:n].reshape(iters, ng) if n else used[:0].reshape(0, ng)
+        return (seqs, u, rec) if aln else (seqs, u)
 

@@ -49,6 +49,7 @@ def build_parser():
     # extensions of this build (not in the reference): shape of the consensus engine.  Defaults = the measured configuration.
     p.add_argument('--poa_tile_depth', type=int, default=4, help='reads per exact-order POA tile (default 4: depth-tiled hierarchy; a positive value also applies to the polishing windows). 0 = one graph per cluster in read order, i.e. spoa\'s order; a graph holds at most 65 520 nodes, so use it with --max_seqs_for_consensus (a few hundred reads); larger clusters are split by the capacity rule')
     p.add_argument('--strand_aware', action='store_true', help='extension: clusters whose representatives are reverse complements of each other (decided by the clustering criteria themselves) are joined BEFORE the consensus stage and their reads are oriented: one cluster per amplicon in final_clusters.tsv; off = the reference (two clusters per amplicon on mixed-strand data, joined after the drafts)')
+    p.add_argument('--skip_paf', action='store_true', help='extension: do not write racon_cl_id_*/read_alignments_it_{i}.paf (the reference leaves minimap2\'s PAF of every polishing iteration there; default: written)')
     p.add_argument('--poa_band', type=int, default=0, help='band of the POA alignments in columns (0 = library default: 64 for reads up to 3 kb, else 128; a tile whose path touches the band edge is redone at twice the band)')
     return p
 

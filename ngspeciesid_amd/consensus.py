@@ -9,6 +9,7 @@ import glob
 import logging
 import os
 import shutil
+import numpy as np
 from . import runtime
 from . import pipeline
 from ._capi import ReadSet, poa_params, polish_params, POA_LOCAL
@@ -56,16 +57,20 @@ def run_racon(reads_to_center, center_file, outfolder, cores, racon_iter, api=No
         f.write("")
     name = caccs[0].split()[0]
     if racon_iter >= 1:
-        its, used = api.polish_trace(ReadSet.from_strings([cseqs[0]]), rs, [0, len(seqs)], prm)
+        its, used, aln = api.polish_trace(ReadSet.from_strings([cseqs[0]]), rs, [0, len(seqs)], prm, aln=True)
         write_racon_iteration_files(outfolder, name, [x[0] for x in its], [int(u[0]) for u in used])
+        from . import fastio                            # read_alignments_it_{i}.paf: the alignments iteration i polished with (consensus.py:112-121)
+        names = fastio.Names.from_list([a.split()[0] for a in accs]); ids = np.arange(len(seqs))
+        for i in range(racon_iter):
+            fastio.write_paf(os.path.join(outfolder, "read_alignments_it_{0}.paf".format(i)), ids, names, rs.off, aln[i], name, len(cseqs[0] if i == 0 else its[i - 1][0]))
     else:                                                       # no iteration: consensus.fasta is the centre file itself (consensus.py:124)
         shutil.copyfile(center_file, os.path.join(outfolder, "consensus.fasta"))
 
 
 def write_racon_iteration_files(outfolder, name, seqs, used):
     """the files run_racon leaves in racon_cl_id_X/ (consensus.py:110-124): racon_polished_it_{i}.fasta after every iteration (racon's header tags),
-    the (empty) stderr files of the two tools, consensus.fasta = the last iteration.  The PAF of minimap2 is not produced: the polisher aligns on
-    the device and keeps no per-read text."""
+    the (empty) stderr files of the two tools, consensus.fasta = the last iteration.  read_alignments_it_{i}.paf is written by the caller from the records of
+    ngsid_polish_trace_aln (fastio.write_paf)."""
     last = None
     for i, (s, u) in enumerate(zip(seqs, used)):
         for fn in ("mm2_stderr_it_{0}.txt", "racon_stderr_it_{0}.txt"):

@@ -343,6 +343,56 @@ extern "C" int32_t ngsid_host_write_records_async(const char* path, int32_t appe
 }
 extern "C" int32_t ngsid_host_async_wait(uint64_t job) { return async_jobs().wait(job); }
 
+// (a17, boundary 8b(1)) read_alignments_it_{i}.paf of run_racon (consensus.py:112-121: `minimap2 -x map-ont center reads` -> 12-column PAF without CIGAR).  Line j (j < n) is read
+// idx[j] with the alignment record aln[6 j ..] of ngsid_polish_trace_aln = {strand, q_begin, q_end, t_begin, t_end, distance}; a record with strand < 0 writes no line (minimap2
+// lists mapped reads only).  Columns: query name = first white-space token of name + suffix (the header the pooled read file carries, consensus.py:213), query length, q_begin,
+// q_end, '+' / '-', target name, target length, t_begin, t_end, residue matches, alignment block length, mapping quality.  The polisher aligns by edit distance and keeps no
+// chain: block length = the longer of the two spans, matches = block length - distance (not below 0), mapping quality 255 (= not available, as the PAF format defines it).
+static int32_t write_paf_impl(const char* path, uint64_t n, const uint64_t* idx, const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len,
+                              const uint8_t* sfx, const uint64_t* sfx_off, const uint64_t* off, const int32_t* aln, const char* tname, uint32_t tlen)
+{
+    if (!path || !tname || (n && (!idx || !names || !name_off || !name_len || !off || !aln))) return NGSID_ERR_ARG;
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666); if (fd < 0) return NGSID_ERR_ARG;
+    const size_t tl = strlen(tname);
+    const int T = std::max(1, n_threads(n * 96));
+    std::vector<std::vector<uint8_t>> part((size_t)T);
+    auto put_u = [](std::vector<uint8_t>& o, uint64_t v) { char b[24]; int k = 0; do { b[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k) o.push_back((uint8_t)b[--k]); };
+    parallel_ranges(n, T, [&](uint64_t a, uint64_t b, int t) {
+        std::vector<uint8_t>& o = part[(size_t)t]; o.reserve((size_t)(b - a) * (64 + tl));
+        for (uint64_t j = a; j < b; ++j) {
+            const int32_t* r = aln + 6 * j; if (r[0] < 0) continue;
+            const uint64_t i = idx[j]; const uint8_t* nm = names + name_off[i]; uint32_t L = name_len[i], k = 0;
+            while (k < L && nm[k] != ' ' && !(nm[k] >= 9 && nm[k] <= 13)) ++k;
+            o.insert(o.end(), nm, nm + k);
+            if (k == L && sfx_off) o.insert(o.end(), sfx + sfx_off[i], sfx + sfx_off[i + 1]);        // (a name cut at a blank loses the suffix behind it: str.split()[0] of name + suffix)
+            const uint64_t qs = (uint64_t)r[1], qe = (uint64_t)r[2], ts = (uint64_t)r[3], te = (uint64_t)r[4];
+            const uint64_t blk = std::max(qe - qs, te - ts), nm_ = r[5] >= 0 ? (blk > (uint64_t)r[5] ? blk - (uint64_t)r[5] : 0) : std::min(qe - qs, te - ts);
+            o.push_back('\t'); put_u(o, off[i + 1] - off[i]); o.push_back('\t'); put_u(o, qs); o.push_back('\t'); put_u(o, qe); o.push_back('\t'); o.push_back(r[0] ? '-' : '+'); o.push_back('\t');
+            o.insert(o.end(), (const uint8_t*)tname, (const uint8_t*)tname + tl); o.push_back('\t'); put_u(o, tlen); o.push_back('\t'); put_u(o, ts); o.push_back('\t'); put_u(o, te); o.push_back('\t');
+            put_u(o, nm_); o.push_back('\t'); put_u(o, blk); o.push_back('\t'); o.push_back('2'); o.push_back('5'); o.push_back('5'); o.push_back('\n');
+        } });
+    std::vector<uint64_t> base((size_t)T + 1, 0); for (int t = 0; t < T; ++t) base[t + 1] = base[t] + part[(size_t)t].size();
+    std::atomic<int> failed{0};
+    parallel_ranges((uint64_t)T, T, [&](uint64_t a, uint64_t b, int) { for (uint64_t t = a; t < b; ++t) {
+        const std::vector<uint8_t>& o = part[(size_t)t]; uint64_t done = 0;
+        while (done < o.size()) { const ssize_t w = pwrite(fd, o.data() + done, (size_t)(o.size() - done), (off_t)(base[t] + done)); if (w <= 0) { failed.store(1); break; } done += (uint64_t)w; } } });
+    int32_t rc = failed.load() ? NGSID_ERR_ARG : NGSID_OK;
+    if (close(fd) != 0) rc = NGSID_ERR_ARG;
+    return rc;
+}
+// job == NULL: synchronous; else queued on the native background writers (every pointer must stay valid until ngsid_host_async_wait(*job) returned; the path and the target name are copied)
+extern "C" int32_t ngsid_host_write_paf(const char* path, uint64_t n, const uint64_t* idx, const uint8_t* names, const uint64_t* name_off, const uint32_t* name_len,
+                                        const uint8_t* sfx, const uint64_t* sfx_off, const uint64_t* off, const int32_t* aln, const char* tname, uint32_t tlen, int32_t max_threads, uint64_t* job)
+{
+    if (!job) return write_paf_impl(path, n, idx, names, name_off, name_len, sfx, sfx_off, off, aln, tname, tlen);
+    if (!path || !tname) return NGSID_ERR_ARG;
+    try {
+        std::string p(path), tn(tname);
+        *job = async_jobs().submit([=] { return write_paf_impl(p.c_str(), n, idx, names, name_off, name_len, sfx, sfx_off, off, aln, tn.c_str(), tlen); }, max_threads);
+        return NGSID_OK;
+    } catch (...) { return NGSID_ERR_ARG; }
+}
+
 // Read-only mapping of an input file and its release (round 5).  Unmapping the 1.5 GB FASTQ of C3 takes ~75 ms (page-table teardown); done by the interpreter's own mmap object it
 // happened on the launch thread, with the interpreter lock held, in the middle of the ingest.  ngsid_host_unmap_file(..., 1) hands it to a detached native thread.
 extern "C" int32_t ngsid_host_map_file(const char* path, const uint8_t** data, uint64_t* len)

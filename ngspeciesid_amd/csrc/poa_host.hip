@@ -742,7 +742,8 @@ std::string revcomp(const std::string& s) { std::string r(s.size(), 'N'); for (s
 
 }  // namespace
 
-struct PolishTrace { std::vector<std::string> seq; std::vector<uint64_t> used; };      // [it * G + g]: the backbones after every iteration
+struct PolishTrace { std::vector<std::string> seq; std::vector<uint64_t> used;           // [it * G + g]: the backbones after every iteration
+                     int32_t* aln = nullptr; };                                          // ngsid_polish_trace_aln: [(it * n_listed + x) * 6 ...] = the read -> backbone alignment of listed read x in iteration it
 
 static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                            const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
@@ -756,14 +757,13 @@ extern "C" int32_t ngsid_polish(ngsid_ctx* ctx, const ngsid_reads_t* backbones, 
     return polish_impl(ctx, backbones, reads, read_order, grp_off, n_groups, prm, out_off, out, out_cap, needed, n_used, nullptr);
 }
 
-extern "C" int32_t ngsid_polish_trace(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
-                                      const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
-                                      uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used)
+static int32_t polish_trace_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
+                                 const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                                 uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used, int32_t* it_aln)
 {
-    ApiClock api_clock_(ctx, "polish_trace");
     if (!ctx) return NGSID_ERR_ARG;
     if (!prm || !it_off || prm->iters < 1) NGSID_FAIL(ctx, NGSID_ERR_ARG, "ngsid_polish_trace: null argument or iters < 1");
-    PolishTrace tr; std::vector<uint64_t> ooff(n_groups + 1, 0); uint64_t need1 = 0;
+    PolishTrace tr; tr.aln = it_aln; std::vector<uint64_t> ooff(n_groups + 1, 0); uint64_t need1 = 0;
     const int32_t rc = polish_impl(ctx, backbones, reads, read_order, grp_off, n_groups, prm, ooff.data(), nullptr, 0, &need1, nullptr, &tr);
     if (rc != NGSID_OK) return rc;                                        // (with a trace the inner call copies nothing out and checks no capacity: ADVICE r4)
     if (tr.seq.size() != (size_t)prm->iters * n_groups || tr.used.size() != tr.seq.size()) NGSID_FAIL(ctx, NGSID_ERR_HIP, "internal: polish trace holds %zu entries for %d x %llu", tr.seq.size(), (int)prm->iters, (unsigned long long)n_groups);
@@ -775,6 +775,24 @@ extern "C" int32_t ngsid_polish_trace(ngsid_ctx* ctx, const ngsid_reads_t* backb
     if (needed) *needed = total;
     if (ovf) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "trace buffer too small: need %llu bytes", (unsigned long long)total);
     return NGSID_OK;
+}
+extern "C" int32_t ngsid_polish_trace(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
+                                      const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                                      uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used)
+{
+    ApiClock api_clock_(ctx, "polish_trace");
+    return polish_trace_impl(ctx, backbones, reads, read_order, grp_off, n_groups, prm, it_off, it_out, it_cap, needed, it_used, nullptr);
+}
+// (a17, boundary 8b(1)) ngsid_polish_trace + what minimap2 leaves in read_alignments_it_{i}.paf (consensus.py:112-121): the read -> backbone alignment of every LISTED read in
+// every iteration, it_aln[(it * n_listed + x) * 6 ...] = {strand (0 +, 1 -, -1 = not aligned: no PAF line), q_begin, q_end, t_begin, t_end, edit distance}, PAF coordinates
+// (0-based, end exclusive, the query interval on the read's ORIGINAL strand); n_listed = grp_off[n_groups].
+extern "C" int32_t ngsid_polish_trace_aln(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
+                                          const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                                          uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used, int32_t* it_aln)
+{
+    ApiClock api_clock_(ctx, "polish_trace");
+    if (ctx && !it_aln) NGSID_FAIL(ctx, NGSID_ERR_ARG, "ngsid_polish_trace_aln: null alignment buffer");
+    return polish_trace_impl(ctx, backbones, reads, read_order, grp_off, n_groups, prm, it_off, it_out, it_cap, needed, it_used, it_aln);
 }
 
 static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
@@ -805,6 +823,7 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         uint64_t total = 0; out_off[0] = 0; bool ovf = false;
         for (uint32_t g = 0; g < G; ++g) { if (trace) {} else if (total + B[g].size() <= out_cap && out) memcpy(out + total, B[g].data(), B[g].size()); else if (B[g].size()) ovf = true; total += B[g].size(); out_off[g + 1] = total; if (n_used) n_used[g] = 0; }
         if (trace) for (int it = 0; it < prm->iters; ++it) for (uint32_t g = 0; g < G; ++g) { trace->seq.push_back(B[g]); trace->used.push_back(0); }
+        if (trace && trace->aln) for (uint64_t x = 0; x < (uint64_t)prm->iters * grp_off[n_groups] * 6; ++x) trace->aln[x] = -1;
         if (needed) *needed = total; if (ovf) NGSID_FAIL(ctx, NGSID_ERR_CAPACITY, "output buffer too small"); return NGSID_OK;
     }
     // ---- read -> group map, mean read length per group (TGS/NGS window type)
@@ -877,7 +896,11 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
     HIPCHK(ctx, hipGetLastError());
     // ---- pairs (usable reads of reads that belong to a group), fixed over the iterations
     static thread_local PinVec<uint32_t> pair_read, pair_group; pair_read.clear(); pair_group.clear();
-    for (uint64_t x = 0; x < grp_off[n_groups]; ++x) { const uint64_t r = read_order ? read_order[x] : x; if (h_orient[r] != 255) { pair_read.push_back((uint32_t)r); pair_group.push_back(h_rgroup[r]); } }
+    const bool want_aln = trace && trace->aln; const uint64_t NL = grp_off[n_groups];
+    std::vector<uint64_t> pair_pos;                    // (alignment trace) position of a pair's read in the caller's list
+    for (uint64_t x = 0; x < grp_off[n_groups]; ++x) { const uint64_t r = read_order ? read_order[x] : x; if (h_orient[r] != 255) { pair_read.push_back((uint32_t)r); pair_group.push_back(h_rgroup[r]); if (want_aln) pair_pos.push_back(x); } }
+    DevBuf<int32_t> d_dist; static thread_local PinVec<int32_t> h_span, h_dist;
+    if (want_aln) { HIPCHK(ctx, d_dist.alloc(pair_read.size() + 1)); h_span.resize(pair_read.size() * 4 + 4); h_dist.resize(pair_read.size() + 1); }
     uint64_t NP = pair_read.size();
     DevBuf<uint32_t> d_pair_read, d_pair_group; DevBuf<int32_t> d_open, d_span, d_blen; DevBuf<int32_t>& d_bp = ctx->pol_bp; DevBuf<uint8_t>& d_lay_raw = ctx->pol_lay; DevBuf<uint16_t>& d_valid = ctx->pol_valid;
     HIPCHK(ctx, d_pair_read.alloc(NP)); HIPCHK(ctx, d_pair_group.alloc(NP)); HIPCHK(ctx, d_open.alloc(NP)); HIPCHK(ctx, d_span.alloc(NP * 4)); HIPCHK(ctx, d_blen.alloc(G));
@@ -894,9 +917,9 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
             if (!any_active) break;
             // drop the pairs of the stable groups (their reads would be aligned and stacked into exactly the same windows again)
             size_t keep = 0;
-            for (size_t p = 0; p < pair_read.size(); ++p) if (!stable[pair_group[p]]) { pair_read[keep] = pair_read[p]; pair_group[keep] = pair_group[p]; ++keep; }
+            for (size_t p = 0; p < pair_read.size(); ++p) if (!stable[pair_group[p]]) { pair_read[keep] = pair_read[p]; pair_group[keep] = pair_group[p]; if (want_aln) pair_pos[keep] = pair_pos[p]; ++keep; }
             if (keep != pair_read.size()) {
-                pair_read.resize(keep); pair_group.resize(keep); NP = keep;
+                pair_read.resize(keep); pair_group.resize(keep); NP = keep; if (want_aln) pair_pos.resize(keep);
                 if (NP) { HIPCHK(ctx, hipMemcpyAsync(d_pair_read.p, pair_read.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipMemcpyAsync(d_pair_group.p, pair_group.data(), 4 * NP, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
             }
         }
@@ -918,7 +941,7 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
             J.score = nullptr; J.ncols = nullptr; J.nmatch = nullptr; J.region = nullptr; J.bp = d_bp.p; J.bp_windows = nwinmax; J.window = W; J.span = d_span.p;
             int aln_mode = prm->aln_mode == 2 ? 1 : prm->aln_mode;
             if (aln_mode == 3) { aln_mode = 1; J.clip = 1; }          // edit distance + overlap-span clipping (include/ngsid.h)
-            if (aln_mode == 1) rc = ngsid_launch_ed_align(ctx, J, RD.maxlen, maxb, nullptr);          // unit-cost, bit-parallel (k_ed_align.hip)
+            if (aln_mode == 1) rc = ngsid_launch_ed_align(ctx, J, RD.maxlen, maxb, want_aln ? d_dist.p : nullptr);          // unit-cost, bit-parallel (k_ed_align.hip)
             else rc = ngsid_launch_align(ctx, J, RD.maxlen, maxb, prm->aln_open);
             if (rc) return rc;
             const uint64_t T = NP * (uint64_t)nwinmax;
@@ -928,8 +951,20 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
             h_valid.resize(T);
             HIPCHK(ctx, hipMemcpyAsync(&max_layer, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(h_valid.data(), d_valid.p, 2 * T, hipMemcpyDeviceToHost, ctx->stream));
+            if (want_aln) { HIPCHK(ctx, hipMemcpyAsync(h_span.data(), d_span.p, 16 * NP, hipMemcpyDeviceToHost, ctx->stream)); if (aln_mode == 1) HIPCHK(ctx, hipMemcpyAsync(h_dist.data(), d_dist.p, 4 * NP, hipMemcpyDeviceToHost, ctx->stream)); }
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        }
+            if (want_aln) {        // this iteration's records: the previous iteration's for the groups that are stable (same backbone, same reads: the same alignments), fresh ones for the pairs just aligned
+                int32_t* A = trace->aln + (size_t)it * NL * 6;
+                if (it == 0) for (uint64_t x = 0; x < NL * 6; ++x) A[x] = -1; else memcpy(A, A - NL * 6, sizeof(int32_t) * NL * 6);
+                for (uint64_t p = 0; p < NP; ++p) {
+                    int32_t* a = A + pair_pos[p] * 6; const uint32_t r = pair_read[p]; const int32_t ql = (int32_t)(RD.h_off[r + 1] - RD.h_off[r]);
+                    const int32_t qf = h_span[p * 4], qe = h_span[p * 4 + 1], tf = h_span[p * 4 + 2], te = h_span[p * 4 + 3];
+                    if (qf < 0) { for (int c = 0; c < 6; ++c) a[c] = -1; continue; }
+                    const bool rcs = h_orient[r] == 1;
+                    a[0] = rcs ? 1 : 0; a[1] = rcs ? ql - 1 - qe : qf; a[2] = rcs ? ql - qf : qe + 1; a[3] = tf; a[4] = te + 1; a[5] = aln_mode == 1 ? h_dist[p] : -1;
+                }
+            }
+        } else if (want_aln) { int32_t* A = trace->aln + (size_t)it * NL * 6; if (it == 0) for (uint64_t x = 0; x < NL * 6; ++x) A[x] = -1; else memcpy(A, A - NL * 6, sizeof(int32_t) * NL * 6); }
         ht.mark("align + layers + valid copy");
         // ---- units = (group, window) with their layers in read order
         std::vector<std::vector<int>> unit_of(G);
@@ -1032,6 +1067,7 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         B.swap(NB);
         if (trace) for (uint32_t g = 0; g < G; ++g) { trace->seq.push_back(B[g]); trace->used.push_back(used[g]); }
     }
+    if (trace && trace->aln) for (size_t it = trace->seq.size() / std::max<uint32_t>(G, 1); it < (size_t)prm->iters; ++it) { if (it == 0) { for (uint64_t x = 0; x < grp_off[n_groups] * 6; ++x) trace->aln[x] = -1; } else memcpy(trace->aln + it * grp_off[n_groups] * 6, trace->aln + (it - 1) * grp_off[n_groups] * 6, sizeof(int32_t) * grp_off[n_groups] * 6); }
     if (trace) while (trace->seq.size() < (size_t)prm->iters * G) { const size_t x = trace->seq.size() - G; trace->seq.push_back(trace->seq[x]); trace->used.push_back(trace->used[x]); }      // every group stable: the remaining iterations return the same strings
     uint64_t total = 0; bool ovf = false; out_off[0] = 0;
     for (uint32_t g = 0; g < G; ++g) {

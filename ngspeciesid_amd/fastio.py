@@ -245,6 +245,22 @@ def write_fastq(path, idx, names: Names, rs: ReadSet, suffixes=None, first_token
     _write_records(path, append, 0, idx, names, first_token, sb, so, sfx_by_read, rs, jobs, threads)
 
 
+def write_paf(path, idx, names: Names, rs_off, aln, tname, tlen, suffixes=None, jobs: NativeJobs = None, threads=0):
+    """read_alignments_it_{i}.paf (consensus.py:112-121): one PAF line per read idx[j] with the record aln[j] = (strand, q_begin, q_end, t_begin, t_end, distance) of
+    ngsid_polish_trace_aln (no line where strand < 0).  suffixes = per-READ CSR (bytes, offsets) appended to the name before it is cut at the first blank."""
+    lib = runtime.load_library()
+    idx = np.ascontiguousarray(idx, dtype=np.uint64); aln = np.ascontiguousarray(aln, dtype=np.int32).reshape(-1, 6); assert len(aln) == len(idx)
+    off = np.ascontiguousarray(rs_off, dtype=np.uint64)
+    sb, so = (None, None) if suffixes is None else suffixes
+    args = (path.encode(), C.c_uint64(len(idx)), _p(idx), _p(names.buf), _p(names.off), _p(names.len), _p(sb), _p(so), _p(off), _p(aln), tname.encode(), C.c_uint32(int(tlen)), C.c_int32(int(threads or 0)))
+    if jobs is not None:
+        jid = C.c_uint64(0)
+        if lib.ngsid_host_write_paf(*args, C.byref(jid)) == 0:
+            jobs.jobs.append((jid.value, path, (idx, names, sb, so, off, aln))); return
+    if lib.ngsid_host_write_paf(*args, None):
+        raise OSError("cannot write %s" % path)
+
+
 def write_tsv(path, idx, names: Names, prefixes, append=False, jobs: NativeJobs = None):
     """lines 'prefix<TAB>name' for reads idx; prefixes = (byte buffer, offsets) CSR or a list of strings, one per line."""
     idx = np.ascontiguousarray(idx, dtype=np.uint64)

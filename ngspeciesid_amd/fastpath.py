@@ -99,7 +99,7 @@ class BackgroundWriters:
             raise err
 
 
-_NATIVE = (fastio.write_fastq, fastio.write_tsv)       # + _write_pooled (below): their work is ONE call of the library's record writer
+_NATIVE = (fastio.write_fastq, fastio.write_tsv, fastio.write_paf)       # + _write_pooled (below): their work is ONE call of the library's record writer
 
 
 def _write(args, fn, *a, **kw):
@@ -479,8 +479,11 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
         bb = ReadSet.from_strings([(polish_backbones or {}).get(m[1], m[2]) for m in merged])
         prm = polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=3 if clip else 2, aln_mode=3 if clip else 2)      # clip: backbones are primer-trimmed (include/ngsid.h: aln_mode 3, trim 3)
         ro = np.concatenate(polish_lists).astype(np.uint32)
-        if args.racon_iter >= 1:                     # every iteration's sequence: run_racon leaves racon_polished_it_{i}.fasta behind (consensus.py:112-120)
-            its, its_used = api.polish_trace(bb, work, p_off, prm, read_order=ro)
+        want_paf = not getattr(args, "skip_paf", False)
+        its_aln = None
+        if args.racon_iter >= 1:                     # every iteration's sequence: run_racon leaves racon_polished_it_{i}.fasta behind (consensus.py:112-120) - and minimap2's PAF
+            if want_paf: its, its_used, its_aln = api.polish_trace(bb, work, p_off, prm, read_order=ro, aln=True)
+            else: its, its_used = api.polish_trace(bb, work, p_off, prm, read_order=ro)
             polished, used = its[-1], its_used[-1]
         else:
             its, its_used = [], []
@@ -493,6 +496,11 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
             name = "consensus_cl_id_{0}_total_supporting_reads_{1}".format(c_id, nr)
             if its:
                 consensus_mod.write_racon_iteration_files(folder, name, [it[x] for it in its], [int(u[x]) for u in its_used])
+                if its_aln is not None:                  # read_alignments_it_{i}.paf (consensus.py:112-121): the alignments iteration i polished with, against the sequence it started from
+                    a, b = int(p_off[x]), int(p_off[x + 1]); start = (polish_backbones or {}).get(c_id, center)
+                    for i in range(len(its)):
+                        _write(args, fastio.write_paf, os.path.join(folder, "read_alignments_it_{0}.paf".format(i)), polish_lists[x], sr.names, sr.rs.off, its_aln[i][a:b], name,
+                               len(start if i == 0 else its[i - 1][x]), suffixes=sr.sfx)
             else:
                 shutil.copyfile(os.path.join(args.outfolder, "consensus_reference_{0}.fasta".format(c_id)), os.path.join(folder, "consensus.fasta"))
             merged[x][2] = polished[x]

@@ -66,6 +66,9 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
 int32_t ongsid_polish_trace(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
                             const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
                             uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used);
+int32_t ongsid_polish_trace_aln(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order,
+                                const uint64_t* grp_off, uint64_t n_groups, const ngsid_polish_params_t* prm,
+                                uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used, int32_t* it_aln);
 /* tile engine of the consensus / polishing oracle: 0 = node-indexed graph (ngsid_oracle_poa.c, the definition), 1 = rank-ordered graph
    (ngsid_oracle_poa_rank.c, the representation of csrc/k_poa.hip); e < 0 only reads.  Returns the previous value. */
 int32_t ongsid_debug_poa_engine(int32_t e);

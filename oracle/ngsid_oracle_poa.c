@@ -502,7 +502,7 @@ static int polish_wlen(int Bl, int W, int w) { return w == polish_nwin(Bl, W) - 
      bit 1  a layer that does not span its window is aligned globally to the sub-graph of its span (POA_SUBGRAPH above) instead of end-free to the whole graph;
      bit 2  PROBE, not a racon rule: unaligned head / tail bases of a window layer create no nodes (run_tile_band) - isolates the effect of source / sink nodes at the window edges. */
 int32_t ongsid_debug_polish_rules(int32_t r) { const int old = g_polish_rules; if (r >= 0) g_polish_rules = r; return old; }
-typedef struct { uint8_t** seq; int* len; uint64_t* used; } ptrace;      /* [it * G + g] */
+typedef struct { uint8_t** seq; int* len; uint64_t* used; int32_t* aln; } ptrace;      /* [it * G + g]; aln (may be NULL): include/ngsid.h ngsid_polish_trace_aln */
 static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                            const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used, ptrace* tr);
 int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
@@ -510,11 +510,11 @@ int32_t ongsid_polish(const ngsid_reads_t* backbones, const ngsid_reads_t* reads
     return polish_impl(backbones, reads, read_order, grp_off, n_groups, prm, out_off, out, out_cap, needed, n_used, NULL);
 }
 /* the sequence after every iteration (include/ngsid.h: ngsid_polish_trace) */
-int32_t ongsid_polish_trace(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
-                            const ngsid_polish_params_t* prm, uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used) {
+static int32_t polish_trace_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                            const ngsid_polish_params_t* prm, uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used, int32_t* it_aln) {
     if (!prm || !it_off || prm->iters < 1) return NGSID_ERR_ARG;
     const size_t n = (size_t)prm->iters * (size_t)n_groups;
-    ptrace tr; tr.seq = calloc(n + 1, sizeof(uint8_t*)); tr.len = calloc(n + 1, sizeof(int)); tr.used = calloc(n + 1, sizeof(uint64_t));
+    ptrace tr; tr.aln = it_aln; tr.seq = calloc(n + 1, sizeof(uint8_t*)); tr.len = calloc(n + 1, sizeof(int)); tr.used = calloc(n + 1, sizeof(uint64_t));
     uint64_t* ooff = calloc((size_t)n_groups + 1, sizeof(uint64_t)); uint64_t need1 = 0;
     int32_t rc = polish_impl(backbones, reads, read_order, grp_off, n_groups, prm, ooff, NULL, 0, &need1, NULL, &tr);
     free(ooff);
@@ -530,6 +530,16 @@ int32_t ongsid_polish_trace(const ngsid_reads_t* backbones, const ngsid_reads_t*
     for (size_t x = 0; x < n; ++x) free(tr.seq[x]);
     free(tr.seq); free(tr.len); free(tr.used);
     return rc;
+}
+int32_t ongsid_polish_trace(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                            const ngsid_polish_params_t* prm, uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used) {
+    return polish_trace_impl(backbones, reads, read_order, grp_off, n_groups, prm, it_off, it_out, it_cap, needed, it_used, NULL);
+}
+/* + the read -> backbone alignment of every listed read in every iteration (include/ngsid.h: ngsid_polish_trace_aln; what minimap2 writes to read_alignments_it_{i}.paf, consensus.py:112-121) */
+int32_t ongsid_polish_trace_aln(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
+                                const ngsid_polish_params_t* prm, uint64_t* it_off, uint8_t* it_out, uint64_t it_cap, uint64_t* needed, uint64_t* it_used, int32_t* it_aln) {
+    if (!it_aln) return NGSID_ERR_ARG;
+    return polish_trace_impl(backbones, reads, read_order, grp_off, n_groups, prm, it_off, it_out, it_cap, needed, it_used, it_aln);
 }
 static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                            const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used, ptrace* tr) {
@@ -576,13 +586,14 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
             const int nwin = polish_nwin(Blen, W);
             layervec* LV = calloc((size_t)nwin + 1, sizeof(layervec));
             used = 0;
+            if (tr && tr->aln) for (int i = 0; i < ns; ++i) for (int x = 0; x < 6; ++x) tr->aln[((size_t)it * (size_t)grp_off[n_groups] + (size_t)grp_off[g] + (size_t)i) * 6 + (size_t)x] = -1;
             for (int i = 0; i < ns; ++i) {
                 if (orient[i] < 0) continue;
                 const int n = rl[i];
                 uint8_t* ops = malloc((size_t)(n + Blen + 2));
                 int c = aln_mode == 1 ? ongsid_i_ed_ops(rs[i], n, B, Blen, ops)
                                            : ongsid_i_sg_ops(rs[i], n, B, Blen, prm->aln_match, prm->aln_mismatch, prm->aln_open, prm->aln_ext, ops);
-                int qi = 0, ti = 0, qb = -1, tb = -1, qe = -1, te = -1;
+                int qi = 0, ti = 0, qb = -1, tb = -1, qe = -1, te = -1, dist = 0;
                 int* wf = malloc(sizeof(int) * 4 * ((size_t)nwin + 1)); for (int x = 0; x < 4 * nwin; ++x) wf[x] = -1;
                 int x0 = 0, x1 = c - 1;
                 if (clip_span) {        /* overlap span: first .. last run of >= 15 equal columns */
@@ -590,6 +601,7 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                     for (int x = 0; x < c; ++x) { if (ops[x] == 0) { if (++run >= 15) { if (first < 0) first = x - 14; last = x; } } else run = 0; }
                     if (first < 0) { x0 = c; x1 = c - 1; } else { x0 = first; x1 = last; }
                 }
+                if (tr && tr->aln) { int a_ = 0; for (int x = 0; x < c; ++x) { if (ops[x] <= 1) { dist += ops[x]; ++a_; } else if (ops[x] == 2) { ++dist; ++a_; } else if (a_ > 0 && a_ < n) ++dist; } }      /* the distance of ongsid_ed_align_batch: the whole read, backbone ends free */
                 for (int x = 0; x < c; ++x) {
                     if (x < x0 || x > x1) { if (ops[x] <= 1) { ++qi; ++ti; } else if (ops[x] == 2) ++qi; else ++ti; continue; }
                     if (ops[x] <= 1) {
@@ -599,6 +611,11 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                     } else if (ops[x] == 2) ++qi; else ++ti;
                 }
                 free(ops);
+                if (tr && tr->aln) {
+                    int32_t* a = tr->aln + ((size_t)it * (size_t)grp_off[n_groups] + (size_t)grp_off[g] + (size_t)i) * 6;
+                    if (qb < 0) { for (int x = 0; x < 6; ++x) a[x] = -1; }
+                    else { const int rcs = orient[i] == 1; a[0] = rcs; a[1] = rcs ? n - 1 - qe : qb; a[2] = rcs ? n - qb : qe + 1; a[3] = tb; a[4] = te + 1; a[5] = aln_mode == 1 ? dist : -1; }
+                }
                 int contributed = 0;
                 if (qb >= 0) {
                     int qs = qe - qb + 1, ts = te - tb + 1; int mn = qs < ts ? qs : ts, mx = qs < ts ? ts : qs;

@@ -227,3 +227,32 @@ def test_a_concatemer_in_an_abundant_cluster_is_left_out_of_the_consensus(oracle
     assert len(pooled) == 1
     cons = sorted(v.split(b"\n")[1] for k, v in files.items() if k.endswith("consensus.fasta"))
     assert len(cons) == len([k for k in base if k.endswith("consensus.fasta")]) and all(600 < len(c) < 720 for c in cons)
+
+
+def test_racon_folder_holds_the_reference_file_list_incl_the_paf(oracle_backend):
+    """run_racon (consensus.py:107-126) leaves, per iteration i, read_alignments_it_{i}.paf, mm2_stderr_it_{i}.txt, racon_stderr_it_{i}.txt and
+    racon_polished_it_{i}.fasta, + stdout.txt and consensus.fasta.  The PAF comes from the records of ngsid_polish_trace_aln: 12 columns, one line per aligned read of the pooled
+    file, coordinates inside the sequences, the target = the sequence the iteration started from; --skip_paf leaves it out."""
+    files = _run(oracle_backend, ["--t", "1", "--consensus", "--racon", "--racon_iter", "2"], False)
+    folder = sorted({k.split("/")[0] for k in files if k.startswith("racon_cl_id_")})
+    assert len(folder) == 1
+    got = sorted(k.split("/", 1)[1] for k in files if k.startswith(folder[0] + "/"))
+    want = sorted(["stdout.txt", "consensus.fasta"] + [f.format(i) for i in range(2) for f in ("read_alignments_it_{0}.paf", "mm2_stderr_it_{0}.txt", "racon_stderr_it_{0}.txt", "racon_polished_it_{0}.fasta")])
+    assert got == want
+    cid = folder[0][len("racon_cl_id_"):]
+    pooled = files["reads_to_consensus_%s.fastq" % cid].decode().split("\n")
+    qlen = {pooled[i][1:]: len(pooled[i + 1]) for i in range(0, len(pooled) - 3, 4)}
+    start = files["consensus_reference_%s.fasta" % cid].decode().split("\n")[1]
+    it0 = files[folder[0] + "/racon_polished_it_0.fasta"].decode().split("\n")[1]
+    for i, target in enumerate((start, it0)):
+        lines = [l.split("\t") for l in files[folder[0] + "/read_alignments_it_%d.paf" % i].decode().splitlines()]
+        assert 200 < len(lines) <= len(qlen) and all(len(l) == 12 for l in lines)
+        assert len({l[0] for l in lines}) == len(lines)                                   # one line per read
+        for l in lines:
+            ql, qs, qe, tl, ts, te, nm, bl = (int(l[x]) for x in (1, 2, 3, 6, 7, 8, 9, 10))
+            assert ql == qlen[l[0]] and 0 <= qs < qe <= ql and tl == len(target) and 0 <= ts < te <= tl
+            assert l[4] in "+-" and l[5] == "consensus_cl_id_%s_total_supporting_reads_253" % cid and l[11] == "255"
+            assert bl == max(qe - qs, te - ts) and 0 <= nm <= bl and nm > 0.6 * bl        # reads of the cluster at ~13 % error
+        assert {l[4] for l in lines} == {"+", "-"}                                         # the merged centre pools the forward and the reverse-complement cluster
+    skipped = _run(oracle_backend, ["--t", "1", "--consensus", "--racon", "--racon_iter", "2", "--skip_paf"], False)
+    assert sorted(k for k in files if not k.endswith(".paf")) == sorted(skipped) and all(files[k] == skipped[k] for k in skipped if k != "logfile.txt")

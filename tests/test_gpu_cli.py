@@ -44,6 +44,17 @@ def test_cli_consensus_racon(gpu_api, tmp_path):
         assert os.path.exists(os.path.join(folder, "racon_stderr_it_%d.txt" % i)) and os.path.exists(os.path.join(folder, "mm2_stderr_it_%d.txt" % i))
     assert open(os.path.join(folder, "consensus.fasta")).read() == gold["consensus_fasta"]
     assert os.path.exists(os.path.join(out, "reads_to_consensus_%s.fastq" % cid))
+    # round 6: the file set of the folder is the reference's list (consensus.py:112-125), incl. minimap2's PAF of every iteration - and the PAF bytes are the oracle backend's
+    want = sorted(["stdout.txt", "consensus.fasta"] + [f.format(i) for i in range(3) for f in ("read_alignments_it_{0}.paf", "mm2_stderr_it_{0}.txt", "racon_stderr_it_{0}.txt", "racon_polished_it_{0}.fasta")])
+    assert sorted(os.listdir(folder)) == want
+    from ngspeciesid_amd import cli as _cli, fastpath
+    from oracle_lib import load_oracle
+    out2 = str(tmp_path / "out_oracle"); os.makedirs(out2)
+    args = _cli.build_parser().parse_args(["--ont", "--fastq", os.path.join(GOLD, "sample_h1.fastq"), "--outfolder", out2, "--t", "1", "--consensus", "--racon", "--racon_iter", "3"]); args.k, args.w = 13, 20
+    fastpath.main(args, api=load_oracle())
+    for i in range(3):
+        a = open(os.path.join(folder, "read_alignments_it_%d.paf" % i)).read(); b = open(os.path.join(out2, "racon_cl_id_%s" % cid, "read_alignments_it_%d.paf" % i)).read()
+        assert a == b and a.count("\n") > 200
 
 
 def test_consensus_deviation_from_the_reference_order_mode(gpu_api):
