@@ -371,9 +371,6 @@ def main():
             names = fastio.Names.from_list(["r%d_sp%d" % (i, hsp[i]) for i in range(n)])
             fq = os.path.join(tmp, "reads.fastq"); fastio.write_fastq(fq, perm, names, hrs)
             in_bytes = os.path.getsize(fq)
-            outd = os.path.join(tmp, "out"); os.makedirs(outd)
-            cargs = _cli.build_parser().parse_args([cfg["preset"], "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", str(AB_)])
-            cargs.k, cargs.w = K_, W_
             def _cg():          # CPU-quota throttling of the container during the leg (cgroup v2 cpu.stat / v1): the writers and the launch thread share one quota
                 for f_ in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
                     try:
@@ -382,22 +379,37 @@ def main():
                     except Exception:
                         pass
                 return None
-            cg0 = _cg()
-            api.__dict__["call_s"] = {}; api.lib.ngsid_profile_enable(api.ctx, C.c_int32(1))
-            tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl
-            cg1 = _cg()
-            pbuf = C.create_string_buffer(1 << 16); api.lib.ngsid_profile_read(api.ctx, pbuf, C.c_uint64(len(pbuf))); api.lib.ngsid_profile_enable(api.ctx, C.c_int32(0))
-            lib_s = {l.split()[0][5:]: float(l.split()[2]) / 1e3 for l in pbuf.value.decode().splitlines() if l.startswith("host_")}
-            bind = {nm: {"caller_s": round(api.call_s.get(nm, 0.0), 3), "library_s": round(v, 3), "difference_s": round(api.call_s.get(nm, 0.0) - v, 3)} for nm, v in lib_s.items()}
-            out_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs)
-            got = sorted(m[2] for m in r["centers"])
-            cli_leg = {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "ratio_to_hot_path": round((n / dcl) / reads_per_s, 3), "t": args.cli_t,
-                       "stage_s": {k_: round(v, 3) for k_, v in r["timings"].items()}, "input_fastq_bytes": in_bytes, "output_bytes": out_bytes,
-                       "files_on": "tmpfs (/dev/shm)" if base else "disk (tmp dir)", "consensus_equals_amplicons": got == sorted(truths),
-                       "binding_overhead_s": bind,
-                       "cgroup_cpu_during_the_leg": None if not (cg0 and cg1) else {"throttled_periods": cg1["nr_throttled"] - cg0["nr_throttled"], "throttled_ms": round(cg1["throttled_ms"] - cg0["throttled_ms"], 1), "cpu_seconds_used": round(cg1["usage_s"] - cg0["usage_s"], 2)},
-                       "what": "python -m ngspeciesid_amd %s --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio %s: FASTQ parse, score, sort, sorted.fastq, "
-                               "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, 3 polishing iterations, racon_cl_id_*/consensus.fasta" % (cfg["preset"], args.cli_t, AB_)}
+            def cli_run(tag, extra):
+                outd = os.path.join(tmp, "out_" + tag); os.makedirs(outd)
+                cargs = _cli.build_parser().parse_args([cfg["preset"], "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", str(AB_)] + extra)
+                cargs.k, cargs.w = K_, W_
+                cg0 = _cg()
+                api.__dict__["call_s"] = {}; api.lib.ngsid_profile_enable(api.ctx, C.c_int32(1))
+                tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl
+                cg1 = _cg()
+                pbuf = C.create_string_buffer(1 << 16); api.lib.ngsid_profile_read(api.ctx, pbuf, C.c_uint64(len(pbuf))); api.lib.ngsid_profile_enable(api.ctx, C.c_int32(0))
+                lib_s = {l.split()[0][5:]: float(l.split()[2]) / 1e3 for l in pbuf.value.decode().splitlines() if l.startswith("host_")}
+                bind = {nm: {"caller_s": round(api.call_s.get(nm, 0.0), 3), "library_s": round(v, 3), "difference_s": round(api.call_s.get(nm, 0.0) - v, 3)} for nm, v in lib_s.items()}
+                out_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs)
+                paf_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs if f.endswith(".paf"))
+                got = sorted(m[2] for m in r["centers"])
+                shutil.rmtree(outd, ignore_errors=True)
+                return {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "stage_s": {k_: round(v, 3) for k_, v in r["timings"].items()}, "output_bytes": out_bytes, "paf_bytes": paf_bytes,
+                        "consensus_equals_amplicons": got == sorted(truths), "binding_overhead_s": bind,
+                        "cgroup_cpu_during_the_leg": None if not (cg0 and cg1) else {"throttled_periods": cg1["nr_throttled"] - cg0["nr_throttled"], "throttled_ms": round(cg1["throttled_ms"] - cg0["throttled_ms"], 1), "cpu_seconds_used": round(cg1["usage_s"] - cg0["usage_s"], 2)}}
+            # three legs on the same file: the CLI as a user runs it (polishing of a cluster stops once an iteration returns its input: the library default), the same with EVERY
+            # iteration (--polish_all_iterations: equal work to `value`, which runs all three - VERDICT r5 item 9), and without the PAF files (--skip_paf: what they cost)
+            leg_stop = cli_run("stop", []); leg_all = cli_run("all", ["--polish_all_iterations"]); leg_nopaf = cli_run("nopaf", ["--polish_all_iterations", "--skip_paf"])
+            cli_leg = dict(leg_all)
+            cli_leg.update({"ratio_to_hot_path": round(leg_all["reads_per_s"] / reads_per_s, 3), "t": args.cli_t, "input_fastq_bytes": in_bytes,
+                            "files_on": "tmpfs (/dev/shm)" if base else "disk (tmp dir)",
+                            "what": "python -m ngspeciesid_amd %s --fastq reads.fastq --outfolder out --t %d --consensus --racon --racon_iter 3 --abundance_ratio %s --polish_all_iterations: FASTQ parse, score, sort, sorted.fastq, "
+                                    "clustering, final_clusters.tsv / final_cluster_origins.tsv, draft consensus, rc merge, consensus_reference_*.fasta, reads_to_consensus_*.fastq, ALL 3 polishing iterations (as `value`), "
+                                    "racon_cl_id_*/{consensus.fasta, racon_polished_it_*.fasta, read_alignments_it_*.paf}" % (cfg["preset"], args.cli_t, AB_),
+                            "with_stable_stop": {"reads_per_s": leg_stop["reads_per_s"], "wall_s": leg_stop["wall_s"], "stage_s": leg_stop["stage_s"], "consensus_equals_amplicons": leg_stop["consensus_equals_amplicons"],
+                                                 "ratio_to_hot_path_with_stable_stop": round(leg_stop["reads_per_s"] / (n_total / dt_stop), 3) if dt_stop > 0 else None,
+                                                 "what": "the CLI's default (no --polish_all_iterations) against the hot path with the same early stop (config.with_stable_stop)"},
+                            "without_paf": {"reads_per_s": leg_nopaf["reads_per_s"], "wall_s": leg_nopaf["wall_s"], "what": "--polish_all_iterations --skip_paf: the cost of writing minimap2's PAF of every iteration is the difference to this leg"}})
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     # ---- CPU baseline: the oracle (a scalar port of the same algorithms) on a bounded sample of the same workload: one core, and all host cores
@@ -471,7 +483,7 @@ def main():
            "config": {"workload": (args.config.upper() + ": %d synthetic %d bp %s-profile reads " + ("in total, one `--t N` batch per GPU" if (args.scaling == "strong" and (world > 1 or force_dist)) else "per GPU") + " (mu=%.0f), %d species @15%% divergence%s, k=%d w=%d, cluster + spoa-style POA + racon-style polish x3, abundance_ratio %s, POA tile depth %d band %s")
                       % (args.reads, args.length, "CCS" if args.mu >= 25 else "ONT", args.mu, args.species, (" with geometric abundance %.1f^i" % cfg["geometric"]) if cfg["geometric"] else "", K_, W_, AB_, args.tile_depth, ("%d" % args.band) if args.band else "%d (library default, widened per tile by the band-edge check)" % (64 if args.length <= 3000 else 128)),
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
-                      "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()}, "stage_s_per_step_max_over_ranks": None if stage_max is None else {k_: round(v / args.steps, 4) for k_, v in stage_max.items()},
+                      "poa_single_below": pipeline.SINGLE_BELOW, "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()}, "stage_s_per_step_max_over_ranks": None if stage_max is None else {k_: round(v / args.steps, 4) for k_, v in stage_max.items()},
                       "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "library_host_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in host_lines.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),
                       "hbm_gb": {"peak_in_timed_steps": round(hbm_peak / 1e9, 2), "held_after": round(hbm_live / 1e9, 2), "what": "bytes handed out by the library's device allocator, whole process (read set included)", "context_scratch_by_purpose": mem_parts},
                       "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok, "sharded_consensus_equals_single_process": single_same}},

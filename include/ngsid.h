@@ -166,7 +166,8 @@ typedef struct {
                               reads goes as well - with tile_depth <= 0 there is one level and the rule never applies).  DESIGN.md section 2 */
     int32_t single_below;  /* round 6: a group with FEWER sequences than this is aligned as ONE graph in file order - spoa's own order (consensus.py:257-266 hands a cluster's
                               reads to one spoa process) - whatever tile_depth says, with a graph capacity of NGSID_POA_SINGLE_NODE_CAP / 16 times its first sequence when the
-                              longest sequence of the call has at most NGSID_POA_SINGLE_MAXLEN bases (else node_cap).  Depth tiling is a throughput device for deep groups; below
+                              longest sequence of the GROUP (polisher: the longest read behind a window's layers, or the window) has at most NGSID_POA_SINGLE_MAXLEN bases (else
+                              node_cap): a rule of the group alone, so the result does not depend on what else the call holds.  Depth tiling is a throughput device for deep groups; below
                               ~100 sequences one graph is at least as accurate (profiles/r06_tile_depth_sweep.txt).  0 = off (every group is tiled at tile_depth) */
 } ngsid_poa_params_t;
 #define NGSID_POA_SINGLE_NODE_CAP 160      /* one-graph units: room for ten times the first sequence, so that no graph is closed early */

@@ -49,6 +49,8 @@ def build_parser():
     # extensions of this build (not in the reference): shape of the consensus engine.  Defaults = the measured configuration.
     p.add_argument('--poa_tile_depth', type=int, default=4, help='reads per exact-order POA tile (default 4: depth-tiled hierarchy; a positive value also applies to the polishing windows). 0 = one graph per cluster in read order, i.e. spoa\'s order; a graph holds at most 65 520 nodes, so use it with --max_seqs_for_consensus (a few hundred reads); larger clusters are split by the capacity rule')
     p.add_argument('--strand_aware', action='store_true', help='extension: clusters whose representatives are reverse complements of each other (decided by the clustering criteria themselves) are joined BEFORE the consensus stage and their reads are oriented: one cluster per amplicon in final_clusters.tsv; off = the reference (two clusters per amplicon on mixed-strand data, joined after the drafts)')
+    p.add_argument('--polish_all_iterations', action='store_true', help='extension: run every --racon_iter iteration even when an iteration returned its input unchanged (the default stops polishing such a cluster: same result, less time)')
+    p.add_argument('--poa_single_below', type=int, default=None, help='extension: clusters / polishing windows with fewer sequences than this are aligned as ONE graph in read order (spoa\'s and racon\'s own order) instead of being depth-tiled; 0 = tile everything; default: the library\'s measured threshold (pipeline.SINGLE_BELOW)')
     p.add_argument('--skip_paf', action='store_true', help='extension: do not write racon_cl_id_*/read_alignments_it_{i}.paf (the reference leaves minimap2\'s PAF of every polishing iteration there; default: written)')
     p.add_argument('--poa_band', type=int, default=0, help='band of the POA alignments in columns (0 = library default: 64 for reads up to 3 kb, else 128; a tile whose path touches the band edge is redone at twice the band)')
     return p
@@ -69,6 +71,9 @@ def cli(argv=None):
         logging.error('k = %d is outside what the minimizer encoder of this build handles (1..32; the shared-minimizer table has rows for k = 10..30).' % args.k); sys.exit(1)
     if 100 < args.w or args.w < args.k:
         logging.error('Please specify a window of size larger or equal to k, and smaller than 100.'); sys.exit(1)
+    if args.poa_single_below is None:
+        from . import pipeline
+        args.poa_single_below = pipeline.SINGLE_BELOW
     if args.outfolder and not os.path.exists(args.outfolder):
         os.makedirs(args.outfolder)
     main(args)

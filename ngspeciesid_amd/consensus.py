@@ -33,26 +33,27 @@ def _read_fastx(path):
     return accs, seqs, quals
 
 
-def run_spoa(reads, spoa_out_file, spoa_path, api=None, tile_depth=DEFAULT_TILE_DEPTH, band=DEFAULT_BAND):
+def run_spoa(reads, spoa_out_file, spoa_path, api=None, tile_depth=DEFAULT_TILE_DEPTH, band=DEFAULT_BAND, single_below=None):
     """`spoa reads -l 0 -r 0 -g -2` (consensus.py:87): reads a FASTQ/FASTA file, writes the 2-line FASTA spoa prints, returns line 2."""
     api = api or runtime.get_api()
     accs, seqs, quals = _read_fastx(reads)
     rs = ReadSet.from_strings(seqs, quals if all(q is not None for q in quals) and quals else None)
     node_cap = 0 if max((len(s) for s in seqs), default=0) <= 1000 else 22
-    consensus = api.poa_consensus(rs, [0, len(seqs)], poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=pipeline.DRAFT_TRIM))[0]
+    consensus = api.poa_consensus(rs, [0, len(seqs)], poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=pipeline.DRAFT_TRIM,
+                                                                 single_below=pipeline.SINGLE_BELOW if single_below is None else single_below))[0]
     with open(spoa_out_file, "w") as f:
         f.write(">Consensus LN:i:{0}\n{1}\n".format(len(consensus), consensus))
     return consensus
 
 
-def run_racon(reads_to_center, center_file, outfolder, cores, racon_iter, api=None, tile_depth=DEFAULT_TILE_DEPTH, band=DEFAULT_BAND, k=13, w=20, trim=2):
+def run_racon(reads_to_center, center_file, outfolder, cores, racon_iter, api=None, tile_depth=DEFAULT_TILE_DEPTH, band=DEFAULT_BAND, k=13, w=20, trim=2, single_below=None):
     """(minimap2 -x map-ont -> racon) x racon_iter (consensus.py:107-126): writes outfolder/racon_polished_it_{i}.fasta for every iteration and consensus.fasta."""
     api = api or runtime.get_api()
     accs, seqs, quals = _read_fastx(reads_to_center)
     caccs, cseqs, _ = _read_fastx(center_file)
     rs = ReadSet.from_strings(seqs, quals if quals and all(q is not None for q in quals) else None)
     node_cap = 0 if max((len(s) for s in seqs), default=0) <= 1000 else 22
-    prm = polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=trim)
+    prm = polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=trim, single_below=pipeline.SINGLE_BELOW if single_below is None else single_below)
     with open(os.path.join(outfolder, "stdout.txt"), "w") as f:
         f.write("")
     name = caccs[0].split()[0]
@@ -104,7 +105,7 @@ def form_draft_consensus(clusters, representatives, sorted_reads_fastq_file, wor
                         break
                     seq, qual = reads[acc]
                     rf.write("@{0}\n{1}\n{2}\n{3}\n".format(acc, seq, "+", qual))
-            center = run_spoa(reads_path_name, os.path.join(work_dir, "spoa_tmp.fa"), "spoa", api=api, tile_depth=getattr(args, "poa_tile_depth", DEFAULT_TILE_DEPTH), band=getattr(args, "poa_band", DEFAULT_BAND))
+            center = run_spoa(reads_path_name, os.path.join(work_dir, "spoa_tmp.fa"), "spoa", api=api, tile_depth=getattr(args, "poa_tile_depth", DEFAULT_TILE_DEPTH), band=getattr(args, "poa_band", DEFAULT_BAND), single_below=getattr(args, "poa_single_below", None))
             centers.append([n, c_id, center, reads_path_name])
         elif n == 1:
             singletons += 1
@@ -147,7 +148,7 @@ def polish_sequences(centers, args, api=None):
             logging.debug("running racon on spoa reference {0} using {1} reads for polishing.".format(c_id, nr_reads_used))
             folder = os.path.join(args.outfolder, "racon_cl_id_{0}".format(c_id))
             mkdir_p(folder)
-            run_racon(all_reads_file, spoa_center_file, folder, "1", args.racon_iter, api=api, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else DEFAULT_TILE_DEPTH), band=getattr(args, "poa_band", DEFAULT_BAND), k=args.k, w=args.w)
+            run_racon(all_reads_file, spoa_center_file, folder, "1", args.racon_iter, api=api, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else DEFAULT_TILE_DEPTH), band=getattr(args, "poa_band", DEFAULT_BAND), k=args.k, w=args.w, single_below=getattr(args, "poa_single_below", None))
             with open(os.path.join(folder, "consensus.fasta")) as cf:
                 centers[i][2] = cf.readlines()[1].strip()
     return centers

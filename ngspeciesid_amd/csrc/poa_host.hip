@@ -17,6 +17,7 @@ struct Unit {                       // one consensus problem: a cluster (spoa st
     std::vector<uint32_t> seqs;     // indices into the CURRENT level's PSeq array, in order
     int bb = -1;                    // backbone index (into the bbs array) or -1
     bool done = false;
+    uint32_t single_maxlen = 0;     // round 6 (single_below): set (> 0) by the caller for a unit that runs as ONE graph = the longest sequence that can enter it (reads of its members / layers, its backbone)
     std::string result; std::vector<uint32_t> cov; bool has_result = false;
 };
 
@@ -35,7 +36,7 @@ __global__ void k_make_pseq_reads(const uint8_t* seq, const uint8_t* qual, const
     out[i] = S;
 }
 
-struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; int trim_tiles; int single_below = 0, single_cap = 0; };      // single_below / single_cap: ngsid_poa_params_t.single_below and the node capacity of such units (0 = node_cap)
+struct HierParams { int m, n, g, band, node_cap, D, upper_mode; bool want_cov; int trim_tiles; int single_below = 0; };      // single_below: ngsid_poa_params_t.single_below (units the caller marked with single_maxlen)
 
 // Runs all units to completion.  level0: device PSeq array (nseq0 entries) whose max length is maxlen0;
 // bbs: device backbone PSeqs (may be null), maxbb = longest backbone.
@@ -530,20 +531,25 @@ int32_t run_hierarchy(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0, co
                       std::vector<Unit>& units, const HierParams& hp)
 {
     if (hp.single_below > 0) {
-        // round 6 (ngsid_poa_params_t.single_below, oracle run_unit): units with fewer sequences than that run as ONE graph in the given order, as a hierarchy of their own (launch
-        // geometry for ten times the first sequence); the others are tiled at depth D exactly as before.  A call without small units takes the unchanged path.
-        std::vector<size_t> small; for (size_t u = 0; u < units.size(); ++u) if (!units[u].done && units[u].seqs.size() < (size_t)hp.single_below) small.push_back(u);
+        // round 6 (ngsid_poa_params_t.single_below, oracle run_unit): the units the caller marked (fewer sequences than the threshold) run as ONE graph in the given order, as
+        // hierarchies of their own - with room for NGSID_POA_SINGLE_NODE_CAP / 16 times the first sequence where the unit's longest sequence has at most NGSID_POA_SINGLE_MAXLEN
+        // bases (launch geometry for that class only), with the caller's capacity otherwise; the others are tiled at depth D exactly as before.  A call without such units
+        // takes the unchanged path.
         HierParams hb = hp; hb.single_below = 0;
-        if (small.empty()) return run_hierarchy(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hb);
-        HierParams hs = hb; hs.D = 0; if (hp.single_cap > 0) hs.node_cap = hp.single_cap;
-        std::vector<Unit> sub; sub.reserve(small.size());
-        for (size_t u : small) sub.push_back(std::move(units[u]));
-        int32_t rc = run_hierarchy(ctx, d_level0, maxlen0, d_bbs, bb_len, sub, hs);
-        for (size_t x = 0; x < small.size(); ++x) { units[small[x]] = std::move(sub[x]); units[small[x]].done = true; }
-        if (rc) return rc;
-        if (small.size() == units.size()) return NGSID_OK;
-        // the large units: the small ones are done (their results stay in place), every loop below skips them
-        return run_hierarchy(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hb);
+        for (int cls = 0; cls < 2; ++cls) {
+            std::vector<size_t> pick; uint32_t mx = 0;
+            for (size_t u = 0; u < units.size(); ++u) if (!units[u].done && units[u].single_maxlen > 0 && (units[u].single_maxlen <= NGSID_POA_SINGLE_MAXLEN) == (cls == 0)) { pick.push_back(u); mx = std::max(mx, units[u].single_maxlen); }
+            if (pick.empty()) continue;
+            HierParams hs = hb; hs.D = 0; if (cls == 0) hs.node_cap = NGSID_POA_SINGLE_NODE_CAP;
+            std::vector<Unit> sub; sub.reserve(pick.size());
+            for (size_t u : pick) sub.push_back(std::move(units[u]));
+            const int32_t rc = run_hierarchy(ctx, d_level0, std::min(maxlen0, mx), d_bbs, bb_len, sub, hs);
+            for (size_t x = 0; x < pick.size(); ++x) { units[pick[x]] = std::move(sub[x]); units[pick[x]].done = true; }
+            if (rc) return rc;
+        }
+        bool any = false; for (const Unit& U : units) any = any || !U.done;
+        if (!any) return NGSID_OK;
+        return run_hierarchy(ctx, d_level0, maxlen0, d_bbs, bb_len, units, hb);      // the large units (the others are done: every loop below skips them)
     }
     size_t budget = 0;
     { const long long mb = ngsid_opt(ctx, "poa_level_budget_mb", 0);
@@ -631,7 +637,8 @@ static int32_t poa_consensus_impl(ngsid_ctx* ctx, const ngsid_reads_t* reads, co
         else { units[g].seqs.resize(grp_off[g + 1] - grp_off[g]); for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) units[g].seqs[r - grp_off[g]] = (uint32_t)r; }
     }
     HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, prm->mode, cov != nullptr, prm->trim > 0 ? 1 : 0};
-    hp.single_below = prm->single_below > 0 ? prm->single_below : 0; hp.single_cap = RD.maxlen <= NGSID_POA_SINGLE_MAXLEN ? NGSID_POA_SINGLE_NODE_CAP : 0;
+    hp.single_below = prm->single_below > 0 ? prm->single_below : 0;
+    if (hp.single_below > 0) for (Unit& U : units) if (!U.seqs.empty() && U.seqs.size() < (size_t)hp.single_below) { uint32_t mx = 1; for (uint32_t r : U.seqs) mx = std::max<uint32_t>(mx, (uint32_t)(RD.h_off[r + 1] - RD.h_off[r])); U.single_maxlen = mx; }
     std::vector<int> nobb;
     htc.mark("units");
     rc = run_hierarchy(ctx, d_seqs.p, RD.maxlen, nullptr, nobb, units, hp); if (rc) return rc;
@@ -1045,7 +1052,13 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         if (!bbs.empty()) HIPCHK(ctx, hipMemcpyAsync(d_bbs.p, bbs.data(), sizeof(PSeq) * bbs.size(), hipMemcpyHostToDevice, ctx->stream));
         bool any_tgs = prm->trim == 2; for (uint32_t g = 0; g < G; ++g) any_tgs = any_tgs || (tgs[g] && prm->trim);
         HierParams hp{prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : (RD.maxlen <= NGSID_POA_BAND64_MAXLEN ? 64 : 128), prm->node_cap, prm->tile_depth, NGSID_POA_GLOBAL, any_tgs, (prm->trim >= 2 ? 1 : 0) | (prm->trim == 3 ? 4 : 0)};      // trim_tiles: 1 = trim tile consensuses, 4 = except the tile that ends a unit (trim 3)
-        hp.single_below = prm->single_below > 0 ? prm->single_below : 0; hp.single_cap = RD.maxlen <= NGSID_POA_SINGLE_MAXLEN ? NGSID_POA_SINGLE_NODE_CAP : 0;
+        hp.single_below = prm->single_below > 0 ? prm->single_below : 0;
+        if (hp.single_below > 0) for (size_t u = 0; u < units.size(); ++u) {       // windows with few layers: ONE graph; the longest sequence that can enter it = the longest READ behind its layers, or the window
+            Unit& U = units[u]; if (U.done || U.seqs.size() >= (size_t)hp.single_below) continue;
+            uint32_t mx = (uint32_t)std::max(1, bb_len[U.bb]);
+            for (uint32_t id : U.seqs) { const uint32_t r = pair_read[id / (uint32_t)nwinmax]; mx = std::max<uint32_t>(mx, (uint32_t)(RD.h_off[r + 1] - RD.h_off[r])); }
+            U.single_maxlen = mx;
+        }
         ht.mark("unit lists");
         rc = run_hierarchy(ctx, (const PSeq*)d_lay_raw.p, (uint32_t)std::max(max_layer, 1), d_bbs.p, bb_len, units, hp); if (rc) return rc;
         ht.mark("hierarchy");

@@ -102,6 +102,11 @@ class BackgroundWriters:
 _NATIVE = (fastio.write_fastq, fastio.write_tsv, fastio.write_paf)       # + _write_pooled (below): their work is ONE call of the library's record writer
 
 
+def _single_below(args):
+    v = getattr(args, "poa_single_below", None)
+    return pipeline.SINGLE_BELOW if v is None else int(v)
+
+
 def _write(args, fn, *a, **kw):
     bg = getattr(args, "_writers", None)
     if bg is None:
@@ -392,7 +397,7 @@ def consensus_and_polish(args, sr, work, reps, sizes, goff, list_order, abundanc
             args._pooled_early[int(reps[c])] = (c,)
     long_reads = gmax > 1000
     node_cap = 22 if long_reads else 0
-    drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=getattr(args, "poa_tile_depth", pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=pipeline.DRAFT_TRIM),
+    drafts = api.poa_consensus(work, sub_off, poa_params(mode=POA_LOCAL, match=5, mismatch=-4, gap=-2, tile_depth=getattr(args, "poa_tile_depth", pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=pipeline.DRAFT_TRIM, single_below=_single_below(args)),
                                read_order=read_order32)
     T["draft_consensus"] = time() - t0
     centers = [[int(sizes[c]), int(reps[c]), drafts[c], [c]] for c in range(nsel)]
@@ -477,7 +482,8 @@ def _merge_and_polish(args, sr, work, centers, groups, node_cap, api, acc_id, T,
     if getattr(args, "racon", False) and args.racon_iter >= 0:
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in polish_lists]))).astype(np.uint64)
         bb = ReadSet.from_strings([(polish_backbones or {}).get(m[1], m[2]) for m in merged])
-        prm = polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=3 if clip else 2, aln_mode=3 if clip else 2)      # clip: backbones are primer-trimmed (include/ngsid.h: aln_mode 3, trim 3)
+        prm = polish_params(iters=args.racon_iter, k=args.k, w=args.w, tile_depth=(getattr(args, "poa_tile_depth", 0) if getattr(args, "poa_tile_depth", 0) > 0 else pipeline.TILE_DEPTH), band=getattr(args, "poa_band", 0), node_cap=node_cap, trim=3 if clip else 2, aln_mode=3 if clip else 2,
+                            stop_when_stable=0 if getattr(args, "polish_all_iterations", False) else 1, single_below=_single_below(args))      # clip: backbones are primer-trimmed (include/ngsid.h: aln_mode 3, trim 3)
         ro = np.concatenate(polish_lists).astype(np.uint32)
         want_paf = not getattr(args, "skip_paf", False)
         its_aln = None

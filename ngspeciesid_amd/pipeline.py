@@ -20,7 +20,7 @@ from ._capi import Api, ReadSet, cluster_params, poa_params, polish_params, POA_
 TILE_DEPTH = 4
 # Round 6: a unit (a cluster in the draft, a window in the polisher) with FEWER sequences than this is aligned as ONE graph in file order - spoa's / racon's own order
 # (consensus.py:257-266,87) - instead of being tiled (ngsid_poa_params_t.single_below).  Tiling is a throughput device for deep clusters; profiles/r06_tile_depth_sweep.txt.
-SINGLE_BELOW = 0
+SINGLE_BELOW = 64
 import os as _os
 _TOUCH = bool(_os.environ.get("NGSID_TOUCH"))          # dev probe (round 5): one trivial device operation in the middle of the host work between clustering and consensus
 DRAFT_TRIM = 1

@@ -420,16 +420,15 @@ static int run_hierarchy(pseq* seqs, int ns, const pseq* backbone, const pprm* P
 }
 
 /* round 6 (ngsid_poa_params_t.single_below): a unit - a cluster in the draft, a window in the polisher - with fewer than `single_below` sequences is ONE graph in the given
-   order (spoa's / racon's own order, consensus.py:257-266), with room for NGSID_POA_SINGLE_NODE_CAP / 16 times its first sequence when the longest sequence of the call is at
-   most NGSID_POA_SINGLE_MAXLEN bases; larger units are tiled at depth D */
-static int run_unit(pseq* seqs, int ns, const pseq* backbone, const pprm* P, int D, int single_below, int call_maxlen, int upper_mode, uint8_t** cons, uint32_t** cov, int want_cov) {
+   order (spoa's / racon's own order, consensus.py:257-266), with room for NGSID_POA_SINGLE_NODE_CAP / 16 times its first sequence when the longest sequence that can enter it
+   (unit_maxlen: the reads of its members / behind its layers, its backbone) has at most NGSID_POA_SINGLE_MAXLEN bases; larger units are tiled at depth D */
+static int run_unit(pseq* seqs, int ns, const pseq* backbone, const pprm* P, int D, int single_below, int unit_maxlen, int upper_mode, uint8_t** cons, uint32_t** cov, int want_cov) {
     if (single_below > 0 && ns < single_below) {
-        pprm PS = *P; if (call_maxlen <= NGSID_POA_SINGLE_MAXLEN) PS.node_cap = NGSID_POA_SINGLE_NODE_CAP;
+        pprm PS = *P; if (unit_maxlen <= NGSID_POA_SINGLE_MAXLEN) PS.node_cap = NGSID_POA_SINGLE_NODE_CAP;
         return run_hierarchy(seqs, ns, backbone, &PS, 0, upper_mode, cons, cov, want_cov);
     }
     return run_hierarchy(seqs, ns, backbone, P, D, upper_mode, cons, cov, want_cov);
 }
-static int call_maxlen_of(const ngsid_reads_t* reads) { uint64_t mx = 0; for (uint64_t i = 0; i < reads->n; ++i) { const uint64_t l = reads->off[i + 1] - reads->off[i]; if (l > mx) mx = l; } return (int)mx; }
 
 /* library default band (band <= 0): 64 columns when every read of the call is at most 1 024 bases, else 128; the band-edge check of
    run_tile widens it per tile where a path asks for more, so the choice only decides how much work the first attempt does */
@@ -458,7 +457,6 @@ int32_t ongsid_poa_consensus_cov(const ngsid_reads_t* reads, const uint32_t* rea
 static int32_t poa_consensus_impl(const ngsid_reads_t* reads, const uint32_t* read_order, const uint64_t* grp_off, uint64_t n_groups,
                                   const ngsid_poa_params_t* prm, uint64_t* cons_off, uint8_t* cons, uint64_t cons_cap, uint64_t* needed, uint32_t* cov_out) {
     pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : default_band(reads), prm->node_cap, prm->trim > 0 };
-    const int call_maxlen = call_maxlen_of(reads);
     uint64_t total = 0; int overflow = 0; cons_off[0] = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         int ns = (int)(grp_off[g + 1] - grp_off[g]);
@@ -469,7 +467,8 @@ static int32_t poa_consensus_impl(const ngsid_reads_t* reads, const uint32_t* re
             seqs[i].uw = 1; seqs[i].cw = 1; seqs[i].mode = prm->mode; seqs[i].a0 = 0; seqs[i].a1 = -1;
             if (g_seq_weight) { const uint32_t wv = g_seq_weight[r]; seqs[i].q = NULL; seqs[i].cw = wv; seqs[i].uw = (int)(wv > (1u << 20) ? (1u << 20) : (wv < 1u ? 1u : wv)); }
         }
-        uint8_t* c = NULL; uint32_t* cv = NULL; int len = run_unit(seqs, ns, NULL, &P, prm->tile_depth, prm->single_below, call_maxlen, prm->mode, &c, cov_out ? &cv : NULL, cov_out != NULL);
+        uint8_t* c = NULL; uint32_t* cv = NULL; int unit_maxlen = 1; for (int i = 0; i < ns; ++i) if (seqs[i].len > unit_maxlen) unit_maxlen = seqs[i].len;
+        int len = run_unit(seqs, ns, NULL, &P, prm->tile_depth, prm->single_below, unit_maxlen, prm->mode, &c, cov_out ? &cv : NULL, cov_out != NULL);
         if (total + (uint64_t)len <= cons_cap) { memcpy(cons + total, c, (size_t)len); if (cov_out) for (int x = 0; x < len; ++x) cov_out[total + (uint64_t)x] = cv ? cv[x] : 0; } else overflow = 1;
         total += (uint64_t)len; cons_off[g + 1] = total;
         free(c); free(cv); free(seqs);
@@ -545,7 +544,6 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                            const ngsid_polish_params_t* prm, uint64_t* out_off, uint8_t* out, uint64_t out_cap, uint64_t* needed, uint64_t* n_used, ptrace* tr) {
     pprm P = { prm->match, prm->mismatch, prm->gap, prm->band > 0 ? prm->band : default_band(reads), prm->node_cap, (prm->trim >= 2 ? 1 : 0) | (prm->trim == 3 ? 4 : 0) };      /* trim_tiles: 1 = trim tile consensuses, 4 = but not the LAST tile of a unit (trim 3) */
     const int W = prm->window > 0 ? prm->window : 500;
-    const int call_maxlen = call_maxlen_of(reads);
     int aln_mode = prm->aln_mode;
     if (aln_mode == 2) aln_mode = 1;
     const int clip_span = (g_polish_rules & 1) || aln_mode == 3;      /* aln_mode 3 (round 5): edit distance + overlap-span clipping, see include/ngsid.h */
@@ -585,6 +583,7 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
         for (int it = 0; it < prm->iters; ++it) {
             const int nwin = polish_nwin(Blen, W);
             layervec* LV = calloc((size_t)nwin + 1, sizeof(layervec));
+            int* wmax = calloc((size_t)nwin + 1, sizeof(int));      /* single_below: the longest READ behind a window's layers */
             used = 0;
             if (tr && tr->aln) for (int i = 0; i < ns; ++i) for (int x = 0; x < 6; ++x) tr->aln[((size_t)it * (size_t)grp_off[n_groups] + (size_t)grp_off[g] + (size_t)i) * 6 + (size_t)x] = -1;
             for (int i = 0; i < ns; ++i) {
@@ -629,7 +628,7 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                             int begin = tf - ws, end = tl - ws; int offset = (int)(0.01 * (double)wlen);
                             pseq S; S.s = rs[i] + qf; S.q = rq[i] ? rq[i] + qf : NULL; S.len = len; S.uw = 1; S.cw = 1; S.a0 = begin; S.a1 = end;
                             S.mode = (begin < offset && end > wlen - offset) ? NGSID_POA_GLOBAL : ((g_polish_rules & 2) ? POA_SUBGRAPH : NGSID_POA_SEMI);
-                            lv_push(&LV[wdx], S); contributed = 1;
+                            lv_push(&LV[wdx], S); contributed = 1; if (n > wmax[wdx]) wmax[wdx] = n;
                         }
                     }
                 }
@@ -648,7 +647,7 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                 uint8_t* c = NULL; uint32_t* cov = NULL; int len = 0;
                 if (LV[wdx].n >= 2) {
                     pseq bb; bb.s = B + ws; bb.q = NULL; bb.len = wlen; bb.uw = 0; bb.cw = 0; bb.mode = NGSID_POA_GLOBAL; bb.a0 = 0; bb.a1 = -1;
-                    len = run_unit(LV[wdx].v, LV[wdx].n, &bb, &P, prm->tile_depth, prm->single_below, call_maxlen, NGSID_POA_GLOBAL, &c, &cov, 1);
+                    len = run_unit(LV[wdx].v, LV[wdx].n, &bb, &P, prm->tile_depth, prm->single_below, wmax[wdx] > wlen ? wmax[wdx] : (wlen > 1 ? wlen : 1), NGSID_POA_GLOBAL, &c, &cov, 1);
                     if (len > 0 && prm->trim && (tgs || prm->trim == 2) && cov) {      /* racon trims TGS windows only; trim == 2 = every window (build choice); trim == 3 = racon's window rule, tiles trimmed */
                         uint32_t avg = (uint32_t)(LV[wdx].n / 2); int b = 0, e = len - 1;
                         for (; b < len; ++b) if (cov[b] >= avg) break;
@@ -661,7 +660,7 @@ static int32_t polish_impl(const ngsid_reads_t* backbones, const ngsid_reads_t* 
                 memcpy(NB + nb, c, (size_t)len); nb += len;
                 free(c); free(cov); free(LV[wdx].v);
             }
-            free(LV); free(B); B = NB; Blen = nb;
+            free(LV); free(wmax); free(B); B = NB; Blen = nb;
             if (tr) { const size_t x = (size_t)it * (size_t)n_groups + (size_t)g; tr->seq[x] = malloc((size_t)Blen + 1); memcpy(tr->seq[x], B, (size_t)Blen); tr->len[x] = Blen; tr->used[x] = used; }
         }
         if (n_used) n_used[g] = used;
