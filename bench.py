@@ -383,6 +383,7 @@ def main():
                 outd = os.path.join(tmp, "out_" + tag); os.makedirs(outd)
                 cargs = _cli.build_parser().parse_args([cfg["preset"], "--fastq", fq, "--outfolder", outd, "--t", str(args.cli_t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", str(AB_)] + extra)
                 cargs.k, cargs.w = K_, W_
+                time.sleep(1.0)         # (outside the timed leg: the leg before released its gigabytes of arrays half a second after its writers were joined - fastio.NativeJobs - which holds the interpreter lock)
                 cg0 = _cg()
                 api.__dict__["call_s"] = {}; api.lib.ngsid_profile_enable(api.ctx, C.c_int32(1))
                 tcl = time.perf_counter(); r = fastpath.main(cargs, api=api); dcl = time.perf_counter() - tcl

@@ -643,11 +643,14 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
 
     // speculative block size: adaptive - blocks grow while new representatives are rare (bigger aligner launches, fewer round trips) and
     // shrink when they are frequent (every new representative re-decides the rest of its block)
-    const uint32_t BLK = 262144;              // capacity of the per-block buffers
+    // capacity of the per-block buffers = the largest speculative block.  Round 6: 1 M items (262 144 until round 5) - while new representatives are rare a block costs nothing for being
+    // large, and every block ends in the tail of a persistent aligner launch (one work item = two pairs = ~2 ms of a wave): fewer, larger launches.  "cluster_block_cap" sets it (tests).
+    uint32_t BLK = 1u << 20;
+    { const long v = (long)ngsid_opt(ctx, "cluster_block_cap", 0); if (v >= 8192 && v <= (1l << 22)) BLK = (uint32_t)v; }
     uint32_t blk = 32768;
     bool blk_fixed = false;
     { const long v = (long)ngsid_opt(ctx, "cluster_block", 0); if (v >= 64 && v <= (long)BLK) { blk = (uint32_t)v; blk_fixed = true; } }     // dev / test knob: the result must not depend on it
-    DevBuf<uint64_t> cnt; uint32_t stride = 0;
+    DevBuf<uint64_t>& cnt = ctx->cl_cnt; uint32_t stride = 0;      // (kept in the context: a block's matrix is up to a few GB, a fresh allocation of it costs 20+ ms)
     DevBuf<uint32_t> req_q, req_t, req_slot, d_scal; DevBuf<int32_t> req_open, req_mid, req_region;
     HIPCHK(ctx, req_q.alloc(BLK)); HIPCHK(ctx, req_t.alloc(BLK)); HIPCHK(ctx, req_slot.alloc(BLK)); HIPCHK(ctx, req_open.alloc(BLK)); HIPCHK(ctx, req_mid.alloc(BLK)); HIPCHK(ctx, req_region.alloc(BLK));
     HIPCHK(ctx, d_scal.alloc(4)); HIPCHK(ctx, hipMemsetAsync(d_scal.p, 0, 16, ctx->stream));
@@ -670,7 +673,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
                 // rows = the items of THIS block (blocks shrink when representatives are frequent, so rows x columns stays moderate: a noisy read
                 // set with 50 k representatives would otherwise ask for BLK x 50 k x 8 B = 100 GB)
                 stride = std::max(stride, want);
-                { const uint64_t need = (uint64_t)(b1 - b0) * stride; if (cnt.n < need) HIPCHK(ctx, cnt.alloc(need + need / 4)); }
+                { const uint64_t need = (uint64_t)(b1 - b0) * stride; if (!cnt.p || cnt.cap < need) HIPCHK(ctx, cnt.alloc(need + need / 4)); }
                 HIPCHK(ctx, hipMemsetAsync(cnt.p, 0, 8ull * (uint64_t)(b1 - b0) * stride, ctx->stream));
                 { ProfScope ps_(ctx, "k_count_hits"); hipLaunchKernelGGL(k_count_hits, dim3((b1 - lo + 3) / 4), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0,
                                    S.dbc[S.cur].p, S.dbs[S.cur].p, 0u, S.n_db, cnt.p, stride); }
@@ -751,7 +754,12 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             HIPCHK(ctx, hipGetLastError());
         }
         b0 = b1;
-        if (!blk_fixed) { if (newreps <= 2) blk = std::min<uint32_t>(blk * 2, BLK); else if (newreps > 32) blk = std::max<uint32_t>(blk / 2, 8192); }
+        if (!blk_fixed) {
+            if (newreps <= 2) blk = std::min<uint32_t>(blk * 2, BLK); else if (newreps > 32) blk = std::max<uint32_t>(blk / 2, 8192);
+            // the hit matrix of a block is rows x (representatives + room) x 8 bytes: a noisy set with thousands of representatives keeps its blocks under 12 GB of it
+            const uint64_t cols = std::max<uint64_t>(stride, ((uint64_t)S.R + 256 + 63) / 64 * 64);
+            while (blk > 8192 && (uint64_t)blk * cols * 8 > ((uint64_t)12 << 30)) blk /= 2;
+        }
     }
     ht.mark("blocks");
     // ---- results

@@ -561,7 +561,7 @@ extern "C" int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev)
 extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return NGSID_ERR_ARG;
-    static const char* known[] = {"minimizers_chunk_bases", "poa_level_budget_mb", "cluster_block", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
+    static const char* known[] = {"minimizers_chunk_bases", "poa_level_budget_mb", "cluster_block", "cluster_block_cap", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
     for (const char* k : known) if (!strcmp(k, name)) { ctx->options[name] = (long long)value; return NGSID_OK; }
     if (!strcmp(name, "touch")) {        // one trivial operation on the context's stream (+ wait): a caller that spends milliseconds on the host between two calls keeps the device out of its idle state
         if (ctx->mzc_fp.n < 2) HIPCHK(ctx, ctx->mzc_fp.alloc(2));
@@ -574,7 +574,7 @@ extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t va
         ctx->poa_h.release(); ctx->poa_d.release(); ctx->poa_g.release(); ctx->poa_cov.release();
         for (auto& L : ctx->poa_lv) { L.out.release(); L.seqs.release(); L.job_final.release(); L.out_len.release(); L.out_span.release(); L.job_bb.release(); L.out_cw.release(); L.out_n.release(); L.out_cov.release(); L.job_off.release(); L.seq_idx.release(); L.flags.release(); L.job_list.release(); L.job_unit.release(); L.job_pos.release(); }
         ctx->mzc.valid = false; ctx->mzc_cnt.release(); ctx->mzc_hlen.release(); ctx->mz_off.release(); ctx->mz_scode.release(); ctx->mz_spos.release();
-        ctx->pol_mzcode.release(); ctx->pol_mzpos.release(); ctx->pol_oseq.release(); ctx->pol_oqual.release(); ctx->pol_valid.release(); ctx->pol_bp.release(); ctx->pol_lay.release();
+        ctx->pol_mzcode.release(); ctx->pol_mzpos.release(); ctx->pol_oseq.release(); ctx->pol_oqual.release(); ctx->pol_valid.release(); ctx->pol_bp.release(); ctx->pol_lay.release(); ctx->cl_cnt.release();
         ngsid_pool_release_all();
         return NGSID_OK;
     }
@@ -606,6 +606,7 @@ extern "C" int32_t ngsid_profile_read(ngsid_ctx* ctx, char* buf, uint64_t cap)
             {"mem_minimizers_compact", ctx->pol_mzcode.abytes + ctx->pol_mzpos.abytes + ctx->mz_off.abytes + ctx->mzc_cnt.abytes + ctx->mzc_hlen.abytes},
             {"mem_minimizers_sparse_chunk", ctx->mz_scode.abytes + ctx->mz_spos.abytes},
             {"mem_oriented_reads", ctx->pol_oseq.abytes + ctx->pol_oqual.abytes},
+            {"mem_cluster_hit_matrix", ctx->cl_cnt.abytes},
             {"mem_polish_layers", ctx->pol_valid.abytes + ctx->pol_bp.abytes + ctx->pol_lay.abytes}};
         for (const auto& pt : parts) { snprintf(line, sizeof line, "%s %llu 0.0\n", pt.nm, (unsigned long long)pt.b); out += line; }
     }   // not a kernel: tiles redone with a wider band (band-edge check)

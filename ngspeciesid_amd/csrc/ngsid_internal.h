@@ -89,6 +89,7 @@ struct ngsid_ctx {
     struct PoaLevelBufs { DevBuf<uint8_t> out, seqs /* PSeq[] */, job_final; DevBuf<int32_t> out_len, out_span, job_bb; DevBuf<uint64_t> out_cw; DevBuf<uint32_t> out_n, out_cov, job_off, seq_idx, flags, job_list, job_unit, job_pos; };
     PoaLevelBufs poa_lv[2];   // hierarchy levels ping-pong between two buffer sets (level L+1 reads what level L wrote)
     DevBuf<uint64_t> pol_mzcode; DevBuf<uint32_t> pol_mzpos; DevBuf<uint8_t> pol_oseq, pol_oqual; DevBuf<uint16_t> pol_valid; DevBuf<int32_t> pol_bp; DevBuf<uint8_t> pol_lay;   // polisher scratch (grow-only)
+    DevBuf<uint64_t> cl_cnt;                                                                   // hit matrix of the clustering driver's current block (grow-only: blocks of up to 1 M items since round 6)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // side streams: the launches of the small length classes overlap the big one
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     void* pin = nullptr; size_t pin_bytes = 0;     // pinned host staging (device -> host copies of offsets)
