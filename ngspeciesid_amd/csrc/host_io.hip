@@ -356,21 +356,25 @@ static int32_t write_paf_impl(const char* path, uint64_t n, const uint64_t* idx,
     const size_t tl = strlen(tname);
     const int T = std::max(1, n_threads(n * 96));
     std::vector<std::vector<uint8_t>> part((size_t)T);
-    auto put_u = [](std::vector<uint8_t>& o, uint64_t v) { char b[24]; int k = 0; do { b[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k) o.push_back((uint8_t)b[--k]); };
+    // raw-pointer formatting into a buffer sized for the worst case of the range (a line = name + suffix + target name + 9 numbers of at most 20 digits + 12 separators)
+    auto put_u = [](uint8_t* o, uint64_t v) -> uint8_t* { char b[24]; int k = 0; do { b[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k) *o++ = (uint8_t)b[--k]; return o; };
     parallel_ranges(n, T, [&](uint64_t a, uint64_t b, int t) {
-        std::vector<uint8_t>& o = part[(size_t)t]; o.reserve((size_t)(b - a) * (64 + tl));
+        size_t cap = 0;
+        for (uint64_t j = a; j < b; ++j) { if (aln[6 * j] < 0) continue; const uint64_t i = idx[j]; cap += (size_t)name_len[i] + (sfx_off ? (size_t)(sfx_off[i + 1] - sfx_off[i]) : 0) + tl + 9 * 20 + 16; }
+        std::vector<uint8_t>& ov = part[(size_t)t]; ov.resize(cap); uint8_t* o = ov.data();
         for (uint64_t j = a; j < b; ++j) {
             const int32_t* r = aln + 6 * j; if (r[0] < 0) continue;
             const uint64_t i = idx[j]; const uint8_t* nm = names + name_off[i]; uint32_t L = name_len[i], k = 0;
             while (k < L && nm[k] != ' ' && !(nm[k] >= 9 && nm[k] <= 13)) ++k;
-            o.insert(o.end(), nm, nm + k);
-            if (k == L && sfx_off) o.insert(o.end(), sfx + sfx_off[i], sfx + sfx_off[i + 1]);        // (a name cut at a blank loses the suffix behind it: str.split()[0] of name + suffix)
+            memcpy(o, nm, k); o += k;
+            if (k == L && sfx_off) { const size_t sl = (size_t)(sfx_off[i + 1] - sfx_off[i]); memcpy(o, sfx + sfx_off[i], sl); o += sl; }        // (a name cut at a blank loses the suffix behind it: str.split()[0] of name + suffix)
             const uint64_t qs = (uint64_t)r[1], qe = (uint64_t)r[2], ts = (uint64_t)r[3], te = (uint64_t)r[4];
             const uint64_t blk = std::max(qe - qs, te - ts), nm_ = r[5] >= 0 ? (blk > (uint64_t)r[5] ? blk - (uint64_t)r[5] : 0) : std::min(qe - qs, te - ts);
-            o.push_back('\t'); put_u(o, off[i + 1] - off[i]); o.push_back('\t'); put_u(o, qs); o.push_back('\t'); put_u(o, qe); o.push_back('\t'); o.push_back(r[0] ? '-' : '+'); o.push_back('\t');
-            o.insert(o.end(), (const uint8_t*)tname, (const uint8_t*)tname + tl); o.push_back('\t'); put_u(o, tlen); o.push_back('\t'); put_u(o, ts); o.push_back('\t'); put_u(o, te); o.push_back('\t');
-            put_u(o, nm_); o.push_back('\t'); put_u(o, blk); o.push_back('\t'); o.push_back('2'); o.push_back('5'); o.push_back('5'); o.push_back('\n');
-        } });
+            *o++ = '\t'; o = put_u(o, off[i + 1] - off[i]); *o++ = '\t'; o = put_u(o, qs); *o++ = '\t'; o = put_u(o, qe); *o++ = '\t'; *o++ = r[0] ? '-' : '+'; *o++ = '\t';
+            memcpy(o, tname, tl); o += tl; *o++ = '\t'; o = put_u(o, tlen); *o++ = '\t'; o = put_u(o, ts); *o++ = '\t'; o = put_u(o, te); *o++ = '\t';
+            o = put_u(o, nm_); *o++ = '\t'; o = put_u(o, blk); *o++ = '\t'; *o++ = '2'; *o++ = '5'; *o++ = '5'; *o++ = '\n';
+        }
+        ov.resize((size_t)(o - ov.data())); });
     std::vector<uint64_t> base((size_t)T + 1, 0); for (int t = 0; t < T; ++t) base[t + 1] = base[t] + part[(size_t)t].size();
     std::atomic<int> failed{0};
     parallel_ranges((uint64_t)T, T, [&](uint64_t a, uint64_t b, int) { for (uint64_t t = a; t < b; ++t) {
