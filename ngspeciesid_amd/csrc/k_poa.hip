@@ -130,6 +130,25 @@ __device__ __forceinline__ int wave_incl_max_scan(int v)
     return v;
 }
 
+// the same scan with its input left intact (round 6): the first step is written OUT of place - v_max_i32_dpp dst, v, v row_shr:1 bound_ctrl:1: a lane without a source reads 0
+// and takes max(0, v) - so the caller keeps v for the "did the chain win" compare without the register copy the in-place form forces (one v_mov per DP row).  Exact for v >= 0;
+// the cell values it is used on are biased by PBIAS (reachable cells ~2^28; an UNREACHABLE cell, whose value and direction nothing ever reads, may come out as 0 instead of a small
+// negative number).
+__device__ __forceinline__ int wave_incl_max_scan_keep(int v)
+{
+    int o;
+    asm volatile(
+        "s_nop 1\n v_max_i32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+        "s_nop 1\n v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+        "s_nop 1\n"
+        : "=&v"(o) : "v"(v));
+    return o;
+}
+
 // inclusive add-scan over the 64 lanes (same DPP pattern as the max-scan; lanes without a source keep their value)
 __device__ __forceinline__ int wave_incl_add_scan(int v)
 {
@@ -488,6 +507,9 @@ __device__ __forceinline__ void poa_row_tail_store(l32 ringrow, LDSP uint8_t* ds
 // All differences between candidates of one cell are the same as in H space, so every maximum and every tie-break is the oracle's.
 // Band columns past the end of the sequence (only when L+1 < BW) see the 0xFF padding and can never beat a real cell.
 #define PBIAS (1 << 28)
+#ifndef POA_SCAN_KEEP
+#define POA_SCAN_KEEP 1
+#endif
 template <int CPL, bool LOCAL>
 __device__ __forceinline__ unsigned poa_row_finish(const int (&X)[CPL], const int (&Dd)[CPL], int floor0, int gp, int (&hout)[CPL])
 {
@@ -496,7 +518,11 @@ __device__ __forceinline__ unsigned poa_row_finish(const int (&X)[CPL], const in
         // the chain iff that value differs from its own candidate, and (local mode) it sits on the floor iff the value equals the floor (the floor grows with the
         // column, so the prefix maximum of the floors is the lane's own).  Same values and directions as the general form below, two instructions less per row.
         const int xf = LOCAL ? max(X[0], floor0) : X[0];
+#if POA_SCAN_KEEP
+        const int incl = LOCAL ? wave_incl_max_scan(xf) : wave_incl_max_scan_keep(xf);      // (local mode: xf is a temporary already)
+#else
         const int incl = wave_incl_max_scan(xf);
+#endif
         int dd = Dd[0];
         if (incl != X[0]) dd = 2;
         if (LOCAL && incl == floor0) dd = 3;
