@@ -457,6 +457,13 @@ __global__ void k_reset_items(ClDev D, const uint32_t* __restrict__ items, uint3
     if (affected) D.dec[items[it]] = DEC_UNDEC;
 }
 
+// round 6: items [it_lo, it_hi) leave the current block undecided (the driver cut the block short: a later block decides them from scratch)
+__global__ void k_undecide(ClDev D, const uint32_t* __restrict__ items, uint32_t it_lo, uint32_t it_hi)
+{
+    const uint32_t it = it_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (it < it_hi) D.dec[items[it]] = DEC_UNDEC;
+}
+
 __global__ void k_finalize(ClDev D, uint64_t n, const uint8_t* __restrict__ seeded, int32_t* __restrict__ rep_of, uint8_t* __restrict__ status,
                            double* __restrict__ herr_out, unsigned long long* __restrict__ counters)
 {
@@ -650,6 +657,8 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     uint32_t blk = 32768;
     bool blk_fixed = false;
     { const long v = (long)ngsid_opt(ctx, "cluster_block", 0); if (v >= 64 && v <= (long)BLK) { blk = (uint32_t)v; blk_fixed = true; } }     // dev / test knob: the result must not depend on it
+    uint32_t trunc = 32768;                  // cap of a restarting block's rest (below); "cluster_trunc" sets it (0 = off) - tests use small values to cut blocks of small sets
+    { const long v = (long)ngsid_opt(ctx, "cluster_trunc", -1); if (v >= 0) trunc = (uint32_t)std::min<long>(v, 1l << 22); }
     DevBuf<uint64_t>& cnt = ctx->cl_cnt; uint32_t stride = 0;      // (kept in the context: a block's matrix is up to a few GB, a fresh allocation of it costs 20+ ms)
     DevBuf<uint32_t> req_q, req_t, req_slot, d_scal; DevBuf<int32_t> req_open, req_mid, req_region;
     HIPCHK(ctx, req_q.alloc(BLK)); HIPCHK(ctx, req_t.alloc(BLK)); HIPCHK(ctx, req_slot.alloc(BLK)); HIPCHK(ctx, req_open.alloc(BLK)); HIPCHK(ctx, req_mid.alloc(BLK)); HIPCHK(ctx, req_region.alloc(BLK));
@@ -661,9 +670,11 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
 
     ht.mark("setup");
     for (uint32_t b0 = 0; b0 < NI; ) {
-        const uint32_t b1 = std::min<uint32_t>(NI, b0 + blk);
+        uint32_t b1 = std::min<uint32_t>(NI, b0 + blk);
+        uint32_t rounds = 0;                      // restart rounds of this block
         uint32_t lo = b0;                         // first uncommitted item
         uint32_t newreps = 0;
+        uint64_t aln_first = 0, aln_total = 0; bool first_round = true;      // pairs aligned in the block's first alignment round / in all of them (round 6: the block size follows the share of RE-alignments)
         bool need_full = true;
         while (lo < b1) {
             refresh();
@@ -698,6 +709,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
                 nreq = (uint32_t)(h_mask[w1] & 0xffffffffull); eflag = (int)(h_mask[w1] >> 32);
                 if (!nreq) break;
+                aln_total += nreq; if (first_round) aln_first += nreq;
                 AlignJob J{};
                 J.qseq = RD.seq; J.qoff = RD.off; J.tseq = RD.seq; J.toff = RD.off; J.qidx = req_q.p; J.tidx = req_t.p; J.npairs = nreq;
                 J.match = 2; J.mismatch = -2; J.ext = 1; J.k = k; J.open = req_open.p; J.match_id = req_mid.p;     // cluster.py:130
@@ -706,6 +718,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
                 hipLaunchKernelGGL(k_cache_insert, dim3((nreq + 255) / 256), dim3(256), 0, ctx->stream, D, req_q.p, req_slot.p, req_region.p, nreq);
                 HIPCHK(ctx, hipGetLastError());
             }
+            first_round = false;
             // ---- the items that decided "new representative", in block order (bit mask of the block, fetched with the last request count above, scanned on the host)
             if (eflag) NGSID_FAIL(ctx, NGSID_ERR_NO_PTABLE, "no p_shared entry for an (e1,e2) pair met during mapping (KeyError in cluster.py:367)");
             uint32_t C[TMAX + 1]; uint32_t nC = 0;
@@ -752,9 +765,25 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             if (S.R + 1 > stride) need_full = true;
             hipLaunchKernelGGL(k_reset_items, dim3((b1 - lo + 255) / 256), dim3(256), 0, ctx->stream, D, d_items.p, lo, b1, b0, cnt.p, stride, R_before, c);
             HIPCHK(ctx, hipGetLastError());
+            // Round 6: a block that keeps restarting is cut short.  Every restart round runs five kernels over the rest of the block (reset, decide, alignment cursor, mask, hit
+            // counts of the next tentative representatives), so its cost grows with that rest, and the NUMBER of rounds is given by the data (one per stretch between dependent
+            // new representatives) - the noisy tail of a score-ordered set brings thousands of them at once (mu = 14: 2 196 new representatives in the last 408 k reads, after
+            // 540 k reads with none, i.e. in a block that had grown to its largest size).  From the third round on the rest is capped at `trunc` items; the items behind the cut
+            // go back to "undecided" and are decided from scratch by the next block, which starts at that size.  Results do not depend on where blocks end (tested).
+            ++rounds;
+            if (trunc && rounds >= 3 && b1 - lo > trunc) {
+                const uint32_t nb1 = lo + trunc;
+                hipLaunchKernelGGL(k_undecide, dim3((b1 - nb1 + 255) / 256), dim3(256), 0, ctx->stream, D, d_items.p, nb1, b1);
+                HIPCHK(ctx, hipGetLastError());
+                b1 = nb1; if (!blk_fixed) blk = std::max<uint32_t>(trunc, 8192);
+            }
         }
         b0 = b1;
         if (!blk_fixed) {
+            // blocks grow while new representatives are rare and shrink when they are frequent (every new representative re-decides part of the rest of its block)
+            const double waste = aln_first ? (double)(aln_total - aln_first) / (double)aln_first : (aln_total ? 1.0 : 0.0);
+            static const bool trace_blocks = getenv("NGSID_CLUSTER_TRACE") != nullptr;      // dev aid: one line per block on stderr
+            if (trace_blocks) fprintf(stderr, "[ngsid cluster] block ending at %u: %u restart rounds, %u new representatives (R = %u), pairs aligned in the first round %llu, later %llu (%.3f)\n", b1, rounds, newreps, S.R, (unsigned long long)aln_first, (unsigned long long)(aln_total - aln_first), waste);
             if (newreps <= 2) blk = std::min<uint32_t>(blk * 2, BLK); else if (newreps > 32) blk = std::max<uint32_t>(blk / 2, 8192);
             // the hit matrix of a block is rows x (representatives + room) x 8 bytes: a noisy set with thousands of representatives keeps its blocks under 12 GB of it
             const uint64_t cols = std::max<uint64_t>(stride, ((uint64_t)S.R + 256 + 63) / 64 * 64);

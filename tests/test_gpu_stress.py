@@ -121,7 +121,7 @@ from ngspeciesid_amd.hostutil import subset_reads
 api = runtime.get_api(0)
 sp = synth.make_species(40, 600, 0.12, seed=21)
 ab = np.array([0.5 ** (i / 4.0) for i in range(40)]); ab /= ab.sum()
-rd = synth.make_reads(sp, 120000, mu=15.0, seed=22, abundance=ab, rc_fraction=0.2)
+rd = synth.make_reads(sp, 120000, mu=14.0, seed=22, abundance=ab, rc_fraction=0.2)
 rs0 = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
 score, err, keep = api.score_reads(rs0, 13, 7.0)
 idx = np.nonzero(keep)[0]; idx = idx[np.argsort(-score[idx], kind="stable")]
@@ -130,11 +130,15 @@ prm = cluster_params(k=13, w=20, p_shared=select_p_table(13, 20))
 ar = np.arange(rs.n, dtype=np.uint32)
 res = []
 import ctypes as C
-for blk in (0, 3000):
+# (block size, cap of a restarting block's rest): adaptive + the default cut, a fixed small block, adaptive with a cut after 500 items (round 6: a block that keeps restarting
+# is cut short and its tail decided again by the next block), adaptive without the cut
+for blk, trunc in ((0, -1), (3000, -1), (0, 500), (0, 0)):
     assert api.lib.ngsid_ctx_option(api.ctx, b"cluster_block", C.c_int64(blk)) == 0
+    assert api.lib.ngsid_ctx_option(api.ctx, b"cluster_trunc", C.c_int64(32768 if trunc < 0 else trunc)) == 0
     rep, herr, st, cnt = api.cluster_greedy(rs, prm, acc_rank=ar)
     res.append((rep.copy(), st.copy(), cnt.copy()))
-assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), "block size changed the result"
+for x in res[1:]:
+    assert np.array_equal(res[0][0], x[0]) and np.array_equal(res[0][1], x[1]) and np.array_equal(res[0][2], x[2]), "block size / block cut changed the result"
 print("ok", rs.n, len(np.unique(res[0][0])), res[0][2])
 ''' % ROOT
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
