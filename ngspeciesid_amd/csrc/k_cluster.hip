@@ -291,6 +291,17 @@ void k_count_hits_rep(ClDev D, const uint32_t* __restrict__ items, uint32_t it_l
     if (lane == 0 && acc) *cell += acc;
 }
 
+// Can a representative that shares nm minimizers with `read` change the decision the read took WITHOUT it?  Only if the reference would ever look at it: get_best_cluster walks
+// the candidates by hit count and stops at the first one below min_shared or below min_fraction x top (cluster.py:82,88), the alignment stage only takes candidates AT the top count
+// (:181) - so a representative below that bound is never visited and, being below the top, does not move the top either.  D.top[read] is the top count over the committed
+// representatives as of the read's last decision; it stays valid while the read is unaffected, because a representative that could raise it is one that "matters" here.
+// (Round 6.  Until round 5 the test was nm >= min_shared alone: in a noisy set nearly every read shares five minimizers with every new noise representative of its species, so
+// almost every restart round committed a single representative.)
+__device__ __forceinline__ bool rep_can_matter(const ClDev& D, uint32_t read, int nm)
+{
+    return nm >= D.min_shared && !((double)nm < D.min_fraction * (double)D.top[read]);
+}
+
 // first block item in [it_lo,it_hi) that shares at least min_shared minimizers with one of the T tentative representatives in the columns
 // R0 .. R0+T-1 (only such an item can decide differently once they exist: get_best_cluster breaks below min_shared, cluster.py:82,88, and the
 // alignment stage only looks at the top count, :181, which is >= min_shared, :310)
@@ -302,7 +313,8 @@ void k_first_affected(ClDev D, const uint32_t* __restrict__ items, uint32_t it_l
     const uint32_t it = it_lo + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (it >= it_hi) return;
     const uint64_t* row = cnt + (uint64_t)(it - row0) * stride;
-    const bool hit = (uint32_t)lane < T && (int)(row[R0 + lane] >> 48) >= D.min_shared;
+    const int nm = (uint32_t)lane < T ? (int)(row[R0 + lane] >> 48) : 0;
+    const bool hit = rep_can_matter(D, items[it], nm);
     if (__ballot(hit) != 0ull && lane == 0) atomicMin(out, it);
 }
 
@@ -453,8 +465,9 @@ __global__ void k_reset_items(ClDev D, const uint32_t* __restrict__ items, uint3
     if (it >= it_hi) return;
     const uint64_t* row = cnt + (uint64_t)(it - row0) * stride + R0;
     bool affected = false;
-    for (uint32_t t = 0; t < nnew; ++t) affected = affected || (int)(row[t] >> 48) >= D.min_shared;
-    if (affected) D.dec[items[it]] = DEC_UNDEC;
+    const uint32_t read = items[it];
+    for (uint32_t t = 0; t < nnew; ++t) affected = affected || rep_can_matter(D, read, (int)(row[t] >> 48));
+    if (affected) D.dec[read] = DEC_UNDEC;
 }
 
 // round 6: items [it_lo, it_hi) leave the current block undecided (the driver cut the block short: a later block decides them from scratch)
@@ -622,6 +635,7 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
     HIPCHK(ctx, hipMemsetAsync(cache_ptr.p, 0, N, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(alnflag.p, 0, N, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(kind.p, 0, N, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(top.p, 0, 4 * N, ctx->stream));            // (read by rep_can_matter for reads that never reached k_decide_map's top pass: short reads)
 
     RepStore S; S.ctx = ctx; S.h_pool_off.push_back(0);
     HIPCHK(ctx, S.d_count.alloc(4)); HIPCHK(ctx, S.rep_read.alloc(1024)); HIPCHK(ctx, S.pool_off.alloc(1025)); S.Rcap = 1024;
@@ -784,7 +798,10 @@ extern "C" int32_t ngsid_cluster_greedy(ngsid_ctx* ctx, const ngsid_reads_t* rea
             const double waste = aln_first ? (double)(aln_total - aln_first) / (double)aln_first : (aln_total ? 1.0 : 0.0);
             static const bool trace_blocks = getenv("NGSID_CLUSTER_TRACE") != nullptr;      // dev aid: one line per block on stderr
             if (trace_blocks) fprintf(stderr, "[ngsid cluster] block ending at %u: %u restart rounds, %u new representatives (R = %u), pairs aligned in the first round %llu, later %llu (%.3f)\n", b1, rounds, newreps, S.R, (unsigned long long)aln_first, (unsigned long long)(aln_total - aln_first), waste);
-            if (newreps <= 2) blk = std::min<uint32_t>(blk * 2, BLK); else if (newreps > 32) blk = std::max<uint32_t>(blk / 2, 8192);
+            // (a rule by restart ROUNDS instead of new representatives was measured in round 6 and lost: 0.45 against 0.41 s at mu = 14 - small blocks stay the better ones while
+            // representatives keep coming, whatever the number of rounds they take)
+            const long s_reps = (long)ngsid_opt(ctx, "cluster_shrink_reps", 32); const uint32_t floor_blk = (uint32_t)ngsid_opt(ctx, "cluster_block_floor", 4096);
+            if (newreps <= 2) blk = std::min<uint32_t>(blk * 2, BLK); else if ((long)newreps > s_reps) blk = std::max<uint32_t>(blk / 2, floor_blk);
             // the hit matrix of a block is rows x (representatives + room) x 8 bytes: a noisy set with thousands of representatives keeps its blocks under 12 GB of it
             const uint64_t cols = std::max<uint64_t>(stride, ((uint64_t)S.R + 256 + 63) / 64 * 64);
             while (blk > 8192 && (uint64_t)blk * cols * 8 > ((uint64_t)12 << 30)) blk /= 2;

@@ -561,7 +561,7 @@ extern "C" int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev)
 extern "C" int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return NGSID_ERR_ARG;
-    static const char* known[] = {"minimizers_chunk_bases", "poa_level_budget_mb", "cluster_block", "cluster_block_cap", "cluster_trunc", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
+    static const char* known[] = {"minimizers_chunk_bases", "poa_level_budget_mb", "cluster_block", "cluster_block_cap", "cluster_trunc", "cluster_shrink_reps", "cluster_block_floor", "ed_band", "ed_win_all", "align32", "align_noclass", "poa_tiles_per_cu", "minimizers_lean", "minimizers_mode", "poa_host_levels", "align_paired", "poa_out_slots", "ed_lds_pad_kb", "ed_win6"};
     for (const char* k : known) if (!strcmp(k, name)) { ctx->options[name] = (long long)value; return NGSID_OK; }
     if (!strcmp(name, "touch")) {        // one trivial operation on the context's stream (+ wait): a caller that spends milliseconds on the host between two calls keeps the device out of its idle state
         if (ctx->mzc_fp.n < 2) HIPCHK(ctx, ctx->mzc_fp.alloc(2));
