@@ -299,7 +299,9 @@ void k_count_hits_rep(ClDev D, const uint32_t* __restrict__ items, uint32_t it_l
 // almost every restart round committed a single representative.)
 __device__ __forceinline__ bool rep_can_matter(const ClDev& D, uint32_t read, int nm)
 {
-    return nm >= D.min_shared && !((double)nm < D.min_fraction * (double)D.top[read]);
+    // (min_fraction above 1 - a legal flag value - makes the walk stop at once, but a representative AT or above the top count still changes the top / joins the alignment candidates)
+    const double mf = D.min_fraction < 1.0 ? D.min_fraction : 1.0;
+    return nm >= D.min_shared && !((double)nm < mf * (double)D.top[read]);
 }
 
 // first block item in [it_lo,it_hi) that shares at least min_shared minimizers with one of the T tentative representatives in the columns

@@ -80,6 +80,26 @@ def test_symmetric_thresholds(gpu_api, oracle):
         assert np.array_equal(x, y, equal_nan=True)
 
 
+@pytest.mark.parametrize("kw", [dict(min_fraction=0.5), dict(min_fraction=1.0), dict(min_fraction=1.2), dict(min_shared=3, min_fraction=0.9), dict(min_shared=12), dict(mapped_threshold=0.9, aligned_threshold=0.7),
+                                dict(symmetric=True, min_fraction=0.6)])
+def test_noisy_reads_cluster_as_the_oracle_says_under_other_criteria(gpu_api, oracle, kw):
+    """round 6: the speculative driver commits several new representatives per restart round; which later reads a new representative can affect is decided by the walk's own bound
+    (nm >= min_shared and not below min(min_fraction, 1) x top, k_cluster.hip rep_can_matter).  A noisy set (many noise representatives of the same species: the case the bound is for)
+    under parameter values that move that bound - incl. min_fraction above 1, where only the top count matters - must cluster exactly as the sequential oracle does: map, statuses, counters."""
+    sp = synth.make_species(4, 500, 0.12, seed=31)
+    rd = synth.make_reads(sp, 6000, mu=12.5, seed=32)
+    rs0 = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    from ngspeciesid_amd.hostutil import subset_reads
+    score, err, keep = gpu_api.score_reads(rs0, 13, 7.0)
+    idx = np.nonzero(keep)[0]; idx = idx[np.argsort(-score[idx], kind="stable")]
+    rs = subset_reads(rs0, idx)
+    prm = cluster_params(k=13, w=20, p_shared=PT, **kw)
+    ar = np.arange(rs.n, dtype=np.uint32)
+    a, b = both(gpu_api, oracle, lambda api: api.cluster_greedy(rs, prm, acc_rank=ar))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert len(np.unique(a[0])) > 40                    # the set does found many representatives
+
+
 def test_device_resident_read_set_and_second_context(gpu_api, oracle):
     """ngsid_reads_upload: one copy to HBM serves several calls and several contexts; results equal the host read set's; a second context
     (own stream and scratch) working from another host thread at the same time gives the same answers."""
