@@ -414,8 +414,11 @@ int32_t run_hierarchy_dev(ngsid_ctx* ctx, const PSeq* d_level0, uint32_t maxlen0
     if (capV > 0xFFF0 || 3 * capV / 2 > 0xFFF0 || (long long)hp.m * Lmax >= 65536 || hp.m < 0 || hp.g >= 0) return NGSID_OK;      // the host loop reports what is wrong (or fits where this margin does not)
     for (int bw = band0; bw <= 256; bw *= 2) if (poa_lds_bytes((int)capV, (int)(3 * capV / 2), Lmax, bw) > 160 * 1024) return NGSID_OK;
     const int slots = (int)std::min<uint32_t>(maxD, (uint32_t)std::max<long long>(1, ngsid_opt(ctx, "poa_out_slots", 4)));      // output slots per tile of the first attempt (a tile that closes its graph more often falls back to the host-driven loop, which retries with more)
-    int levels_est = 1; { uint64_t n = maxn; const uint64_t Dd = hp.D > 0 ? (uint64_t)hp.D : maxn; while (n > 1 && levels_est < C_MAXLV - 4) { n = (n + Dd - 1) / std::max<uint64_t>(Dd, 2); ++levels_est; } }
-    levels_est = std::min(levels_est + 1, C_MAXLV - 2);
+    // levels the LARGEST unit needs when every tile returns one consensus (the tile counts of poa_ntiles, level by level).  Round 6: exactly that many are enqueued before the first
+    // synchronisation (it used to be two more - an off-by-one and a spare - i.e. 2 x 9 empty dispatches per hierarchy); a tile that closes its graph early and returns two
+    // sequences can make a unit need one level more: the loop below then enqueues three more after looking at the counters.
+    int levels_est = 0; { uint64_t n = maxn; const uint32_t Dd = hp.D > 0 ? (uint32_t)hp.D : (uint32_t)std::min<uint64_t>(maxn, 0xffffffffull); while (n > 1 && levels_est < C_MAXLV - 4) { n = poa_ntiles((uint32_t)n, std::max<uint32_t>(Dd, 2u)); ++levels_est; } }
+    levels_est = std::min(std::max(levels_est, 1), C_MAXLV - 2);
     uint32_t cap[2]; cap[0] = njobs0;
     { const uint64_t e1 = hp.D > 0 ? (njobs0 + (uint64_t)hp.D - 1) / (uint64_t)hp.D * (uint64_t)slots + U : U; cap[1] = (uint32_t)std::min<uint64_t>(njobs0, e1 + e1 / 4 + 1024); }
     PoaPlan plan{(int)capV, (int)(3 * capV / 2), Lmax, 0, 0, band0};
