@@ -16,6 +16,29 @@ def main(args, api=None):
     return fastpath.main(args, api=api)
 
 
+def write_fastq(args):
+    """the `write_fastq` sub-command (NGSpeciesID:161-182, :238-245): one <cluster id>.fastq per cluster of final_clusters.tsv with at least --N reads.  The reference's
+    semantics: the id and the accession are the first two white-space separated fields of a line, the reads are looked up by their WHOLE header line (an accession the FASTQ does
+    not hold under that name is a KeyError, as there)."""
+    from .help_functions import readfq, mkdir_p
+    members = {}
+    with open(args.clusters) as fh:
+        for line in fh:
+            f = line.split()
+            if len(f) >= 2:
+                members.setdefault(f[0], []).append(f[1])
+    mkdir_p(args.outfolder)
+    with open(args.fastq) as fh:
+        record = {name: sq for name, sq in readfq(fh)}
+    for cl_id, accs in members.items():
+        if len(accs) < args.N:
+            continue
+        with open(os.path.join(args.outfolder, str(cl_id) + ".fastq"), "w") as out:
+            for acc in accs:
+                seq, qual = record[acc]
+                out.write("@{0}\n{1}\n+\n{2}\n".format(acc, seq, qual))
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="Reference-free clustering and consensus forming of targeted ONT or PacBio reads (MI355X hot path)",
                                 formatter_class=argparse.ArgumentDefaultsHelpFormatter)
@@ -52,6 +75,14 @@ def build_parser():
     p.add_argument('--polish_all_iterations', action='store_true', help='extension: run every --racon_iter iteration even when an iteration returned its input unchanged (the default stops polishing such a cluster: same result, less time)')
     p.add_argument('--poa_single_below', type=int, default=None, help='extension: clusters / polishing windows with fewer sequences than this are aligned as ONE graph in read order (spoa\'s and racon\'s own order) instead of being depth-tiled; 0 = tile everything; default: the library\'s measured threshold (pipeline.SINGLE_BELOW)')
     p.add_argument('--skip_paf', action='store_true', help='extension: do not write racon_cl_id_*/read_alignments_it_{i}.paf (the reference leaves minimap2\'s PAF of every polishing iteration there; default: written)')
+    p.set_defaults(which='main')
+    sub = p.add_subparsers(help='sub-command help')
+    wf = sub.add_parser('write_fastq', help='write the reads of every cluster of final_clusters.tsv to <outfolder>/<cluster id>.fastq (NGSpeciesID:238-245)')
+    wf.add_argument('--clusters', type=str, help='final_clusters.tsv of a run')
+    wf.add_argument('--fastq', type=str, help='Input fastq file')
+    wf.add_argument('--outfolder', type=str, help='Output folder')
+    wf.add_argument('--N', type=int, default=0, help='Write out clusters with more or equal than N reads')
+    wf.set_defaults(which='write_fastq')
     p.add_argument('--poa_band', type=int, default=0, help='band of the POA alignments in columns (0 = library default: 64 for reads up to 3 kb, else 128; a tile whose path touches the band edge is redone at twice the band)')
     return p
 
@@ -59,6 +90,10 @@ def build_parser():
 def cli(argv=None):
     args = build_parser().parse_args(argv)
     logging.basicConfig(level=logging.DEBUG if args.debug else logging.INFO, format='%(message)s')
+    if getattr(args, "which", "main") == 'write_fastq':          # NGSpeciesID:255-258
+        write_fastq(args)
+        logging.info("Wrote clusters to separate fastq files.")
+        sys.exit(0)
     if args.ont and args.isoseq:
         logging.error("Arguments mutually exclusive, specify either --isoseq or --ont. "); sys.exit()
     elif args.isoseq:

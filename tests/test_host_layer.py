@@ -70,3 +70,22 @@ def test_clusters_from_rep_matches_the_plain_definition():
         sel = select_centers(r, counts, score, 3)
         assert all(counts[i] >= 3 for i in sel)
         assert sel == sorted(sel, key=lambda i: (-counts[i], -score[r[i]]))
+
+
+def test_write_fastq_subcommand(tmp_path):
+    """the reference's `write_fastq` sub-command (NGSpeciesID:161-182,238-245): <cluster id>.fastq per cluster with at least --N reads, looked up by whole header line"""
+    import os, pytest
+    from ngspeciesid_amd import cli
+    fq = tmp_path / "r.fastq"
+    fq.write_text("".join("@r%d\n%s\n+\n%s\n" % (i, "ACGT" * (i + 1), "I" * (4 * (i + 1))) for i in range(5)))
+    cl = tmp_path / "final_clusters.tsv"
+    cl.write_text("0\tr0\n0\tr3\n1\tr1\n2\tr2\n0\tr4\n")
+    out = tmp_path / "o"
+    with pytest.raises(SystemExit) as e:
+        cli.cli(["--fastq", str(fq), "write_fastq", "--clusters", str(cl), "--fastq", str(fq), "--outfolder", str(out), "--N", "2"])
+    assert e.value.code == 0
+    assert sorted(os.listdir(out)) == ["0.fastq"]
+    assert (out / "0.fastq").read_text() == "@r0\nACGT\n+\nIIII\n@r3\n%s\n+\n%s\n@r4\n%s\n+\n%s\n" % ("ACGT" * 4, "I" * 16, "ACGT" * 5, "I" * 20)
+    with pytest.raises(SystemExit):
+        cli.cli(["--fastq", str(fq), "write_fastq", "--clusters", str(cl), "--fastq", str(fq), "--outfolder", str(out), "--N", "0"])
+    assert sorted(os.listdir(out)) == ["0.fastq", "1.fastq", "2.fastq"]
