@@ -280,7 +280,9 @@ def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None, T=Non
             r = api.cluster_greedy(subset_reads(work, read_idx), prm, acc_rank=rank[read_idx], prev_batch=prev_batch, known_err=known_err)
             counters[:] += r[3]
             return r
-        rep_l, herr_l, joins = parallelize.tree_cluster(fn, lens, score, args.nr_cores, getattr(args, "batch_type", "total_nt"))
+        def dump(it, reps, rep_now, herr_now, joins_now):
+            write_round_dump(args, sr, sel, it, reps, rep_now, herr_now, joins_now)
+        rep_l, herr_l, joins = parallelize.tree_cluster(fn, lens, score, args.nr_cores, getattr(args, "batch_type", "total_nt"), on_round=dump if getattr(args, "outfolder", None) else None)
         pos_l = parallelize.list_positions(len(sel), joins)
     else:
         t1 = time()
@@ -302,6 +304,31 @@ def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None, T=Non
     if len(rank) and int(rank.max()) + 1 < len(rank):                  # duplicate accessions exist (same name AND same score)
         acc_id = np.full(n, -1, dtype=np.int64); acc_id[sel] = rank
     return rep_of, herr, pos, counters, acc_id
+
+
+def write_round_dump(args, sr, sel, it, reps, rep_now, herr, joins):
+    """<outfolder>/<it>/pre_clusters.csv and cluster_origins.csv of a round of the --t > 1 schedule (parallelize.py:85-104,193): the clusters by size, largest first, ties in the
+    order of the merged dictionaries (= reps); members in list order, names without the score suffix; cluster ids are positions in the sorted read file (sel maps the clustered reads to them).  Written at once (no
+    background job: the next round follows and the files are small beside the final ones)."""
+    n = len(sel)
+    r = rep_now.copy()
+    while True:
+        nxt = r[r]
+        if np.array_equal(nxt, r): break
+        r = nxt
+    sizes = np.bincount(r, minlength=n)
+    by_size = reps[np.argsort(-sizes[reps], kind="stable")]
+    rank = np.zeros(n, dtype=np.int64); rank[by_size] = np.arange(len(by_size))
+    members = np.lexsort((parallelize.list_positions(n, joins), rank[r]))
+    folder = os.path.join(args.outfolder, str(it))
+    os.makedirs(folder, exist_ok=True)
+    fastio.write_tsv(os.path.join(folder, "pre_clusters.csv"), sel[members], sr.names, fastio.int_prefixes(sel[r[members]]))
+    with open(os.path.join(folder, "cluster_origins.csv"), "w") as f:
+        for c in by_size.tolist():
+            g = int(sel[c]); seq, qual = sr.rs.get(g); e = herr[c]
+            f.write("{0}\t{1}\t{2}\t{3}\t{4}\t{5}\n".format(g, sr.names.get(g) + sr.suffix(g), seq, qual, float(sr.score[g]), "" if np.isnan(e) else float(e)))
+    logging.debug("Nr clusters larger than 1: %d", int((sizes[reps] > 1).sum()))
+    logging.debug("Nr clusters (all):  %d", len(reps))
 
 
 def cluster_table(sr, sel, rep_of, pos, single_pass=False):

@@ -47,7 +47,7 @@ def batch_merge_consecutive(prev_idx):
     return out
 
 
-def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state=None):
+def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state=None, on_round=None):
     """The whole parallel_clustering schedule on index arrays.
 
     cluster_fn(read_idx, prev_batch, known_err) -> (rep_local, herr, status, counters): clusters the reads `read_idx`
@@ -56,6 +56,9 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
       bidx[i] >= 1 with HPC error rate herr[i]); the multi-GPU path runs round 1 on the ranks, all-gathers the
       representatives and enters here for the merge rounds only.
     Returns (rep_of [N] global representative per read, herr [N] (NaN where unknown), joins)
+    on_round(it, reps, rep_of, herr, joins): called after every round but the last (where the reference writes its per-round dumps, parallelize.py:193) with the surviving
+      representatives in the order of the merged cluster dictionaries (batch by batch, input order within a batch), rep_of as it stands (direct parents: not path-compressed)
+      and the joins so far.
     where joins lists, per cluster_fn call, the arrays (joining_reps, new_reps) in the order the reference moves read lists
     (cluster.py:338-345); within one call nothing joins a read that itself joined (a joined read is no representative any more).
     """
@@ -111,6 +114,8 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
         if single or num_batches == 1:
             break
         reps = np.concatenate(alive_next) if alive_next else np.zeros(0, dtype=np.int64)
+        if on_round is not None:
+            on_round(it, reps, rep_of, herr, joins)
         # sorted(all_representatives, key=score, reverse=True): stable; dict order = batch order then read order
         order = np.lexsort((-score[reps], bidx[reps]))                 # = sort by score on contiguous batches (see above)
         reps = reps[order]
@@ -167,6 +172,25 @@ def list_positions(N, joins):
     return pos
 
 
+def write_round_dumps(clusters, representatives, args, it):
+    """<outfolder>/<it>/pre_clusters.csv and cluster_origins.csv after a round of parallel_clustering (parallelize.py:85-104,193): the clusters by size, largest first (ties in
+    dict order), members in list order with the score suffix cut off; one origin line per cluster.  Write-only in the reference as well."""
+    import os
+    from .help_functions import mkdir_p
+    folder = os.path.join(args.outfolder, str(it))
+    mkdir_p(folder)
+    by_size = sorted(clusters, key=lambda c: len(clusters[c]), reverse=True)
+    with open(os.path.join(folder, "pre_clusters.csv"), "w") as out:
+        for c in by_size:
+            out.writelines("{0}\t{1}\n".format(c, acc.rsplit("_", 1)[0]) for acc in clusters[c])
+    logging.debug("Nr clusters larger than 1: %d", sum(1 for c in by_size if len(clusters[c]) > 1))
+    logging.debug("Nr clusters (all):  %d", len(clusters))
+    with open(os.path.join(folder, "cluster_origins.csv"), "w") as out:
+        for c in by_size:
+            t = representatives[c]
+            out.write("{0}\t{1}\t{2}\t{3}\t{4}\t{5}\n".format(t[0], t[2], t[3], t[4], t[5], t[6] if len(t) > 6 else ""))     # (a read whose compressed form is shorter than k has none)
+
+
 def parallel_clustering(read_array, p_emp_probs, args, api=None):
     """parallelize.parallel_clustering(read_array, p_emp_probs, args) -> (clusters, representatives)  (parallelize.py:107-217).
     Same batches, same merge rounds; batches of a round run one after the other on this process's GPU (or are spread over
@@ -201,6 +225,8 @@ def parallel_clustering(read_array, p_emp_probs, args, api=None):
                       sorted(all_repr.items(), key=lambda x: x[1][5], reverse=True)]
         if num_batches == 1:
             return all_cl, all_repr
+        if getattr(args, "outfolder", None):
+            write_round_dumps(all_cl, all_repr, args, it)                     # parallelize.py:193
         it += 1
         groups = batch_merge_consecutive([r[1] for r in read_array])
         read_batches = [[read_array[j] for j in g] for g in groups]

@@ -43,6 +43,15 @@ def test_array_path_writes_the_same_files_as_the_dict_layer(oracle_backend, extr
     if extra == ["--t", "1"]:                                  # and the reference's own files (tests/golden, written by the reference CLI)
         assert b["final_clusters.tsv"] == open(os.path.join(GOLD, "sample_h1_t1_final_clusters.tsv"), "rb").read()
         assert hashlib.md5(b["sorted.fastq"]).hexdigest() == open(os.path.join(GOLD, "sample_h1_t1_sorted.fastq.md5")).read().strip()
+    if extra[:2] == ["--t", "4"]:                              # the per-round dumps of --t 4 (parallelize.py:85-104,193) as the reference wrote them
+        import json
+        gold = json.load(open(os.path.join(GOLD, "sample_h1_t4_round_dumps.json")))
+        assert sorted(k for k in b if k[0].isdigit()) == sorted(gold)
+        for k in gold:
+            if k.endswith("pre_clusters.csv"):
+                assert b[k].decode() == gold[k], k
+            else:                                              # (the error-rate column: summed in hash order there)
+                assert [l.split("\t")[:5] for l in b[k].decode().splitlines()] == [l.split("\t")[:5] for l in gold[k].splitlines()]
 
 
 def test_soft_masked_iupac_and_overlong_reads_do_not_abort(oracle_backend, tmp_path, caplog):

@@ -68,3 +68,39 @@ def run_round1_then_c_merge(api, tag, t):
 @pytest.mark.parametrize("tag,t", [("sample_h1", 2), ("sample_h1", 4), ("sample_h1", 8), ("synth2k_d15", 8), ("synth600_d10_q14", 4), ("synth300_ccs", 4)])
 def test_c_merge_schedule_matches_reference(oracle, tag, t):
     run_round1_then_c_merge(oracle, tag, t)
+
+
+def test_round_dumps_of_parallel_clustering_equal_the_reference(oracle, tmp_path, monkeypatch):
+    """parallelize.py:85-104,193: after every round but the last, parallel_clustering leaves <outfolder>/<it>/pre_clusters.csv and cluster_origins.csv.  The reference's own files
+    (tests/golden/sample_h1_t4_round_dumps.json, written by oracle/make_golden_rounds.py: the reference imported and run on its test/sample_h1.fastq with --t 4) against the
+    reference-shaped function of this package on the oracle backend: pre_clusters.csv byte for byte, cluster_origins.csv field for field (the error-rate column to a few ulp:
+    the reference sums it in hash order)."""
+    import argparse, json, os
+    from oracle_lib import GOLD
+    from ngspeciesid_amd import runtime, parallelize, get_sorted_fastq_for_cluster, help_functions
+    from ngspeciesid_amd.ptable import p_emp_probs_dict
+    monkeypatch.setattr(runtime, "get_api", lambda device=None: oracle)
+    gold = json.load(open(os.path.join(GOLD, "sample_h1_t4_round_dumps.json")))
+    out = str(tmp_path / "o"); os.makedirs(out)
+    args = argparse.Namespace(k=13, w=20, min_shared=5, mapped_threshold=0.7, aligned_threshold=0.4, symmetric_map_align_thresholds=False, min_fraction=0.8, min_prob_no_hits=0.1,
+                              print_output=10 ** 9, nr_cores=4, batch_type="total_nt", quality_threshold=7.0, outfolder=out, fastq=os.path.join(GOLD, "sample_h1.fastq"), use_old_sorted_file=False)
+    args.outfile = os.path.join(out, "sorted.fastq")
+    path = get_sorted_fastq_for_cluster.main(args)
+    with open(path) as fh:
+        reads = [(i, 0, acc, s, q, float(acc.rsplit("_", 1)[1])) for i, (acc, (s, q)) in enumerate(help_functions.readfq(fh))]
+    parallelize.parallel_clustering(reads, p_emp_probs_dict(13, 20), args)
+    got = {}
+    for it in os.listdir(out):
+        if it.isdigit():
+            for f in os.listdir(os.path.join(out, it)):
+                got["%s/%s" % (it, f)] = open(os.path.join(out, it, f)).read()
+    assert sorted(got) == sorted(gold)
+    for k in gold:
+        if k.endswith("pre_clusters.csv"):
+            assert got[k] == gold[k], k
+        else:
+            a = [l.split("\t") for l in got[k].splitlines()]; b = [l.split("\t") for l in gold[k].splitlines()]
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                assert x[:5] == y[:5]
+                assert abs(float(x[5]) - float(y[5])) <= 16 * np.spacing(float(y[5]))
