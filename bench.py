@@ -357,6 +357,21 @@ def main():
                                    "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "frac_at_measured_mix_rate": round(wi / (peak_issue * 4.0 / 4.3), 4), "frac_at_the_guides_2_cycles": round(wi / (peak_issue * 2.0), 4), "peak_basis": peak_basis, "instructions_per_cell_source": src}
         if dom[0] in views: roof["valu_issue"] = dict(views[dom[0]], kernel=dom[0])
         roof["dp_kernels"] = views
+    # ---- host buffers in (the C-ABI takes either): ONE copy of the read set over PCIe (ngsid_reads_upload) + one pass of the hot path on it; reported beside `value`, never as it
+    host_leg = None
+    if not args.no_extra_step and world == 1:
+        try:
+            hrs_ = ReadSet(rd["seq"].cpu().numpy(), rd["qual"].cpu().numpy(), rd["off"].cpu().numpy().astype(np.uint64))
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            drs_ = api.upload_reads(hrs_); torch.cuda.synchronize(); up_s = time.perf_counter() - t_
+            r_ = pipeline.run_hot_path(api, drs_, rd["score"], acc_rank=acc_rank, **kw); torch.cuda.synchronize(); tot_s = time.perf_counter() - t_
+            nbytes = int(hrs_.seq.nbytes + hrs_.qual.nbytes + hrs_.off.nbytes)
+            host_leg = {"what": "pageable host arrays -> ngsid_reads_upload (one PCIe copy) -> the same pass of the hot path", "upload_s": round(up_s, 4), "upload_GBps": round(nbytes / up_s / 1e9, 2), "bytes": nbytes,
+                        "wall_s": round(tot_s, 4), "reads_per_s": round(n / tot_s, 1), "same_consensus": [c[3] for c in r_["centers"]] == [c[3] for c in res["centers"]]}
+            if drs_ is not hrs_ and hasattr(drs_, "release"): drs_.release()
+            del hrs_, drs_, r_
+        except Exception as e:          # (never fails the line)
+            host_leg = {"error": repr(e)}
     # ---- the drop-in surface (runs before the CPU baseline leg): FASTQ file in -> the reference's output files out (python -m ngspeciesid_amd ...), same reads, same flags as C3
     cli_leg = None
     if not args.no_cli and world == 1:
@@ -496,6 +511,7 @@ def main():
                                                          "its per-GPU shape repeated on every GPU with an independent read set per rank (weak scaling%s)" % ("; C3 is BASELINE's 1-GPU configuration" if args.config == "c3" else "")))
         out["config"]["eight_gpu_configurations"] = "BASELINE.json quotes C4 (10 M x 750 bp, 50 species) and C5 (2 M x 2 kb CCS, 20 species) on 8 GPUs as ONE global set: python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench.py --gpus 8 --config c4 --scaling strong --check-membership   (likewise --config c5)"
     if cli_leg is not None: out["config"]["cli"] = cli_leg
+    if host_leg is not None: out["config"]["host_buffers_in"] = host_leg
     if res_stop is not None: out["config"]["with_stable_stop"] = {"reads_per_s": round(n_total / dt_stop, 1), "ms_per_step": round(dt_stop * 1e3, 2), "same_result": stop_same,
                                           "note": "library default stop_when_stable=1 (not used for `value`): a cluster whose polished sequence equals its backbone is not polished again"}
     sys.stdout.flush()
