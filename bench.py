@@ -137,7 +137,7 @@ def main():
     trace("context created")
     if world > ndev:      # dev aid (ranks sharing one GPU): the aligners' scratch budget is sized for a GPU of one's own by default
         import ctypes as _C
-        api.lib.ngsid_ctx_option(api.ctx, b"scratch_budget_mb", _C.c_int64(max(2048, 32768 // world)))
+        api.set_option("scratch_budget_mb", max(2048, 32768 // world))
     ptab = select_p_table(K_, W_)
     # multi-process runs draw their reads from plain integer tensor arithmetic (synth._HashRng) instead of torch generators: eight processes sharing one GPU were seen to
     # stall inside torch's generator kernels; the one-GPU workload keeps the torch generator = the read set of every earlier round
@@ -186,7 +186,7 @@ def main():
         res = step()
     trace("warm-up done")
     import ctypes as C
-    api.lib.ngsid_profile_enable(api.ctx, C.c_int32(0 if os.environ.get("NGSID_BENCH_NOPROF") else 1))      # (dev aid: NGSID_BENCH_NOPROF=1 times the steps without the per-launch HIP events)
+    api.profile_enable(not os.environ.get("NGSID_BENCH_NOPROF"))      # (this context and its lane contexts; dev aid: NGSID_BENCH_NOPROF=1 times the steps without the per-launch HIP events)
     T = {}
     barrier(); t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -197,18 +197,26 @@ def main():
         for f_ in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.stat"):
             try: trace("%s: %s" % (f_, open(f_).read().replace("\n", " ")))
             except Exception: pass
-    buf = C.create_string_buffer(1 << 16)
-    api.lib.ngsid_profile_read(api.ctx, buf, C.c_uint64(len(buf)))
-    api.lib.ngsid_profile_enable(api.ctx, C.c_int32(0))
-    kern = {}
-    for line in buf.value.decode().splitlines():
-        nm, cnt, ms = line.split(); kern[nm] = (int(cnt), float(ms))
+    kern, kern_per_ctx = api.profile_read()          # summed over the lane contexts (config.lanes): the host_<api> lines are wall clocks of calls that run side by side
+    api.profile_enable(False)
+    n_lanes = len(kern_per_ctx)
+    for nm_ in ("hbm_peak_bytes", "hbm_live_bytes"):          # (process-wide figures: every context reports the same one)
+        if nm_ in kern: kern[nm_] = max((d_.get(nm_, (0, 0.0)) for d_ in kern_per_ctx), key=lambda v_: v_[0])
     # one extra (untimed for `value`) step with the library default: polishing of a cluster stops once an iteration leaves it unchanged
     res_stop, dt_stop = None, 0.0
     if not args.no_extra_step:
         barrier(); t1 = time.perf_counter()
         res_stop = step(polish_stop_when_stable=True)
         barrier(); dt_stop = time.perf_counter() - t1
+    # with lanes (config.lanes) the launches of two contexts overlap on the device and the HIP-event bracket of a launch includes what it waited for the other lane: one more
+    # untimed step in ONE context gives every kernel's time alone (roofline.one_lane: the figures the committed counter passes and rocprof summaries of a single lane match)
+    one_lane = None
+    if n_lanes > 1 and not args.no_extra_step:
+        saved_ = api.lanes; api.lanes = 1; api.profile_enable(True)
+        try: step()
+        finally: api.lanes = saved_
+        k1_, _ = api.profile_read(); api.profile_enable(False)
+        one_lane = {nm_: v_[1] for nm_, v_ in k1_.items() if nm_.startswith("k_")}
     ranks_seen = 1; stage_max = None
     if dist is not None:
         t = torch.tensor([dt], device=comm_dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
@@ -357,6 +365,15 @@ def main():
                                    "unit": "G wave-instructions/s", "frac": round(wi / peak_issue, 4), "frac_at_measured_mix_rate": round(wi / (peak_issue * 4.0 / 4.3), 4), "frac_at_the_guides_2_cycles": round(wi / (peak_issue * 2.0), 4), "peak_basis": peak_basis, "instructions_per_cell_source": src}
         if dom[0] in views: roof["valu_issue"] = dict(views[dom[0]], kernel=dom[0])
         roof["dp_kernels"] = views
+        if n_lanes > 1:
+            roof["lanes"] = {"contexts": n_lanes, "note": "the draft and the polishing call are dealt to %d contexts of this device (two host threads, two HIP streams: _capi.Api lanes); launches of the two overlap on the device, and the HIP-event bracket of a launch (`avg_launch_ms`, `kernels`, `dp_kernels`; rocprofv3's durations alike) then includes what it waited for the other lane - the fractions above are lower bounds" % n_lanes}
+            if one_lane and one_lane.get(dom[0]):
+                ms1 = one_lane[dom[0]]; ol = {"what": "one more step in ONE context, untimed for `value`: every kernel's time alone (what the committed counter passes and single-lane rocprof summaries match)",
+                                              "kernel_ms_per_step": {k_: round(v_, 2) for k_, v_ in sorted(one_lane.items(), key=lambda kv: -kv[1])[:6]},
+                                              "frac": round(alg_step.get(dom[0], n * 2.0 * L) / (ms1 / 1e3) / 8e12, 6)}
+                vv = views.get(dom[0])
+                if vv and vv.get("frac") and vv.get("kernel_ms"): ol["valu_issue_frac"] = round(vv["frac"] * (vv["kernel_ms"] / args.steps) / ms1, 4)
+                roof["one_lane"] = ol
     # ---- host buffers in (the C-ABI takes either): ONE copy of the read set over PCIe (ngsid_reads_upload) + one pass of the hot path on it; reported beside `value`, never as it
     host_leg = None
     if not args.no_extra_step and world == 1:
@@ -500,7 +517,7 @@ def main():
                       % (args.reads, args.length, "CCS" if args.mu >= 25 else "ONT", args.mu, args.species, (" with geometric abundance %.1f^i" % cfg["geometric"]) if cfg["geometric"] else "", K_, W_, AB_, args.tile_depth, ("%d" % args.band) if args.band else "%d (library default, widened per tile by the band-edge check)" % (64 if args.length <= 3000 else 128)),
                       "parallelism": ("1 GPU" if world == 1 else "%d shards (one per GPU), RCCL all-gather of representatives + partial consensuses" % world),
                       "poa_single_below": pipeline.SINGLE_BELOW, "reads_clustered_per_gpu": n, "f_aln": round(f_aln, 4), "stage_s_per_step": {k_: round(v / args.steps, 4) for k_, v in T.items()}, "stage_s_per_step_max_over_ranks": None if stage_max is None else {k_: round(v / args.steps, 4) for k_, v in stage_max.items()},
-                      "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "library_host_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in host_lines.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),
+                      "kernel_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in kern.items()}, "kernel_ms_per_step_one_lane": None if not one_lane else {k_: round(v_, 2) for k_, v_ in one_lane.items()}, "lanes": n_lanes, "library_host_ms_per_step": {k_: round(v[1] / args.steps, 2) for k_, v in host_lines.items()}, "poa_tiles_redone_with_wider_band_per_step": round(redo_tiles / args.steps, 1),
                       "hbm_gb": {"peak_in_timed_steps": round(hbm_peak / 1e9, 2), "held_after": round(hbm_live / 1e9, 2), "what": "bytes handed out by the library's device allocator, whole process (read set included)", "context_scratch_by_purpose": mem_parts},
                       "check": {"cluster_purity": round(purity, 5), "centers": len(big), "consensus_edit_distance_vs_truth": ed, "membership_equals_reference_t_n": membership_ok, "sharded_consensus_equals_single_process": single_same}},
            "roofline": roof, "cpu_baseline": cpu}

@@ -5,6 +5,7 @@ the tests bind the CPU oracle with the same wrapper (prefix ``ongsid_``, no ctx)
 never bound from inside this package.
 """
 from __future__ import annotations
+import os
 import ctypes as C
 from time import perf_counter as _perf
 import numpy as np
@@ -125,6 +126,39 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+LANES = int(os.environ.get("NGSID_LANES", "2"))           # contexts a consensus / polishing call is dealt to (Api.lanes); 1 = off
+LANE_MIN_READS = 50_000                                    # below: one context (nothing to hide; the small calls of the tests and of the dict layer stay as they were)
+LANE_MAX_READS = 4_000_000                                 # above: one context (a second one doubles the grow-only scratch: 130 - 140 GB at 10 M reads)
+
+
+def lane_deal(sizes, lanes):
+    """groups -> lanes: largest first to the lightest lane; per lane the group numbers ascending"""
+    load = [0] * lanes; deal = [[] for _ in range(lanes)]
+    for g in sorted(range(len(sizes)), key=lambda g: (-int(sizes[g]), g)):
+        x = int(np.argmin(load))
+        deal[x].append(g); load[x] += int(sizes[g])
+    return [sorted(d) for d in deal if d]
+
+
+def _lane_lists(grp_off, read_order, gs):
+    """(grp_off, read_order) of the groups gs of a call"""
+    go = np.asarray(grp_off, dtype=np.int64)
+    off = np.zeros(len(gs) + 1, dtype=np.uint64); off[1:] = np.cumsum([int(go[g + 1] - go[g]) for g in gs])
+    if read_order is None:
+        ro = np.concatenate([np.arange(go[g], go[g + 1], dtype=np.uint32) for g in gs])
+    else:
+        r = np.asarray(read_order); ro = np.concatenate([r[int(go[g]):int(go[g + 1])] for g in gs]).astype(np.uint32)
+    return off, ro
+
+
+def _lane_backbones(bb: "ReadSet", gs):
+    o = bb.off.astype(np.int64)
+    off = np.zeros(len(gs) + 1, dtype=np.uint64); off[1:] = np.cumsum([int(o[g + 1] - o[g]) for g in gs])
+    seq = np.concatenate([bb.seq[int(o[g]):int(o[g + 1])] for g in gs]) if len(gs) else np.zeros(0, np.uint8)
+    qual = None if bb.qual is None else np.concatenate([bb.qual[int(o[g]):int(o[g + 1])] for g in gs])
+    return ReadSet(seq, qual, off)
+
+
 class Api:
     def __init__(self, lib: C.CDLL, prefix: str, ctx=None):
         self.lib, self.prefix, self.ctx = lib, prefix, ctx
@@ -134,6 +168,8 @@ class Api:
         """ngsid_destroy: releases the context's stream, side streams, pinned staging and scratch buffers (and, with the last context of the
         process, the device-memory cache and the read sets uploaded through it).  Contexts from runtime.get_api() are shared and stay open;
         the ones from runtime.new_api() belong to their caller: close them (or use `with runtime.new_api() as api:`)."""
+        for t, ex in self.__dict__.pop("_twin_list", []):
+            ex.shutdown(wait=True); t.close()
         if self.has_ctx and self.ctx is not None:
             f = getattr(self.lib, self.prefix + "destroy"); f.restype = None
             f(self.ctx)
@@ -158,6 +194,73 @@ class Api:
         cs = self.__dict__.setdefault("call_s", {})        # wall time per entry point as THIS side sees it (ctypes call + the wait for the interpreter lock on return); the library's
         cs[name] = cs.get(name, 0.0) + _perf() - t0        # own clock for the same calls: "host_<name>" lines of ngsid_profile_read (bench.py config.cli.binding_overhead_s)
         return rc
+
+    # ---- lanes (round 6): the groups of ONE consensus / polishing call are independent, so they are dealt to `lanes` contexts of the same device, each driven by its own long-lived
+    # host thread on its own HIP stream.  One lane's kernels then run in the other's host gaps (the unit and tile lists between the aligner and the POA levels of every polishing
+    # iteration: ~3 ms each, GPU idle) and under the latency-bound top levels of its hierarchy.  Same results group by group (tests run both ways).  lanes = 1: off.
+    lanes = LANES
+
+    def _lane_deal(self, rs, grp_off, backbones=None):
+        """-> per lane the (ascending) group numbers, or None when the call runs in this context alone"""
+        ng = len(grp_off) - 1
+        if self.lanes < 2 or ng < 2 or not self.has_ctx or self.prefix != "ngsid_" or rs.mem != MEM_DEVICE or (backbones is not None and backbones.mem != MEM_HOST):
+            return None
+        sizes = np.diff(np.asarray(grp_off, dtype=np.int64))
+        if not (LANE_MIN_READS <= int(sizes.sum()) <= LANE_MAX_READS):
+            return None
+        return lane_deal(sizes, min(self.lanes, ng))
+
+    def set_option(self, name, value):
+        """ngsid_ctx_option on this context and on its lane contexts (present and future)"""
+        self.__dict__.setdefault("_options", {})[name] = int(value)
+        for a in self.contexts():
+            if a.lib.ngsid_ctx_option(a.ctx, name.encode(), C.c_int64(int(value))) != 0: a._err(-2)
+
+    def _twins(self, n):
+        tw = self.__dict__.setdefault("_twin_list", [])
+        while len(tw) < n:
+            from . import runtime
+            from concurrent.futures import ThreadPoolExecutor
+            # ONE long-lived thread per twin: the library keeps its pinned staging vectors per host thread; a fresh thread per call would allocate them again every time, and
+            # releasing pinned memory waits for the whole device - i.e. for the other lane
+            tw.append((runtime.new_api(self.__dict__.get("device"), options=dict(self.__dict__.get("_options", {}))), ThreadPoolExecutor(max_workers=1, thread_name_prefix="ngsid-lane")))
+            tw[-1][0].lanes = 1
+        return tw[:n]
+
+    def _lane_run(self, deal, fn):
+        tw = self._twins(len(deal) - 1)
+        futs = [tw[x - 1][1].submit(fn, tw[x - 1][0], deal[x]) for x in range(1, len(deal))]
+        try:
+            res = [fn(self, deal[0])]
+        finally:
+            excs = [f.exception() for f in futs]          # (waits for every lane, whatever happened here)
+        for e in excs:
+            if e is not None: raise e
+        return res + [f.result() for f in futs]
+
+    def contexts(self):
+        """this context and the lane contexts it has made (profiling and statistics are per context)"""
+        return [self] + [t[0] for t in self.__dict__.get("_twin_list", [])]
+
+    def profile_enable(self, on: bool):
+        """ngsid_profile_enable on this context and its lane contexts"""
+        for a in self.contexts(): a.lib.ngsid_profile_enable(a.ctx, C.c_int32(1 if on else 0))
+
+    def profile_read(self):
+        """ngsid_profile_read of this context and its lane contexts -> ({name: (count, ms)} summed, [the same per context]).  Kernel lines are HIP-event brackets of every launch
+        on its own stream: launches of two lanes that overlap on the device are both counted in full."""
+        per = []
+        for a in self.contexts():
+            buf = C.create_string_buffer(1 << 16); a.lib.ngsid_profile_read(a.ctx, buf, C.c_uint64(len(buf)))
+            d = {}
+            for line in buf.value.decode().splitlines():
+                nm, cnt, ms = line.split(); d[nm] = (int(cnt), float(ms))
+            per.append(d)
+        tot = {}
+        for d in per:
+            for nm, (c_, m_) in d.items():
+                c0, m0 = tot.get(nm, (0, 0.0)); tot[nm] = (c0 + c_, m0 + m_)
+        return tot, per
 
     def upload_reads(self, rs: "ReadSet") -> "ReadSet":
         """host read set -> device-resident read set (one PCIe copy for all the calls that follow); backends without the entry point
@@ -268,6 +371,18 @@ class Api:
 
     # ---- (a13,a14)
     def poa_consensus(self, rs: ReadSet, grp_off, prm: PoaParams, cap=None, read_order=None):
+        deal = self._lane_deal(rs, grp_off) if cap is None else None
+        if deal is None:
+            return self._poa_consensus1(rs, grp_off, prm, cap, read_order)
+        def one(a, gs):
+            off, ro = _lane_lists(grp_off, read_order, gs)
+            return a._poa_consensus1(rs, off, prm, None, ro)
+        out = [None] * (len(grp_off) - 1)
+        for gs, r in zip(deal, self._lane_run(deal, one)):
+            for x, g in enumerate(gs): out[g] = r[x]
+        return out
+
+    def _poa_consensus1(self, rs: ReadSet, grp_off, prm: PoaParams, cap=None, read_order=None):
         grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
         ro = None if read_order is None else np.ascontiguousarray(read_order, dtype=np.uint32)
         ng = len(grp_off) - 1
@@ -308,6 +423,18 @@ class Api:
 
     # ---- (a16,a17)
     def polish(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None, read_order=None):
+        deal = self._lane_deal(rs, grp_off, backbones) if cap is None else None
+        if deal is None:
+            return self._polish1(backbones, rs, grp_off, prm, cap, read_order)
+        def one(a, gs):
+            off, ro = _lane_lists(grp_off, read_order, gs)
+            return a._polish1(_lane_backbones(backbones, gs), rs, off, prm, None, ro)
+        ng = len(grp_off) - 1; seqs = [None] * ng; used = np.zeros(ng, dtype=np.uint64)
+        for gs, (sq, us) in zip(deal, self._lane_run(deal, one)):
+            for x, g in enumerate(gs): seqs[g] = sq[x]; used[g] = us[x]
+        return seqs, used
+
+    def _polish1(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None, read_order=None):
         grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
         ro = None if read_order is None else np.ascontiguousarray(read_order, dtype=np.uint32)
         ng = len(grp_off) - 1
@@ -321,6 +448,26 @@ class Api:
     def polish_trace(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None, read_order=None, aln=False):
         """ngsid_polish_trace: -> (seqs[it][g], used[it][g]): every group's sequence after every iteration (the last one is what polish() returns).
         aln=True (ngsid_polish_trace_aln): -> (seqs, used, aln[it][x] = (strand, q_begin, q_end, t_begin, t_end, distance) of listed read x) - the PAF records of every iteration."""
+        deal = self._lane_deal(rs, grp_off, backbones) if cap is None else None
+        if deal is None:
+            return self._polish_trace1(backbones, rs, grp_off, prm, cap, read_order, aln)
+        def one(a, gs):
+            off, ro = _lane_lists(grp_off, read_order, gs)
+            return a._polish_trace1(_lane_backbones(backbones, gs), rs, off, prm, None, ro, aln)
+        go = np.asarray(grp_off, dtype=np.int64); ng = len(go) - 1; iters = int(prm.iters)
+        seqs = [[None] * ng for _ in range(iters)]; used = np.zeros((iters, ng), dtype=np.uint64)
+        rec = np.empty((iters, int(go[-1]), 6), dtype=np.int32) if aln else None
+        for gs, r in zip(deal, self._lane_run(deal, one)):
+            pos = 0
+            for x, g in enumerate(gs):
+                n = int(go[g + 1] - go[g])
+                for it in range(iters): seqs[it][g] = r[0][it][x]
+                used[:, g] = r[1][:, x]
+                if aln: rec[:, int(go[g]):int(go[g + 1])] = r[2][:, pos:pos + n]
+                pos += n
+        return (seqs, used, rec) if aln else (seqs, used)
+
+    def _polish_trace1(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None, read_order=None, aln=False):
         grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
         ro = None if read_order is None else np.ascontiguousarray(read_order, dtype=np.uint32)
         ng = len(grp_off) - 1; iters = int(prm.iters); n = iters * ng

@@ -23,6 +23,7 @@ struct PoolBlocks { void* p[3] = {nullptr, nullptr, nullptr}; size_t b[3] = {0, 
 inline size_t pool_class(size_t b) { if (b < 4096) return 4096; int sh = 63 - __builtin_clzll((unsigned long long)b) - 3; size_t m = ((size_t)1 << sh) - 1; return (b + m) & ~m; }
 inline unsigned long long pool_key(int dev, size_t cls) { return ((unsigned long long)dev << 56) | (unsigned long long)cls; }
 }
+thread_local ngsid_ctx* g_ngsid_tls_ctx = nullptr;
 hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got)
 {
     const size_t cls = pool_class(bytes ? bytes : 1); int dev = 0; (void)hipGetDevice(&dev);
@@ -50,7 +51,11 @@ void ngsid_pool_free(void* p, size_t bytes)
     if (!p) return;
     // like hipFree, giving a block back waits for the device: a buffer may be replaced (alloc / reserve / grow, error paths) while kernels that
     // use the old block are still in flight, and the block can be handed out again at once.  On an idle device this costs microseconds.
-    (void)hipDeviceSynchronize();
+    // Round 6: inside an API call of a context (ApiClock) the wait is for that context's streams - nothing else can have used the block.
+    if (ngsid_ctx* c = g_ngsid_tls_ctx) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->ev_fork) for (int i = 0; i < 4; ++i) if (c->side[i]) (void)hipStreamSynchronize(c->side[i]);
+    } else (void)hipDeviceSynchronize();
     int dev = 0; (void)hipGetDevice(&dev);
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
@@ -99,6 +104,7 @@ extern "C" int32_t ngsid_create(int32_t device_ordinal, uint32_t flags, ngsid_ct
 extern "C" void ngsid_destroy(ngsid_ctx* ctx)
 {
     if (!ctx) return;
+    if (g_ngsid_tls_ctx == ctx) g_ngsid_tls_ctx = nullptr;
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i < 4; ++i) { if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); } if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

@@ -21,6 +21,10 @@
 // streams, and returning a block waits for the device like hipFree does, so reuse is safe.  The cache is released with the last context.
 hipError_t ngsid_pool_alloc(void** p, size_t bytes, size_t* got);
 void ngsid_pool_free(void* p, size_t bytes);
+// Round 6: the context whose API call the calling thread is in (set by ApiClock for the duration of the call).  ngsid_pool_free waits for THAT context's streams only - the blocks a call
+// frees were used by its own launches - instead of the whole device, so that two contexts driven by two host threads (pipeline.polish_lanes) do not serialise on each other's kernels.
+struct ngsid_ctx;
+extern thread_local ngsid_ctx* g_ngsid_tls_ctx;
 void ngsid_pool_release_all();
 int ngsid_pool_contexts();            // live contexts of this process (they share the device: budgets derived from free memory are divided by it)
 size_t ngsid_pool_cached_bytes();      // bytes the cache holds for reuse (they count as used in hipMemGetInfo)
@@ -123,9 +127,9 @@ static inline long long ngsid_opt(const ngsid_ctx* ctx, const char* name, long l
 // wall time of an API call as the LIBRARY sees it (profiling on): "host_<name> <calls> <ms>" lines of ngsid_profile_read.  The caller's own clock around the same call, minus this, is
 // what the binding layer adds (for a Python caller with busy worker threads: the wait for the interpreter lock when the call returns) - round 5, the CLI's sporadic stalls
 struct ApiClock {
-    ngsid_ctx* c; const char* nm; struct timespec t0; bool on;
-    ApiClock(ngsid_ctx* ctx, const char* name) : c(ctx), nm(name), on(ctx && ctx->prof) { if (on) clock_gettime(CLOCK_MONOTONIC, &t0); }
-    ~ApiClock() { if (!on) return; struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); auto& a = c->prof_acc[std::string("host_") + nm]; a.first += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6; a.second += 1; }
+    ngsid_ctx* c; const char* nm; struct timespec t0; bool on; ngsid_ctx* prev_;
+    ApiClock(ngsid_ctx* ctx, const char* name) : c(ctx), nm(name), on(ctx && ctx->prof), prev_(g_ngsid_tls_ctx) { g_ngsid_tls_ctx = ctx; if (on) clock_gettime(CLOCK_MONOTONIC, &t0); }
+    ~ApiClock() { g_ngsid_tls_ctx = prev_; if (!on) return; struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); auto& a = c->prof_acc[std::string("host_") + nm]; a.first += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6; a.second += 1; }
 };
 
 struct ProfScope {

@@ -898,7 +898,7 @@ static int32_t polish_impl(ngsid_ctx* ctx, const ngsid_reads_t* backbones, const
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     static thread_local PinVec<uint8_t> h_orient; h_orient.resize(N);
-    HIPCHK(ctx, hipMemcpy(h_orient.data(), d_orient.p, N, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpyAsync(h_orient.data(), d_orient.p, N, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ht.mark("minimizers + strand");
     // ---- oriented copies of the reads
     DevBuf<uint8_t>& oseq = ctx->pol_oseq; DevBuf<uint8_t>& oqual = ctx->pol_oqual; HIPCHK(ctx, oseq.reserve(RD.total + 16)); if (RD.qual) HIPCHK(ctx, oqual.reserve(RD.total + 16));

@@ -159,10 +159,9 @@ def run_hot_path(api: Api, rs: ReadSet, score: np.ndarray, acc_rank=None, k=13, 
                 b = min(b, a + max_seqs_for_consensus)                          # the pooled file is built from the truncated reads_c_id files
             return order[a:b]
         lists = pooled_read_lists(merged, group_reads)
+        pprm = polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=polish_trim, aln_mode=polish_aln_mode, stop_when_stable=polish_stop_when_stable, single_below=single_below)
         p_off = np.concatenate(([0], np.cumsum([len(x) for x in lists])))
-        p_order = np.concatenate(lists)
-        bb = ReadSet.from_strings([m[2] for m in merged])
-        polished, used = api.polish(bb, rs, p_off, polish_params(iters=racon_iter, k=k, w=w, tile_depth=tile_depth, band=band, node_cap=node_cap, trim=polish_trim, aln_mode=polish_aln_mode, stop_when_stable=polish_stop_when_stable, single_below=single_below), read_order=p_order)
+        polished, used = api.polish(ReadSet.from_strings([m[2] for m in merged]), rs, p_off, pprm, read_order=np.concatenate(lists))      # (dealt to two contexts when it pays: _capi.Api lanes)
         T["polish"] = T.get("polish", 0.0) + time.perf_counter() - t0
     res["centers"] = [(m[0], m[1], m[2], polished[i], [int(reps[ci]) for ci in m[3]]) for i, m in enumerate(merged)]
     return res

@@ -37,9 +37,12 @@ def get_api(device: int | None = None) -> Api:
         if rc != 0:
             raise NgsidError(rc, (lib.ngsid_last_error(None) or b"").decode())
         _apis[device] = Api(lib, "ngsid_", ctx)
+        _apis[device].device = device
+        _apis[device]._options = {}
         # test / tool hook: NGSID_OPTIONS="ed_band=12,cluster_block=3000" -> ngsid_ctx_option calls on the new context (the LIBRARY reads no environment)
         for kv in filter(None, os.environ.get("NGSID_OPTIONS", "").split(",")):
             name, val = kv.split("=")
+            _apis[device]._options[name.strip()] = int(val)
             rc = lib.ngsid_ctx_option(ctx, name.strip().encode(), C.c_int64(int(val)))
             if rc != 0:
                 raise NgsidError(rc, (lib.ngsid_last_error(ctx) or b"").decode())
@@ -55,8 +58,14 @@ def new_api(device: int | None = None, options: dict | None = None) -> Api:
     rc = lib.ngsid_create(C.c_int32(device), C.c_uint32(0), C.byref(ctx))
     if rc != 0:
         raise NgsidError(rc, (lib.ngsid_last_error(None) or b"").decode())
+    if options is None:          # (the same test / tool hook as get_api)
+        options = {kv.split("=")[0].strip(): int(kv.split("=")[1]) for kv in filter(None, os.environ.get("NGSID_OPTIONS", "").split(","))}
     for name, val in (options or {}).items():
         rc = lib.ngsid_ctx_option(ctx, name.encode(), C.c_int64(int(val)))
         if rc != 0:
             raise NgsidError(rc, (lib.ngsid_last_error(ctx) or b"").decode())
-    return Api(lib, "ngsid_", ctx)
+    api = Api(lib, "ngsid_", ctx)
+    api.device = device
+    api.lanes = 1                # a caller that makes contexts of its own runs its own concurrent pipelines (virtual ranks, tools): no lanes below them (_capi.Api.lanes)
+    api._options = dict(options or {})
+    return api

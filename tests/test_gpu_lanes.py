@@ -1,0 +1,63 @@
+"""GPU: a consensus / polishing call dealt to several contexts of the device (_capi.Api lanes: two host threads, two HIP streams) returns, group by group, what one
+context returns - and what the oracle returns."""
+import numpy as np
+import pytest
+from ngspeciesid_amd import _capi
+from ngspeciesid_amd._capi import ReadSet, poa_params, polish_params, POA_LOCAL, NgsidError
+from test_consensus_oracle import make_set
+
+pytestmark = pytest.mark.gpu
+
+
+def _groups(rd, rs, sizes):
+    spc = rd["species"].numpy(); order = np.argsort(spc, kind="stable").astype(np.uint32)
+    first = np.concatenate(([0], np.cumsum(np.bincount(spc))))
+    lists = [order[first[g]:first[g] + sizes[g]] for g in range(len(sizes))]
+    off = np.concatenate(([0], np.cumsum([len(x) for x in lists]))).astype(np.uint64)
+    return np.concatenate(lists).astype(np.uint32), off, ReadSet.from_strings([rs.get(int(x[0]))[0] for x in lists])          # raw reads as backbones: every iteration changes them
+
+
+def test_lanes_return_what_one_context_returns(gpu_api, oracle, monkeypatch):
+    sp, rd, rs = make_set(1000, L=640, mu=13.0, seed=31, nsp=5)
+    sizes = [min(s, int((rd["species"].numpy() == g).sum())) for g, s in enumerate([150, 60, 190, 90, 120])]
+    ro, off, bb = _groups(rd, rs, sizes)
+    dev = gpu_api.upload_reads(rs)
+    monkeypatch.setattr(_capi, "LANE_MIN_READS", 0)
+    saved = gpu_api.lanes
+    try:
+        out = {}
+        for lanes in (1, 2, 3):
+            gpu_api.lanes = lanes
+            prm = polish_params(iters=2, k=13, w=20, tile_depth=4, band=0, trim=2)
+            out[lanes] = (gpu_api.polish(bb, dev, off, prm, read_order=ro), gpu_api.polish_trace(bb, dev, off, prm, read_order=ro, aln=True),
+                          gpu_api.poa_consensus(dev, off, poa_params(mode=POA_LOCAL, tile_depth=4, band=0, trim=1), read_order=ro),
+                          gpu_api.polish(bb, dev, off, polish_params(iters=3, k=13, w=20, tile_depth=4, band=0, trim=2, stop_when_stable=1, single_below=64), read_order=ro))
+        assert len(gpu_api.contexts()) == 3                                     # the lanes ran in contexts of their own
+        for lanes in (2, 3):
+            a, b = out[1], out[lanes]
+            assert a[0][0] == b[0][0] and np.array_equal(a[0][1], b[0][1])
+            assert a[1][0] == b[1][0] and np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[1][2], b[1][2])
+            assert a[2] == b[2]
+            assert a[3][0] == b[3][0] and np.array_equal(a[3][1], b[3][1])
+        want, used = oracle.polish(bb, rs, off, polish_params(iters=2, k=13, w=20, tile_depth=4, band=0, trim=2), read_order=ro)
+        assert out[2][0][0] == want and np.array_equal(out[2][0][1], used)
+        # an error in a lane's group reaches the caller (a base outside ACGTN in a read of the LAST group: dealt to the second context)
+        gpu_api.lanes = 2
+        bad = rs.seq.copy(); bad[int(rs.off[int(ro[-1])]) + 5] = ord("!")
+        dbad = gpu_api.upload_reads(ReadSet(bad, rs.qual, rs.off))
+        with pytest.raises(NgsidError):
+            gpu_api.polish(bb, dbad, off, polish_params(iters=1, k=13, w=20, tile_depth=4), read_order=ro)
+        dbad.release()
+    finally:
+        gpu_api.lanes = saved
+        dev.release()
+
+
+def test_one_group_or_few_reads_stay_in_one_context(gpu_api):
+    sp, rd, rs = make_set(300, L=500, mu=14.0, seed=5, nsp=2)
+    dev = gpu_api.upload_reads(rs)
+    try:
+        assert gpu_api._lane_deal(dev, [0, 150, 300]) is None                   # below LANE_MIN_READS
+        assert gpu_api._lane_deal(rs, [0, 150, 300]) is None                    # host buffers: every lane would upload them again
+    finally:
+        dev.release()

@@ -9,6 +9,11 @@ timeout 900 python $R/bench.py > $O/r06_bench_1m.json 2> $O/r06_bench_1m.err
 # 2. kernel trace + stats of the same command
 rm -rf $O/prof_stats; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o r04 -- python $R/bench.py --steps 2 --warmup 1 $BARGS > $O/prof_stats.log 2>&1
 cp $(find $O/prof_stats -name "*kernel_stats.csv" | head -1) $O/r06_rocprofv3_kernel_stats_1m.csv 2>/dev/null
+# 2b. the same in ONE context (NGSID_LANES=1): with the default two lanes the launches of the two contexts overlap on the device and a launch's duration includes what it waited for
+#     the other lane; this pass gives every kernel's time alone (bench.py: roofline.one_lane).  The counter passes below run in one context as well.
+rm -rf $O/prof_stats1; NGSID_LANES=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats1 -o r04 -- python $R/bench.py --steps 2 --warmup 1 $BARGS > $O/prof_stats1.log 2>&1
+cp $(find $O/prof_stats1 -name "*kernel_stats.csv" | head -1) $O/r06_rocprofv3_kernel_stats_1m_one_lane.csv 2>/dev/null
+export NGSID_LANES=1
 # 3. HBM traffic: separate FETCH_SIZE / WRITE_SIZE passes, one bench step
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_$C; timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_$C -o pmc -- python $R/bench.py --steps 1 --warmup 0 $BARGS --no-extra-step > $O/pmc_$C.log 2>&1
