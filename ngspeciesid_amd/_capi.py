@@ -159,6 +159,42 @@ def _lane_backbones(bb: "ReadSet", gs):
     return ReadSet(seq, qual, off)
 
 
+class LaneRecords:
+    """alignment records [it][x][6] of a polish_trace(aln=True) call that ran in lanes: rec[it][a:b] of ONE group's range (what the PAF writers take) is a view into that lane's
+    array; anything else goes through the merged array, built on first use (72 MB per million reads and three iterations: not copied unless somebody asks)"""
+    def __init__(self, go, iters, where):
+        self.go, self.iters, self.where, self._all = go, iters, where, None
+        self.shape = (iters, int(go[-1]), 6); self._start = {int(go[g]): g for g in range(len(go) - 1)}
+
+    def __array__(self, dtype=None, copy=None):
+        if self._all is None:
+            self._all = np.empty(self.shape, dtype=np.int32)
+            for g, (arr, pos, n) in enumerate(self.where): self._all[:, int(self.go[g]):int(self.go[g + 1])] = arr[:, pos:pos + n]
+        return self._all if dtype is None else self._all.astype(dtype)
+
+    def __len__(self):
+        return self.iters
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)): return _LaneRecordsOfIteration(self, int(i))
+        return np.asarray(self)[i]
+
+
+class _LaneRecordsOfIteration:
+    def __init__(self, parent, it): self.p, self.it = parent, it
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self.p)[self.it]; return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, sl):
+        p = self.p
+        if isinstance(sl, slice) and sl.step in (None, 1) and sl.start is not None and sl.stop is not None:
+            g = p._start.get(int(sl.start))
+            if g is not None and int(p.go[g + 1]) == int(sl.stop):
+                arr, pos, n = p.where[g]; return arr[self.it, pos:pos + n]
+        return np.asarray(p)[self.it][sl]
+
+
 class Api:
     def __init__(self, lib: C.CDLL, prefix: str, ctx=None):
         self.lib, self.prefix, self.ctx = lib, prefix, ctx
@@ -455,17 +491,16 @@ class Api:
             off, ro = _lane_lists(grp_off, read_order, gs)
             return a._polish_trace1(_lane_backbones(backbones, gs), rs, off, prm, None, ro, aln)
         go = np.asarray(grp_off, dtype=np.int64); ng = len(go) - 1; iters = int(prm.iters)
-        seqs = [[None] * ng for _ in range(iters)]; used = np.zeros((iters, ng), dtype=np.uint64)
-        rec = np.empty((iters, int(go[-1]), 6), dtype=np.int32) if aln else None
+        seqs = [[None] * ng for _ in range(iters)]; used = np.zeros((iters, ng), dtype=np.uint64); where = [None] * ng
         for gs, r in zip(deal, self._lane_run(deal, one)):
             pos = 0
             for x, g in enumerate(gs):
                 n = int(go[g + 1] - go[g])
                 for it in range(iters): seqs[it][g] = r[0][it][x]
                 used[:, g] = r[1][:, x]
-                if aln: rec[:, int(go[g]):int(go[g + 1])] = r[2][:, pos:pos + n]
+                if aln: where[g] = (r[2], pos, n)
                 pos += n
-        return (seqs, used, rec) if aln else (seqs, used)
+        return (seqs, used, LaneRecords(go, iters, where)) if aln else (seqs, used)
 
     def _polish_trace1(self, backbones: ReadSet, rs: ReadSet, grp_off, prm: PolishParams, cap=None, read_order=None, aln=False):
         grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)

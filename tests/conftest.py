@@ -23,3 +23,17 @@ def gpu_api():
         pytest.skip("no GPU")
     from ngspeciesid_amd import runtime
     return runtime.get_api()
+
+
+def release_gpu_memory():
+    """before a test starts other PROCESSES on the same GPU: give back what this process's contexts (the shared one and its lane contexts) hold - their grow-only scratch and the
+    allocator's cache - and torch's cache"""
+    try:
+        import gc, torch
+        from ngspeciesid_amd import runtime
+        gc.collect()
+        for api in list(runtime._apis.values()):
+            api.set_option("release_scratch", 1)
+        if torch.cuda.is_available(): torch.cuda.empty_cache()
+    except Exception:
+        pass

@@ -35,3 +35,8 @@ def test_split_calls_merge_to_the_unsplit_result(oracle, monkeypatch):
     assert got[0][0] == want[0][0] and np.array_equal(got[0][1], want[0][1])
     assert got[1][0] == want[1][0] and np.array_equal(got[1][1], want[1][1]) and np.array_equal(got[1][2], want[1][2])
     assert got[2] == want[2]
+    rec = got[1][2]; go = off.astype(np.int64)                       # the records of a lane call: a group's range is a view into the lane's array, anything else the merged one
+    assert isinstance(rec, _capi.LaneRecords) and rec.shape == want[1][2].shape and len(rec) == 2
+    for it in range(2):
+        for g in range(3): assert np.array_equal(rec[it][int(go[g]):int(go[g + 1])], want[1][2][it, int(go[g]):int(go[g + 1])])
+        assert np.array_equal(rec[it][3:17], want[1][2][it, 3:17]) and np.array_equal(np.asarray(rec[it]), want[1][2][it])
