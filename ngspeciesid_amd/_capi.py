@@ -244,7 +244,13 @@ class Api:
         sizes = np.diff(np.asarray(grp_off, dtype=np.int64))
         if not (LANE_MIN_READS <= int(sizes.sum()) <= LANE_MAX_READS):
             return None
-        return lane_deal(sizes, min(self.lanes, ng))
+        deal = lane_deal(sizes, min(self.lanes, ng))
+        try:
+            self._twins(len(deal) - 1)
+        except NgsidError:                # no second context to be had (memory): this one does the work, from now on
+            self.lanes = 1
+            return None
+        return deal
 
     def set_option(self, name, value):
         """ngsid_ctx_option on this context and on its lane contexts (present and future)"""

@@ -61,3 +61,24 @@ def test_one_group_or_few_reads_stay_in_one_context(gpu_api):
         assert gpu_api._lane_deal(rs, [0, 150, 300]) is None                    # host buffers: every lane would upload them again
     finally:
         dev.release()
+
+
+def test_a_context_of_ones_own_closes_its_lane_contexts(monkeypatch):
+    """runtime.new_api() contexts have no lanes unless asked (their makers run pipelines of their own); with lanes their twins are made on first use and go with close()"""
+    from ngspeciesid_amd import runtime
+    sp, rd, rs = make_set(400, L=500, mu=14.0, seed=8, nsp=2)
+    ro, off, bb = _groups(rd, rs, [150, 150])
+    monkeypatch.setattr(_capi, "LANE_MIN_READS", 0)
+    prm = polish_params(iters=1, k=13, w=20, tile_depth=4, band=0, trim=2)
+    with runtime.new_api() as a:
+        assert a.lanes == 1
+        dev = a.upload_reads(rs)
+        one = a.polish(bb, dev, off, prm, read_order=ro)
+        assert len(a.contexts()) == 1
+        a.lanes = 2
+        two = a.polish(bb, dev, off, prm, read_order=ro)
+        assert len(a.contexts()) == 2 and one[0] == two[0] and np.array_equal(one[1], two[1])
+        a.set_option("poa_host_levels", 1)                                      # an option reaches the lane contexts as well
+        assert a.polish(bb, dev, off, prm, read_order=ro)[0] == one[0]
+        dev.release()
+    assert a.ctx is None and a.contexts() == [a]
