@@ -82,3 +82,28 @@ def test_a_context_of_ones_own_closes_its_lane_contexts(monkeypatch):
         assert a.polish(bb, dev, off, prm, read_order=ro)[0] == one[0]
         dev.release()
     assert a.ctx is None and a.contexts() == [a]
+
+
+def test_cli_writes_the_same_files_with_and_without_lanes(gpu_api, tmp_path, monkeypatch):
+    """file in -> files out (draft, three polishing iterations, the PAF of every iteration): byte-identical whether the consensus calls run in one context or in two"""
+    import os
+    from ngspeciesid_amd import synth, fastio
+    from ngspeciesid_amd.cli import cli
+    from test_gpu_cli import _files
+    sp = synth.make_species(4, 700, 0.15, seed=3)
+    rd = synth.make_reads(sp, 12000, mu=15.0, seed=4, abundance=[0.4, 0.3, 0.2, 0.1])
+    rs = ReadSet(rd["seq"].numpy(), rd["qual"].numpy(), rd["off"].numpy().astype(np.uint64))
+    names = fastio.Names.from_list(["r%d" % i for i in range(rs.n)])
+    fq = str(tmp_path / "in.fastq"); fastio.write_fastq(fq, np.arange(rs.n), names, rs)
+    monkeypatch.setattr(_capi, "LANE_MIN_READS", 0)
+    saved = gpu_api.lanes; res = {}
+    try:
+        for lanes in (1, 2):
+            gpu_api.lanes = lanes; out = str(tmp_path / ("out%d" % lanes))
+            cli(["--ont", "--fastq", fq, "--outfolder", out, "--t", "1", "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", "0.02", "--polish_all_iterations"])
+            res[lanes] = _files(out)
+    finally:
+        gpu_api.lanes = saved
+    assert sorted(res[1]) == sorted(res[2]) and any(f.endswith("read_alignments_it_2.paf") for f in res[1])
+    for f in res[1]: assert res[1][f] == res[2][f], f
+    assert len([f for f in res[1] if f.endswith("consensus.fasta")]) == 4
