@@ -137,7 +137,7 @@ def main():
     trace("context created")
     if world > ndev:      # dev aid (ranks sharing one GPU): the aligners' scratch budget is sized for a GPU of one's own by default
         api.set_option("scratch_budget_mb", max(2048, 32768 // world))
-        api.lanes = 1     # ... and the ranks already overlap each other on the device: no lanes below them (each would bring a second context's scratch)
+        if not os.environ.get("NGSID_LANES_FORCE"): api.lanes = 1     # ... and the ranks already overlap each other on the device: no lanes below them (each would bring a second context's scratch; NGSID_LANES_FORCE=1 keeps them: the test of lanes under ranks on a one-GPU box)
     ptab = select_p_table(K_, W_)
     # multi-process runs draw their reads from plain integer tensor arithmetic (synth._HashRng) instead of torch generators: eight processes sharing one GPU were seen to
     # stall inside torch's generator kernels; the one-GPU workload keeps the torch generator = the read set of every earlier round

@@ -53,22 +53,23 @@ def test_c5_shard_shape_250k_ccs_2kb_20_species_geometric_abundance(gpu_api):
     assert sizes[0] > 40 * sizes[-1] > 0                      # the abundance really is mixed
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_strong_scaling_ranks_on_one_gpu_membership_equals_t_n(world):
+@pytest.mark.parametrize("world,lanes_under_ranks", [(2, False), (4, False), (2, True)])
+def test_strong_scaling_ranks_on_one_gpu_membership_equals_t_n(world, lanes_under_ranks):
     """bench.py --scaling strong under torch.distributed.run (gloo collectives, HIP compute, all ranks on cuda:0): the merged N-rank membership
     must equal parallelize.tree_cluster(..., N) = the reference's `--t N` schedule on the same global set, and every consensus its amplicon."""
     env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"; env["NGSID_DIST_BACKEND"] = "gloo"
     for v_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK"): env.pop(v_, None)
     from conftest import release_gpu_memory; release_gpu_memory()          # the ranks below share the GPU with what earlier tests left in THIS process
+    if lanes_under_ranks: env["NGSID_LANES_FORCE"] = "1"                   # every rank deals its consensus calls to two contexts, as it does on a GPU of its own (bench.py turns the lanes off when ranks share a device)
     # world 2: `python bench.py --gpus 2 ...` as the driver types it - bench.py starts its own ranks (VERDICT r5 item 2); world 4: under the launcher, as the contract's N > 1 command
-    head = [sys.executable] if world == 2 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29530 + world)]
+    head = [sys.executable] if (world == 2 and not lanes_under_ranks) else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29530 + world + (10 if lanes_under_ranks else 0))]
     cmd = head + [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--reads", "240000", "--scaling", "strong", "--check-membership",
            "--no-cpu-baseline", "--no-extra-step"]
     p = subprocess.run(cmd, env=env, timeout=1200, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0, "\n".join(l for l in p.stderr.splitlines() if "Error" in l and "ChildFailed" not in l)[:3000] + "\n...\n" + p.stderr[-1500:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == world and out["scaling"] == "strong"
+    assert out["n_gpus"] == world and out["scaling"] == "strong" and out["config"]["lanes"] == (2 if lanes_under_ranks else 1)
     assert out["rccl_ranks_seen"] == world and out["config"]["ranks"]["ranks_in_the_all_reduce"] == world
     assert set(out["config"]["stage_s_per_step_max_over_ranks"]) >= {"cluster_local", "merge"}
     chk = out["config"]["check"]
