@@ -239,7 +239,7 @@ class Api:
     def _lane_deal(self, rs, grp_off, backbones=None):
         """-> per lane the (ascending) group numbers, or None when the call runs in this context alone"""
         ng = len(grp_off) - 1
-        if self.lanes < 2 or ng < 2 or not self.has_ctx or self.prefix != "ngsid_" or rs.mem != MEM_DEVICE or (backbones is not None and backbones.mem != MEM_HOST):
+        if self.lanes < 2 or ng < 2 or not self.has_ctx or self.prefix != "ngsid_" or "device" not in self.__dict__ or rs.mem != MEM_DEVICE or (backbones is not None and backbones.mem != MEM_HOST):
             return None
         sizes = np.diff(np.asarray(grp_off, dtype=np.int64))
         if not (LANE_MIN_READS <= int(sizes.sum()) <= LANE_MAX_READS):
