@@ -64,6 +64,35 @@ void ngsid_pool_free(void* p, size_t bytes)
     }
     (void)hipFree(p);
 }
+// pinned host blocks of the PinVec staging vectors (ngsid_internal.h): same size classes as the device cache, freed blocks are kept (at most PIN_LIMIT bytes)
+namespace { struct PinPool { std::mutex mu; std::multimap<size_t, void*> free_; size_t cached = 0; }; PinPool g_pin; const size_t PIN_LIMIT = (size_t)4 << 30; }
+void* ngsid_pinned_alloc(size_t bytes)
+{
+    const size_t cls = pool_class(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> lk(g_pin.mu);
+        auto it = g_pin.free_.find(cls);
+        if (it != g_pin.free_.end()) { void* p = it->second; g_pin.free_.erase(it); g_pin.cached -= cls; return p; }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess) {          // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        std::vector<void*> old; { std::lock_guard<std::mutex> lk(g_pin.mu); for (auto& kv : g_pin.free_) old.push_back(kv.second); g_pin.free_.clear(); g_pin.cached = 0; }
+        for (void* q : old) (void)hipHostFree(q);
+        if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    return p;
+}
+void ngsid_pinned_free(void* p, size_t bytes)
+{
+    if (!p) return;
+    const size_t cls = pool_class(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> lk(g_pin.mu);
+        if (g_pin.cached + cls <= PIN_LIMIT) { g_pin.free_.emplace(cls, p); g_pin.cached += cls; return; }
+    }
+    (void)hipHostFree(p);
+}
 size_t ngsid_pool_cached_bytes() { std::lock_guard<std::mutex> lk(g_pool.mu); return g_pool.cached; }
 int ngsid_pool_contexts() { std::lock_guard<std::mutex> lk(g_pool.mu); return g_pool.contexts > 0 ? g_pool.contexts : 1; }
 void ngsid_pool_stats(size_t* live, size_t* peak, bool reset_peak) { std::lock_guard<std::mutex> lk(g_pool.mu); if (live) *live = g_pool.live; if (peak) *peak = g_pool.peak; if (reset_peak) g_pool.peak = g_pool.live; }
@@ -119,6 +148,8 @@ extern "C" void ngsid_destroy(ngsid_ctx* ctx)
             g_pool.uploads.clear();
         }
         ngsid_pool_release_all();
+        std::vector<void*> pins; { std::lock_guard<std::mutex> lk(g_pin.mu); for (auto& kv : g_pin.free_) pins.push_back(kv.second); g_pin.free_.clear(); g_pin.cached = 0; }
+        for (void* q : pins) (void)hipHostFree(q);          // (the pinned staging blocks no vector holds any more)
     }
 }
 

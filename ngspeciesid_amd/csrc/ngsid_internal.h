@@ -55,6 +55,8 @@ template <typename T> struct DevBuf {
     }
 };
 
+void* ngsid_pinned_alloc(size_t bytes);
+void ngsid_pinned_free(void* p, size_t bytes);
 // Host vectors in pinned memory for the big, recurring host <-> device copies.  A copy from / to pageable memory makes the runtime pin the
 // pages for the transfer and release them afterwards; with 8-40 MB per hierarchy level that showed up as milliseconds on the NEXT
 // submission (8 ms after the clustering results, rocprofv3 trace + host timers).  These vectors live in thread-local statics and only grow.
@@ -62,8 +64,12 @@ template <typename T> struct PinnedAlloc {
     using value_type = T;
     PinnedAlloc() = default;
     template <class U> PinnedAlloc(const PinnedAlloc<U>&) {}
-    T* allocate(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, (n ? n : 1) * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc(); return (T*)p; }
-    void deallocate(T* p, size_t) { (void)hipHostFree(p); }
+    // Round 6: blocks come from and go back to a process-wide cache (ngsid_pinned_alloc / _free in ngsid_api.hip: power-of-two-ish size classes, at most 4 GB kept).
+    // hipHostFree waits for the whole DEVICE; with the vectors thread_local, a caller that drives a context from short-lived threads paid that wait at every growth step and
+    // at every thread exit - and, with two contexts on one device, waited for the OTHER context's kernels.  The users of these vectors synchronise their stream before they touch
+    // a vector again, so a block that leaves a vector is not in flight.
+    T* allocate(size_t n) { void* p = ngsid_pinned_alloc((n ? n : 1) * sizeof(T)); if (!p) throw std::bad_alloc(); return (T*)p; }
+    void deallocate(T* p, size_t n) { ngsid_pinned_free(p, (n ? n : 1) * sizeof(T)); }
     template <class U> bool operator==(const PinnedAlloc<U>&) const { return true; }
     template <class U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
 };

@@ -107,3 +107,20 @@ def test_cli_writes_the_same_files_with_and_without_lanes(gpu_api, tmp_path, mon
     assert sorted(res[1]) == sorted(res[2]) and any(f.endswith("read_alignments_it_2.paf") for f in res[1])
     for f in res[1]: assert res[1][f] == res[2][f], f
     assert len([f for f in res[1] if f.endswith("consensus.fasta")]) == 4
+
+
+def test_calls_from_short_lived_threads(gpu_api, oracle):
+    """a context driven from a fresh host thread per call (a server's request threads): the library's pinned staging vectors are per thread, their blocks come from and go back to
+    a process-wide cache (no hipHostFree, which waits for the device, at thread exit) - same bytes from every thread, and the same as from this one"""
+    import threading
+    sp, rd, rs = make_set(600, L=520, mu=13.0, seed=17, nsp=2)
+    ro, off, bb = _groups(rd, rs, [250, 250])
+    prm = polish_params(iters=2, k=13, w=20, tile_depth=4, band=0, trim=2)
+    want = gpu_api.polish(bb, rs, off, prm, read_order=ro)
+    got = []
+    def work(): got.append(gpu_api.polish(bb, rs, off, prm, read_order=ro))
+    for _ in range(4):
+        th = threading.Thread(target=work); th.start(); th.join()
+    assert len(got) == 4
+    for g in got: assert g[0] == want[0] and np.array_equal(g[1], want[1])
+    assert want[0] == oracle.polish(bb, rs, off, prm, read_order=ro)[0]
