@@ -280,6 +280,19 @@ class Api:
             if e is not None: raise e
         return res + [f.result() for f in futs]
 
+    def _lanes_or_none(self, deal, fn):
+        """the lanes' results, or None when a lane ran out of device memory (a second context's working set did not fit beside the first): the lane contexts give their
+        memory back, this context does the call alone - now (the caller repeats it) and from now on"""
+        try:
+            return self._lane_run(deal, fn)
+        except NgsidError as e:
+            if "out of memory" not in str(e).lower(): raise
+            self.lanes = 1
+            for t, _ in self.__dict__.get("_twin_list", []):
+                try: t.lib.ngsid_ctx_option(t.ctx, b"release_scratch", C.c_int64(1))
+                except Exception: pass
+            return None
+
     def contexts(self):
         """this context and the lane contexts it has made (profiling and statistics are per context)"""
         return [self] + [t[0] for t in self.__dict__.get("_twin_list", [])]
@@ -419,8 +432,10 @@ class Api:
         def one(a, gs):
             off, ro = _lane_lists(grp_off, read_order, gs)
             return a._poa_consensus1(rs, off, prm, None, ro)
+        parts = self._lanes_or_none(deal, one)
+        if parts is None: return self._poa_consensus1(rs, grp_off, prm, cap, read_order)
         out = [None] * (len(grp_off) - 1)
-        for gs, r in zip(deal, self._lane_run(deal, one)):
+        for gs, r in zip(deal, parts):
             for x, g in enumerate(gs): out[g] = r[x]
         return out
 
@@ -471,8 +486,10 @@ class Api:
         def one(a, gs):
             off, ro = _lane_lists(grp_off, read_order, gs)
             return a._polish1(_lane_backbones(backbones, gs), rs, off, prm, None, ro)
+        parts = self._lanes_or_none(deal, one)
+        if parts is None: return self._polish1(backbones, rs, grp_off, prm, cap, read_order)
         ng = len(grp_off) - 1; seqs = [None] * ng; used = np.zeros(ng, dtype=np.uint64)
-        for gs, (sq, us) in zip(deal, self._lane_run(deal, one)):
+        for gs, (sq, us) in zip(deal, parts):
             for x, g in enumerate(gs): seqs[g] = sq[x]; used[g] = us[x]
         return seqs, used
 
@@ -497,8 +514,10 @@ class Api:
             off, ro = _lane_lists(grp_off, read_order, gs)
             return a._polish_trace1(_lane_backbones(backbones, gs), rs, off, prm, None, ro, aln)
         go = np.asarray(grp_off, dtype=np.int64); ng = len(go) - 1; iters = int(prm.iters)
+        parts = self._lanes_or_none(deal, one)
+        if parts is None: return self._polish_trace1(backbones, rs, grp_off, prm, cap, read_order, aln)
         seqs = [[None] * ng for _ in range(iters)]; used = np.zeros((iters, ng), dtype=np.uint64); where = [None] * ng
-        for gs, r in zip(deal, self._lane_run(deal, one)):
+        for gs, r in zip(deal, parts):
             pos = 0
             for x, g in enumerate(gs):
                 n = int(go[g + 1] - go[g])

@@ -40,3 +40,27 @@ def test_split_calls_merge_to_the_unsplit_result(oracle, monkeypatch):
     for it in range(2):
         for g in range(3): assert np.array_equal(rec[it][int(go[g]):int(go[g + 1])], want[1][2][it, int(go[g]):int(go[g + 1])])
         assert np.array_equal(rec[it][3:17], want[1][2][it, 3:17]) and np.array_equal(np.asarray(rec[it]), want[1][2][it])
+
+
+def test_a_lane_out_of_memory_falls_back_to_one_context(oracle, monkeypatch):
+    """a second context's working set that does not fit beside the first (NGSID_ERR_HIP "out of memory" from a lane): the call is repeated in one context, lanes stay off"""
+    from ngspeciesid_amd._capi import NgsidError
+    sp, rd, rs = make_set(120, L=300, mu=15.0, seed=2, nsp=2)
+    spc = rd["species"].numpy(); order = np.argsort(spc, kind="stable").astype(np.uint32)
+    off = np.concatenate(([0], np.cumsum(np.bincount(spc)))).astype(np.uint64)
+    bb = ReadSet.from_strings([rs.get(int(order[int(off[g])]))[0] for g in range(2)])
+    prm = polish_params(iters=1, k=13, w=20, tile_depth=4, band=0, trim=2)
+    want = oracle.polish(bb, rs, off, prm, read_order=order)
+    def boom(self, deal, fn): raise NgsidError(-6, "poa_host.hip:1 hipMalloc -> out of memory")
+    monkeypatch.setattr(_capi.Api, "_lane_deal", lambda self, rs_, go, backbones=None: lane_deal(np.diff(np.asarray(go, dtype=np.int64)), 2))
+    monkeypatch.setattr(_capi.Api, "_lane_run", boom)
+    import pytest
+    try:
+        oracle.lanes = 2
+        got = oracle.polish(bb, rs, off, prm, read_order=order)
+        assert got[0] == want[0] and oracle.lanes == 1
+        def other(self, deal, fn): raise NgsidError(-3, "base outside ACGTN")
+        monkeypatch.setattr(_capi.Api, "_lane_run", other); oracle.lanes = 2
+        with pytest.raises(NgsidError): oracle.polish(bb, rs, off, prm, read_order=order)
+    finally:
+        oracle.__dict__.pop("lanes", None)
