@@ -47,7 +47,7 @@ def batch_merge_consecutive(prev_idx):
     return out
 
 
-def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state=None, on_round=None):
+def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state=None, on_round=None, track=None):
     """The whole parallel_clustering schedule on index arrays.
 
     cluster_fn(read_idx, prev_batch, known_err) -> (rep_local, herr, status, counters): clusters the reads `read_idx`
@@ -56,9 +56,10 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
       bidx[i] >= 1 with HPC error rate herr[i]); the multi-GPU path runs round 1 on the ranks, all-gathers the
       representatives and enters here for the merge rounds only.
     Returns (rep_of [N] global representative per read, herr [N] (NaN where unknown), joins)
-    on_round(it, reps, rep_of, herr, joins): called after every round but the last (where the reference writes its per-round dumps, parallelize.py:193) with the surviving
-      representatives in the order of the merged cluster dictionaries (batch by batch, input order within a batch), rep_of as it stands (direct parents: not path-compressed)
-      and the joins so far.
+    track: optional dict; on return track["pos"] = list_positions(N, joins), kept up to date round by round (ListPositions) instead of replayed from the joins afterwards.
+    on_round(it, reps, root, herr, joins, pos): called after every round but the last (where the reference writes its per-round dumps, parallelize.py:193) with the surviving
+      representatives in the order of the merged cluster dictionaries (batch by batch, input order within a batch), every read's representative and list position as they stand
+      (ListPositions) and the joins so far.
     where joins lists, per cluster_fn call, the arrays (joining_reps, new_reps) in the order the reference moves read lists
     (cluster.py:338-345); within one call nothing joins a read that itself joined (a joined read is no representative any more).
     """
@@ -88,9 +89,10 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
             return rep_of, herr, joins
     # ---- round structure of parallelize.py:136-217
     it = 1
+    lp = ListPositions(N) if (track is not None or on_round is not None) else None
     while True:
         single = len(cur_batches) == 1
-        alive_next = []
+        alive_next = []; n_before = len(joins)
         for bi, idx in enumerate(cur_batches):
             new_index = 1 if single else bi + 1
             if len(idx) == 0:
@@ -111,11 +113,12 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
             keep_old = np.asarray(st)[~moved] == 3
             bidx[surv[~keep_old]] = new_index
             alive_next.append(surv)
+        if lp is not None: lp.apply(joins[n_before:])
         if single or num_batches == 1:
             break
         reps = np.concatenate(alive_next) if alive_next else np.zeros(0, dtype=np.int64)
         if on_round is not None:
-            on_round(it, reps, rep_of, herr, joins)
+            on_round(it, reps, lp.root, herr, joins, lp.pos)
         # sorted(all_representatives, key=score, reverse=True): stable; dict order = batch order then read order
         order = np.lexsort((-score[reps], bidx[reps]))                 # = sort by score on contiguous batches (see above)
         reps = reps[order]
@@ -131,6 +134,7 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
         if np.array_equal(nxt, rep_of):
             break
         rep_of = nxt
+    if track is not None: track["pos"] = lp.pos
     return rep_of, herr, joins
 
 
@@ -142,6 +146,33 @@ def cluster_lists_from_joins(N, joins):
         for a, b in zip(np.asarray(aa).tolist(), np.asarray(bb).tolist()):
             clusters[b].extend(clusters[a]); del clusters[a]
     return clusters
+
+
+class ListPositions:
+    """list_positions() kept up to date round by round: root[x] = the representative whose list read x is in, pos[x] = its place there.  A round's joins (one entry per
+    cluster_fn call; the calls of a round work on disjoint representatives, and within a call nothing joins a read that itself joined) move every list behind the list it joins:
+    all reads of a moved list shift by the same offset, so a round costs a few passes over the reads instead of a replay of all rounds."""
+    def __init__(self, N):
+        self.N = N; self.root = np.arange(N, dtype=np.int64); self.pos = np.zeros(N, dtype=np.int64); self.size = np.ones(N, dtype=np.int64)
+
+    def apply(self, round_joins):
+        N = self.N; size = self.size
+        off = np.zeros(N, dtype=np.int64); new = np.arange(N, dtype=np.int64); any_ = False
+        for aa, bb in round_joins:
+            a = np.asarray(aa, dtype=np.int64); b = np.asarray(bb, dtype=np.int64)
+            if len(a) == 0: continue
+            any_ = True
+            sa = size[a]
+            o = np.argsort(b, kind="stable"); bs = b[o]; sas = sa[o]
+            csum = np.cumsum(sas) - sas
+            first = np.ones(len(bs), dtype=bool); first[1:] = bs[1:] != bs[:-1]
+            gstart = csum[first][np.cumsum(first) - 1]
+            off[a[o]] = size[bs] + (csum - gstart)
+            new[a] = b
+            np.add.at(size, b, sa)
+        if any_:
+            self.pos += off[self.root]; self.root = new[self.root]
+        return self.pos
 
 
 def list_positions(N, joins):

@@ -104,3 +104,25 @@ def test_round_dumps_of_parallel_clustering_equal_the_reference(oracle, tmp_path
             for x, y in zip(a, b):
                 assert x[:5] == y[:5]
                 assert abs(float(x[5]) - float(y[5])) <= 16 * np.spacing(float(y[5]))
+
+
+def test_list_positions_kept_up_to_date_round_by_round():
+    """parallelize.ListPositions (one pass over the reads per ROUND) == parallelize.list_positions (replay of all joins) == the plain replay of the reference's list moves, on
+    random merge trees: rounds of disjoint calls in which surviving representatives join earlier ones"""
+    rng = np.random.default_rng(12)
+    for N, rounds, calls in ((40, 3, 2), (500, 4, 4), (3000, 5, 8)):
+        alive = np.arange(N); joins = []; lp = parallelize.ListPositions(N)
+        for _ in range(rounds):
+            parts = np.array_split(rng.permutation(alive), calls); n0 = len(joins); gone = []
+            for p in parts:
+                p = np.sort(p)
+                if len(p) < 2: continue
+                k = max(1, len(p) // 3); keep = p[:k]; mov = p[k:][rng.random(len(p) - k) < 0.6]
+                if len(mov) == 0: continue
+                joins.append((mov, keep[rng.integers(0, k, len(mov))])); gone.append(mov)
+            pos = lp.apply(joins[n0:]).copy()
+            if gone: alive = np.setdiff1d(alive, np.concatenate(gone))
+            assert np.array_equal(pos, parallelize.list_positions(N, joins))
+            lists = parallelize.cluster_lists_from_joins(N, joins)
+            for rep, members in lists.items():
+                assert [int(pos[m]) for m in members] == list(range(len(members))) and all(int(lp.root[m]) == rep for m in members)
