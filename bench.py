@@ -427,7 +427,7 @@ def main():
                 paf_bytes = sum(os.path.getsize(os.path.join(rt, f)) for rt, _, fs in os.walk(outd) for f in fs if f.endswith(".paf"))
                 got = sorted(m[2] for m in r["centers"])
                 shutil.rmtree(outd, ignore_errors=True)
-                return {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "stage_s": {k_: (round(v, 3) if not isinstance(v, dict) else {a_: round(b_, 3) for a_, b_ in v.items()}) for k_, v in r["timings"].items()}, "output_bytes": out_bytes, "paf_bytes": paf_bytes,
+                return {"reads_per_s": round(n / dcl, 1), "wall_s": round(dcl, 3), "stage_s": {k_: (round(v, 3) if isinstance(v, float) else ({a_: round(b_, 3) for a_, b_ in v.items()} if isinstance(v, dict) else v)) for k_, v in r["timings"].items()}, "output_bytes": out_bytes, "paf_bytes": paf_bytes,
                         "consensus_equals_amplicons": got == sorted(truths), "binding_overhead_s": bind,
                         "cgroup_cpu_during_the_leg": None if not (cg0 and cg1) else {"throttled_periods": cg1["nr_throttled"] - cg0["nr_throttled"], "throttled_ms": round(cg1["throttled_ms"] - cg0["throttled_ms"], 1), "cpu_seconds_used": round(cg1["usage_s"] - cg0["usage_s"], 2)}}
             # three legs on the same file: the CLI as a user runs it (polishing of a cluster stops once an iteration returns its input: the library default), the same with EVERY

@@ -326,7 +326,8 @@ int32_t ngsid_ctx_option(ngsid_ctx* ctx, const char* name, int64_t value);
 /* (b, f2) A caller that makes several calls on the SAME reads (the CLI: cluster + draft consensus + polish; NGSpeciesID:88-131 keeps one
  * sorted read list for all stages) copies them to HBM once: *dev receives a read set with mem = NGSID_MEM_DEVICE whose buffers belong to the
  * library until ngsid_reads_release (or ngsid_destroy of the last context).  host->qual may be NULL.  The device read set is valid for
- * every context on the same device. */
+ * every context on the same device.  Release it when no call of ANY context that uses it is in flight: the release waits for the streams of `ctx` only
+ * (round 6: contexts that work side by side on one device do not wait for each other's kernels). */
 int32_t ngsid_reads_upload(ngsid_ctx* ctx, const ngsid_reads_t* host, ngsid_reads_t* dev);
 int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev);
 /* (b, f2) the reads idx[0..n) (host array) of a device-resident read set, in that order, as a NEW device-resident read set (released like the one of ngsid_reads_upload).

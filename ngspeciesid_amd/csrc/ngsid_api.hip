@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256) void k_reads_subset(const uint8_t* __restrict_
 extern "C" int32_t ngsid_reads_subset(ngsid_ctx* ctx, const ngsid_reads_t* dev_in, const uint64_t* idx, uint64_t n, ngsid_reads_t* dev_out, uint64_t* foreign)
 {
     if (!ctx) return NGSID_ERR_ARG;
+    ApiClock api_clock_(ctx, "reads_subset");          // (also: the temporaries freed below wait for THIS context's streams, not for the device - two contexts cluster side by side)
     if (!dev_in || !dev_out || (n && !idx) || dev_in->mem != NGSID_MEM_DEVICE) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_subset: a device read set, an index list and an output are required");
     DevReads R; int32_t rc = ngsid_upload_reads(ctx, dev_in, &R, false); if (rc) return rc;
     static thread_local PinVec<uint64_t> h_noff; h_noff.resize(n + 1); h_noff[0] = 0;
@@ -587,6 +588,7 @@ extern "C" int32_t ngsid_reads_subset(ngsid_ctx* ctx, const ngsid_reads_t* dev_i
 extern "C" int32_t ngsid_reads_release(ngsid_ctx* ctx, ngsid_reads_t* dev)
 {
     if (!ctx) return NGSID_ERR_ARG;
+    ApiClock api_clock_(ctx, "reads_release");         // the blocks go back to the cache once THIS context's streams are idle: release a read set through a context only when no call of ANOTHER context that uses it is in flight
     if (!dev || dev->mem != NGSID_MEM_DEVICE) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_release: not a device read set");
     DevPool::Upload u;
     { std::lock_guard<std::mutex> lk(g_pool.mu); auto it = g_pool.uploads.find((void*)dev->seq); if (it == g_pool.uploads.end()) NGSID_FAIL(ctx, NGSID_ERR_ARG, "reads_release: this read set was not made by ngsid_reads_upload (or was released already)"); u = it->second; g_pool.uploads.erase(it); }

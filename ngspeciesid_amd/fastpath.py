@@ -275,16 +275,51 @@ def cluster(sr: SortedReads, work: ReadSet, sel, args, api, work_dev=None, T=Non
     lens = lens_all[sel]; score = sr.score[sel]
     counters = np.zeros(4, dtype=np.uint64)
     if args.nr_cores > 1:
-        def fn(read_idx, prev_batch, known_err):
+        on_dev = work_dev is not None and getattr(api, "has_ctx", False) and hasattr(api.lib, api.prefix + "reads_subset")
+        def one_call(a, read_idx, prev_batch, known_err):
+            # a batch = a gather on the DEVICE out of the resident read set (the host route - the test oracle - uploads the batch again)
             read_idx = np.asarray(read_idx, dtype=np.int64)
-            r = api.cluster_greedy(subset_reads(work, read_idx), prm, acc_rank=rank[read_idx], prev_batch=prev_batch, known_err=known_err)
+            got = a.reads_subset(work_dev, sel[read_idx]) if on_dev else None
+            sub_ = got[0] if got is not None else subset_reads(work, read_idx)
+            try:
+                return a.cluster_greedy(sub_, prm, acc_rank=rank[read_idx], prev_batch=prev_batch, known_err=known_err)
+            finally:
+                if got is not None: sub_.release()
+        def fn(read_idx, prev_batch, known_err):
+            t3 = time(); r = one_call(api, read_idx, prev_batch, known_err)
             counters[:] += r[3]
+            T.setdefault("cluster_calls", []).append((len(read_idx), round(time() - t3, 4)))
             return r
+        def fn_many(calls):
+            # the batches of a round side by side in two contexts of the device (_capi.Api lanes): the last batch of the first round holds the worst reads - hundreds of
+            # representatives, restart round after restart round of a few pairs each (0.27 s of latency for 125 k reads at C3) - and the other seven fit beside it
+            from ._capi import LANE_MIN_READS, NgsidError
+            tw = None
+            if on_dev and getattr(api, "lanes", 1) >= 2 and "device" in api.__dict__ and sum(len(c[0]) for c in calls) >= LANE_MIN_READS:
+                try: tw = api._twins(1)[0]
+                except NgsidError: tw = None
+            if tw is None:
+                return [fn(*c) for c in calls]
+            import threading
+            order = [len(calls) - 1] + list(range(len(calls) - 1)); nxt = [0]; lock = threading.Lock(); res = [None] * len(calls); tms = [None] * len(calls)
+            def worker(a):
+                while True:
+                    with lock:
+                        if nxt[0] >= len(order): return
+                        x = order[nxt[0]]; nxt[0] += 1
+                    t3 = time(); res[x] = one_call(a, *calls[x]); tms[x] = round(time() - t3, 4)
+            f = tw[1].submit(worker, tw[0])
+            try: worker(api)
+            finally: e = f.exception()
+            if e is not None: raise e
+            for x, r in enumerate(res):
+                counters[:] += r[3]; T.setdefault("cluster_calls", []).append((len(calls[x][0]), tms[x]))
+            return res
         def dump(it, reps, rep_now, herr_now, joins_now, pos_now):
             if os.environ.get("NGSID_CLI_DUMP_TIMES"): args._dump_t = T.setdefault("round_dump_parts", {})
             t2 = time(); write_round_dump(args, sr, sel, it, reps, rep_now, herr_now, pos_now); T["cluster_round_dumps"] = T.get("cluster_round_dumps", 0.0) + time() - t2
         trk = {}
-        rep_l, herr_l, joins = parallelize.tree_cluster(fn, lens, score, args.nr_cores, getattr(args, "batch_type", "total_nt"), on_round=dump if getattr(args, "outfolder", None) else None, track=trk)
+        rep_l, herr_l, joins = parallelize.tree_cluster(fn, lens, score, args.nr_cores, getattr(args, "batch_type", "total_nt"), on_round=dump if getattr(args, "outfolder", None) else None, track=trk, cluster_fn_many=fn_many)
         pos_l = trk["pos"]                     # (= parallelize.list_positions(len(sel), joins), kept up to date round by round)
     else:
         t1 = time()
@@ -590,7 +625,7 @@ def main(args, api=None):
                 args._writers.pool.shutdown(wait=True); args._writers = None
             wait = time() - t0
     res["timings"]["wait_for_writers"] = wait if os.environ.get("NGSID_CLI_SYNC_WRITES") is None else 0.0
-    logging.debug("stage seconds: %s" % {k: (round(v, 3) if not isinstance(v, dict) else v) for k, v in res["timings"].items()})
+    logging.debug("stage seconds: %s" % {k: (round(v, 3) if isinstance(v, float) else v) for k, v in res["timings"].items()})
     return res
 
 

@@ -47,7 +47,7 @@ def batch_merge_consecutive(prev_idx):
     return out
 
 
-def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state=None, on_round=None, track=None):
+def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state=None, on_round=None, track=None, cluster_fn_many=None):
     """The whole parallel_clustering schedule on index arrays.
 
     cluster_fn(read_idx, prev_batch, known_err) -> (rep_local, herr, status, counters): clusters the reads `read_idx`
@@ -56,6 +56,8 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
       bidx[i] >= 1 with HPC error rate herr[i]); the multi-GPU path runs round 1 on the ranks, all-gathers the
       representatives and enters here for the merge rounds only.
     Returns (rep_of [N] global representative per read, herr [N] (NaN where unknown), joins)
+    cluster_fn_many([(read_idx, prev_batch, known_err), ...]) -> [results]: optional; the calls of ONE round (disjoint batches: none reads what another writes) handed over together,
+      so that the caller may run them side by side (fastpath: two contexts of the device); results in the order of the calls.
     track: optional dict; on return track["pos"] = list_positions(N, joins), kept up to date round by round (ListPositions) instead of replayed from the joins afterwards.
     on_round(it, reps, root, herr, joins, pos): called after every round but the last (where the reference writes its per-round dumps, parallelize.py:193) with the surviving
       representatives in the order of the merged cluster dictionaries (batch by batch, input order within a batch), every read's representative and list position as they stand
@@ -93,13 +95,11 @@ def tree_cluster(cluster_fn, lens, score, nr_cores, batch_type="total_nt", state
     while True:
         single = len(cur_batches) == 1
         alive_next = []; n_before = len(joins)
-        for bi, idx in enumerate(cur_batches):
+        todo = [(bi, idx, None if prev is None else bidx[idx].astype(np.int32), None if prev is None else herr[idx]) for bi, idx in enumerate(cur_batches) if len(idx)]
+        done = cluster_fn_many([c[1:] for c in todo]) if (cluster_fn_many is not None and len(todo) > 1) else None
+        for x, (bi, idx, pb, ke) in enumerate(todo):
             new_index = 1 if single else bi + 1
-            if len(idx) == 0:
-                continue
-            pb = None if prev is None else bidx[idx].astype(np.int32)
-            ke = None if prev is None else herr[idx]
-            rep_local, he, st, _ = cluster_fn(idx, pb, ke)
+            rep_local, he, st, _ = done[x] if done is not None else cluster_fn(idx, pb, ke)
             rep_g = idx[np.asarray(rep_local, dtype=np.int64)]
             moved = rep_g != idx
             if moved.any():

@@ -84,8 +84,10 @@ def test_a_context_of_ones_own_closes_its_lane_contexts(monkeypatch):
     assert a.ctx is None and a.contexts() == [a]
 
 
-def test_cli_writes_the_same_files_with_and_without_lanes(gpu_api, tmp_path, monkeypatch):
-    """file in -> files out (draft, three polishing iterations, the PAF of every iteration): byte-identical whether the consensus calls run in one context or in two"""
+@pytest.mark.parametrize("t", [1, 4])
+def test_cli_writes_the_same_files_with_and_without_lanes(gpu_api, tmp_path, monkeypatch, t):
+    """file in -> files out (draft, three polishing iterations, the PAF of every iteration): byte-identical whether the consensus calls run in one context or in two;
+    --t 4: the batches of a clustering round run side by side in the two contexts as well (fastpath.cluster fn_many), the per-round dumps included"""
     import os
     from ngspeciesid_amd import synth, fastio
     from ngspeciesid_amd.cli import cli
@@ -100,13 +102,15 @@ def test_cli_writes_the_same_files_with_and_without_lanes(gpu_api, tmp_path, mon
     try:
         for lanes in (1, 2):
             gpu_api.lanes = lanes; out = str(tmp_path / ("out%d" % lanes))
-            cli(["--ont", "--fastq", fq, "--outfolder", out, "--t", "1", "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", "0.02", "--polish_all_iterations"])
+            cli(["--ont", "--fastq", fq, "--outfolder", out, "--t", str(t), "--consensus", "--racon", "--racon_iter", "3", "--abundance_ratio", "0.02", "--polish_all_iterations"])
             res[lanes] = _files(out)
     finally:
         gpu_api.lanes = saved
     assert sorted(res[1]) == sorted(res[2]) and any(f.endswith("read_alignments_it_2.paf") for f in res[1])
     for f in res[1]: assert res[1][f] == res[2][f], f
     assert len([f for f in res[1] if f.endswith("consensus.fasta")]) == 4
+    assert (t == 1) == (not any(f.startswith("1/") for f in res[1]))
+    assert len(gpu_api.contexts()) >= 2
 
 
 def test_calls_from_short_lived_threads(gpu_api, oracle):
